@@ -1,0 +1,12 @@
+"""alg_amd -- MI355X-native Adaptive Low-pass Guidance (ALG) image-to-video sampler.
+
+Only what the hot path needs: the HIP kernels + C ABI (``csrc/``, ``libalg_hip.so``), and the host-side
+mirror of the reference interface (``lp_utils``, the CogVideoX pipeline / transformer / scheduler).
+"""
+from . import lp_utils  # noqa: F401
+from ._lib import AlgHipError, build_library, load_library  # noqa: F401
+from .pipeline_cogvideox_image2video_lowpass import CogVideoXImageToVideoPipeline, CogVideoXPipelineOutput  # noqa: F401
+from .schedulers import CogVideoXDDIMScheduler  # noqa: F401
+from .transformer_cogvideox import CogVideoXTransformer3DModel, CogVideoXTransformerConfig  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,232 @@
+"""ctypes binding of libalg_hip.so (C ABI: include/alg_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every hot-path computation is a
+hand-written gfx950 kernel behind the C ABI.  There is NO CPU fallback: if the library is missing or a
+call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libalg_hip.so")
+
+ALG_F32, ALG_BF16 = 0, 1
+ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
+GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS = 1, 4
+
+EXPORTS = (
+    "alg_version", "alg_last_error", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16",
+    "alg_flash_attn_d64", "alg_layernorm_modulate", "alg_qk_norm_rope", "alg_patchify", "alg_unpatchify",
+    "alg_timestep_embedding",
+)
+
+
+class AlgHipError(RuntimeError):
+    pass
+
+
+class GemmArgs(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("R", c_void_p), ("gate", c_void_p),
+        ("lda", c_int64), ("ldb", c_int64), ("ldc", c_int64), ("ldr", c_int64),
+        ("strideA", c_int64), ("strideB", c_int64), ("strideC", c_int64), ("strideR", c_int64),
+        ("strideGate", c_int64),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32), ("batch", c_int32),
+        ("seg_split", c_int32), ("act", c_int32), ("flags", c_int32),
+    ]
+
+
+_lib = None
+
+
+def build_library(verbose=False):
+    """Compile libalg_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    import subprocess
+
+    src = os.path.join(_HERE, "csrc")
+    r = subprocess.run(["make", "-C", src, "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise AlgHipError("building libalg_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def load_library():
+    """dlopen the library and declare the prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AlgHipError(
+            "%s not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C alg_amd/csrc`).  There is no CPU fallback for the ALG hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.alg_version.restype = c_int
+    lib.alg_last_error.restype = c_char_p
+    lib.alg_down_up.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.alg_gaussian_blur.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p]
+    lib.alg_cfg_ddim_step.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_float, c_float, c_float,
+                                      c_float, c_float, c_void_p]
+    lib.alg_gemm_bf16.argtypes = [POINTER(GemmArgs), c_void_p]
+    lib.alg_flash_attn_d64.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
+                                       c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]
+    lib.alg_layernorm_modulate.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                           c_int, c_int, c_int64, c_int64, c_int, c_float, c_void_p]
+    lib.alg_qk_norm_rope.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_int, c_int, c_int, c_float, c_void_p]
+    lib.alg_patchify.argtypes = [c_void_p, c_int64, POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, c_void_p]
+    lib.alg_unpatchify.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.alg_timestep_embedding.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("alg_version", "alg_last_error"):
+            fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().alg_last_error()
+        raise AlgHipError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return ALG_F32
+    if t.dtype == torch.bfloat16:
+        return ALG_BF16
+    raise AlgHipError("unsupported dtype %s (the HIP path handles float32 and bfloat16)" % t.dtype)
+
+
+def _dev(t, name):
+    if not t.is_cuda:
+        raise AlgHipError("%s must be a device tensor: the ALG hot path is HIP-only (no CPU fallback)" % name)
+    return t
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# thin typed wrappers (shape/dtype checks live here; arithmetic lives in the kernels)
+# ---------------------------------------------------------------------------------------------------
+
+def down_up(x, h1, w1, round_intermediate=True):
+    """x: [..., H, W] contiguous device tensor -> new tensor, antialiased bilinear down to (h1, w1) and back."""
+    lib = load_library()
+    _dev(x, "x")
+    if not x.is_contiguous():
+        raise AlgHipError("down_up needs a contiguous tensor")
+    H, W = x.shape[-2:]
+    planes = x.numel() // (H * W) if x.numel() else 0
+    out = torch.empty_like(x)
+    _check(lib.alg_down_up(_ptr(x), _ptr(out), planes, H, W, h1, w1, _dt(x), 1 if round_intermediate else 0,
+                           _stream()), "alg_down_up")
+    return out
+
+
+def gaussian_blur(x, ksize, sigma):
+    lib = load_library()
+    _dev(x, "x")
+    if not x.is_contiguous():
+        raise AlgHipError("gaussian_blur needs a contiguous tensor")
+    H, W = x.shape[-2:]
+    planes = x.numel() // (H * W) if x.numel() else 0
+    out = torch.empty_like(x)
+    _check(lib.alg_gaussian_blur(_ptr(x), _ptr(out), planes, H, W, int(ksize), float(sigma), _dt(x), _stream()),
+           "alg_gaussian_blur")
+    return out
+
+
+def cfg_ddim_step_(pred, latents, n_pass, guidance_scale, sqrt_alpha_t, sqrt_beta_t, coef_a, coef_b):
+    """In place on ``latents``; pred [n_pass, *latents.shape[1:]...] flattened as [n_pass, numel]."""
+    lib = load_library()
+    _dev(pred, "pred")
+    _dev(latents, "latents")
+    if not (pred.is_contiguous() and latents.is_contiguous()):
+        raise AlgHipError("cfg_ddim_step_ needs contiguous tensors")
+    numel = latents.numel()
+    if pred.numel() != n_pass * numel:
+        raise AlgHipError("pred has %d elements, expected n_pass*numel = %d" % (pred.numel(), n_pass * numel))
+    _check(lib.alg_cfg_ddim_step(_ptr(pred), _dt(pred), _ptr(latents), _dt(latents), n_pass, numel,
+                                 float(guidance_scale), float(sqrt_alpha_t), float(sqrt_beta_t), float(coef_a),
+                                 float(coef_b), _stream()), "alg_cfg_ddim_step")
+    return latents
+
+
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=None, batch=1, strideA=0, strideB=0,
+         strideC=0, strideR=0, strideGate=0, seg_split=0, act=ACT_NONE, flags=0, a_off=0, b_off=0, c_off=0, r_off=0,
+         gate_off=0):
+    """Raw pointer-level GEMM: C = R + gate * act(A @ B^T + bias); offsets in elements."""
+    lib = load_library()
+    args = GemmArgs()
+    args.A = A.data_ptr() + 2 * a_off
+    args.B = B.data_ptr() + 2 * b_off
+    args.C = C.data_ptr() + 2 * c_off
+    args.bias = bias.data_ptr() if bias is not None else None
+    args.R = (R.data_ptr() + 2 * r_off) if R is not None else None
+    args.gate = (gate.data_ptr() + 2 * gate_off) if gate is not None else None
+    args.lda, args.ldb, args.ldc, args.ldr = lda, ldb, ldc, ldr
+    args.strideA, args.strideB, args.strideC, args.strideR, args.strideGate = strideA, strideB, strideC, strideR, strideGate
+    args.M, args.N, args.K, args.batch = M, N, K, batch
+    args.seg_split, args.act, args.flags = seg_split, act, flags
+    _check(lib.alg_gemm_bf16(ctypes.byref(args), _stream()), "alg_gemm_bf16")
+
+
+def flash_attn_d64(q, k, vt, o, batch, heads, S, q_bstride, q_rstride, vt_bstride, vt_rstride, o_bstride, o_rstride,
+                   scale, q_off=0, k_off=0):
+    lib = load_library()
+    _check(lib.alg_flash_attn_d64(c_void_p(q.data_ptr() + 2 * q_off), c_void_p(k.data_ptr() + 2 * k_off), _ptr(vt),
+                                  _ptr(o), batch, heads, S, q_bstride, q_rstride, vt_bstride, vt_rstride, o_bstride,
+                                  o_rstride, float(scale), _stream()), "alg_flash_attn_d64")
+
+
+def layernorm_modulate(x, y, weight, bias, scale, shift, mod_bstride, batch, rows, D, seg_split, eps,
+                       x_bstride=None, y_bstride=None, x_off=0, y_off=0, scale_off=0, shift_off=0):
+    """Pointer-level LayerNorm(+modulate); *_off are element offsets into the given tensors."""
+    lib = load_library()
+    x_bstride = rows * D if x_bstride is None else x_bstride
+    y_bstride = rows * D if y_bstride is None else y_bstride
+    sc = c_void_p(scale.data_ptr() + 2 * scale_off) if scale is not None else c_void_p(0)
+    sh = c_void_p(shift.data_ptr() + 2 * shift_off) if shift is not None else c_void_p(0)
+    _check(lib.alg_layernorm_modulate(c_void_p(x.data_ptr() + 2 * x_off), c_void_p(y.data_ptr() + 2 * y_off),
+                                      _ptr(weight), _ptr(bias), sc, sh, mod_bstride, batch, rows, D, x_bstride,
+                                      y_bstride, seg_split, float(eps), _stream()), "alg_layernorm_modulate")
+
+
+def qk_norm_rope_(qk, wq, bq, wk, bk, cos, sin, batch, S, heads, text_len, eps):
+    lib = load_library()
+    _check(lib.alg_qk_norm_rope(_ptr(qk), _ptr(wq), _ptr(bq), _ptr(wk), _ptr(bk), _ptr(cos), _ptr(sin), batch, S,
+                                heads, text_len, float(eps), _stream()), "alg_qk_norm_rope")
+
+
+def patchify(latents, lat_bstride, conds, out, n_samples, frames, C, H, W, p):
+    lib = load_library()
+    arr = (c_void_p * n_samples)(*[c.data_ptr() for c in conds])
+    _check(lib.alg_patchify(_ptr(latents), lat_bstride, arr, _ptr(out), n_samples, frames, C, H, W, p, _stream()),
+           "alg_patchify")
+
+
+def unpatchify(x, out, n_samples, frames, C, H, W, p):
+    lib = load_library()
+    _check(lib.alg_unpatchify(_ptr(x), _ptr(out), n_samples, frames, C, H, W, p, _stream()), "alg_unpatchify")
+
+
+def timestep_embedding(t, out, n, dim, flip_sin_to_cos=True):
+    lib = load_library()
+    _check(lib.alg_timestep_embedding(_ptr(t), _ptr(out), n, dim, 1 if flip_sin_to_cos else 0, _stream()),
+           "alg_timestep_embedding")

@@ -1,0 +1,220 @@
+// HBM-bound row kernels of the DiT block: LayerNorm + AdaLN modulation, and per-head QK LayerNorm + RoPE.
+// One wave (64 lanes) owns one row / eight head vectors, 16-byte accesses per lane, fp32 statistics with a
+// two-pass variance held in registers, cross-lane reduction by DPP-style shuffles (no LDS).
+//
+// Rounding points mirror the reference's bf16 tensors (every torch op returns bf16): LayerNorm output,
+// (1 + scale), the product and the sum are each rounded.
+#include "common.h"
+
+namespace alg {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
+  const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f[2 * k] = __uint_as_float(u[k] << 16);
+    f[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u);
+  }
+}
+
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 v;
+  v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]); v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
+  return v;
+}
+
+// y = LN(x) * (1 + scale[seg]) + shift[seg]; D = ITERS * 512
+template <int ITERS>
+__global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                     const bf16_t* __restrict__ w, const bf16_t* __restrict__ bs,
+                                                     const bf16_t* __restrict__ scale,
+                                                     const bf16_t* __restrict__ shift, int64_t mod_bs,
+                                                     int64_t x_bs, int64_t y_bs, int64_t total_rows, int rows,
+                                                     int seg_split, float eps) {
+  constexpr int D = ITERS * 512;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= total_rows) return;
+  const int bidx = (int)(row / rows);
+  const int r = (int)(row - (int64_t)bidx * rows);
+  const int seg = r >= seg_split ? 1 : 0;
+  const bf16_t* xr = x + (int64_t)bidx * x_bs + (int64_t)r * D;
+  float v[ITERS][8];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    unpack8(*(const uint4*)(xr + i * 512 + lane * 8), v[i]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[i][k];
+  }
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float d = v[i][k] - mean;
+      q = fmaf(d, d, q);
+    }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+  const bf16_t* sc = scale ? scale + (int64_t)bidx * mod_bs + (int64_t)seg * D : nullptr;
+  const bf16_t* sh = shift ? shift + (int64_t)bidx * mod_bs + (int64_t)seg * D : nullptr;
+  bf16_t* yr = y + (int64_t)bidx * y_bs + (int64_t)r * D;
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int c0 = i * 512 + lane * 8;
+    float wv[8], bv[8], o[8];
+    if (w) unpack8(*(const uint4*)(w + c0), wv);
+    if (bs) unpack8(*(const uint4*)(bs + c0), bv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float n = (v[i][k] - mean) * rstd;
+      if (w) n = n * wv[k];
+      if (bs) n = n + bv[k];
+      o[k] = rbf(n);
+    }
+    if (sc) {
+      float scv[8], shv[8];
+      unpack8(*(const uint4*)(sc + c0), scv);
+      unpack8(*(const uint4*)(sh + c0), shv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = rbf(rbf(o[k] * rbf(1.0f + scv[k])) + shv[k]);
+    }
+    *(uint4*)(yr + c0) = pack8(o);
+  }
+}
+
+// In place per-head LayerNorm(64) + RoPE on qk [batch][S][2][heads][64]; 8 lanes per head vector.
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ qk, const bf16_t* __restrict__ wq,
+                                                           const bf16_t* __restrict__ bq,
+                                                           const bf16_t* __restrict__ wk,
+                                                           const bf16_t* __restrict__ bk,
+                                                           const float* __restrict__ cos_tab,
+                                                           const float* __restrict__ sin_tab, int64_t total_vec, int S,
+                                                           int heads, int text_len, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;
+  const int64_t vec = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);
+  const bool live = vec < total_vec;
+  const int64_t vv = live ? vec : total_vec - 1;
+  const int hv = (int)(vv % (2 * heads));
+  const int64_t tok = vv / (2 * heads);
+  const int s = (int)(tok % S);
+  const bool is_k = hv >= heads;
+  bf16_t* ptr = qk + vv * 64 + sub * 8;
+  float v[8];
+  unpack8(*(const uint4*)ptr, v);
+  float sum = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sum += v[k];
+  sum += __shfl_xor(sum, 1, 64);
+  sum += __shfl_xor(sum, 2, 64);
+  sum += __shfl_xor(sum, 4, 64);
+  const float mean = sum * (1.0f / 64);
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float d = v[k] - mean;
+    q = fmaf(d, d, q);
+  }
+  q += __shfl_xor(q, 1, 64);
+  q += __shfl_xor(q, 2, 64);
+  q += __shfl_xor(q, 4, 64);
+  const float rstd = rsqrtf(q * (1.0f / 64) + eps);
+  float wv[8], bv[8];
+  unpack8(*(const uint4*)((is_k ? wk : wq) + sub * 8), wv);
+  unpack8(*(const uint4*)((is_k ? bk : bq) + sub * 8), bv);
+  float o[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = rbf((v[k] - mean) * rstd * wv[k] + bv[k]);
+  if (s >= text_len && cos_tab) {
+    const int64_t pos = (int64_t)(s - text_len) * 64 + sub * 8;
+    const float4 c0 = *(const float4*)(cos_tab + pos), c1 = *(const float4*)(cos_tab + pos + 4);
+    const float4 s0 = *(const float4*)(sin_tab + pos), s1 = *(const float4*)(sin_tab + pos + 4);
+    const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // x.float() * cos + rotate(x).float() * sin, rotate = (-x_odd, x_even) interleaved; unfused like eager
+      r[2 * k] = __fadd_rn(__fmul_rn(o[2 * k], cs[2 * k]), __fmul_rn(-o[2 * k + 1], sn[2 * k]));
+      r[2 * k + 1] = __fadd_rn(__fmul_rn(o[2 * k + 1], cs[2 * k + 1]), __fmul_rn(o[2 * k], sn[2 * k + 1]));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = r[k];
+  }
+  if (live) *(uint4*)ptr = pack8(o);
+}
+
+}  // namespace alg
+
+using namespace alg;
+
+extern "C" int alg_layernorm_modulate(const void* x, void* y, const void* weight, const void* bias,
+                                      const void* scale, const void* shift, int64_t mod_bstride, int batch, int rows,
+                                      int D, int64_t x_bstride, int64_t y_bstride, int seg_split, float eps,
+                                      void* stream) {
+  if (!x || !y || batch <= 0 || rows <= 0 || D <= 0) {
+    set_error("alg_layernorm_modulate: bad argument (batch=%d rows=%d D=%d)", batch, rows, D);
+    return ALG_EINVAL;
+  }
+  if (D % 512 != 0 || D > 8192) {
+    set_error("alg_layernorm_modulate: D=%d must be a multiple of 512 and <= 8192", D);
+    return ALG_EINVAL;
+  }
+  if ((scale == nullptr) != (shift == nullptr)) {
+    set_error("alg_layernorm_modulate: scale and shift must be given together");
+    return ALG_EINVAL;
+  }
+  if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)weight & 15) || ((uintptr_t)bias & 15) ||
+      ((uintptr_t)scale & 15) || ((uintptr_t)shift & 15) || (mod_bstride % 8) || (x_bstride % 8) ||
+      (y_bstride % 8)) {
+    set_error("alg_layernorm_modulate: pointers must be 16-byte aligned");
+    return ALG_EINVAL;
+  }
+  const int64_t total = (int64_t)batch * rows;
+  const unsigned grid = (unsigned)((total + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+#define LN_CASE(I)                                                                                                  \
+  case I:                                                                                                           \
+    hipLaunchKernelGGL(ln_mod_kernel<I>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,                  \
+                       (const bf16_t*)weight, (const bf16_t*)bias, (const bf16_t*)scale, (const bf16_t*)shift,      \
+                       mod_bstride, x_bstride, y_bstride, total, rows, seg_split, eps);                                                   \
+    break;
+  switch (D / 512) {
+    LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+    LN_CASE(9) LN_CASE(10) LN_CASE(11) LN_CASE(12) LN_CASE(13) LN_CASE(14) LN_CASE(15) LN_CASE(16)
+  }
+#undef LN_CASE
+  return check_launch("alg_layernorm_modulate");
+}
+
+extern "C" int alg_qk_norm_rope(void* qk, const void* wq, const void* bq, const void* wk, const void* bk,
+                                const float* cos_tab, const float* sin_tab, int batch, int S, int heads,
+                                int text_len, float eps, void* stream) {
+  if (!qk || !wq || !bq || !wk || !bk || batch <= 0 || S <= 0 || heads <= 0 || text_len < 0) {
+    set_error("alg_qk_norm_rope: bad argument (batch=%d S=%d heads=%d text_len=%d)", batch, S, heads, text_len);
+    return ALG_EINVAL;
+  }
+  if ((cos_tab == nullptr) != (sin_tab == nullptr)) {
+    set_error("alg_qk_norm_rope: cos and sin tables must be given together");
+    return ALG_EINVAL;
+  }
+  if (((uintptr_t)qk & 15) || ((uintptr_t)wq & 15) || ((uintptr_t)bq & 15) || ((uintptr_t)wk & 15) ||
+      ((uintptr_t)bk & 15) || ((uintptr_t)cos_tab & 15) || ((uintptr_t)sin_tab & 15)) {
+    set_error("alg_qk_norm_rope: pointers must be 16-byte aligned");
+    return ALG_EINVAL;
+  }
+  const int64_t total_vec = (int64_t)batch * S * 2 * heads;
+  const unsigned grid = (unsigned)((total_vec + 31) / 32);
+  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qk,
+                     (const bf16_t*)wq, (const bf16_t*)bq, (const bf16_t*)wk, (const bf16_t*)bk, cos_tab, sin_tab,
+                     total_vec, S, heads, text_len, eps);
+  return check_launch("alg_qk_norm_rope");
+}

@@ -1,0 +1,90 @@
+"""Data-parallel plumbing: one process per GPU, independent videos per rank, ONE weight broadcast over
+RCCL/xGMI at start-up and no data-path collective afterwards.
+
+The reference has no distributed code at all; this is the build's own addition.  ``torch.distributed`` backend
+"nccl" is RCCL on ROCm; "gloo" is used by the CPU tests (world_size 2).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_distributed(backend=None):
+    """Initialise the default process group from the torchrun environment; no-op for world_size 1."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_videos(num_videos, rank, world):
+    """video v -> rank v mod world (independent videos share nothing but weights)."""
+    return [v for v in range(num_videos) if v % world == rank]
+
+
+def broadcast_state_dict(make_state_dict, shapes, device, src=0, dtype=torch.bfloat16, bucket_bytes=1 << 30):
+    """Rank ``src`` materialises the weights (``make_state_dict()``), every other rank allocates empty tensors of
+    ``shapes`` and receives them.  Tensors are coalesced into ~1 GiB flat buckets so the broadcast is a handful of
+    large collectives (xGMI is point-to-point: few, large transfers) rather than ~700 small ones."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return make_state_dict()
+    rank = dist.get_rank()
+    sd = make_state_dict() if rank == src else None
+    out = {}
+    esize = torch.empty((), dtype=dtype).element_size()
+    names = list(shapes.keys())
+    i = 0
+    while i < len(names):
+        group, nbytes = [], 0
+        while i < len(names) and (not group or nbytes + _numel(shapes[names[i]]) * esize <= bucket_bytes):
+            group.append(names[i])
+            nbytes += _numel(shapes[names[i]]) * esize
+            i += 1
+        flat = torch.empty(nbytes // esize, device=device, dtype=dtype)
+        if rank == src:
+            off = 0
+            for n in group:
+                k = _numel(shapes[n])
+                flat[off:off + k].copy_(sd[n].to(device=device, dtype=dtype).reshape(-1))
+                off += k
+        dist.broadcast(flat, src=src)
+        off = 0
+        for n in group:
+            k = _numel(shapes[n])
+            out[n] = flat[off:off + k].view(shapes[n])
+            off += k
+    return out
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return n
+
+
+def max_over_ranks(value, device):
+    """MAX all-reduce of a python float (the bench's timing rule)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,109 @@
+"""Weight sources for the CogVideoX DiT: a local diffusers-format checkpoint, or seeded synthetic weights at
+the same shapes (no network here, so benches and tests run on synthetic weights and say so)."""
+from __future__ import annotations
+
+import glob
+import json
+import math
+import os
+
+import torch
+
+
+def parameter_shapes(cfg):
+    """diffusers state-dict name -> shape for CogVideoXTransformer3DModel (patch_size_t None)."""
+    D, H = cfg.inner_dim, cfg.attention_head_dim
+    p = cfg.patch_size
+    lat_f = (cfg.sample_frames - 1) // cfg.temporal_compression_ratio + 1
+    n_patch = (cfg.sample_height // p) * (cfg.sample_width // p) * lat_f
+    E = cfg.time_embed_dim
+    F4 = cfg.ff_inner_mult * D
+    shapes = {
+        "patch_embed.proj.weight": (D, cfg.in_channels, p, p),
+        "patch_embed.proj.bias": (D,),
+        "patch_embed.text_proj.weight": (D, cfg.text_embed_dim),
+        "patch_embed.text_proj.bias": (D,),
+        "time_embedding.linear_1.weight": (E, D),
+        "time_embedding.linear_1.bias": (E,),
+        "time_embedding.linear_2.weight": (E, E),
+        "time_embedding.linear_2.bias": (E,),
+        "norm_final.weight": (D,),
+        "norm_final.bias": (D,),
+        "norm_out.linear.weight": (2 * D, E),
+        "norm_out.linear.bias": (2 * D,),
+        "norm_out.norm.weight": (D,),
+        "norm_out.norm.bias": (D,),
+        "proj_out.weight": (p * p * cfg.out_channels, D),
+        "proj_out.bias": (p * p * cfg.out_channels,),
+    }
+    if cfg.use_learned_positional_embeddings:
+        shapes["patch_embed.pos_embedding"] = (1, cfg.max_text_seq_length + n_patch, D)
+    for i in range(cfg.num_layers):
+        b = "transformer_blocks.%d." % i
+        for nm in ("norm1", "norm2"):
+            shapes[b + nm + ".linear.weight"] = (6 * D, E)
+            shapes[b + nm + ".linear.bias"] = (6 * D,)
+            shapes[b + nm + ".norm.weight"] = (D,)
+            shapes[b + nm + ".norm.bias"] = (D,)
+        for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+            shapes[b + "attn1." + nm + ".weight"] = (D, D)
+            shapes[b + "attn1." + nm + ".bias"] = (D,)
+        for nm in ("norm_q", "norm_k"):
+            shapes[b + "attn1." + nm + ".weight"] = (H,)
+            shapes[b + "attn1." + nm + ".bias"] = (H,)
+        shapes[b + "ff.net.0.proj.weight"] = (F4, D)
+        shapes[b + "ff.net.0.proj.bias"] = (F4,)
+        shapes[b + "ff.net.2.weight"] = (D, F4)
+        shapes[b + "ff.net.2.bias"] = (D,)
+    return shapes
+
+
+def count_parameters(cfg):
+    return sum(math.prod(s) for s in parameter_shapes(cfg).values())
+
+
+def synthetic_state_dict(cfg, seed=1234, std=0.02, device="cuda", randomize_affine=False):
+    """N(0, std^2) matrices / positional table, zero biases, unit norm gains, bf16, generated tensor by tensor
+    on ``device`` from one seeded generator (deterministic for a given device type)."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    sd = {}
+    for name, shape in parameter_shapes(cfg).items():
+        is_matrix = name.endswith("pos_embedding") or (name.endswith(".weight") and len(shape) >= 2)
+        if is_matrix:
+            t = torch.randn(shape, generator=g, device=dev, dtype=torch.float32).mul_(std)
+        elif name.endswith(".weight"):
+            t = torch.ones(shape, device=dev)
+            if randomize_affine:
+                t = t + 0.1 * torch.randn(shape, generator=g, device=dev)
+        else:
+            t = torch.zeros(shape, device=dev)
+            if randomize_affine:
+                t = 0.05 * torch.randn(shape, generator=g, device=dev)
+        sd[name] = t.to(torch.bfloat16)
+    return sd
+
+
+def load_diffusers_transformer(path, subfolder="transformer"):
+    """Read config.json + safetensors shards of a diffusers CogVideoXTransformer3DModel from local disk."""
+    from safetensors.torch import load_file
+
+    from .transformer_cogvideox import CogVideoXTransformerConfig
+
+    root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
+    cfg_path = os.path.join(root, "config.json")
+    if not os.path.exists(cfg_path):
+        raise FileNotFoundError(
+            "%s not found: weights must be on local disk (this build has no network access; use "
+            "CogVideoXTransformer3DModel.from_synthetic for shape-faithful synthetic weights)" % cfg_path)
+    with open(cfg_path) as f:
+        raw = json.load(f)
+    fields = CogVideoXTransformerConfig.__dataclass_fields__
+    cfg = CogVideoXTransformerConfig(**{k: v for k, v in raw.items() if k in fields})
+    sd = {}
+    for shard in sorted(glob.glob(os.path.join(root, "*.safetensors"))):
+        sd.update(load_file(shard))
+    missing = [k for k in parameter_shapes(cfg) if k not in sd]
+    if missing:
+        raise KeyError("checkpoint is missing %d tensors, e.g. %s" % (len(missing), missing[:3]))
+    return cfg, sd

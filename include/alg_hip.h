@@ -1,0 +1,140 @@
+/*
+ * alg_hip.h -- C ABI of libalg_hip.so, the MI355X (gfx950) native hot path of the ALG sampler.
+ *
+ * The reference (choi403/ALG) has no native/FFI layer of its own: its hot path is PyTorch ops called
+ * from Python.  Each entry point below therefore cites the reference *call site* it replaces
+ * (paths relative to the reference checkout).  Abbreviations:
+ *   lp:  lp_utils.py            cog: pipeline_cogvideox_image2video_lowpass.py
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); kernels never allocate or free
+ *   - enqueue-only on `stream` (a hipStream_t, may be NULL = default stream); no internal sync
+ *   - in/out may not alias unless stated
+ *   - return 0 on success, negative ALG_E* on failure; message via alg_last_error() (thread local)
+ *   - dtype codes: ALG_F32 = 0, ALG_BF16 = 1
+ */
+#ifndef ALG_HIP_H
+#define ALG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALG_F32 0
+#define ALG_BF16 1
+
+#define ALG_OK 0
+#define ALG_EINVAL (-1)   /* bad argument (shape, dtype, alignment, null pointer) */
+#define ALG_ELAUNCH (-2)  /* HIP launch / runtime error */
+#define ALG_ELIMIT (-3)   /* shape exceeds what the kernel supports (e.g. plane does not fit LDS) */
+
+#define ALG_VERSION 100
+
+int alg_version(void);
+const char* alg_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Low-pass filters on [planes, H, W] contiguous planes (a 4-D/5-D tensor viewed per (H, W) plane,
+ * lp:31-37).  One workgroup per plane, plane resident in LDS, taps computed in-kernel.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* lp:49-54  F.interpolate(bilinear, antialias) to (h1, w1) then back to (H, W).
+ * h1, w1 are computed by the caller exactly as lp:51-52 (Python banker's rounding).
+ * round_intermediate != 0 rounds the (h1, w1) intermediate to bf16 (the reference's two separate
+ * interpolate calls each return a tensor of the input dtype); only meaningful for ALG_BF16. */
+int alg_down_up(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype,
+                int round_intermediate, void* stream);
+
+/* lp:40-47  torchvision gaussian_blur(kernel_size=[k,k], sigma=[s,s]): reflect pad k/2, separable
+ * correlation with g = exp(-0.5 (x/s)^2)/sum.  ksize must be odd, ksize/2 < min(H, W), sigma > 0. */
+int alg_gaussian_blur(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * cog:1091-1123  noise_pred.float(); chunk; CFG combine; CogVideoXDDIMScheduler.step (v-prediction,
+ * eta = 0); cast back -- one fused elementwise pass, latents updated IN PLACE.
+ *   n_pass = 3: u0 + g*(text - u)   (pred = [uncond_init, uncond, text], cog:1099-1102)
+ *   n_pass = 2: u  + g*(text - u)   (cog:1096-1097)
+ *   n_pass = 1: pred                (no CFG)
+ *   x0 = sqrt_alpha_t * x - sqrt_beta_t * v ;  x <- coef_a * x + coef_b * x0
+ * pred: [n_pass, numel] of pred_dtype;  latents: [numel] of lat_dtype.
+ * ---------------------------------------------------------------------------------------------- */
+int alg_cfg_ddim_step(const void* pred, int pred_dtype, void* latents, int lat_dtype, int n_pass, int64_t numel,
+                      float guidance_scale, float sqrt_alpha_t, float sqrt_beta_t, float coef_a, float coef_b,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Video-DiT forward building blocks (cog:1082-1090 self.transformer(...); the arithmetic is
+ * diffusers' CogVideoXTransformer3DModel -- see DESIGN.md).  All activations bf16, fp32 accumulate.
+ * ---------------------------------------------------------------------------------------------- */
+
+#define ALG_ACT_NONE 0
+#define ALG_ACT_GELU_TANH 1
+#define ALG_ACT_SILU 2
+
+#define ALG_GEMM_BIAS_PER_ROW 1   /* bias indexed by output row (used for the transposed V projection) */
+#define ALG_GEMM_PERMUTE_COLS 4   /* store column n at n with bits 2 and 3 swapped (MFMA k-order for V^T) */
+
+typedef struct alg_gemm_args {
+  const void* A;      /* [batch][M][K] bf16, row stride lda, batch stride strideA (elements) */
+  const void* B;      /* [batch][N][K] bf16 (nn.Linear weight layout), ldb, strideB (0 = shared)  */
+  void* C;            /* [batch][M][N] bf16, ldc, strideC */
+  const void* bias;   /* [N] (or [M] with BIAS_PER_ROW) bf16, may be NULL */
+  const void* R;      /* residual [batch][M][N] bf16 (ldr, strideR), may be NULL; may alias C   */
+  const void* gate;   /* [batch][2][N] bf16: gate[0] for rows < seg_split, gate[1] otherwise; NULL = 1 */
+  int64_t lda, ldb, ldc, ldr;
+  int64_t strideA, strideB, strideC, strideR, strideGate;
+  int32_t M, N, K, batch;
+  int32_t seg_split;
+  int32_t act;        /* ALG_ACT_* applied to (acc + bias) */
+  int32_t flags;      /* ALG_GEMM_* */
+} alg_gemm_args;
+
+/* C = R + gate * act(A @ B^T + bias)   (bias optional; either act or the residual(+gate) form).  K % 64 == 0, lda/ldb % 8 == 0,
+ * A and B 16-byte aligned.  M and N are arbitrary (edge tiles clamp loads and guard stores). */
+int alg_gemm_bf16(const alg_gemm_args* args, void* stream);
+
+/* Full (unmasked) softmax attention, head_dim 64.
+ *   q, k : bf16, element (b, s, h, d) at  base + b*q_bstride + s*q_rstride + h*64 + d   (same strides for k)
+ *   vt   : bf16 V transposed, element (b, h, d, s') at base + b*vt_bstride + (h*64+d)*vt_rstride + perm(s'),
+ *          perm = swap of index bits 2 and 3 (what alg_gemm_bf16 + ALG_GEMM_PERMUTE_COLS writes);
+ *          columns >= S up to the next multiple of 64 must be readable and finite (zero)
+ *   o    : bf16, element (b, s, h, d) at base + b*o_bstride + s*o_rstride + h*64 + d
+ * softmax(q k^T * scale) v, fp32 accumulate, P rounded to bf16 before P@V. */
+int alg_flash_attn_d64(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S,
+                       int64_t q_bstride, int64_t q_rstride, int64_t vt_bstride, int64_t vt_rstride,
+                       int64_t o_bstride, int64_t o_rstride, float scale, void* stream);
+
+/* y = LayerNorm(x; weight, bias, eps) * (1 + scale[seg]) + shift[seg]       (CogVideoXLayerNormZero / AdaLayerNorm)
+ * x, y: [batch][rows][D] bf16, rows contiguous, batch strides x_bstride / y_bstride (elements);
+ * weight/bias: [D] bf16 (may be NULL);
+ * scale/shift: [batch][2][D] bf16 at batch stride mod_bstride (seg 0 = rows < seg_split, seg 1 = the rest),
+ * NULL = plain LayerNorm.  D % 512 == 0, D <= 8192. */
+int alg_layernorm_modulate(const void* x, void* y, const void* weight, const void* bias, const void* scale,
+                           const void* shift, int64_t mod_bstride, int batch, int rows, int D, int64_t x_bstride,
+                           int64_t y_bstride, int seg_split, float eps, void* stream);
+
+/* In place on qk: [batch][S][2][heads][64] bf16 (q then k per token):
+ * per-head LayerNorm(64) with (wq,bq) / (wk,bk), then RoPE (cos/sin fp32 [S - text_len][64], interleaved-pair
+ * convention) on tokens >= text_len. */
+int alg_qk_norm_rope(void* qk, const void* wq, const void* bq, const void* wk, const void* bk, const float* cos_tab,
+                     const float* sin_tab, int batch, int S, int heads, int text_len, float eps, void* stream);
+
+/* Patch gather for the patch-embed GEMM (cog:1060-1070 batch assembly folded in, no materialised cat):
+ * out[n][(f, gy, gx)][c*p*p + py*p + px]; channels [0, C) come from latents (sample stride lat_bstride, 0 =
+ * broadcast), channels [C, 2C) from cond[n] (cond_ptrs: n device pointers to [F][C][H][W] tensors). */
+int alg_patchify(const void* latents, int64_t lat_bstride, const void* const* cond_ptrs, void* out, int n_samples,
+                 int frames, int C, int H, int W, int p, void* stream);
+
+/* proj_out rows [n][(f,gy,gx)][c*p*p + py*p + px] -> [n][F][C][H][W] bf16. */
+int alg_unpatchify(const void* in, void* out, int n_samples, int frames, int C, int H, int W, int p, void* stream);
+
+/* Timesteps(dim, flip_sin_to_cos, freq_shift=0): out [n][dim] bf16 sinusoid of t[n] (fp32 timesteps). */
+int alg_timestep_embedding(const float* t, void* out, int n, int dim, int flip_sin_to_cos, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALG_HIP_H */

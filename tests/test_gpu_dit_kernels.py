@@ -1,0 +1,217 @@
+"""GPU parity of the DiT building-block kernels (C ABI) against plain fp32 torch restatements on CPU."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from alg_amd import _lib
+from oracle import dit_oracle
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rnd(shape, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(BF)
+
+
+def swap23(n):
+    return (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1)
+
+
+def rel_err(got, ref):
+    return ((got.double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-30)).item()
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (300, 520, 128), (17, 64, 512), (2, 1000, 64),
+                                   (1111, 96, 3072)])
+def test_gemm_plain_bias(device, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B, bias = rnd((M, K), g), rnd((N, K), g, 0.1), rnd((N,), g)
+    C = torch.full((M, N), 7.0, dtype=BF, device=device)
+    _lib.gemm(A.to(device), B.to(device), C, M, N, K, K, K, N, bias=bias.to(device))
+    ref = A.float() @ B.float().t() + bias.float()
+    got = C.float().cpu()
+    assert rel_err(got, ref) < 4e-3
+    assert (got - ref).abs().max() <= 2e-2 * ref.abs().max()
+
+
+def test_gemm_is_transpose_detecting(device):
+    """A = I with an asymmetric B: catches a swapped C/D fragment layout (guide rule 16)."""
+    M = N = K = 256
+    A = torch.eye(M).to(BF)
+    B = (torch.arange(N)[:, None] * 0.25 + torch.arange(K)[None, :] * 0.001953125).to(BF)
+    C = torch.empty(M, N, dtype=BF, device=device)
+    _lib.gemm(A.to(device), B.to(device), C, M, N, K, K, K, N)
+    assert torch.equal(C.cpu().float(), B.float().t())
+
+
+@pytest.mark.parametrize("act", [_lib.ACT_GELU_TANH, _lib.ACT_SILU])
+def test_gemm_activation(device, act):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 333, 512, 192
+    A, B, bias = rnd((M, K), g), rnd((N, K), g, 0.2), rnd((N,), g)
+    C = torch.empty(M, N, dtype=BF, device=device)
+    _lib.gemm(A.to(device), B.to(device), C, M, N, K, K, K, N, bias=bias.to(device), act=act)
+    lin = (A.float() @ B.float().t() + bias.float()).to(BF).float()
+    ref = F.gelu(lin, approximate="tanh") if act == _lib.ACT_GELU_TANH else F.silu(lin)
+    got = C.float().cpu()
+    assert rel_err(got, ref) < 6e-3
+    assert (got - ref).abs().max() <= 3e-2 * ref.abs().max()
+
+
+def test_gemm_batched_gated_residual_in_place(device):
+    """The out-projection / FF2 form: x <- x + gate[seg] * (A @ W^T + b), per-sample batch, text/video segments."""
+    g = torch.Generator().manual_seed(9)
+    nb, S, N, K, T = 2, 290, 512, 128, 26
+    A, Wt, bias = rnd((nb, S, K), g), rnd((N, K), g, 0.2), rnd((N,), g)
+    X = rnd((nb, S, N), g)
+    gate = rnd((nb, 7, N), g)  # strideGate = 7*N, pairs live at [:, 2:4]
+    Xd = X.to(device).clone()
+    _lib.gemm(A.to(device), Wt.to(device), Xd, S, N, K, K, K, N, bias=bias.to(device), R=Xd, ldr=N,
+              gate=gate.to(device), gate_off=2 * N, strideGate=7 * N, seg_split=T, batch=nb, strideA=S * K,
+              strideC=S * N, strideR=S * N)
+    lin = (A.float() @ Wt.float().t() + bias.float()).to(BF)
+    gsel = torch.where(torch.arange(S)[None, :, None] < T, gate[:, 2:3].float(), gate[:, 3:4].float())
+    ref = (X.float() + (gsel * lin.float()).to(BF).float()).to(BF).float()
+    got = Xd.float().cpu()
+    assert rel_err(got, ref) < 5e-3
+    assert (got - ref).abs().max() <= 3e-2 * ref.abs().max()
+
+
+def test_gemm_transposed_v_projection(device):
+    """V^T = Wv @ y^T with per-row bias and the bits-2/3 column permutation, pad columns untouched."""
+    g = torch.Generator().manual_seed(11)
+    nb, S, D = 2, 200, 256
+    S_pad = 256
+    y, Wv, bv = rnd((nb, S, D), g), rnd((D, D), g, 0.1), rnd((D,), g)
+    vt = torch.zeros(nb, D, S_pad, dtype=BF, device=device)
+    _lib.gemm(Wv.to(device), y.to(device), vt, D, S, D, D, D, S_pad, bias=bv.to(device), batch=nb, strideB=S * D,
+              strideC=D * S_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
+    v = y.float() @ Wv.float().t() + bv.float()  # [nb, S, D]
+    ref = torch.zeros(nb, D, S_pad)
+    perm = torch.tensor([swap23(n) for n in range(S)])
+    ref[:, :, perm] = v.transpose(1, 2)
+    got = vt.float().cpu()
+    live = torch.zeros(S_pad, dtype=torch.bool)
+    live[perm] = True
+    assert torch.count_nonzero(got[:, :, ~live]) == 0
+    assert rel_err(got, ref) < 4e-3
+
+
+# ------------------------------------------------------------------------------------- attention
+def run_attention(device, q, k, v, scale):
+    """q,k,v [B, S, H, 64] bf16 (CPU) -> o [B, S, H, 64] via the kernel's strided layouts."""
+    Bn, S, H, _ = q.shape
+    D = H * 64
+    S_pad = (S + 63) // 64 * 64
+    qk = torch.cat([q.reshape(Bn, S, D), k.reshape(Bn, S, D)], dim=-1).contiguous().to(device)
+    vt = torch.zeros(Bn, D, S_pad, dtype=BF)
+    perm = torch.tensor([swap23(n) for n in range(S)])
+    vt[:, :, perm] = v.reshape(Bn, S, D).transpose(1, 2)
+    o = torch.zeros(Bn, S, D, dtype=BF, device=device)
+    _lib.flash_attn_d64(qk, qk, vt.to(device), o, Bn, H, S, S * 2 * D, 2 * D, D * S_pad, S_pad, S * D, D, scale, k_off=D)
+    return o.cpu().reshape(Bn, S, H, 64)
+
+
+def sdpa_ref(q, k, v, scale):
+    qq, kk, vv = (t.double().transpose(1, 2) for t in (q, k, v))
+    p = torch.softmax(qq @ kk.transpose(-1, -2) * scale, dim=-1)
+    return (p @ vv).transpose(1, 2)
+
+
+@pytest.mark.parametrize("Bn,S,H", [(1, 64, 1), (1, 100, 3), (2, 273, 9), (1, 1000, 8), (3, 994, 2), (1, 17, 1)])
+def test_flash_attention_vs_sdpa(device, Bn, S, H):
+    g = torch.Generator().manual_seed(S + H)
+    q, k, v = rnd((Bn, S, H, 64), g), rnd((Bn, S, H, 64), g), rnd((Bn, S, H, 64), g)
+    got = run_attention(device, q, k, v, 0.125).double()
+    ref = sdpa_ref(q, k, v, 0.125)
+    assert (got - ref).abs().max() <= 2e-2, (got - ref).abs().max()
+    assert rel_err(got, ref) < 1e-2
+
+
+def test_flash_attention_forced_rescale_and_asymmetry(device):
+    """A key that dominates late in the sequence forces the online-softmax rescale; V = one-hot rows make any
+    kv-order / transpose mistake in the P@V operand layout visible."""
+    g = torch.Generator().manual_seed(2)
+    S = 320
+    q, k = rnd((1, S, 1, 64), g), rnd((1, S, 1, 64), g)
+    k[0, 257, 0] = q[0, 5, 0] * 4  # spike for query 5 at tile 4
+    v = torch.zeros(1, S, 1, 64, dtype=BF)
+    v[0, torch.arange(S), 0, torch.arange(S) % 64] = 1.0
+    v[0, :, 0, 63] += (torch.arange(S) / S).to(BF)
+    got = run_attention(device, q, k, v, 0.125).double()
+    ref = sdpa_ref(q, k, v, 0.125)
+    assert (got - ref).abs().max() <= 1e-2
+    assert ref[0, 5, 0, 257 % 64] > 0.9  # the spike really dominates
+
+
+# ------------------------------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("D,rows,T", [(512, 37, 5), (3072, 20, 7), (1024, 9, 0)])
+def test_layernorm_modulate(device, D, rows, T):
+    g = torch.Generator().manual_seed(D)
+    nb = 2
+    x, w, b = rnd((nb, rows, D), g, 2.0), (1 + 0.1 * torch.randn(D, generator=g)).to(BF), rnd((D,), g, 0.1)
+    mod = rnd((nb, 6 * D), g, 0.5)
+    y = torch.empty(nb, rows, D, dtype=BF, device=device)
+    _lib.layernorm_modulate(x.to(device), y, w.to(device), b.to(device), mod.to(device), mod.to(device), 6 * D, nb,
+                            rows, D, T, 1e-5, scale_off=2 * D, shift_off=0)
+    n = F.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5).to(BF)
+    seg = (torch.arange(rows) >= T).long()
+    shift = torch.stack([mod[:, :D], mod[:, D:2 * D]], 1)[:, seg]       # [nb, rows, D]
+    scale = torch.stack([mod[:, 2 * D:3 * D], mod[:, 3 * D:4 * D]], 1)[:, seg]
+    ref = (n * (1 + scale) + shift).float()
+    got = y.float().cpu()
+    assert (got - ref).abs().max() <= 4e-2 and rel_err(got, ref) < 6e-3
+    # plain LayerNorm + strided batches (the final-norm form)
+    y2 = torch.zeros(nb, rows - 2, D, dtype=BF, device=device)
+    _lib.layernorm_modulate(x.to(device), y2, w.to(device), b.to(device), None, None, 0, nb, rows - 2, D, 0, 1e-5,
+                            x_bstride=rows * D, y_bstride=(rows - 2) * D, x_off=2 * D)
+    assert (y2.float().cpu() - n[:, 2:].float()).abs().max() <= 2e-2
+
+
+def test_qk_norm_rope(device):
+    g = torch.Generator().manual_seed(4)
+    nb, S, H, T = 2, 50, 3, 10
+    cfg = dit_oracle.DiTConfig(sample_height=8, sample_width=10, sample_frames=5)
+    cos, sin = dit_oracle.rope_tables(cfg, 64, 80, 2)  # 2 * 4 * 5 = 40 video tokens
+    assert cos.shape == (S - T, 64)
+    qk = rnd((nb, S, 2, H, 64), g, 1.5)
+    wq, bq, wk, bk = [(1 + 0.1 * torch.randn(64, generator=g)).to(BF) if i % 2 == 0 else rnd((64,), g, 0.1)
+                      for i in range(4)]
+    d = qk.to(device).clone()
+    _lib.qk_norm_rope_(d, wq.to(device), bq.to(device), wk.to(device), bk.to(device), cos.to(device), sin.to(device),
+                       nb, S, H, T, 1e-6)
+    q = F.layer_norm(qk[:, :, 0].float(), (64,), wq.float(), bq.float(), 1e-6).to(BF).transpose(1, 2)  # [nb,H,S,64]
+    k = F.layer_norm(qk[:, :, 1].float(), (64,), wk.float(), bk.float(), 1e-6).to(BF).transpose(1, 2)
+    q = torch.cat([q[:, :, :T], dit_oracle.apply_rotary(q[:, :, T:], cos, sin)], dim=2)
+    k = torch.cat([k[:, :, :T], dit_oracle.apply_rotary(k[:, :, T:], cos, sin)], dim=2)
+    ref = torch.stack([q.transpose(1, 2), k.transpose(1, 2)], dim=2).float()
+    got = d.float().cpu()
+    assert (got - ref).abs().max() <= 4e-2 and rel_err(got, ref) < 5e-3
+
+
+def test_patchify_unpatchify_timestep(device):
+    g = torch.Generator().manual_seed(6)
+    n, Fr, C, H, W, p = 3, 2, 4, 6, 10, 2
+    lat = rnd((1, Fr, C, H, W), g)
+    conds = [rnd((1, Fr, C, H, W), g) for _ in range(n)]
+    out = torch.empty(n, Fr * (H // p) * (W // p), 2 * C * p * p, dtype=BF, device=device)
+    _lib.patchify(lat.to(device), 0, [c.to(device) for c in conds], out, n, Fr, C, H, W, p)
+    for i in range(n):
+        x = torch.cat([lat[0], conds[i][0]], dim=1).float()  # [F, 2C, H, W]  (cog:1068-1070 channel concat)
+        ref = F.unfold(x, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, 2 * C * p * p)  # conv2d im2col order
+        assert torch.equal(out[i].float().cpu(), ref)
+    tok = rnd((n, Fr * (H // p) * (W // p), C * p * p), g)
+    back = torch.empty(n, Fr, C, H, W, dtype=BF, device=device)
+    _lib.unpatchify(tok.to(device), back, n, Fr, C, H, W, p)
+    ref = tok.reshape(n, Fr, H // p, W // p, C, p, p).permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
+    assert torch.equal(back.cpu(), ref)
+    t = torch.tensor([999.0, 19.0, 500.0])
+    emb = torch.empty(3, 512, dtype=BF, device=device)
+    _lib.timestep_embedding(t.to(device), emb, 3, 512, True)
+    ref = dit_oracle.timestep_sinusoid(t, 512, True, 0)
+    assert (emb.float().cpu() - ref).abs().max() <= 8e-3  # bf16 output of values in [-1, 1]

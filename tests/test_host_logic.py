@@ -1,0 +1,200 @@
+"""CPU tests of the product's host-side logic (no kernel is launched): the lp_utils mirror, the scheduler
+tables, RoPE tables, the C-ABI surface, pipeline argument checking and the loop's branch table."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import alg_amd
+from alg_amd import lp_utils
+from alg_amd.pipeline_cogvideox_image2video_lowpass import (CogVideoXImageToVideoPipeline, get_resize_crop_region_for_grid,
+                                                            rotary_tables)
+from alg_amd.schedulers import CogVideoXDDIMScheduler
+from alg_amd.transformer_cogvideox import CogVideoXTransformerConfig
+from alg_amd import weights as W
+from oracle import ddim_oracle, dit_oracle, loop_oracle, lp_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(ps, i, total):
+    return dict(step_index=i, total_steps=total, lp_strength_schedule_type=ps["kind"],
+                schedule_interval_start_time=ps.get("start", 0.0), schedule_interval_end_time=ps.get("end", 0.05),
+                schedule_linear_start_weight=ps.get("w0", 1.0), schedule_linear_end_weight=ps.get("w1", 0.0),
+                schedule_linear_end_time=ps.get("t1", 0.5), schedule_exp_decay_rate=ps.get("rate", 10.0))
+
+
+def test_get_lp_strength_bit_exact_vs_reference(golden_dir, capsys):
+    with open(os.path.join(golden_dir, "schedule_tables.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        for i, hx in enumerate(c["strength_hex"]):
+            assert float(lp_utils.get_lp_strength(**_args(c["params"], i, c["total_steps"]))).hex() == hx
+    capsys.readouterr()
+    lp_utils.get_lp_strength(**_args(dict(kind="bogus"), 0, 5))
+    assert "Unknown lp_strength_schedule_type" in capsys.readouterr().out
+    lp_utils.get_lp_strength(**_args(dict(kind="exponential", rate=-1.0), 1, 5))
+    assert "Negative exponential_decay_rate" in capsys.readouterr().out
+
+
+def test_apply_low_pass_filter_host_contract():
+    x = torch.zeros(1, 2, 3, 4, 5)
+    assert lp_utils.apply_low_pass_filter(x, "none", 1.0, 3, 0.5) is x
+    assert lp_utils.apply_low_pass_filter(x, "down_up", 1.0, 3, 1.0) is x
+    assert lp_utils.apply_low_pass_filter(x, "gaussian_blur", 0, 3, 0.5) is x
+    assert lp_utils.apply_low_pass_filter(x, "median", 1.0, 3, 0.5) is x  # unknown filter: untouched, like the reference
+    with pytest.raises(RuntimeError):  # non-contiguous 5-D input: same failure as the reference's .view (lp:35)
+        lp_utils.apply_low_pass_filter(torch.zeros(1, 3, 2, 4, 5).permute(0, 2, 1, 3, 4), "down_up", 0.0, 0, 0.5)
+    with pytest.raises(ValueError):
+        lp_utils.apply_low_pass_filter(torch.zeros(1, 3, 8, 8), "gaussian_blur", -1.0, 3, 0.5)
+    with pytest.raises(RuntimeError):  # reflect pad larger than the plane (quirk a-Q3: 15*1.0 is a float -> 15*H)
+        lp_utils.apply_low_pass_filter(torch.zeros(1, 3, 60, 90), "gaussian_blur", 2.0, 15 * 1.0, 0.5)
+    # no CPU fallback: a CPU tensor that needs real filtering fails loudly
+    with pytest.raises(alg_amd.AlgHipError):
+        lp_utils.apply_low_pass_filter(torch.zeros(1, 3, 8, 8), "down_up", 0.0, 0, 0.5)
+
+
+def test_hunyuan_buckets_vs_reference(golden_dir):
+    with open(os.path.join(golden_dir, "lp_misc.json")) as f:
+        misc = json.load(f)
+
+    class Img:
+        def __init__(self, wh):
+            self.size = tuple(wh)
+
+    for b in misc["hunyuan_buckets"]:
+        assert lp_utils.get_hunyuan_video_size(b["resolution"], Img(b["image_wh"])) == (b["height"], b["width"])
+    assert [list(p) for p in lp_utils._generate_crop_size_list(480, 32)] == misc["crop_size_list_480_32"]
+    with pytest.raises(NameError):
+        lp_utils.get_hunyuan_video_size("1080p", Img((832, 480)))
+
+
+def test_scheduler_tables_vs_oracle():
+    for steps in (1, 2, 7, 50):
+        s, o = CogVideoXDDIMScheduler(), ddim_oracle.DDIMOracle()
+        s.set_timesteps(steps)
+        o.set_timesteps(steps)
+        assert torch.equal(s.timesteps, o.timesteps)
+        for t in s.timesteps:
+            a = s.step_coefficients(t)
+            b = tuple(float(v) for v in o.coefficients(t))
+            assert a == b
+    s = CogVideoXDDIMScheduler()
+    s.set_timesteps(50)
+    ts = s.timesteps.tolist()
+    assert ts[0] == 999 and ts[1] == 979 and ts[-1] == 19 and len(ts) == 50  # 'trailing' spacing
+    assert s.alphas_cumprod[-1].item() == 0.0  # zero terminal SNR
+    assert s.init_noise_sigma == 1.0 and s.order == 1
+    with pytest.raises(ValueError):
+        CogVideoXDDIMScheduler().step_coefficients(10)
+
+
+def test_rotary_tables_vs_oracle():
+    cfg = dit_oracle.DiTConfig()
+    cos, sin = dit_oracle.rope_tables(cfg, 480, 720, 13)
+    crops = get_resize_crop_region_for_grid((30, 45), 45, 30)
+    assert crops == ((0, 0), (30, 45))
+    c2, s2 = rotary_tables(64, crops, (30, 45), 13)
+    assert cos.shape == (17550, 64) and torch.equal(cos, c2) and torch.equal(sin, s2)
+    assert torch.equal(cos[:, 0::2], cos[:, 1::2])  # repeat-interleaved pairs
+    small = dit_oracle.DiTConfig(sample_height=32, sample_width=32, sample_frames=9)
+    c3, _ = dit_oracle.rope_tables(small, 256, 256, 3)
+    assert c3.shape == (3 * 16 * 16, 64)
+
+
+def test_param_count_and_shapes():
+    cfg = CogVideoXTransformerConfig()
+    n = W.count_parameters(cfg)
+    assert abs(n - 5.55e9) / 5.55e9 < 0.02, n  # "5B" sanity (SURVEY a-6)
+    assert n == dit_oracle.count_params(dit_oracle.DiTConfig())
+    assert W.parameter_shapes(cfg) == dit_oracle.param_shapes(dit_oracle.DiTConfig())
+    tokens = 13 * 30 * 45 + 226
+    assert tokens == 17776
+    assert abs(dit_oracle.flops_per_forward(dit_oracle.DiTConfig(), tokens) - 3.322e14) / 3.322e14 < 0.01
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "alg_hip.h")).read()
+    declared = set(re.findall(r"\b(alg_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(alg_amd._lib.EXPORTS), declared ^ set(alg_amd._lib.EXPORTS)
+    lib = alg_amd.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.alg_version() == 100
+    assert ctypes.sizeof(alg_amd._lib.GemmArgs) == 6 * 8 + 9 * 8 + 7 * 4 + 4  # matches struct alg_gemm_args (+pad)
+
+
+def test_c_abi_argument_errors_without_gpu():
+    """Argument validation happens before any launch, so it is testable on CPU."""
+    lib = alg_amd.load_library()
+    rc = lib.alg_down_up(None, None, 1, 4, 4, 2, 2, 0, 0, None)
+    assert rc == -1 and b"alg_down_up" in lib.alg_last_error()
+    buf = (ctypes.c_float * 16)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.alg_gaussian_blur(p, ctypes.c_void_p(p.value + 4), 1, 4, 4, 4, 1.0, 0, None) == -1  # even kernel
+    assert b"odd" in lib.alg_last_error()
+    assert lib.alg_gaussian_blur(p, ctypes.c_void_p(p.value + 4), 1, 4, 4, 9, 1.0, 0, None) == -1  # pad >= plane
+    assert lib.alg_gaussian_blur(p, ctypes.c_void_p(p.value + 4), 1, 4, 4, 3, 0.0, 0, None) == -1  # sigma
+    assert lib.alg_cfg_ddim_step(p, 0, p, 0, 4, 16, 1.0, 1.0, 1.0, 1.0, 1.0, None) == -1
+    assert lib.alg_down_up(p, p, 1, 4, 4, 2, 2, 0, 0, None) == -1  # aliasing
+    assert lib.alg_down_up(p, ctypes.c_void_p(p.value + 4), 0, 4, 4, 2, 2, 0, 0, None) == 0  # empty input is fine
+
+
+class _FakeTransformer:
+    dtype = torch.bfloat16
+    config = CogVideoXTransformerConfig()
+
+
+def test_check_inputs_errors():
+    pipe = CogVideoXImageToVideoPipeline(transformer=_FakeTransformer(), scheduler=CogVideoXDDIMScheduler())
+    ok = dict(image=torch.zeros(1, 3, 8, 8), prompt="a", height=480, width=720, negative_prompt=None,
+              callback_on_step_end_tensor_inputs=["latents"])
+    pipe.check_inputs(**ok)
+    for bad, msg in ((dict(image=3), "`image` has to be of type"), (dict(height=481), "divisible by 8"),
+                     (dict(callback_on_step_end_tensor_inputs=["x"]), "callback_on_step_end_tensor_inputs"),
+                     (dict(prompt=None), "Provide either `prompt`"), (dict(prompt=7), "`prompt` has to be of type"),
+                     (dict(prompt_embeds=torch.zeros(1, 2, 3)), "Cannot forward both `prompt`")):
+        with pytest.raises(ValueError, match=re.escape(msg)):
+            pipe.check_inputs(**{**ok, **bad})
+    with pytest.raises(ValueError, match="must have the same shape"):
+        pipe.check_inputs(**{**ok, "prompt": None, "prompt_embeds": torch.zeros(1, 2, 3),
+                             "negative_prompt_embeds": torch.zeros(1, 3, 3)})
+    # HIP-only: running the sampler on a CPU device fails loudly instead of falling back
+    pipe.to("cpu")
+    with pytest.raises(alg_amd.AlgHipError):
+        pipe(image=None, image_latents=torch.zeros(1, 1, 16, 60, 90), prompt_embeds=torch.zeros(1, 226, 4096),
+             negative_prompt_embeds=torch.zeros(1, 226, 4096), output_type="latent")
+
+
+def test_loop_branch_table_oracle():
+    """The reference loop's 2-/3-pass structure (102 forwards at C2, 5 at C1) from the oracle loop
+    with a stand-in transformer."""
+    def run(steps, **kw):
+        calls = []
+
+        def tf(x, emb, ts, rope):
+            calls.append((x.shape[0], emb.shape[0]))
+            return torch.zeros(x.shape[0], x.shape[1], x.shape[2] // 2, *x.shape[3:])
+
+        trace = []
+        lat = torch.zeros(1, 3, 4, 8, 8)
+        cond = torch.randn(1, 3, 4, 8, 8)
+        pe, ne = torch.zeros(1, 5, 16), torch.zeros(1, 5, 16)
+        loop_oracle.alg_denoise_loop(tf, ddim_oracle.DDIMOracle(), lat, cond, pe, ne, steps, trace=trace, **kw)
+        return trace, calls
+
+    trace, calls = run(50, lp_strength_schedule_type="interval", schedule_interval_end_time=0.04)
+    assert sum(n for _, _, n in trace) == 102 and [tp for _, tp, _ in trace[:3]] == [False, False, True]
+    assert all(a == b for a, b in calls)
+    trace, _ = run(2, lp_strength_schedule_type="interval", schedule_interval_end_time=0.04)
+    assert [n for _, _, n in trace] == [3, 2]
+    trace, _ = run(40, lp_filter_type="gaussian_blur", lp_blur_kernel_size=3, lp_strength_schedule_type="linear")
+    assert sum(n for _, _, n in trace) == 100
+    trace, _ = run(50, lp_strength_schedule_type="exponential")
+    assert sum(1 for _, tp, _ in trace if not tp) == 12
+    trace, _ = run(10, use_low_pass_guidance=False)
+    assert all(n == 2 for _, _, n in trace)
