@@ -10,10 +10,18 @@
 //                   no LDS round trip for P.  The contraction index order of B is whatever the C layout hands
 //                   out (kv = 16g + 8(j>>2) + 4h + (j&3)); V^T is stored by its producer GEMM with index bits
 //                   2 and 3 swapped so one ds_read_b128 yields the matching A fragment.
-// Workgroup = 8 waves x 32 queries = 256 queries of one (batch, head); KV tiles of 64 stream through a
-// double-buffered 32 KiB LDS ring with 16-byte global_load_lds; the bank swizzle sits on the source address
-// (same scheme as gemm.hip).  Workgroups are ordered so that one XCD works on one head at a time (K/V of a
-// head = 4.5 MB, re-read by the 70 query blocks of that head out of the XCD's L2).
+// Workgroup = 8 waves x 32 queries = 256 queries of one (batch, head); KV tiles of 64 stream through an LDS
+// ring with 16-byte global_load_lds; the bank swizzle sits on the source address (same scheme as gemm.hip).
+// Workgroups are ordered so that one XCD works on one head at a time (K/V of a head = 4.5 MB, re-read by the
+// 70 query blocks of that head out of the XCD's L2).
+//
+// Variants (template parameter, selected per call; ALG_ATTN_VARIANT env overrides for A/B runs):
+//   0  straight loop: QK^T -> softmax -> PV per tile
+//   1  + the O / l rescale is skipped (exactly: alpha == 1) when no lane's running max grew
+//   2  + software pipelined: QK^T of tile t+1 is issued before the softmax of tile t, so the MFMA pipe works
+//        under the VALU-heavy softmax; K runs one tile ahead of V through a 3-slot ring
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace alg {
@@ -22,7 +30,6 @@ constexpr int ATT_THREADS = 512;
 constexpr int QB = 256;   // queries per workgroup
 constexpr int KVB = 64;   // kv rows per tile
 constexpr int ATT_TILE = KVB * 64 * 2;     // 8 KiB (K tile; V^T tile is the same size)
-constexpr int ATT_LDS = 4 * ATT_TILE;      // 2 stages x (K + V^T)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -37,8 +44,91 @@ struct AttnP {
   float scale_log2;  // scale * log2(e)
 };
 
+struct Frag {
+  int row_off;  // l31 * 128
+  int sw;       // (l31 >> 1) & 7
+  int h2;
+};
+
+// S^T sub-tiles of one 64-row K tile: s[sub] = K[sub] Q^T
+__device__ __forceinline__ void qk_tile(const char* Ks, const bf16x8 (&qf)[4], const Frag f, f32x16 (&s)[2]) {
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[sub][e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 kf = *(const bf16x8*)(Ks + f.row_off + sub * 4096 + (((2 * ks + f.h2) ^ f.sw) * 16));
+      s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sub], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void mask_tail(f32x16 (&s)[2], int kv0, int S, int h2) {
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int kv = kv0 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2;
+      if (kv >= S) s[sub][e] = -INFINITY;
+    }
+}
+
+// online softmax of one tile's scores -> bf16 P fragments; updates m, l and rescales O when needed
+template <bool SKIP>
+__device__ __forceinline__ void softmax_tile(const f32x16 (&s)[2], float c, float& m_run, float& l_run,
+                                             f32x16 (&o_acc)[2], bf16x8 (&pf)[4]) {
+  float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+  for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
+  mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+  const bool grow = mt > m_run;
+  if (!SKIP || __any(grow)) {
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    m_run = m_new;
+    l_run *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+  }
+  const float mc = m_run * c;
+  float psum = 0.0f;
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p0 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j] * c - mc);
+        const float p1 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j + 1] * c - mc);
+        psum += p0 + p1;  // the row sum uses the unrounded fp32 probabilities (as the math SDPA path does)
+        pk.u[j] = pack_bf2(p0, p1);
+      }
+      pf[sub * 2 + g] = pk.v;
+    }
+  l_run += psum;
+}
+
+// O^T += V^T P^T for one 64-row tile
+__device__ __forceinline__ void pv_tile(const char* Vs, const bf16x8 (&pf)[4], const Frag f, f32x16 (&o_acc)[2]) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {  // kk = sub*2 + g : kv block [16 kk, 16 kk + 16)
+      const bf16x8 vf = *(const bf16x8*)(Vs + f.row_off + dt * 4096 + (((2 * kk + f.h2) ^ f.sw) * 16));
+      o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kk], o_acc[dt], 0, 0, 0);
+    }
+}
+
+template <int VARIANT>
 __global__ __launch_bounds__(ATT_THREADS) void flash_attn_d64_kernel(const AttnP p) {
-  __shared__ __attribute__((aligned(16))) char smem[ATT_LDS];
+  constexpr int K_SLOTS = VARIANT >= 2 ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) char smem[(K_SLOTS + 2) * ATT_TILE];
+  char* const k_ring = smem;
+  char* const v_ring = smem + K_SLOTS * ATT_TILE;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -50,11 +140,10 @@ __global__ __launch_bounds__(ATT_THREADS) void flash_attn_d64_kernel(const AttnP
   {
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int per = (nbh + 7) >> 3;               // (batch*head) slots per XCD
     const int slot = idx / p.q_blocks;
     qb = idx - slot * p.q_blocks;
     bh = slot * 8 + xcd;
-    if (slot >= per || bh >= nbh) return;
+    if (bh >= nbh) return;
   }
   const int b = bh / p.heads, h = bh - b * p.heads;
   const int S = p.S;
@@ -75,15 +164,19 @@ __global__ __launch_bounds__(ATT_THREADS) void flash_attn_d64_kernel(const AttnP
   const int srow = tid >> 3;                        // K: kv row, V^T: d row   (0..63)
   const int sslot = (tid & 7) ^ ((tid >> 4) & 7);
   const bf16_t* vt_src = VT + (int64_t)srow * p.vt_rs + sslot * 8;
-  auto stage = [&](int buf, int kv0) {
-    char* base = smem + buf * 2 * ATT_TILE;
+  auto stage_k = [&](int slot, int kv0) {
     const bf16_t* ks = K + (int64_t)min(kv0 + srow, S - 1) * p.q_rs + sslot * 8;
-    __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(base + wave * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(vt_src + kv0), (lptr_t)(base + ATT_TILE + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + slot * ATT_TILE + wave * 1024), 16, 0, 0);
+  };
+  auto stage_v = [&](int slot, int kv0) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(vt_src + kv0), (lptr_t)(v_ring + slot * ATT_TILE + wave * 1024), 16, 0,
+                                     0);
   };
 
-  const int sw = (l31 >> 1) & 7;
-  const int frag_row_off = l31 * 128;   // + sub*32*128 (K) / dt*32*128 (V^T)
+  Frag f;
+  f.row_off = l31 * 128;
+  f.sw = (l31 >> 1) & 7;
+  f.h2 = h2;
 
   f32x16 o_acc[2];
 #pragma unroll
@@ -93,80 +186,57 @@ __global__ __launch_bounds__(ATT_THREADS) void flash_attn_d64_kernel(const AttnP
   float m_run = -INFINITY;   // running max of raw scores (this lane's query)
   float l_run = 0.0f;        // this half-wave's share of the running sum
   const float c = p.scale_log2;
-
   const int n_tiles = (S + KVB - 1) / KVB;
-  stage(0, 0);
-  for (int t = 0; t < n_tiles; ++t) {
+  const bool ragged = (S & (KVB - 1)) != 0;
+
+  if (VARIANT < 2) {
+    stage_k(0, 0);
+    stage_v(0, 0);
+    for (int t = 0; t < n_tiles; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t + 1 < n_tiles) {
+        stage_k((t + 1) & 1, (t + 1) * KVB);
+        stage_v((t + 1) & 1, (t + 1) * KVB);
+      }
+      f32x16 s[2];
+      qk_tile(k_ring + (t & 1) * ATT_TILE, qf, f, s);
+      if (ragged && t == n_tiles - 1) mask_tail(s, t * KVB, S, h2);
+      bf16x8 pf[4];
+      softmax_tile<(VARIANT >= 1)>(s, c, m_run, l_run, o_acc, pf);
+      pv_tile(v_ring + (t & 1) * ATT_TILE, pf, f, o_acc);
+    }
+  } else {
+    // K one tile ahead of V: iteration t computes S(t+1) = K(t+1) Q^T, softmax(S(t)), O += V(t)^T P(t)
+    f32x16 s_a[2], s_b[2];
+    stage_k(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < n_tiles) stage((t + 1) & 1, (t + 1) * KVB);
-    const char* Ks = smem + (t & 1) * 2 * ATT_TILE;
-    const char* Vs = Ks + ATT_TILE;
-
-    // ---- S^T = K Q^T : two 32-kv sub-tiles ----
-    f32x16 s_acc[2];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s_acc[sub][e] = 0.0f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(Ks + frag_row_off + sub * 4096 + (((2 * ks + h2) ^ sw) * 16));
-        s_acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[sub], 0, 0, 0);
+    if (n_tiles > 1) stage_k(1, KVB);
+    stage_v(0, 0);
+    qk_tile(k_ring, qf, f, s_a);
+    if (ragged && n_tiles == 1) mask_tail(s_a, 0, S, h2);
+    int ks_next = 1;  // ring slot of K(t+1)
+    // one pipeline step; called with (s_a, s_b) and (s_b, s_a) alternately so the score registers are never copied
+    auto step = [&](int t, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2]) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // K(t+1) and V(t) landed; every wave is done with K(t-1)'s slot and V(t-1)'s slot
+      const int ks_nn = ks_next == 2 ? 0 : ks_next + 1;
+      if (t + 2 < n_tiles) stage_k(ks_nn, (t + 2) * KVB);
+      if (t + 1 < n_tiles) stage_v((t + 1) & 1, (t + 1) * KVB);
+      if (t + 1 < n_tiles) {
+        qk_tile(k_ring + ks_next * ATT_TILE, qf, f, s_nxt);
+        if (ragged && t + 1 == n_tiles - 1) mask_tail(s_nxt, (t + 1) * KVB, S, h2);
       }
+      bf16x8 pf[4];
+      softmax_tile<true>(s_cur, c, m_run, l_run, o_acc, pf);
+      pv_tile(v_ring + (t & 1) * ATT_TILE, pf, f, o_acc);
+      ks_next = ks_nn;
+    };
+    for (int t = 0; t < n_tiles; t += 2) {
+      step(t, s_a, s_b);
+      if (t + 1 < n_tiles) step(t + 1, s_b, s_a);
     }
-    // mask kv >= S (last tile only)
-    if (t == n_tiles - 1 && (S & (KVB - 1))) {
-      const int kv0 = t * KVB;
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int kv = kv0 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2;
-          if (kv >= S) s_acc[sub][e] = -INFINITY;
-        }
-    }
-    // ---- online softmax (per-lane scalars) ----
-    float mt = s_acc[0][0];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mt = fmaxf(mt, s_acc[sub][e]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    m_run = m_new;
-    float psum = 0.0f;
-    bf16x8 pf[4];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        union { bf16x8 v; uint32_t u[4]; } pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float p0 = __builtin_amdgcn_exp2f(s_acc[sub][8 * g + 2 * j] * c - mc);
-          const float p1 = __builtin_amdgcn_exp2f(s_acc[sub][8 * g + 2 * j + 1] * c - mc);
-          // the row sum uses the unrounded fp32 probabilities (as the math SDPA path does)
-          psum += p0 + p1;
-          pk.u[j] = pack_bf2(p0, p1);
-        }
-        pf[sub * 2 + g] = pk.v;
-      }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
-    // ---- O^T += V^T P^T ----
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {   // kk = sub*2 + g : kv block [16 kk, 16 kk + 16)
-        const bf16x8 vf = *(const bf16x8*)(Vs + frag_row_off + dt * 4096 + (((2 * kk + h2) ^ sw) * 16));
-        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kk], o_acc[dt], 0, 0, 0);
-      }
   }
 
   // ---- finish: combine the half-waves' sums, normalise, store O[q][d] ----
@@ -185,6 +255,13 @@ __global__ __launch_bounds__(ATT_THREADS) void flash_attn_d64_kernel(const AttnP
         *(uint2*)(op + d) = v;
       }
   }
+}
+
+// default = the fastest measured variant; ALG_ATTN_VARIANT (read per call) overrides it for A/B runs and tests
+static int attn_variant() {
+  const char* e = getenv("ALG_ATTN_VARIANT");
+  const int v = e ? atoi(e) : 1;
+  return (v < 0 || v > 2) ? 1 : v;
 }
 
 }  // namespace alg
@@ -216,6 +293,12 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
   p.scale_log2 = scale * 1.4426950408889634f;
   const int nbh = batch * heads;
   const int64_t grid = (int64_t)((nbh + 7) / 8) * 8 * p.q_blocks;
-  hipLaunchKernelGGL(flash_attn_d64_kernel, dim3((unsigned)grid), dim3(ATT_THREADS), 0, (hipStream_t)stream, p);
+  const dim3 g((unsigned)grid), blk(ATT_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+  switch (attn_variant()) {
+    case 0: hipLaunchKernelGGL(flash_attn_d64_kernel<0>, g, blk, 0, s, p); break;
+    case 1: hipLaunchKernelGGL(flash_attn_d64_kernel<1>, g, blk, 0, s, p); break;
+    default: hipLaunchKernelGGL(flash_attn_d64_kernel<2>, g, blk, 0, s, p); break;
+  }
   return check_launch("alg_flash_attn_d64");
 }

@@ -20,20 +20,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// gfx950 packed fp32 -> bf16 conversion, round-to-nearest-even: {bf16(hi), bf16(lo)} in one VALU op
+// (there is no clang builtin for it; plain asm so the scheduler may move it freely)
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
+
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, f) & 0xffffu); }
 
 // fp32 value rounded through bf16 (the reference's bf16 tensors round after every op)
-__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
-
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
-}
+__device__ __forceinline__ float rbf(float f) { return __uint_as_float(pack_bf2(f, f) << 16); }
 
 template <typename T>
 __device__ __forceinline__ float load_as_float(const T* p, int64_t i);

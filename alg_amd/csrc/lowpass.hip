@@ -242,6 +242,7 @@ using namespace alg;
 
 extern "C" int alg_down_up(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype,
                            int round_intermediate, void* stream) {
+  if (planes == 0 && H > 0 && W > 0) return ALG_OK;  // empty batch: nothing to do (pointers may be null)
   if (!in || !out || planes < 0 || H <= 0 || W <= 0 || h1 <= 0 || w1 <= 0) {
     set_error("alg_down_up: bad argument (planes=%lld H=%d W=%d h1=%d w1=%d)", (long long)planes, H, W, h1, w1);
     return ALG_EINVAL;
@@ -280,6 +281,7 @@ extern "C" int alg_down_up(const void* in, void* out, int64_t planes, int H, int
 
 extern "C" int alg_gaussian_blur(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma,
                                  int dtype, void* stream) {
+  if (planes == 0 && H > 0 && W > 0) return ALG_OK;
   if (!in || !out || planes < 0 || H <= 0 || W <= 0) {
     set_error("alg_gaussian_blur: bad argument (planes=%lld H=%d W=%d)", (long long)planes, H, W);
     return ALG_EINVAL;

@@ -1,0 +1,54 @@
+#!/bin/bash
+# One GPU-box session: GPU tests, smoke, benches, rocprof.  Everything lands in gpurun_out/.
+# usage: bash scripts/gpu_session.sh [tests] [smoke] [quick] [bench] [prof]
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+export TMPDIR=/tmp
+WHAT=${@:-tests smoke quick bench prof}
+for w in $WHAT; do
+  case $w in
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider 2>&1 | tail -300 > $O/pytest_gpu.log
+      echo "pytest exit ${PIPESTATUS[0]}" >> $O/pytest_gpu.log
+      tail -25 $O/pytest_gpu.log ;;
+    smoke)
+      timeout 600 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log; tail -3 $O/smoke.log ;;
+    quick)
+      timeout 900 python bench.py --layers 4 --steps 6 --warmup 1 --no-cpu-baseline > $O/bench_quick.json 2> $O/bench_quick.err
+      echo "quick exit $?"; tail -c 3000 $O/bench_quick.json; tail -5 $O/bench_quick.err ;;
+    bench)
+      timeout 1800 python bench.py > $O/bench_full.json 2> $O/bench_full.err
+      echo "bench exit $?"; tail -c 4000 $O/bench_full.json; tail -5 $O/bench_full.err ;;
+    kbench)
+      for v in 0 1 2; do
+        echo "== ALG_ATTN_VARIANT=$v" | tee -a $O/kbench.log
+        ALG_ATTN_VARIANT=$v timeout 600 python scripts/kbench.py --only attn --check 2>&1 | tee -a $O/kbench.log
+      done
+      timeout 600 python scripts/kbench.py 2>&1 | tee -a $O/kbench.log ;;
+    pmc)
+      cd /tmp
+      mkdir -p $O/pmc; rocprofv3 -L > $O/pmc_list.txt 2>&1
+      for k in attn gemm_qk gemm_ff2; do
+        i=0
+        for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+                    "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" \
+                    "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+          i=$((i+1))
+          timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $O/pmc/${k}_p$i -o p -- python $R/scripts/kbench.py --only $k --iters 2 > /dev/null 2> $O/pmc/${k}_p$i.err
+        done
+      done
+      cd $R
+      python scripts/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1; cat $O/pmc_summary.txt | tail -40
+      find $O/pmc -name "*.csv" -size +4M -delete ;;
+    prof)
+      cd /tmp
+      timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r1 -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err
+      echo "prof exit $?"
+      cd $R
+      find $O/prof -name "*stats*" | head; ls -la $O/prof | head
+      # keep only the small summaries (the per-dispatch trace is large)
+      find $O/prof -name "*kernel_trace*" -size +8M -delete ;;
+  esac
+done

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Kernel-level micro-benchmark at the C2 shapes (CogVideoX-5B, N samples x 17,776 tokens x 3072).
+Used for rocprofv3 kernel-trace / PMC passes and for A/B-ing kernel variants (env ALG_*_VARIANT).
+
+    python scripts/kbench.py [--only attn,gemm_qk,...] [--iters 5] [--n 2] [--check]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from alg_amd import _lib  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def timeit(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ms = sorted(x.elapsed_time(y) for x, y in evs)
+    return ms[len(ms) // 2], ms[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--n", type=int, default=2)
+    ap.add_argument("--S", type=int, default=17776)
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    dev = torch.device("cuda:0")
+    N, S, D, H, T = args.n, args.S, 3072, 48, 226
+    S_pad = (S + 63) // 64 * 64
+    g = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g, device=dev) * sc).to(BF)
+    y = rn(N, S, D)
+    x = rn(N, S, D)
+    qk = rn(N, S, 2 * D)
+    vt = torch.zeros(N, D, S_pad, dtype=BF, device=dev)
+    vt[:, :, :S] = rn(N, D, S)
+    att = torch.empty(N, S, D, dtype=BF, device=dev)
+    h = rn(N, S, 4 * D)
+    wqk, bqk = rn(2 * D, D, sc=0.02), rn(2 * D, sc=0.02)
+    wv, bv = rn(D, D, sc=0.02), rn(D, sc=0.02)
+    wo, bo = rn(D, D, sc=0.02), rn(D, sc=0.02)
+    wf1, bf1 = rn(4 * D, D, sc=0.02), rn(4 * D, sc=0.02)
+    wf2, bf2 = rn(D, 4 * D, sc=0.02), rn(D, sc=0.02)
+    mod = rn(N, 12 * D, sc=0.1)
+    lnw, lnb = rn(D), rn(D, sc=0.1)
+    nq = [rn(64) for _ in range(4)]
+    cos = torch.rand(S - T, 64, device=dev)
+    sin = torch.rand(S - T, 64, device=dev)
+    G = _lib.gemm
+    F4 = 4 * D
+    cases = {
+        "gemm_qk": (lambda: G(y, wqk, qk, S, 2 * D, D, D, D, 2 * D, bias=bqk, batch=N, strideA=S * D, strideC=S * 2 * D),
+                    2.0 * N * S * D * 2 * D, "flop"),
+        "gemm_vt": (lambda: G(wv, y, vt, D, S, D, D, D, S_pad, bias=bv, batch=N, strideB=S * D, strideC=D * S_pad,
+                              flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS), 2.0 * N * S * D * D, "flop"),
+        "gemm_out": (lambda: G(att, wo, x, S, D, D, D, D, D, bias=bo, R=x, ldr=D, gate=mod, gate_off=4 * D,
+                               strideGate=12 * D, seg_split=T, batch=N, strideA=S * D, strideC=S * D, strideR=S * D),
+                     2.0 * N * S * D * D, "flop"),
+        "gemm_ff1": (lambda: G(y, wf1, h, S, F4, D, D, D, F4, bias=bf1, act=_lib.ACT_GELU_TANH, batch=N, strideA=S * D,
+                               strideC=S * F4), 2.0 * N * S * D * F4, "flop"),
+        "gemm_ff2": (lambda: G(h, wf2, x, S, D, F4, F4, F4, D, bias=bf2, R=x, ldr=D, gate=mod, gate_off=10 * D,
+                               strideGate=12 * D, seg_split=T, batch=N, strideA=S * F4, strideC=S * D, strideR=S * D),
+                     2.0 * N * S * D * F4, "flop"),
+        "attn": (lambda: _lib.flash_attn_d64(qk, qk, vt, att, N, H, S, S * 2 * D, 2 * D, D * S_pad, S_pad, S * D, D,
+                                             0.125, k_off=D), 4.0 * N * H * S * S * 64, "flop"),
+        "ln_mod": (lambda: _lib.layernorm_modulate(x, y, lnw, lnb, mod, mod, 12 * D, N, S, D, T, 1e-5, scale_off=2 * D,
+                                                   shift_off=0), 2.0 * N * S * D * 2, "byte"),
+        "qk_norm_rope": (lambda: _lib.qk_norm_rope_(qk, nq[0], nq[1], nq[2], nq[3], cos, sin, N, S, H, T, 1e-6),
+                         2.0 * N * S * 2 * D * 2, "byte"),
+    }
+    res = {}
+    for name, (fn, work, kind) in cases.items():
+        if only and name not in only:
+            continue
+        if name == "attn":
+            att.zero_()
+        med, best = timeit(fn, args.iters)
+        rate = work / (med / 1e3) / (1e12 if kind == "flop" else 1e9)
+        res[name] = dict(ms=round(med, 4), best_ms=round(best, 4), rate=round(rate, 1),
+                         unit="TFLOP/s" if kind == "flop" else "GB/s")
+        print("%-14s %9.3f ms (best %9.3f)  %8.1f %s" % (name, med, best, rate, res[name]["unit"]), flush=True)
+    if args.check and (not only or "attn" in only):
+        # spot-check attention rows of one head against fp32 SDPA on the GPU (torch as checker)
+        b, hh = N - 1, 5
+        q = qk[b, :, hh * 64:(hh + 1) * 64].float()
+        k = qk[b, :, D + hh * 64:D + (hh + 1) * 64].float()
+        perm = torch.tensor([(n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1) for n in range(S)], device=dev)
+        v = vt[b, hh * 64:(hh + 1) * 64][:, perm].t().float()   # logical kv s sits at position perm(s)
+        rows = torch.tensor([0, 1, 31, 32, 255, 256, 4097, S - 1], device=dev)
+        p = torch.softmax(q[rows] @ k.t() * 0.125, dim=-1)
+        ref = p @ v
+        got = att[b, rows, hh * 64:(hh + 1) * 64].float()
+        err = (got - ref).abs().max().item()
+        res["attn_check_maxerr"] = err
+        print("attn spot-check max err %.3e" % err)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

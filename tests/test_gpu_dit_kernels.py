@@ -123,8 +123,10 @@ def sdpa_ref(q, k, v, scale):
     return (p @ vv).transpose(1, 2)
 
 
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
 @pytest.mark.parametrize("Bn,S,H", [(1, 64, 1), (1, 100, 3), (2, 273, 9), (1, 1000, 8), (3, 994, 2), (1, 17, 1)])
-def test_flash_attention_vs_sdpa(device, Bn, S, H):
+def test_flash_attention_vs_sdpa(device, monkeypatch, Bn, S, H, variant):
+    monkeypatch.setenv("ALG_ATTN_VARIANT", variant)  # every kernel variant must pass, not just the default
     g = torch.Generator().manual_seed(S + H)
     q, k, v = rnd((Bn, S, H, 64), g), rnd((Bn, S, H, 64), g), rnd((Bn, S, H, 64), g)
     got = run_attention(device, q, k, v, 0.125).double()
@@ -133,9 +135,11 @@ def test_flash_attention_vs_sdpa(device, Bn, S, H):
     assert rel_err(got, ref) < 1e-2
 
 
-def test_flash_attention_forced_rescale_and_asymmetry(device):
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
+def test_flash_attention_forced_rescale_and_asymmetry(device, monkeypatch, variant):
     """A key that dominates late in the sequence forces the online-softmax rescale; V = one-hot rows make any
     kv-order / transpose mistake in the P@V operand layout visible."""
+    monkeypatch.setenv("ALG_ATTN_VARIANT", variant)
     g = torch.Generator().manual_seed(2)
     S = 320
     q, k = rnd((1, S, 1, 64), g), rnd((1, S, 1, 64), g)

@@ -1,5 +1,11 @@
 """GPU parity of the fused CFG-combine + DDIM-step kernel against the reference's expression sequence
-(cog:1091-1123) evaluated by torch on CPU (oracle) -- same rounding points, so bit-exact is expected."""
+(cog:1091-1123), evaluated by torch through the oracle scheduler in two ways:
+
+  * on DEVICE tensors -- exactly what the reference executes on a GPU: the scheduler's 0-dim float64 scalars are CPU
+    tensors, and a GPU elementwise op reads such a scalar as fp32 (opmath) without rounding it to the tensor dtype.
+    The kernel reproduces these rounding points -> bit-exact expected;
+  * on CPU tensors -- torch's CPU TensorIterator first casts the 0-dim scalar to the common dtype (bf16!), so the CPU
+    result differs from the GPU one by up to ~1 bf16 ulp.  Checked within the stated bf16 tolerance (2 ulps)."""
 import numpy as np
 import pytest
 import torch
@@ -35,17 +41,28 @@ def test_cfg_ddim_step(device, n_pass, pred_dtype, lat_dtype, shape):
     sched.set_timesteps(50)
     orc.set_timesteps(50)
     for t in (sched.timesteps[0], sched.timesteps[17], sched.timesteps[-1]):
-        ref = reference_step(pred, lat, n_pass, 6.0, orc, t)
+        ref_cpu = reference_step(pred, lat, n_pass, 6.0, orc, t)
+        ref_dev = reference_step(pred.to(device), lat.to(device), n_pass, 6.0, orc, t).cpu()
         out = lat.clone().to(device)
         sched.fused_cfg_step_(pred.to(device), out, n_pass, 6.0, t)
         got = out.cpu()
         assert got.dtype == lat_dtype
         if lat_dtype == torch.float32:
-            assert (got - ref).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item())
+            assert (got - ref_cpu).abs().max() <= 2e-6 * max(1.0, ref_cpu.abs().max().item())
+            assert (got - ref_dev).abs().max() <= 2e-6 * max(1.0, ref_dev.abs().max().item())
         else:
-            mism = (got != ref).float().mean().item()
-            ulp = (got.float() - ref.float()).abs() / ref.float().abs().clamp_min(1e-30)
-            assert mism <= 1e-3 and ulp.max() <= 2.0 ** -6, (mism, ulp.max().item())
+            assert torch.equal(got, ref_dev), (got != ref_dev).float().mean().item()  # the reference's GPU semantics
+            # CPU semantics: each bf16-rounded scalar moves its term by <= 2^-8 relative -> bound on the terms' sizes
+            err = (got.float() - ref_cpu.float()).abs()
+            sa, sb, ca, cb = (float(c) for c in orc.coefficients(t))
+            v = pred.float()
+            if n_pass == 3:
+                v = v[0:1] + 6.0 * (v[2:3] - v[1:2])
+            elif n_pass == 2:
+                v = v[0:1] + 6.0 * (v[1:2] - v[0:1])
+            x = lat.float()
+            terms = (ca * x).abs() + abs(cb) * ((sa * x).abs() + (sb * v).abs()) + ref_cpu.float().abs()
+            assert (err <= 2.0 ** -7 * terms + 1e-6).all()
 
 
 def test_generic_step_api(device):
@@ -57,9 +74,8 @@ def test_generic_step_api(device):
     x = torch.randn(1, 2, 4, 8, 8, generator=g).to(torch.bfloat16)
     t = sched.timesteps[3]
     out = sched.step(v.to(device), t, x.to(device), return_dict=False)[0]
-    ref = orc.step(v, t, x).to(torch.bfloat16)
-    assert out.data_ptr() != x.data_ptr()
-    assert (out.cpu() != ref).float().mean() <= 1e-3
+    ref = orc.step(v.to(device), t, x.to(device)).to(torch.bfloat16).cpu()
+    assert torch.equal(out.cpu(), ref)
     # last step: x_prev is the predicted x0 (alpha_prev = 1)
     t_last = sched.timesteps[-1]
     sa, sb, ca, cb = sched.step_coefficients(t_last)
