@@ -20,12 +20,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// gfx950 packed fp32 -> bf16 conversion, round-to-nearest-even: {bf16(hi), bf16(lo)} in one VALU op
-// (there is no clang builtin for it; plain asm so the scheduler may move it freely)
+// gfx950 packed fp32 -> bf16 conversion, round-to-nearest-even: {bf16(hi), bf16(lo)} in one VALU op.
+// Written as a vector fptrunc so hipcc selects v_cvt_pk_bf16_f32 itself AND pads the VALU->MFMA operand hazard;
+// the same instruction in inline asm fed an MFMA B operand without wait states and gave wrong P@V products.
+typedef __bf16 bf16x2_native __attribute__((ext_vector_type(2)));
+typedef float f32x2_native __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  const f32x2_native v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_native));
 }
 
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, f) & 0xffffu); }

@@ -1,26 +1,29 @@
 // bf16 GEMM for the DiT linears on gfx950 MFMA:  C = R + gate * act(A @ B^T + bias).
 //
 // Shape of the design (MI355X-first, 64-wide waves):
-//   * 256x256 output tile per workgroup, BK = 64, 8 waves as 2(M) x 4(N); each wave owns 128x64 =
-//     4x2 tiles of v_mfma_f32_32x32x16_bf16 (128 fp32 accumulators per lane, 32 MFMAs per K-tile).
-//   * A and B (both K-contiguous: activations [M][K], nn.Linear weights [N][K]) stream HBM -> LDS with
-//     16-byte global_load_lds (no VGPR round trip), double-buffered: 2 x (32 KiB A + 32 KiB B) = 128 KiB.
-//   * LDS-DMA writes lane-linear, so the bank swizzle lives on the per-lane SOURCE address: a tile row is
-//     128 B = eight 16-B slots; slot s of row r is stored at slot s ^ ((r >> 1) & 7), which makes the
-//     ds_read_b128 fragment reads (16 rows per lane group, same logical slot) conflict free.
-//   * one barrier per K-tile: wait vmcnt(0) -> barrier -> issue tile t+1's DMA -> MFMA on tile t.
+//   * 256x256 output tile per workgroup, 8 waves as 2(M) x 4(N); each wave owns 128x64 = 4x2 tiles of
+//     v_mfma_f32_32x32x16_bf16 (128 fp32 accumulators per lane).  The MFMA is issued as (B-fragment, A-fragment),
+//     i.e. it produces C^T tiles: a lane then holds 4 CONSECUTIVE output columns of one row per register quad,
+//     so the epilogue loads bias/gate/residual and stores C with 8-byte accesses (32 stores per lane, not 128).
+//   * A and B (both K-contiguous: activations [M][K], nn.Linear weights [N][K]) stream L2 -> LDS with 16-byte
+//     global_load_lds (no VGPR round trip) through a 128 KiB ring:
+//        PIPE 1 (default): 4 stages of BK = 32; three stages are always in flight behind the one being
+//                multiplied (counted s_waitcnt vmcnt(8), raw s_barrier, never a full drain in the main loop);
+//        PIPE 0: 2 stages of BK = 64, drain + barrier per K-tile (kept for A/B measurements).
+//   * LDS-DMA writes lane-linear, so the bank swizzle lives on the per-lane SOURCE address; the matching XOR is
+//     applied on the ds_read_b128 fragment reads, which are conflict free (measured SQ_LDS_BANK_CONFLICT = 0).
 //   * workgroup ids are remapped so each XCD (private 4 MiB L2) walks a contiguous run of tiles, grouped
 //     8 M-tiles deep so concurrently resident workgroups share A and B panels.
 //   * edge tiles: source rows are clamped (min(row, M-1)), stores are guarded -- no padding contract.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace alg {
 
-constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int BM = 256, BN = 256;
 constexpr int GEMM_THREADS = 512;
-constexpr int TILE_BYTES = BM * BK * 2;          // 32 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;        // double buffered: 128 KiB
+constexpr int GEMM_LDS = 128 * 1024;
 constexpr int GROUP_M = 8;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -38,14 +41,28 @@ __device__ __forceinline__ float act_apply(float x, int act) {
   return x;
 }
 
-__device__ __forceinline__ int swap_bits23(int n) {
-  return (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);
+__device__ __forceinline__ void unpack4(const uint2 v, float (&f)[4]) {
+  f[0] = __uint_as_float(v.x << 16);
+  f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16);
+  f[3] = __uint_as_float(v.y & 0xffff0000u);
 }
 
-// ACT: ALG_ACT_*; RES: residual (+ optional gate) epilogue.  Compile-time so the 128-accumulator epilogue stays
-// fully unrolled with static register indexing.
-template <int ACT, bool RES>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_args p, int m_tiles, int n_tiles) {
+// ACT: ALG_ACT_*; RES: residual (+ optional gate) epilogue; PIPE: staging pipeline (see header).  All compile-time
+// so the 128-accumulator epilogue stays fully unrolled with static register indexing.
+template <int ACT, bool RES, int PIPE>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_args p, int m_tiles, int n_tiles,
+                                                                 int group_m) {
+  constexpr int BK = PIPE ? 32 : 64;
+  constexpr int NSTAGE = PIPE ? 4 : 2;
+  constexpr int ROW_BYTES = BK * 2;                // 64 or 128
+  constexpr int SLOTS = ROW_BYTES / 16;            // 4 or 8 sixteen-byte slots per tile row
+  constexpr int TILE_BYTES = BM * ROW_BYTES;       // one operand tile of one stage
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int LD_PER_OP = TILE_BYTES / (GEMM_THREADS * 16);  // glds instructions per thread per operand: 2 or 4
+  constexpr int ROWS_PER_LD = GEMM_THREADS / SLOTS;            // tile rows covered by one glds round: 128 or 64
+  static_assert(NSTAGE * STAGE_BYTES == GEMM_LDS, "ring must fill the 128 KiB LDS budget");
+
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -62,31 +79,34 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
   const int tiles = m_tiles * n_tiles;
   const int b = wg / tiles;
   int t = wg - b * tiles;
-  const int grp = t / (GROUP_M * n_tiles);
-  const int first_m = grp * GROUP_M;
-  const int gsize = min(m_tiles - first_m, GROUP_M);
-  t -= grp * GROUP_M * n_tiles;
+  const int grp = t / (group_m * n_tiles);
+  const int first_m = grp * group_m;
+  const int gsize = min(m_tiles - first_m, group_m);
+  t -= grp * group_m * n_tiles;
   const int m0 = (first_m + t % gsize) * BM;
   const int n0 = (t / gsize) * BN;
 
   const bf16_t* A = (const bf16_t*)p.A + (int64_t)b * p.strideA;
   const bf16_t* B = (const bf16_t*)p.B + (int64_t)b * p.strideB;
 
-  // ---- per-thread DMA sources: 4 rows of A and 4 rows of B, one 16-B slot each ----
-  const int srow = tid >> 3;                          // 0..63 (+64 i)
-  const int sslot = (tid & 7) ^ ((tid >> 4) & 7);     // logical slot fetched into physical slot tid&7
-  const bf16_t* a_src[4];
-  const bf16_t* b_src[4];
+  // ---- per-thread DMA sources: LD_PER_OP rows of A and of B, one 16-B slot each ----
+  // tile row r, logical slot s lives at physical slot s ^ swz(r); the thread that fills physical slot (tid % SLOTS)
+  // of row r therefore fetches logical slot (tid % SLOTS) ^ swz(r).  swz(r) only depends on tid (see below).
+  const int srow = tid / SLOTS;
+  const int sw_src = PIPE ? ((tid >> 4) & 3) : ((tid >> 4) & 7);   // PIPE1: (r >> 2) & 3, PIPE0: (r >> 1) & 7
+  const int sslot = (tid & (SLOTS - 1)) ^ sw_src;
+  const bf16_t* a_src[LD_PER_OP];
+  const bf16_t* b_src[LD_PER_OP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = i * 64 + srow;
+  for (int i = 0; i < LD_PER_OP; ++i) {
+    const int r = i * ROWS_PER_LD + srow;
     a_src[i] = A + (int64_t)min(m0 + r, p.M - 1) * p.lda + sslot * 8;
     b_src[i] = B + (int64_t)min(n0 + r, p.N - 1) * p.ldb + sslot * 8;
   }
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < LD_PER_OP; ++i) {
       __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + kt * BK), (lptr_t)(base + (i * 512 + wave * 64) * 16), 16,
                                        0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + kt * BK),
@@ -96,11 +116,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
 
   // ---- fragment read offsets ----
   const int l31 = lane & 31, h2 = lane >> 5;
-  const int sw = (l31 >> 1) & 7;
-  const int a_row_off = (wm * 128 + l31) * 128;   // + mt*32*128
-  const int b_row_off = (wn * 64 + l31) * 128;    // + nt*32*128
+  const int sw = PIPE ? ((l31 >> 2) & 3) : ((l31 >> 1) & 7);
+  const int a_row_off = (wm * 128 + l31) * ROW_BYTES;   // + mt*32*ROW_BYTES
+  const int b_row_off = (wn * 64 + l31) * ROW_BYTES;    // + nt*32*ROW_BYTES
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][2];  // acc[mt][nt] holds the TRANSPOSED 32x32 tile: D[n][m]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -108,72 +128,196 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  const int nk = p.K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* As = smem + (kt & 1) * STAGE_BYTES;
+  // Fragments are double-buffered in registers: the 6 ds_read_b128 of k-step ks+1 are issued BEFORE the 8 MFMAs
+  // of k-step ks (pinned with sched_barrier: hipcc otherwise sinks the reads behind the MFMAs to save VGPRs and
+  // every k-step then eats a full LDS round trip at s_waitcnt lgkmcnt(0)).
+  auto load_frags = [&](const char* As, const char* Bs, int ks, bf16x8 (&af)[4], bf16x8 (&bfr)[2]) {
+    const int so = ((2 * ks + h2) ^ sw) * 16;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) af[mt] = *(const bf16x8*)(As + a_row_off + mt * 32 * ROW_BYTES + so);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bfr[nt] = *(const bf16x8*)(Bs + b_row_off + nt * 32 * ROW_BYTES + so);
+  };
+  auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[2]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+  };
+  auto compute = [&](int buf) {
+    const char* As = smem + buf * STAGE_BYTES;
     const char* Bs = As + TILE_BYTES;
+    constexpr int KS = BK / 16;
+    bf16x8 af0[4], bf0[2], af1[4], bf1[2];
+    load_frags(As, Bs, 0, af0, bf0);
+    // interleave: one ds_read of the NEXT k-step behind each of the first six MFMAs of the current one (an MFMA
+    // occupies the matrix pipe for 32 cycles but the wave's issue slot for only 4, so the reads go out under it)
+    auto interleave = [&]() {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int so = ((2 * ks + h2) ^ sw) * 16;
-      bf16x8 af[4], bfr[2];
+      for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    };
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) af[mt] = *(const bf16x8*)(As + a_row_off + mt * 4096 + so);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) bfr[nt] = *(const bf16x8*)(Bs + b_row_off + nt * 4096 + so);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+    for (int ks = 0; ks < KS; ks += 2) {
+      load_frags(As, Bs, ks + 1, af1, bf1);
+      mma(af0, bf0);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 2 < KS) {
+        load_frags(As, Bs, ks + 2, af0, bf0);
+        mma(af1, bf1);
+        interleave();
+      } else {
+        mma(af1, bf1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const int nk = p.K / BK;
+  if (PIPE == 0) {
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      compute(kt & 1);
+    }
+  } else {
+    // 4-deep ring: stages kt+1 and kt+2 stay in flight while stage kt is multiplied; stage kt+3 is issued right
+    // after the barrier that proves everybody is done reading its buffer (the one stage kt-1 lived in).
+    constexpr int LDS_PER_STAGE = 2 * LD_PER_OP;  // 4 glds per thread per stage
+    static_assert(PIPE == 0 || LDS_PER_STAGE == 4, "the counted waits below assume 4 DMA instructions per stage");
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 2) stage(2, 2);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 3 < nk) stage((kt + 3) & 3, kt + 3);
+      compute(kt & 3);
     }
   }
 
-  // ---- epilogue: bias, activation, gate, residual, store ----
+  // ---- epilogue: bias, activation, gate, residual, 8-byte stores ----
+  // lane owns row m = m0 + wm*128 + mt*32 + l31 and, per register quad g, columns n = nbase + 8g + 4h2 + (0..3)
   const bf16_t* bias = (const bf16_t*)p.bias;
   const bf16_t* R = RES ? (const bf16_t*)p.R + (int64_t)b * p.strideR : nullptr;
   const bf16_t* gate = (RES && p.gate) ? (const bf16_t*)p.gate + (int64_t)b * p.strideGate : nullptr;
   const bool bias_row = p.flags & ALG_GEMM_BIAS_PER_ROW;
   const bool perm = p.flags & ALG_GEMM_PERMUTE_COLS;
   bf16_t* Cb = (bf16_t*)p.C + (int64_t)b * p.strideC;
-  const int row_base = m0 + wm * 128 + 4 * h2;
+  const int ldc = (int)p.ldc, ldr = (int)p.ldr;
+  const bool n_vec = (p.N & 3) == 0;  // whole quads are either inside or outside N
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int col = n0 + wn * 64 + nt * 32 + l31;
-    const bool col_ok = col < p.N;
-    const int colc = col_ok ? col : p.N - 1;
-    const float bcol = (bias && !bias_row) ? bf2f(bias[colc]) : 0.0f;
-    const int ccol = perm ? swap_bits23(colc) : colc;
-    float g0 = 1.0f, g1 = 1.0f;
-    if (RES && gate) {
-      g0 = bf2f(gate[colc]);
-      g1 = bf2f(gate[p.N + colc]);
-    }
+  for (int mt = 0; mt < 4; ++mt) {
+    const int row = m0 + wm * 128 + mt * 32 + l31;
+    const bool row_ok = row < p.M;
+    const int rowc = row_ok ? row : p.M - 1;
+    const float brow = (bias && bias_row) ? bf2f(bias[rowc]) : 0.0f;
+    const bool seg1 = row >= p.seg_split;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = row_base + mt * 32 + (e & 3) + 8 * (e >> 2);
-        float v = acc[mt][nt][e] + bcol;
-        if (bias_row && bias) v += bf2f(bias[min(row, p.M - 1)]);
-        v = rbf(v);  // nn.Linear returns a bf16 tensor
-        if (ACT != ALG_ACT_NONE) v = rbf(act_apply(v, ACT));
-        if (RES) {
-          v = rbf((row < p.seg_split ? g0 : g1) * v);
-          v = rbf(bf2f(R[(int64_t)min(row, p.M - 1) * p.ldr + colc]) + v);
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + nt * 32 + 8 * g + 4 * h2;
+        if (n_vec) {
+          if (n < p.N) {
+            float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f}, rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias && !bias_row) unpack4(*(const uint2*)(bias + n), bv);
+            if (RES && gate) unpack4(*(const uint2*)(gate + (seg1 ? p.N : 0) + n), gv);
+            if (RES) unpack4(*(const uint2*)(R + rowc * ldr + n), rv);
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float x = rbf(acc[mt][nt][4 * g + i] + bv[i] + brow);  // nn.Linear returns a bf16 tensor
+              if (ACT != ALG_ACT_NONE) x = rbf(act_apply(x, ACT));
+              if (RES) x = rv[i] + rbf(gv[i] * x);
+              v[i] = x;
+            }
+            if (row_ok) {
+              // PERMUTE_COLS swaps index bits 2 and 3: quad (g, h2) lands where (h2, g & 1) says
+              const int nc = perm ? ((n & ~12) | (h2 << 3) | ((g & 1) << 2)) : n;
+              uint2 o;
+              o.x = pack_bf2(v[0], v[1]);
+              o.y = pack_bf2(v[2], v[3]);
+              *(uint2*)(Cb + row * ldc + nc) = o;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int nn = n + i;
+            if (nn < p.N && row_ok) {
+              float x = rbf(acc[mt][nt][4 * g + i] + ((bias && !bias_row) ? bf2f(bias[nn]) : 0.0f) + brow);
+              if (ACT != ALG_ACT_NONE) x = rbf(act_apply(x, ACT));
+              if (RES) {
+                const float gg = gate ? bf2f(gate[(seg1 ? p.N : 0) + nn]) : 1.0f;
+                x = bf2f(R[rowc * ldr + nn]) + rbf(gg * x);
+              }
+              const int nc = perm ? ((nn & ~12) | ((nn & 4) << 1) | ((nn & 8) >> 1)) : nn;
+              Cb[row * ldc + nc] = f2bf(x);
+            }
+          }
         }
-        if (col_ok && row < p.M) Cb[(int64_t)row * p.ldc + ccol] = f2bf(v);
       }
     }
   }
 }
 
+static int gemm_pipe() {
+  const char* e = getenv("ALG_GEMM_PIPE");
+  return e ? (atoi(e) != 0) : 0;
+}
+
+static int gemm_group_m() {
+  const char* e = getenv("ALG_GEMM_GROUP_M");
+  const int v = e ? atoi(e) : GROUP_M;
+  return v < 1 ? GROUP_M : v;
+}
+
 }  // namespace alg
 
 using namespace alg;
+
+template <int PIPE>
+static int launch_gemm(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* fns[4] = {(const void*)gemm_bf16_kernel<ALG_ACT_NONE, true, PIPE>,
+                          (const void*)gemm_bf16_kernel<ALG_ACT_GELU_TANH, false, PIPE>,
+                          (const void*)gemm_bf16_kernel<ALG_ACT_SILU, false, PIPE>,
+                          (const void*)gemm_bf16_kernel<ALG_ACT_NONE, false, PIPE>};
+    for (const void* fn : fns) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+      if (e != hipSuccess) {
+        set_error("alg_gemm_bf16: hipFuncSetAttribute(%d B LDS): %s", GEMM_LDS, hipGetErrorString(e));
+        return ALG_ELAUNCH;
+      }
+    }
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)nwg), block(GEMM_THREADS);
+  const int gm = gemm_group_m();
+  if (a->R) {
+    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, true, PIPE>), grid, block, GEMM_LDS, s, *a, m_tiles, n_tiles, gm);
+  } else if (a->act == ALG_ACT_GELU_TANH) {
+    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_GELU_TANH, false, PIPE>), grid, block, GEMM_LDS, s, *a, m_tiles,
+                       n_tiles, gm);
+  } else if (a->act == ALG_ACT_SILU) {
+    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_SILU, false, PIPE>), grid, block, GEMM_LDS, s, *a, m_tiles, n_tiles, gm);
+  } else {
+    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, false, PIPE>), grid, block, GEMM_LDS, s, *a, m_tiles, n_tiles, gm);
+  }
+  return check_launch("alg_gemm_bf16");
+}
 
 extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->B || !a->C) {
@@ -184,8 +328,8 @@ extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) {
     set_error("alg_gemm_bf16: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
     return ALG_EINVAL;
   }
-  if (a->K % BK != 0) {
-    set_error("alg_gemm_bf16: K=%d must be a multiple of %d", a->K, BK);
+  if (a->K % 64 != 0) {
+    set_error("alg_gemm_bf16: K=%d must be a multiple of 64", a->K);
     return ALG_EINVAL;
   }
   if (a->lda % 8 || a->ldb % 8 || a->strideA % 8 || a->strideB % 8 || ((uintptr_t)a->A & 15) ||
@@ -209,20 +353,20 @@ extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) {
     set_error("alg_gemm_bf16: gate needs a residual");
     return ALG_EINVAL;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    const void* fns[4] = {(const void*)gemm_bf16_kernel<ALG_ACT_NONE, true>,
-                          (const void*)gemm_bf16_kernel<ALG_ACT_GELU_TANH, false>,
-                          (const void*)gemm_bf16_kernel<ALG_ACT_SILU, false>,
-                          (const void*)gemm_bf16_kernel<ALG_ACT_NONE, false>};
-    for (const void* fn : fns) {
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-      if (e != hipSuccess) {
-        set_error("alg_gemm_bf16: hipFuncSetAttribute(%d B LDS): %s", GEMM_LDS, hipGetErrorString(e));
-        return ALG_ELAUNCH;
-      }
+  if ((int64_t)a->M * a->ldc >= (1ll << 31) || (a->R && (int64_t)a->M * a->ldr >= (1ll << 31))) {
+    set_error("alg_gemm_bf16: M*ldc must stay below 2^31 (32-bit epilogue offsets)");
+    return ALG_ELIMIT;
+  }
+  // 8-byte epilogue accesses need 8-byte aligned quads whenever N is a multiple of 4
+  if ((a->N & 3) == 0) {
+    const bool bad = (a->ldc & 3) || (a->strideC & 3) || ((uintptr_t)a->C & 7) ||
+                     (a->bias && !(a->flags & ALG_GEMM_BIAS_PER_ROW) && ((uintptr_t)a->bias & 7)) ||
+                     (a->R && ((a->ldr & 3) || (a->strideR & 3) || ((uintptr_t)a->R & 7))) ||
+                     (a->gate && ((a->strideGate & 3) || ((uintptr_t)a->gate & 7)));
+    if (bad) {
+      set_error("alg_gemm_bf16: C/bias/R/gate must be 8-byte aligned with ldc/ldr/strides multiples of 4 elements");
+      return ALG_EINVAL;
     }
-    attr_set = true;
   }
   const int m_tiles = (a->M + BM - 1) / BM, n_tiles = (a->N + BN - 1) / BN;
   const int64_t nwg = (int64_t)m_tiles * n_tiles * a->batch;
@@ -230,16 +374,6 @@ extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) {
     set_error("alg_gemm_bf16: grid too large");
     return ALG_ELIMIT;
   }
-  const dim3 grid((unsigned)nwg), block(GEMM_THREADS);
   hipStream_t s = (hipStream_t)stream;
-  if (a->R) {
-    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, true>), grid, block, GEMM_LDS, s, *a, m_tiles, n_tiles);
-  } else if (a->act == ALG_ACT_GELU_TANH) {
-    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_GELU_TANH, false>), grid, block, GEMM_LDS, s, *a, m_tiles, n_tiles);
-  } else if (a->act == ALG_ACT_SILU) {
-    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_SILU, false>), grid, block, GEMM_LDS, s, *a, m_tiles, n_tiles);
-  } else {
-    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, false>), grid, block, GEMM_LDS, s, *a, m_tiles, n_tiles);
-  }
-  return check_launch("alg_gemm_bf16");
+  return gemm_pipe() ? launch_gemm<1>(a, m_tiles, n_tiles, nwg, s) : launch_gemm<0>(a, m_tiles, n_tiles, nwg, s);
 }

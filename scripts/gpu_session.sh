@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: GPU tests, smoke, benches, rocprof.  Everything lands in gpurun_out/.
-# usage: bash scripts/gpu_session.sh [tests] [smoke] [quick] [bench] [prof]
+# usage: bash scripts/gpu_session.sh [tests] [smoke] [quick] [bench] [kbench] [gsweep] [pmc] [prof]
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
@@ -24,13 +24,21 @@ for w in $WHAT; do
     kbench)
       for v in 0 1 2; do
         echo "== ALG_ATTN_VARIANT=$v" | tee -a $O/kbench.log
-        ALG_ATTN_VARIANT=$v timeout 600 python scripts/kbench.py --only attn --check 2>&1 | tee -a $O/kbench.log
+        ALG_ATTN_VARIANT=$v timeout 600 python scripts/kbench.py --only attn --check 2>&1 | grep -v amdgpu.ids | tee -a $O/kbench.log
       done
-      timeout 600 python scripts/kbench.py 2>&1 | tee -a $O/kbench.log ;;
+      for v in 0 1; do
+        echo "== ALG_GEMM_PIPE=$v" | tee -a $O/kbench.log
+        ALG_GEMM_PIPE=$v timeout 600 python scripts/kbench.py --only gemm_qk,gemm_vt,gemm_out,gemm_ff1,gemm_ff2 2>&1 | grep -v amdgpu.ids | tee -a $O/kbench.log
+      done ;;
+    gsweep)
+      for gm in 1 2 4 8 16 32 1000; do
+        echo "== ALG_GEMM_GROUP_M=$gm" | tee -a $O/gsweep.log
+        ALG_GEMM_GROUP_M=$gm timeout 600 python scripts/kbench.py --only gemm_qk,gemm_ff1,gemm_ff2 2>&1 | grep -v -E "amdgpu.ids|^\{" | tee -a $O/gsweep.log
+      done ;;
     pmc)
       cd /tmp
       mkdir -p $O/pmc; rocprofv3 -L > $O/pmc_list.txt 2>&1
-      for k in attn gemm_qk gemm_ff2; do
+      for k in ${PMC_KERNELS:-attn gemm_qk gemm_ff2}; do
         i=0
         for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
                     "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" \
@@ -40,7 +48,7 @@ for w in $WHAT; do
         done
       done
       cd $R
-      python scripts/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1; cat $O/pmc_summary.txt | tail -40
+      python scripts/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1; cat $O/pmc_summary.txt | tail -60
       find $O/pmc -name "*.csv" -size +4M -delete ;;
     prof)
       cd /tmp

@@ -26,9 +26,16 @@ def rel_err(got, ref):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+@pytest.fixture(params=["1", "0"], ids=["ring4xBK32", "dbufBK64"])
+def gemm_pipe(request, monkeypatch):
+    """Every GEMM test runs on both staging pipelines (the default 4-stage ring and the 2-stage A/B variant)."""
+    monkeypatch.setenv("ALG_GEMM_PIPE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (300, 520, 128), (17, 64, 512), (2, 1000, 64),
-                                   (1111, 96, 3072)])
-def test_gemm_plain_bias(device, M, N, K):
+                                   (1111, 96, 3072), (70, 250, 192), (33, 6, 64)])
+def test_gemm_plain_bias(device, gemm_pipe, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     A, B, bias = rnd((M, K), g), rnd((N, K), g, 0.1), rnd((N,), g)
     C = torch.full((M, N), 7.0, dtype=BF, device=device)
@@ -39,7 +46,7 @@ def test_gemm_plain_bias(device, M, N, K):
     assert (got - ref).abs().max() <= 2e-2 * ref.abs().max()
 
 
-def test_gemm_is_transpose_detecting(device):
+def test_gemm_is_transpose_detecting(device, gemm_pipe):
     """A = I with an asymmetric B: catches a swapped C/D fragment layout (guide rule 16)."""
     M = N = K = 256
     A = torch.eye(M).to(BF)
@@ -50,7 +57,7 @@ def test_gemm_is_transpose_detecting(device):
 
 
 @pytest.mark.parametrize("act", [_lib.ACT_GELU_TANH, _lib.ACT_SILU])
-def test_gemm_activation(device, act):
+def test_gemm_activation(device, gemm_pipe, act):
     g = torch.Generator().manual_seed(5)
     M, N, K = 333, 512, 192
     A, B, bias = rnd((M, K), g), rnd((N, K), g, 0.2), rnd((N,), g)
@@ -63,7 +70,7 @@ def test_gemm_activation(device, act):
     assert (got - ref).abs().max() <= 3e-2 * ref.abs().max()
 
 
-def test_gemm_batched_gated_residual_in_place(device):
+def test_gemm_batched_gated_residual_in_place(device, gemm_pipe):
     """The out-projection / FF2 form: x <- x + gate[seg] * (A @ W^T + b), per-sample batch, text/video segments."""
     g = torch.Generator().manual_seed(9)
     nb, S, N, K, T = 2, 290, 512, 128, 26
@@ -82,7 +89,7 @@ def test_gemm_batched_gated_residual_in_place(device):
     assert (got - ref).abs().max() <= 3e-2 * ref.abs().max()
 
 
-def test_gemm_transposed_v_projection(device):
+def test_gemm_transposed_v_projection(device, gemm_pipe):
     """V^T = Wv @ y^T with per-row bias and the bits-2/3 column permutation, pad columns untouched."""
     g = torch.Generator().manual_seed(11)
     nb, S, D = 2, 200, 256
