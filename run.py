@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""ALG image-to-video sampling on MI355X -- same CLI and YAML schema as the reference's run.py
+(/root/reference/run.py:26-144): --config --image_path --prompt --output_path --model_cache_dir.
+
+YAML: model.{path,dtype[,flow_shift,flow_reverse]}, generation.*, alg.*, video.{fps[,resolution]}; the merged
+generation + alg sections are passed verbatim as __call__ keyword arguments, null = "use the default" (run.py:96-106).
+The model family is chosen by substring of model.path (run.py:45,64,70).
+
+What differs from the reference: the hot path runs on alg_amd's HIP kernels; weights are read from local disk only
+(no hub download here); the text encoder / VAE are once-per-video components outside the hot path -- without them
+(`--synthetic`) the run uses seeded synthetic weights, embeddings and image latents and writes the final latents.
+"""
+import argparse
+import logging
+import sys
+
+import torch
+import yaml
+
+from alg_amd import (CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, CogVideoXTransformer3DModel,
+                     CogVideoXTransformerConfig)
+from alg_amd.lp_utils import get_hunyuan_video_size  # noqa: F401  (kept importable here, as in the reference)
+
+logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s", stream=sys.stdout)
+logger = logging.getLogger(__name__)
+
+
+def main(args):
+    with open(args.config, "r") as f:
+        config = yaml.safe_load(f)
+    model_path = config["model"]["path"]
+    model_dtype = getattr(torch, config["model"]["dtype"])
+    device = "cuda" if torch.cuda.is_available() else "cpu"
+    logger.info(f"Using device: {device}")
+
+    if "CogVideoX" in model_path:
+        if args.synthetic:
+            transformer = CogVideoXTransformer3DModel.from_synthetic(CogVideoXTransformerConfig(), device=device)
+            pipe = CogVideoXImageToVideoPipeline(transformer=transformer, scheduler=CogVideoXDDIMScheduler())
+        else:
+            pipe = CogVideoXImageToVideoPipeline.from_pretrained(model_path, torch_dtype=model_dtype,
+                                                                 cache_dir=args.model_cache_dir)
+    elif "Wan" in model_path or "HunyuanVideo" in model_path:
+        raise NotImplementedError(
+            "the Wan / HunyuanVideo DiT forwards are the next rows of the build (SURVEY.md section 8f-2); their ALG "
+            "filters, strength schedule and resolution buckets are available in alg_amd.lp_utils")
+    else:
+        raise ValueError(f"unknown model family in model.path: {model_path}")
+    pipe.to(device)
+    logger.info("Pipeline loaded successfully.")
+
+    generator = torch.Generator(device="cpu").manual_seed(42)  # CPU stream so runs are comparable with the oracle
+    pipe_kwargs = {"generator": generator}
+    params_from_config = {**config.get("generation", {}), **config.get("alg", {})}
+    for key, value in params_from_config.items():
+        if value is not None:
+            pipe_kwargs[key] = value
+
+    if args.synthetic:
+        g = torch.Generator().manual_seed(42)
+        pipe_kwargs["prompt_embeds"] = torch.randn(1, 226, 4096, generator=g).to(model_dtype)
+        pipe_kwargs["negative_prompt_embeds"] = torch.randn(1, 226, 4096, generator=g).to(model_dtype)
+        pipe_kwargs["image_latents"] = (torch.randn(1, 1, 16, 60, 90, generator=g) * 0.7).to(model_dtype)
+        pipe_kwargs["output_type"] = "latent"
+    else:
+        from PIL import Image
+        pipe_kwargs["image"] = Image.open(args.image_path).convert("RGB")
+        pipe_kwargs["prompt"] = args.prompt
+
+    logger.info("Starting video generation...")
+    log_subset = {k: v for k, v in pipe_kwargs.items() if not torch.is_tensor(v) and k not in ("image", "generator")}
+    logger.info(f"Pipeline arguments: {log_subset}")
+    video_output = pipe(**pipe_kwargs)
+    frames = video_output.frames
+    if pipe_kwargs.get("output_type") == "latent":
+        torch.save(frames.cpu(), args.output_path)
+        logger.info(f"Saved final latents {tuple(frames.shape)} to: {args.output_path}")
+        return
+    video_frames = frames[0]
+    logger.info(f"Video generation complete. Received {len(video_frames)} frames.")
+    import numpy as np
+    arr = np.stack([np.asarray(f) for f in video_frames])  # [T, H, W, C] uint8
+    np.save(args.output_path, arr)  # the h264 writer (torchvision/PyAV) is outside the hot path and not installed
+    logger.info(f"Saved frames array {arr.shape} (fps {config['video']['fps']}) to: {args.output_path}")
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser(description="Arguments")
+    parser.add_argument("--config", type=str, default="./configs/cogvideox_alg.yaml")
+    parser.add_argument("--image_path", type=str, default="./assets/a red double decker bus driving down a street.jpg")
+    parser.add_argument("--prompt", type=str, default="a red double decker bus driving down a street")
+    parser.add_argument("--output_path", type=str, default="output.mp4")
+    parser.add_argument("--model_cache_dir", type=str, default=None)
+    parser.add_argument("--synthetic", action="store_true",
+                        help="extension: seeded synthetic weights/inputs (no checkpoint, text encoder or VAE needed)")
+    main(parser.parse_args())
