@@ -20,6 +20,11 @@
 //   1  + the O / l rescale is skipped (exactly: alpha == 1) when no lane's running max grew
 //   2  + software pipelined: QK^T of tile t+1 is issued before the softmax of tile t, so the MFMA pipe works
 //        under the VALU-heavy softmax; K runs one tile ahead of V through a 3-slot ring
+//   3/4  "lean" softmax (pre-scaled Q, -m folded into the accumulator chain, packed row sums) -- see below
+//   5  variant 1 with 4-wave workgroups;  6/7  64 queries per wave (8 / 4 waves per workgroup)
+// Measured on MI355X at the C2 shape (2 x 48 heads x 17,776 tokens, profiles/): 1: 850-915 TFLOP/s (default),
+// 0: 875, 2: 830, 3: 867, 4: 861, 5: 836, 6: 804, 7: 599 -- every restructuring that trades occupancy (4 waves per
+// SIMD at 110 VGPRs) for less VALU, less LDS traffic or more ILP loses; the variants stay selectable for A/B runs.
 #include <stdlib.h>
 
 #include "common.h"
@@ -123,8 +128,12 @@ __device__ __forceinline__ void pv_tile(const char* Vs, const bf16x8 (&pf)[4], c
     }
 }
 
-template <int VARIANT>
-__global__ __launch_bounds__(ATT_THREADS) void flash_attn_d64_kernel(const AttnP p) {
+// NW = waves per workgroup (8 or 4).  With 4 waves a workgroup puts ONE wave on each SIMD, so the waves that share a
+// SIMD belong to different workgroups and are not phase-locked by the per-tile barrier (one runs MFMAs while the
+// other runs its softmax); the price is that K/V^T tiles are staged once per 128 instead of 256 queries.
+template <int VARIANT, int NW = 8>
+__global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d64_kernel(const AttnP p) {
+  constexpr int ROUNDS = 8 / NW;  // DMA rounds per 8 KiB tile (one round = NW KiB)
   constexpr int K_SLOTS = VARIANT >= 2 ? 3 : 2;
   __shared__ __attribute__((aligned(16))) char smem[(K_SLOTS + 2) * ATT_TILE];
   char* const k_ring = smem;
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(ATT_THREADS) void flash_attn_d64_kernel(const AttnP
   const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
 
   // ---- Q^T fragments (B operand): lane (q = l31, h2) holds Q[q][16 ks + 8 h2 .. +8] ----
-  const int q_row = qb * QB + wave * 32 + l31;
+  const int q_row = qb * (NW * 32) + wave * 32 + l31;
   bf16x8 qf[4];
   {
     const bf16_t* qp = Q + (int64_t)min(q_row, S - 1) * p.q_rs + h2 * 8;
@@ -160,17 +169,36 @@ __global__ __launch_bounds__(ATT_THREADS) void flash_attn_d64_kernel(const AttnP
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
   }
 
-  // ---- DMA sources: one 16-B piece of K and one of V^T per thread per tile ----
-  const int srow = tid >> 3;                        // K: kv row, V^T: d row   (0..63)
-  const int sslot = (tid & 7) ^ ((tid >> 4) & 7);
-  const bf16_t* vt_src = VT + (int64_t)srow * p.vt_rs + sslot * 8;
+  // ---- DMA sources: ROUNDS 16-B pieces of K and of V^T per thread per tile ----
+  // per-lane base pointers for tile 0; a tile adds a wave-uniform byte offset (scalar multiply), and the row clamp
+  // (rows >= S re-read row S-1, masked later) only exists on the last, ragged tile
+  const int srow = tid >> 3;                        // K: kv row, V^T: d row   (+ NW*8 per round)
+  const int sslot = (tid & 7) ^ ((tid >> 4) & 7);   // (row >> 1) & 7 does not depend on the round
+  const bf16_t* k_src[ROUNDS];
+  const bf16_t* v_src[ROUNDS];
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    k_src[i] = K + (int64_t)min(srow + i * NW * 8, S - 1) * p.q_rs + sslot * 8;
+    v_src[i] = VT + (int64_t)(srow + i * NW * 8) * p.vt_rs + sslot * 8;
+  }
+  const int64_t k_tile_stride = (int64_t)KVB * p.q_rs;
+  const int last_tile = (S + KVB - 1) / KVB - 1;
+  const bool ragged_src = (S & (KVB - 1)) != 0;
   auto stage_k = [&](int slot, int kv0) {
-    const bf16_t* ks = K + (int64_t)min(kv0 + srow, S - 1) * p.q_rs + sslot * 8;
-    __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + slot * ATT_TILE + wave * 1024), 16, 0, 0);
+    const int t = kv0 / KVB;
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+      const bf16_t* ks = k_src[i] + t * k_tile_stride;
+      if (ragged_src && t == last_tile) ks = K + (int64_t)min(kv0 + srow + i * NW * 8, S - 1) * p.q_rs + sslot * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + slot * ATT_TILE + (i * NW + wave) * 1024), 16, 0,
+                                       0);
+    }
   };
   auto stage_v = [&](int slot, int kv0) {
-    __builtin_amdgcn_global_load_lds((gptr_t)(vt_src + kv0), (lptr_t)(v_ring + slot * ATT_TILE + wave * 1024), 16, 0,
-                                     0);
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(v_src[i] + kv0),
+                                       (lptr_t)(v_ring + slot * ATT_TILE + (i * NW + wave) * 1024), 16, 0, 0);
   };
 
   Frag f;
@@ -257,11 +285,354 @@ __global__ __launch_bounds__(ATT_THREADS) void flash_attn_d64_kernel(const AttnP
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant 3: same tiling as variant 1, with the per-score VALU work cut down.  Measured on variants 1/2
+// (rocprofv3 PMC): a KV tile costs a wave ~150 VALU instructions against 16 MFMAs, and MFMA issue shares the SIMD's
+// VALU issue slot, so at d = 64 the softmax -- not the matrix pipe -- bounds the kernel.  Changes:
+//   * Q is pre-multiplied by scale*log2(e) once per workgroup and the MFMA accumulator chain STARTS from -m (the
+//     running max, replicated over the 16 accumulator registers, which all belong to the lane's query): the matrix
+//     pipe hands back s*c - m*c directly, so the common case is p = exp2(acc) with no per-score fma;
+//   * row sums accumulate as float2 (v_pk_add_f32): 16 adds instead of 32;
+//   * the half-wave max exchange is a v_permlane32_swap (VALU) instead of an LDS bpermute round trip;
+//   * per-tile DMA addresses advance by a constant stride; the row clamp only exists on the last tile.
+// The max / rescale bookkeeping is exact (same m, l, O as variant 1 up to the rounding of q*c to bf16).
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// MSEED = false: the accumulator chain is seeded with a register vector holding -m (costs 16 v_mov_b64 per tile because
+//                 hipcc ties the MFMA's C and D operands);
+// MSEED = true : -m enters through one extra MFMA k-step per sub-tile instead: A = ones in k-slots 0..2, B = the three
+//                 bf16 pieces (hi, mid, lo) of -m, which reproduce the fp32 value exactly; the chain starts from the
+//                 inline constant 0, so the per-tile VALU copies disappear at the price of 18 instead of 16 MFMAs.
+template <bool MSEED>
+__global__ __launch_bounds__(ATT_THREADS, 4) void flash_attn_d64_lean_kernel(const AttnP p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE];
+  char* const k_ring = smem;
+  char* const v_ring = smem + 2 * ATT_TILE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h2 = lane >> 5;
+
+  const int nbh = p.batch * p.heads;
+  int bh, qb;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int slot = idx / p.q_blocks;
+    qb = idx - slot * p.q_blocks;
+    bh = slot * 8 + xcd;
+    if (bh >= nbh) return;
+  }
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int S = p.S;
+  const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* K = p.k + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
+
+  // Q^T fragments, pre-scaled by c = scale * log2(e) (one extra bf16 rounding of q*c, see header)
+  const int q_row = qb * QB + wave * 32 + l31;
+  const float c = p.scale_log2;
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = Q + (int64_t)min(q_row, S - 1) * p.q_rs + h2 * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      union { bf16x8 v; uint32_t u[4]; } raw, sc;
+      raw.v = *(const bf16x8*)(qp + ks * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        sc.u[j] = pack_bf2(__uint_as_float(raw.u[j] << 16) * c, __uint_as_float(raw.u[j] & 0xffff0000u) * c);
+      qf[ks] = sc.v;
+    }
+  }
+
+  const int srow = tid >> 3;
+  const int sslot = (tid & 7) ^ ((tid >> 4) & 7);
+  const bf16_t* vt_src = VT + (int64_t)srow * p.vt_rs + sslot * 8;
+  const bf16_t* k_src = K + (int64_t)min(srow, S - 1) * p.q_rs + sslot * 8;   // tile 0
+  const int64_t k_step = (int64_t)KVB * p.q_rs;
+  const int n_tiles = (S + KVB - 1) / KVB;
+  const bool ragged = (S & (KVB - 1)) != 0;
+  auto stage = [&](int slot, int t) {  // tile t: K rows [64 t, 64 t + 64), V^T columns likewise
+    const bf16_t* ks = k_src + t * k_step;
+    if (ragged && t == n_tiles - 1) ks = K + (int64_t)min(t * KVB + srow, S - 1) * p.q_rs + sslot * 8;
+    __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + slot * ATT_TILE + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(vt_src + t * KVB), (lptr_t)(v_ring + slot * ATT_TILE + wave * 1024), 16,
+                                     0, 0);
+  };
+
+  Frag f;
+  f.row_off = l31 * 128;
+  f.sw = (l31 >> 1) & 7;
+  f.h2 = h2;
+
+  f32x16 o_acc[2], negm;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    o_acc[0][e] = 0.0f;
+    o_acc[1][e] = 0.0f;
+    negm[e] = 0.0f;  // first tile runs against m = 0 and then adopts its own max
+  }
+  float m_run = 0.0f;  // running max in scaled (log2) units
+  float l_run = 0.0f;
+  // MSEED operands: ones in k-slots 0..2 of the lower half-wave (k = 8 h2 + j), and -m split into three bf16 pieces
+  bf16x8 ones_f, negm_f;
+  {
+    union { bf16x8 v; uint32_t u[4]; } a;
+    a.u[0] = h2 ? 0u : 0x3f803f80u;  // (1.0, 1.0)
+    a.u[1] = h2 ? 0u : 0x00003f80u;  // (1.0, 0)
+    a.u[2] = 0u;
+    a.u[3] = 0u;
+    ones_f = a.v;
+    a.u[0] = a.u[1] = 0u;
+    negm_f = a.v;
+  }
+
+  stage(0, 0);
+  for (int t = 0; t < n_tiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < n_tiles) stage((t + 1) & 1, t + 1);
+    const char* Ks = k_ring + (t & 1) * ATT_TILE;
+    const char* Vs = v_ring + (t & 1) * ATT_TILE;
+
+    // s[sub] = K[sub] (c Q)^T - m   (accumulator chain seeded with -m)
+    f32x16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      bf16x8 kf = *(const bf16x8*)(Ks + f.row_off + sub * 4096 + ((h2 ^ f.sw) * 16));
+      if (MSEED) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] = 0.0f;
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_f, negm_f, s[sub], 0, 0, 0);
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], s[sub], 0, 0, 0);
+      } else {
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], negm, 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) {
+        kf = *(const bf16x8*)(Ks + f.row_off + sub * 4096 + (((2 * ks + h2) ^ f.sw) * 16));
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sub], 0, 0, 0);
+      }
+    }
+    if (ragged && t == n_tiles - 1) mask_tail(s, t * KVB, S, h2);
+
+    float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
+    {
+      // other half-wave's max: after the swap r[0] = mt[lane & 31], r[1] = mt[32 + (lane & 31)] in every lane
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+      mt = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    // mt is the tile max RELATIVE to the running max: growth iff mt > 0 (always adopt it on the first tile)
+    float d = 0.0f;
+    const bool first = t == 0;
+    if (first || __any(mt > 0.0f)) {
+      d = first ? mt : fmaxf(mt, 0.0f);
+      const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);   // first tile: O = l = 0, nothing to rescale
+      m_run += d;
+      l_run *= alpha;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        o_acc[0][e] *= alpha;
+        o_acc[1][e] *= alpha;
+        if (!MSEED) negm[e] = -m_run;
+      }
+      if (MSEED) {
+        // -m = hi + mid + lo exactly (3 x 8 mantissa bits); only the lower half-wave's k-slots are live
+        const float nm = -m_run;
+        const float hi = rbf(nm), r1 = nm - hi;
+        const float mid = rbf(r1), lo = r1 - mid;
+        union { bf16x8 v; uint32_t u[4]; } a;
+        a.u[0] = h2 ? 0u : pack_bf2(hi, mid);
+        a.u[1] = h2 ? 0u : (pack_bf2(lo, 0.0f) & 0xffffu);
+        a.u[2] = 0u;
+        a.u[3] = 0u;
+        negm_f = a.v;
+      }
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] -= d;
+    }
+    f32x2v psum2 = {0.0f, 0.0f};
+    bf16x8 pf[4];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x2v pp;
+          pp[0] = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j]);
+          pp[1] = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j + 1]);
+          psum2 += pp;
+          pk.u[j] = pack_bf2(pp[0], pp[1]);
+        }
+        pf[sub * 2 + g] = pk.v;
+      }
+    l_run += psum2[0] + psum2[1];
+    pv_tile(Vs, pf, f, o_acc);
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q_row < S) {
+    bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * h2;
+        uint2 v;
+        v.x = pack_bf2(o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv);
+        v.y = pack_bf2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
+        *(uint2*)(op + d) = v;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Variant 6: 64 queries per wave (two independent 32-query groups that share every K / V^T fragment read).
+// Ablations on the GEMM (same LDS-DMA + ds_read_b128 + MFMA structure) showed that LDS traffic does not hide behind
+// the matrix pipe: at 32 queries per wave this kernel needs 16 KiB of fragment reads per 16 MFMAs -- 256 B/clk/CU at
+// full MFMA rate, the LDS peak.  Sharing each fragment between two query groups halves that (and halves the DMA per
+// MFMA: a workgroup now covers NW*64 queries).  The two groups are independent instruction streams inside one wave, so
+// one group's MFMAs run under the other group's softmax.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const AttnP p) {
+  constexpr int ROUNDS = 8 / NW;
+  __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE];
+  char* const k_ring = smem;
+  char* const v_ring = smem + 2 * ATT_TILE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h2 = lane >> 5;
+
+  const int nbh = p.batch * p.heads;
+  int bh, qb;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int slot = idx / p.q_blocks;
+    qb = idx - slot * p.q_blocks;
+    bh = slot * 8 + xcd;
+    if (bh >= nbh) return;
+  }
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int S = p.S;
+  const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* K = p.k + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
+
+  int q_row[2];
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    q_row[g] = qb * (NW * 64) + wave * 64 + g * 32 + l31;
+    const bf16_t* qp = Q + (int64_t)min(q_row[g], S - 1) * p.q_rs + h2 * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[g][ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+
+  const int srow = tid >> 3;
+  const int sslot = (tid & 7) ^ ((tid >> 4) & 7);
+  const bf16_t* vt_src = VT + (int64_t)srow * p.vt_rs + sslot * 8;
+  auto stage = [&](int slot, int kv0) {
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+      const bf16_t* ks = K + (int64_t)min(kv0 + srow + i * NW * 8, S - 1) * p.q_rs + sslot * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + slot * ATT_TILE + (i * NW + wave) * 1024), 16, 0,
+                                       0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vt_src + (int64_t)i * NW * 8 * p.vt_rs + kv0),
+                                       (lptr_t)(v_ring + slot * ATT_TILE + (i * NW + wave) * 1024), 16, 0, 0);
+    }
+  };
+
+  const int row_off = l31 * 128, sw = (l31 >> 1) & 7;
+  f32x16 o_acc[2][2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o_acc[g][i][e] = 0.0f;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+  const float c = p.scale_log2;
+  const int n_tiles = (S + KVB - 1) / KVB;
+  const bool ragged = (S & (KVB - 1)) != 0;
+
+  stage(0, 0);
+  for (int t = 0; t < n_tiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < n_tiles) stage((t + 1) & 1, (t + 1) * KVB);
+    const char* Ks = k_ring + (t & 1) * ATT_TILE;
+    const char* Vs = v_ring + (t & 1) * ATT_TILE;
+
+    // S^T for both query groups from ONE read of each K fragment
+    f32x16 s[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[g][sub][e] = 0.0f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(Ks + row_off + sub * 4096 + (((2 * ks + h2) ^ sw) * 16));
+        s[0][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], s[0][sub], 0, 0, 0);
+        s[1][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], s[1][sub], 0, 0, 0);
+      }
+    bf16x8 pf[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      if (ragged && t == n_tiles - 1) mask_tail(s[g], t * KVB, S, h2);
+      softmax_tile<true>(s[g], c, m_run[g], l_run[g], o_acc[g], pf[g]);
+    }
+    // O^T for both groups from ONE read of each V^T fragment
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 vf = *(const bf16x8*)(Vs + row_off + dt * 4096 + (((2 * kk + h2) ^ sw) * 16));
+        o_acc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0][kk], o_acc[0][dt], 0, 0, 0);
+        o_acc[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1][kk], o_acc[1][dt], 0, 0, 0);
+      }
+  }
+
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const float l_tot = l_run[g] + __shfl_xor(l_run[g], 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row[g] < S) {
+      bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row[g] * p.o_rs + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          const int d = dt * 32 + 8 * gg + 4 * h2;
+          uint2 v;
+          v.x = pack_bf2(o_acc[g][dt][4 * gg] * inv, o_acc[g][dt][4 * gg + 1] * inv);
+          v.y = pack_bf2(o_acc[g][dt][4 * gg + 2] * inv, o_acc[g][dt][4 * gg + 3] * inv);
+          *(uint2*)(op + d) = v;
+        }
+    }
+  }
+}
+
 // default = the fastest measured variant; ALG_ATTN_VARIANT (read per call) overrides it for A/B runs and tests
 static int attn_variant() {
   const char* e = getenv("ALG_ATTN_VARIANT");
   const int v = e ? atoi(e) : 1;
-  return (v < 0 || v > 2) ? 1 : v;
+  return (v < 0 || v > 7) ? 1 : v;
 }
 
 }  // namespace alg
@@ -287,18 +658,26 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
   AttnP p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;
   p.batch = batch; p.heads = heads; p.S = S;
-  p.q_blocks = (S + QB - 1) / QB;
+  const int variant = attn_variant();
+  const int nw = (variant == 5 || variant == 7) ? 4 : 8;
+  const int q_per_wave = variant >= 6 ? 64 : 32;
+  p.q_blocks = (S + nw * q_per_wave - 1) / (nw * q_per_wave);
   p.q_bs = q_bstride; p.q_rs = q_rstride; p.vt_bs = vt_bstride; p.vt_rs = vt_rstride;
   p.o_bs = o_bstride; p.o_rs = o_rstride;
   p.scale_log2 = scale * 1.4426950408889634f;
   const int nbh = batch * heads;
   const int64_t grid = (int64_t)((nbh + 7) / 8) * 8 * p.q_blocks;
-  const dim3 g((unsigned)grid), blk(ATT_THREADS);
+  const dim3 g((unsigned)grid), blk(nw * 64);
   hipStream_t s = (hipStream_t)stream;
-  switch (attn_variant()) {
+  switch (variant) {
     case 0: hipLaunchKernelGGL(flash_attn_d64_kernel<0>, g, blk, 0, s, p); break;
     case 1: hipLaunchKernelGGL(flash_attn_d64_kernel<1>, g, blk, 0, s, p); break;
-    default: hipLaunchKernelGGL(flash_attn_d64_kernel<2>, g, blk, 0, s, p); break;
+    case 2: hipLaunchKernelGGL(flash_attn_d64_kernel<2>, g, blk, 0, s, p); break;
+    case 3: hipLaunchKernelGGL(flash_attn_d64_lean_kernel<false>, g, blk, 0, s, p); break;
+    case 5: hipLaunchKernelGGL((flash_attn_d64_kernel<1, 4>), g, blk, 0, s, p); break;
+    case 6: hipLaunchKernelGGL(flash_attn_d64_q64_kernel<8>, g, blk, 0, s, p); break;
+    case 7: hipLaunchKernelGGL(flash_attn_d64_q64_kernel<4>, g, blk, 0, s, p); break;
+    default: hipLaunchKernelGGL(flash_attn_d64_lean_kernel<true>, g, blk, 0, s, p); break;
   }
   return check_launch("alg_flash_attn_d64");
 }

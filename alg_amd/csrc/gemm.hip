@@ -7,9 +7,11 @@
 //     so the epilogue loads bias/gate/residual and stores C with 8-byte accesses (32 stores per lane, not 128).
 //   * A and B (both K-contiguous: activations [M][K], nn.Linear weights [N][K]) stream L2 -> LDS with 16-byte
 //     global_load_lds (no VGPR round trip) through a 128 KiB ring:
-//        PIPE 1 (default): 4 stages of BK = 32; three stages are always in flight behind the one being
-//                multiplied (counted s_waitcnt vmcnt(8), raw s_barrier, never a full drain in the main loop);
-//        PIPE 0: 2 stages of BK = 64, drain + barrier per K-tile (kept for A/B measurements).
+//        PIPE 2 (default): 4 stages of BK = 32, counted s_waitcnt vmcnt(4) + raw s_barrier, and a register fragment
+//                pipeline that runs across the barrier (stage kt+1 is already visible while stage kt is multiplied),
+//                so the matrix pipe never waits for an LDS round trip after a barrier;
+//        PIPE 1: same ring, fragments re-started after every barrier, two stages kept in flight;
+//        PIPE 0: 2 stages of BK = 64, drain + barrier per K-tile.   (1 and 0 are kept for A/B measurements)
 //   * LDS-DMA writes lane-linear, so the bank swizzle lives on the per-lane SOURCE address; the matching XOR is
 //     applied on the ds_read_b128 fragment reads, which are conflict free (measured SQ_LDS_BANK_CONFLICT = 0).
 //   * workgroup ids are remapped so each XCD (private 4 MiB L2) walks a contiguous run of tiles, grouped
@@ -76,6 +78,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  // debug-only ablation bits ride in the upper half of group_m (ALG_GEMM_ABLATE: 1 = no DMA after the prologue,
+  // 2 = no LDS fragment reads in the PIPE 3 main loop); results are garbage, timing shows what the loop is bound by
+  const int abl = group_m >> 16;
+  group_m &= 0xffff;
   const int tiles = m_tiles * n_tiles;
   const int b = wg / tiles;
   int t = wg - b * tiles;
@@ -100,8 +106,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
 #pragma unroll
   for (int i = 0; i < LD_PER_OP; ++i) {
     const int r = i * ROWS_PER_LD + srow;
-    a_src[i] = A + (int64_t)min(m0 + r, p.M - 1) * p.lda + sslot * 8;
-    b_src[i] = B + (int64_t)min(n0 + r, p.N - 1) * p.ldb + sslot * 8;
+    const int am = (abl & 8) ? 0 : m0, bn = (abl & 8) ? 0 : n0;  // ablation bit 8: every tile streams tile (0, 0)
+    a_src[i] = A + (int64_t)min(am + r, p.M - 1) * p.lda + sslot * 8;
+    b_src[i] = B + (int64_t)min(bn + r, p.N - 1) * p.ldb + sslot * 8;
   }
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE_BYTES;
@@ -112,6 +119,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
       __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + kt * BK),
                                        (lptr_t)(base + TILE_BYTES + (i * 512 + wave * 64) * 16), 16, 0, 0);
     }
+  };
+
+  // one DMA instruction of a stage (w = 2*i + operand), so the main loop can spread a stage's DMA between MFMAs
+  auto stage_piece = [&](int buf, int kt, int w) {
+    char* base = smem + buf * STAGE_BYTES;
+    const int i = w >> 1;
+    if (w & 1)
+      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + kt * BK),
+                                       (lptr_t)(base + TILE_BYTES + (i * 512 + wave * 64) * 16), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + kt * BK), (lptr_t)(base + (i * 512 + wave * 64) * 16), 16,
+                                       0, 0);
   };
 
   // ---- fragment read offsets ----
@@ -133,10 +152,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
   // every k-step then eats a full LDS round trip at s_waitcnt lgkmcnt(0)).
   auto load_frags = [&](const char* As, const char* Bs, int ks, bf16x8 (&af)[4], bf16x8 (&bfr)[2]) {
     const int so = ((2 * ks + h2) ^ sw) * 16;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) af[mt] = *(const bf16x8*)(As + a_row_off + mt * 32 * ROW_BYTES + so);
+    // B fragments first: the MFMA order below (mt outer, nt inner) then needs the reads in exactly issue order, so
+    // the counted lgkmcnt waits hipcc emits leave the later reads in flight under the earlier MFMAs
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) bfr[nt] = *(const bf16x8*)(Bs + b_row_off + nt * 32 * ROW_BYTES + so);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) af[mt] = *(const bf16x8*)(As + a_row_off + mt * 32 * ROW_BYTES + so);
   };
   auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[2]) {
 #pragma unroll
@@ -188,6 +209,124 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
       if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
       compute(kt & 1);
     }
+  } else if (PIPE == 2) {
+    // 4-deep BK = 32 ring whose fragment pipeline runs ACROSS the barrier: at the top of iteration kt, stage kt+1 is
+    // already landed and visible, so the first fragments of stage kt+1 are read under the last MFMAs of stage kt and
+    // the matrix pipe never waits for an LDS round trip after a barrier.  The barrier itself only (a) publishes
+    // stage kt+1 and (b) proves every wave is done with the buffer stage kt+3 is about to overwrite.
+    stage(0, 0);
+    stage(1, 1);                      // K % 64 == 0  =>  nk >= 2
+    if (nk > 2) stage(2, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // stage 0 readable
+    bf16x8 af0[4], bf0[2], af1[4], bf1[2];
+    load_frags(smem, smem + TILE_BYTES, 0, af0, bf0);
+    auto interleave = [&]() {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    };
+    for (int kt = 0; kt < nk - 1; ++kt) {
+      // stage kt+1 landed (only stage kt+2 may still be in flight)
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 3 < nk) stage((kt + 3) & 3, kt + 3);
+      const char* As = smem + (kt & 3) * STAGE_BYTES;
+      const char* An = smem + ((kt + 1) & 3) * STAGE_BYTES;
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(As, As + TILE_BYTES, 1, af1, bf1);
+      mma(af0, bf0);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(An, An + TILE_BYTES, 0, af0, bf0);
+      mma(af1, bf1);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {  // last stage: already published by the previous iteration's barrier, nothing left to prefetch
+      const char* As = smem + ((nk - 1) & 3) * STAGE_BYTES;
+      load_frags(As, As + TILE_BYTES, 1, af1, bf1);
+      mma(af0, bf0);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(af1, bf1);
+    }
+  } else if (PIPE == 3) {
+    // PIPE 2's schedule with the LDS side taken out of hipcc's hands: hipcc guards every 8-MFMA block with
+    // s_waitcnt lgkmcnt(0), i.e. it waits for the six fragment reads it issued two MFMAs earlier.  Here the ds_reads
+    // are inline asm (invisible to its scoreboard) and the waits are COUNTED: LDS returns in order, so
+    // lgkmcnt(3/4/5/6) releases exactly the fragment the next MFMA pair needs while the later reads stay in flight.
+    // Invariant at every block start: the 6 reads of the block's own fragments are pending in the order
+    // b0 b1 a0 a1 a2 a3; the block issues the next block's 6 reads in the same order.
+    stage(0, 0);
+    stage(1, 1);
+    if (nk > 2) stage(2, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    const unsigned a_off0 = lds0 + a_row_off + ((h2 ^ sw) * 16), a_off1 = lds0 + a_row_off + (((2 + h2) ^ sw) * 16);
+    const unsigned b_off0 = lds0 + b_row_off + ((h2 ^ sw) * 16), b_off1 = lds0 + b_row_off + (((2 + h2) ^ sw) * 16);
+    bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+#define DSR(dst, addr, imm) \
+  if (!(abl & 2)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define LGKM(n)                                           \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0)
+#define MM(fa, fb, mt, nt) \
+  acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0)
+#define ISSUE6(na, nb, aaddr, baddr)                    \
+  DSR(nb[0], baddr, TILE_BYTES); DSR(nb[1], baddr, TILE_BYTES + 2048); \
+  DSR(na[0], aaddr, 0); DSR(na[1], aaddr, 2048); DSR(na[2], aaddr, 4096); DSR(na[3], aaddr, 6144)
+    // one 8-MFMA block on (fa, fb) that puts the next block's fragments (na, nb) in flight
+  // G0..G3: statements dropped between the MFMA pairs (the stage's four DMA instructions in block 1, nothing in
+  // block 2): an LDS-DMA costs its wave 60-180 issue cycles, so it goes out under MFMAs already in the matrix pipe
+  // instead of in a burst behind the barrier
+#define BLOCK(fa, fb, na, nb, aaddr, baddr, G0, G1, G2, G3)                                    \
+  LGKM(3); MM(fa, fb, 0, 0); DSR(nb[0], baddr, TILE_BYTES); MM(fa, fb, 0, 1); DSR(nb[1], baddr, TILE_BYTES + 2048); G0; \
+  LGKM(4); MM(fa, fb, 1, 0); DSR(na[0], aaddr, 0); MM(fa, fb, 1, 1); DSR(na[1], aaddr, 2048); G1; \
+  LGKM(5); MM(fa, fb, 2, 0); DSR(na[2], aaddr, 4096); MM(fa, fb, 2, 1); DSR(na[3], aaddr, 6144); G2; \
+  LGKM(6); MM(fa, fb, 3, 0); MM(fa, fb, 3, 1); G3; __builtin_amdgcn_sched_barrier(0)
+    {
+      const unsigned aa = a_off0, ba = b_off0;
+      ISSUE6(fa0, fb0, aa, ba);  // (stage 0, k-step 0)
+    }
+    for (int kt = 0; kt < nk - 1; ++kt) {
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const bool dma = kt + 3 < nk && !(abl & 1);
+      const int nb_ = (kt + 3) & 3;
+      if (dma && !(abl & 4)) stage(nb_, kt + 3);   // ablation bit 4: burst form (all four DMA right behind the barrier)
+      const bool spread = dma && (abl & 4);
+      const unsigned cur = (kt & 3) * STAGE_BYTES, nxt = ((kt + 1) & 3) * STAGE_BYTES;
+      const unsigned a1 = a_off1 + cur, b1 = b_off1 + cur, a0n = a_off0 + nxt, b0n = b_off0 + nxt;
+      __builtin_amdgcn_sched_barrier(0);
+      // (kt, ks0) while (kt, ks1) streams in
+      BLOCK(fa0, fb0, fa1, fb1, a1, b1, if (spread) stage_piece(nb_, kt + 3, 0), if (spread) stage_piece(nb_, kt + 3, 1),
+            if (spread) stage_piece(nb_, kt + 3, 2), if (spread) stage_piece(nb_, kt + 3, 3));
+      // (kt, ks1) while (kt+1, ks0) streams in
+      BLOCK(fa1, fb1, fa0, fb0, a0n, b0n, (void)0, (void)0, (void)0, (void)0);
+    }
+    {
+      const unsigned cur = ((nk - 1) & 3) * STAGE_BYTES;
+      const unsigned a1 = a_off1 + cur, b1 = b_off1 + cur;
+      __builtin_amdgcn_sched_barrier(0);
+      BLOCK(fa0, fb0, fa1, fb1, a1, b1, (void)0, (void)0, (void)0, (void)0);
+      LGKM(0);
+      MM(fa1, fb1, 0, 0); MM(fa1, fb1, 0, 1); MM(fa1, fb1, 1, 0); MM(fa1, fb1, 1, 1);
+      MM(fa1, fb1, 2, 0); MM(fa1, fb1, 2, 1); MM(fa1, fb1, 3, 0); MM(fa1, fb1, 3, 1);
+    }
+#undef BLOCK
+#undef ISSUE6
+#undef MM
+#undef LGKM
+#undef DSR
   } else {
     // 4-deep ring: stages kt+1 and kt+2 stay in flight while stage kt is multiplied; stage kt+3 is issued right
     // after the barrier that proves everybody is done reading its buffer (the one stage kt-1 lived in).
@@ -274,13 +413,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
 
 static int gemm_pipe() {
   const char* e = getenv("ALG_GEMM_PIPE");
-  return e ? (atoi(e) != 0) : 0;
+  const int v = e ? atoi(e) : 0;
+  return (v < 0 || v > 3) ? 0 : v;
 }
 
 static int gemm_group_m() {
   const char* e = getenv("ALG_GEMM_GROUP_M");
   const int v = e ? atoi(e) : GROUP_M;
-  return v < 1 ? GROUP_M : v;
+  const char* a = getenv("ALG_GEMM_ABLATE");
+  return ((v < 1 || v > 0xffff) ? GROUP_M : v) | ((a ? atoi(a) : 0) << 16);
 }
 
 }  // namespace alg
@@ -375,5 +516,10 @@ extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) {
     return ALG_ELIMIT;
   }
   hipStream_t s = (hipStream_t)stream;
-  return gemm_pipe() ? launch_gemm<1>(a, m_tiles, n_tiles, nwg, s) : launch_gemm<0>(a, m_tiles, n_tiles, nwg, s);
+  switch (gemm_pipe()) {
+    case 0: return launch_gemm<0>(a, m_tiles, n_tiles, nwg, s);
+    case 1: return launch_gemm<1>(a, m_tiles, n_tiles, nwg, s);
+    case 2: return launch_gemm<2>(a, m_tiles, n_tiles, nwg, s);
+    default: return launch_gemm<3>(a, m_tiles, n_tiles, nwg, s);
+  }
 }

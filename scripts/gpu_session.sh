@@ -22,11 +22,11 @@ for w in $WHAT; do
       timeout 1800 python bench.py > $O/bench_full.json 2> $O/bench_full.err
       echo "bench exit $?"; tail -c 4000 $O/bench_full.json; tail -5 $O/bench_full.err ;;
     kbench)
-      for v in 0 1 2; do
+      for v in 1 5; do
         echo "== ALG_ATTN_VARIANT=$v" | tee -a $O/kbench.log
         ALG_ATTN_VARIANT=$v timeout 600 python scripts/kbench.py --only attn --check 2>&1 | grep -v amdgpu.ids | tee -a $O/kbench.log
       done
-      for v in 0 1; do
+      for v in 0; do
         echo "== ALG_GEMM_PIPE=$v" | tee -a $O/kbench.log
         ALG_GEMM_PIPE=$v timeout 600 python scripts/kbench.py --only gemm_qk,gemm_vt,gemm_out,gemm_ff1,gemm_ff2 2>&1 | grep -v amdgpu.ids | tee -a $O/kbench.log
       done ;;
@@ -44,7 +44,7 @@ for w in $WHAT; do
                     "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" \
                     "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
           i=$((i+1))
-          timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $O/pmc/${k}_p$i -o p -- python $R/scripts/kbench.py --only $k --iters 2 > /dev/null 2> $O/pmc/${k}_p$i.err
+          timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $O/pmc/${k}${PMC_TAG:-}_p$i -o p -- python $R/scripts/kbench.py --only $k --iters 2 > /dev/null 2> $O/pmc/${k}${PMC_TAG:-}_p$i.err
         done
       done
       cd $R
