@@ -41,6 +41,27 @@ def event_ms(pairs):
     return [a.elapsed_time(b) for a, b in pairs]
 
 
+def pmc_traffic(kernel_substr, profile="profiles/r1_pmc_summary.txt"):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
+    collected in separate passes and reported in KiB).  gfx950 correction from MI355X_MICROARCH.md section HBM: a wide
+    coalesced 16-B/lane stream (our global_load_lds staging) is tallied at half its bytes in FETCH_SIZE -> x2.
+    The PMC passes profile the kernel micro-benchmark (scripts/kbench.py) at the N = 2 C2 shape, i.e. a two-pass step."""
+    path = os.path.join(ROOT, profile)
+    if not os.path.exists(path):
+        return None
+    vals = {}
+    with open(path) as f:
+        for line in f:
+            if kernel_substr in line:
+                for name in ("FETCH_SIZE", "WRITE_SIZE"):
+                    if (" " + name + " ") in line:
+                        vals[name] = float(line.rsplit("mean=", 1)[1])
+    if len(vals) != 2:
+        return None
+    return dict(bytes_per_launch=(2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, fetch_kib_raw=vals["FETCH_SIZE"],
+                write_kib_raw=vals["WRITE_SIZE"], samples_per_launch=2, source=profile)
+
+
 def cpu_baseline(budget_s=30.0):
     """One of the 42 DiT blocks of one sample-forward at the C2 token count, fp32, on the host cores, through the CPU
     oracle; scaled to frames/s of the whole workload (x 42 layers x 102 forwards per 49 frames)."""
@@ -204,7 +225,7 @@ def main():
     extra["time_share"] = {k: round(sum(v) / 1e3 / elapsed, 4) for k, v in ms.items()}
     attn_tflops = attn_flops_total / attn_time_total / 1e12 if attn_time_total > 0 else 0.0
     roofline = dict(bound="mfma", kernel="flash_attn_d64_kernel", achieved=attn_tflops, peak=MFMA_PEAK_TFLOPS,
-                    unit="TFLOP/s", frac=attn_tflops / MFMA_PEAK_TFLOPS, traffic=None,
+                    unit="TFLOP/s", frac=attn_tflops / MFMA_PEAK_TFLOPS, traffic=pmc_traffic("flash_attn_d64_kernel"),
                     launches=len(ms.get("attn", [])),
                     mean_launch_ms=(sum(ms["attn"]) / len(ms["attn"])) if ms.get("attn") else None, extra=extra)
     flops_total = (attn_flops_total + sum(gemm_flops.values()) * total_samples * cfg.num_layers)

@@ -50,6 +50,13 @@ for w in $WHAT; do
       cd $R
       python scripts/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1; cat $O/pmc_summary.txt | tail -60
       find $O/pmc -name "*.csv" -size +4M -delete ;;
+    profdefault)
+      # rocprofv3 kernel stats of the DEFAULT bench command (what profiles/ is judged against); the trace is dropped
+      cd /tmp
+      timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profd -o r1 -- python $R/bench.py > $O/profd_bench.json 2> $O/profd.err
+      echo "profdefault exit $?"
+      cd $R
+      rm -f $O/profd/*kernel_trace*; ls -la $O/profd; tail -c 600 $O/profd_bench.json ;;
     prof)
       cd /tmp
       timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r1 -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err
