@@ -22,8 +22,9 @@
 //        under the VALU-heavy softmax; K runs one tile ahead of V through a 3-slot ring
 //   3/4  "lean" softmax (pre-scaled Q, -m folded into the accumulator chain, packed row sums) -- see below
 //   5  variant 1 with 4-wave workgroups;  6/7  64 queries per wave (8 / 4 waves per workgroup)
+//   8/9  two KV tiles per barrier (9: + s_setprio around the MFMA clusters);  12  16-wave workgroups
 // Measured on MI355X at the C2 shape (2 x 48 heads x 17,776 tokens, profiles/): 1: 850-915 TFLOP/s (default),
-// 0: 875, 2: 830, 3: 867, 4: 861, 5: 836, 6: 804, 7: 599 -- every restructuring that trades occupancy (4 waves per
+// 0: 875, 2: 830, 3: 867, 4: 861, 5: 836, 6: 804, 7: 599, 8: 899, 9: 893, 12: 860 -- every restructuring that trades occupancy (4 waves per
 // SIMD at 110 VGPRs) for less VALU, less LDS traffic or more ILP loses; the variants stay selectable for A/B runs.
 #include <stdlib.h>
 
@@ -55,7 +56,8 @@ struct Frag {
   int h2;
 };
 
-// S^T sub-tiles of one 64-row K tile: s[sub] = K[sub] Q^T
+// S^T sub-tiles of one 64-row K tile: s[sub] = K[sub] Q^T   (NOLDS: measurement only, A operand = the Q fragment)
+template <bool NOLDS = false>
 __device__ __forceinline__ void qk_tile(const char* Ks, const bf16x8 (&qf)[4], const Frag f, f32x16 (&s)[2]) {
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub) {
@@ -63,7 +65,8 @@ __device__ __forceinline__ void qk_tile(const char* Ks, const bf16x8 (&qf)[4], c
     for (int e = 0; e < 16; ++e) s[sub][e] = 0.0f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 kf = *(const bf16x8*)(Ks + f.row_off + sub * 4096 + (((2 * ks + f.h2) ^ f.sw) * 16));
+      const bf16x8 kf =
+          NOLDS ? qf[ks ^ 1] : *(const bf16x8*)(Ks + f.row_off + sub * 4096 + (((2 * ks + f.h2) ^ f.sw) * 16));
       s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sub], 0, 0, 0);
     }
   }
@@ -80,7 +83,8 @@ __device__ __forceinline__ void mask_tail(f32x16 (&s)[2], int kv0, int S, int h2
 }
 
 // online softmax of one tile's scores -> bf16 P fragments; updates m, l and rescales O when needed
-template <bool SKIP>
+// NOEXP (measurement only, wrong results): 1 = half of the exp2 replaced by the bare fma, 2 = all of them
+template <bool SKIP, int NOEXP = 0>
 __device__ __forceinline__ void softmax_tile(const f32x16 (&s)[2], float c, float& m_run, float& l_run,
                                              f32x16 (&o_acc)[2], bf16x8 (&pf)[4]) {
   float mt = fmaxf(s[0][0], s[1][0]);
@@ -107,8 +111,9 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&s)[2], float c, floa
       union { bf16x8 v; uint32_t u[4]; } pk;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float p0 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j] * c - mc);
-        const float p1 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j + 1] * c - mc);
+        const float x0 = s[sub][8 * g + 2 * j] * c - mc, x1 = s[sub][8 * g + 2 * j + 1] * c - mc;
+        const float p0 = NOEXP >= 2 ? x0 : __builtin_amdgcn_exp2f(x0);
+        const float p1 = NOEXP >= 1 ? x1 : __builtin_amdgcn_exp2f(x1);
         psum += p0 + p1;  // the row sum uses the unrounded fp32 probabilities (as the math SDPA path does)
         pk.u[j] = pack_bf2(p0, p1);
       }
@@ -118,12 +123,14 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&s)[2], float c, floa
 }
 
 // O^T += V^T P^T for one 64-row tile
+template <bool NOLDS = false>
 __device__ __forceinline__ void pv_tile(const char* Vs, const bf16x8 (&pf)[4], const Frag f, f32x16 (&o_acc)[2]) {
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {  // kk = sub*2 + g : kv block [16 kk, 16 kk + 16)
-      const bf16x8 vf = *(const bf16x8*)(Vs + f.row_off + dt * 4096 + (((2 * kk + f.h2) ^ f.sw) * 16));
+      const bf16x8 vf =
+          NOLDS ? pf[kk ^ 1] : *(const bf16x8*)(Vs + f.row_off + dt * 4096 + (((2 * kk + f.h2) ^ f.sw) * 16));
       o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kk], o_acc[dt], 0, 0, 0);
     }
 }
@@ -133,8 +140,9 @@ __device__ __forceinline__ void pv_tile(const char* Vs, const bf16x8 (&pf)[4], c
 // other runs its softmax); the price is that K/V^T tiles are staged once per 128 instead of 256 queries.
 template <int VARIANT, int NW = 8>
 __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d64_kernel(const AttnP p) {
-  constexpr int ROUNDS = 8 / NW;  // DMA rounds per 8 KiB tile (one round = NW KiB)
-  constexpr int K_SLOTS = VARIANT >= 2 ? 3 : 2;
+  constexpr int ROUNDS = NW >= 8 ? 1 : 8 / NW;  // DMA rounds per 8 KiB tile (one round = min(NW, 8) KiB)
+  constexpr int DW = NW >= 8 ? 8 : NW;           // waves that issue DMA (a 16-wave workgroup only needs half)
+  constexpr int K_SLOTS = VARIANT == 2 ? 3 : 2;
   __shared__ __attribute__((aligned(16))) char smem[(K_SLOTS + 2) * ATT_TILE];
   char* const k_ring = smem;
   char* const v_ring = smem + K_SLOTS * ATT_TILE;
@@ -178,27 +186,29 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
   const bf16_t* v_src[ROUNDS];
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i) {
-    k_src[i] = K + (int64_t)min(srow + i * NW * 8, S - 1) * p.q_rs + sslot * 8;
-    v_src[i] = VT + (int64_t)(srow + i * NW * 8) * p.vt_rs + sslot * 8;
+    k_src[i] = K + (int64_t)min(srow + i * DW * 8, S - 1) * p.q_rs + sslot * 8;
+    v_src[i] = VT + (int64_t)(srow + i * DW * 8) * p.vt_rs + sslot * 8;
   }
   const int64_t k_tile_stride = (int64_t)KVB * p.q_rs;
   const int last_tile = (S + KVB - 1) / KVB - 1;
   const bool ragged_src = (S & (KVB - 1)) != 0;
   auto stage_k = [&](int slot, int kv0) {
+    if (NW > 8 && wave >= 8) return;
     const int t = kv0 / KVB;
 #pragma unroll
     for (int i = 0; i < ROUNDS; ++i) {
       const bf16_t* ks = k_src[i] + t * k_tile_stride;
-      if (ragged_src && t == last_tile) ks = K + (int64_t)min(kv0 + srow + i * NW * 8, S - 1) * p.q_rs + sslot * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + slot * ATT_TILE + (i * NW + wave) * 1024), 16, 0,
+      if (ragged_src && t == last_tile) ks = K + (int64_t)min(kv0 + srow + i * DW * 8, S - 1) * p.q_rs + sslot * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + slot * ATT_TILE + (i * DW + wave) * 1024), 16, 0,
                                        0);
     }
   };
   auto stage_v = [&](int slot, int kv0) {
+    if (NW > 8 && wave >= 8) return;
 #pragma unroll
     for (int i = 0; i < ROUNDS; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(v_src[i] + kv0),
-                                       (lptr_t)(v_ring + slot * ATT_TILE + (i * NW + wave) * 1024), 16, 0, 0);
+                                       (lptr_t)(v_ring + slot * ATT_TILE + (i * DW + wave) * 1024), 16, 0, 0);
   };
 
   Frag f;
@@ -217,22 +227,30 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
   const int n_tiles = (S + KVB - 1) / KVB;
   const bool ragged = (S & (KVB - 1)) != 0;
 
-  if (VARIANT < 2) {
+  if (VARIANT < 2 || VARIANT >= 10) {
+    // VARIANT >= 16 (measurement only, wrong results, NOT reachable from the C ABI -- instantiate by hand): ablation
+    // bits 1 no DMA after tile 0, 2 no LDS fragment reads, 4 no exp2, 8 no per-tile wait + barrier.  Round-1 readings
+    // at the C2 shape (ms per 2-sample launch): full 8.75 | no DMA 7.62 | no LDS reads 6.76 | neither 6.10 |
+    // no barrier 8.62 | no exp2 7.95 | no DMA/LDS/exp2 5.30 (MFMA floor at the sustained clock ~3.9)
+    constexpr int ABL = VARIANT >= 16 ? VARIANT - 16 : 0;
+    constexpr int NOEXP = VARIANT == 10 ? 1 : (VARIANT == 11 || (ABL & 4)) ? 2 : 0;
     stage_k(0, 0);
     stage_v(0, 0);
     for (int t = 0; t < n_tiles; ++t) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (t + 1 < n_tiles) {
+      if (!(ABL & 8) || t == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      if (t + 1 < n_tiles && !(ABL & 1)) {
         stage_k((t + 1) & 1, (t + 1) * KVB);
         stage_v((t + 1) & 1, (t + 1) * KVB);
       }
       f32x16 s[2];
-      qk_tile(k_ring + (t & 1) * ATT_TILE, qf, f, s);
+      qk_tile<(ABL & 2) != 0>(k_ring + (t & 1) * ATT_TILE, qf, f, s);
       if (ragged && t == n_tiles - 1) mask_tail(s, t * KVB, S, h2);
       bf16x8 pf[4];
-      softmax_tile<(VARIANT >= 1)>(s, c, m_run, l_run, o_acc, pf);
-      pv_tile(v_ring + (t & 1) * ATT_TILE, pf, f, o_acc);
+      softmax_tile<(VARIANT >= 1), NOEXP>(s, c, m_run, l_run, o_acc, pf);
+      pv_tile<(ABL & 2) != 0>(v_ring + (t & 1) * ATT_TILE, pf, f, o_acc);
     }
   } else {
     // K one tile ahead of V: iteration t computes S(t+1) = K(t+1) Q^T, softmax(S(t)), O += V(t)^T P(t)
@@ -628,11 +646,109 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const AttnP
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant 8 / 9: variant 1 with TWO 64-row KV tiles per ring stage (one workgroup barrier per 128 kv instead of per
+// 64; 64 KiB of LDS per workgroup, still two workgroups per CU) and, for 9, s_setprio(1) around the MFMA clusters.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool PRIO>
+__global__ __launch_bounds__(512, 4) void flash_attn_d64_kv128_kernel(const AttnP p) {
+  constexpr int STAGE = 4 * ATT_TILE;  // K0 K1 V0 V1
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h2 = lane >> 5;
+  const int nbh = p.batch * p.heads;
+  int bh, qb;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int slot = idx / p.q_blocks;
+    qb = idx - slot * p.q_blocks;
+    bh = slot * 8 + xcd;
+    if (bh >= nbh) return;
+  }
+  const int b = bh / p.heads, h = bh - b * p.heads, S = p.S;
+  const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* K = p.k + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
+  const int q_row = qb * 256 + wave * 32 + l31;
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = Q + (int64_t)min(q_row, S - 1) * p.q_rs + h2 * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+  const int srow = tid >> 3, sslot = (tid & 7) ^ ((tid >> 4) & 7);
+  const bf16_t* v_src = VT + (int64_t)srow * p.vt_rs + sslot * 8;
+  const int n_tiles = (S + KVB - 1) / KVB;       // 64-row tiles
+  const int n_stages = (n_tiles + 1) / 2;
+  const bool ragged = (S & (KVB - 1)) != 0;
+  // stage st holds tiles 2 st and 2 st + 1 (the second may lie entirely beyond S: its K rows clamp to S-1, its V^T
+  // columns are the zero pad -- vt rows cover S rounded up to 128 -- and its scores are masked)
+  auto stage = [&](int buf, int st) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kv0 = (2 * st + j) * KVB;
+      const bf16_t* ks = K + (int64_t)min(kv0 + srow, S - 1) * p.q_rs + sslot * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(base + j * ATT_TILE + wave * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(v_src + kv0), (lptr_t)(base + (2 + j) * ATT_TILE + wave * 1024), 16, 0,
+                                       0);
+    }
+  };
+  Frag f;
+  f.row_off = l31 * 128;
+  f.sw = (l31 >> 1) & 7;
+  f.h2 = h2;
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o_acc[i][e] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+  const float c = p.scale_log2;
+  stage(0, 0);
+  for (int st = 0; st < n_stages; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 1 < n_stages) stage((st + 1) & 1, st + 1);
+    const char* base = smem + (st & 1) * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = 2 * st + j;
+      if (t < n_tiles) {
+        f32x16 s[2];
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        qk_tile(base + j * ATT_TILE, qf, f, s);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (ragged && t == n_tiles - 1) mask_tail(s, t * KVB, S, h2);
+        bf16x8 pf[4];
+        softmax_tile<true>(s, c, m_run, l_run, o_acc, pf);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        pv_tile(base + (2 + j) * ATT_TILE, pf, f, o_acc);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  }
+  const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+  if (q_row < S) {
+    bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 v;
+        v.x = pack_bf2(o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv);
+        v.y = pack_bf2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
+        *(uint2*)(op + dt * 32 + 8 * g + 4 * h2) = v;
+      }
+  }
+}
+
 // default = the fastest measured variant; ALG_ATTN_VARIANT (read per call) overrides it for A/B runs and tests
 static int attn_variant() {
   const char* e = getenv("ALG_ATTN_VARIANT");
   const int v = e ? atoi(e) : 1;
-  return (v < 0 || v > 7) ? 1 : v;
+  return (v < 0 || v > 12 || v == 10 || v == 11) ? 1 : v;
 }
 
 }  // namespace alg
@@ -655,12 +771,14 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
     set_error("alg_flash_attn_d64: vt row stride %lld must cover S rounded up to %d", (long long)vt_rstride, KVB);
     return ALG_EINVAL;
   }
+  const bool vt128 = vt_rstride >= (int64_t)((S + 127) / 128) * 128;  // the 128-kv stage variants read one tile further
   AttnP p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;
   p.batch = batch; p.heads = heads; p.S = S;
-  const int variant = attn_variant();
-  const int nw = (variant == 5 || variant == 7) ? 4 : 8;
-  const int q_per_wave = variant >= 6 ? 64 : 32;
+  int variant = attn_variant();
+  if (variant >= 8 && !vt128) variant = 1;
+  const int nw = (variant == 5 || variant == 7) ? 4 : (variant == 12 ? 16 : 8);
+  const int q_per_wave = (variant == 6 || variant == 7) ? 64 : 32;
   p.q_blocks = (S + nw * q_per_wave - 1) / (nw * q_per_wave);
   p.q_bs = q_bstride; p.q_rs = q_rstride; p.vt_bs = vt_bstride; p.vt_rs = vt_rstride;
   p.o_bs = o_bstride; p.o_rs = o_rstride;
@@ -677,6 +795,9 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
     case 5: hipLaunchKernelGGL((flash_attn_d64_kernel<1, 4>), g, blk, 0, s, p); break;
     case 6: hipLaunchKernelGGL(flash_attn_d64_q64_kernel<8>, g, blk, 0, s, p); break;
     case 7: hipLaunchKernelGGL(flash_attn_d64_q64_kernel<4>, g, blk, 0, s, p); break;
+    case 12: hipLaunchKernelGGL((flash_attn_d64_kernel<1, 16>), g, blk, 0, s, p); break;
+    case 8: hipLaunchKernelGGL(flash_attn_d64_kv128_kernel<false>, g, blk, 0, s, p); break;
+    case 9: hipLaunchKernelGGL(flash_attn_d64_kv128_kernel<true>, g, blk, 0, s, p); break;
     default: hipLaunchKernelGGL(flash_attn_d64_lean_kernel<true>, g, blk, 0, s, p); break;
   }
   return check_launch("alg_flash_attn_d64");

@@ -198,7 +198,7 @@ class CogVideoXTransformer3DModel:
         cfg, dev = self.config, self.device
         D = cfg.inner_dim
         bf = dict(device=dev, dtype=torch.bfloat16)
-        S_pad = (S + 63) // 64 * 64
+        S_pad = (S + 127) // 128 * 128  # V^T rows: S rounded up to the widest KV stage of the attention variants
         ws = dict(
             S_pad=S_pad,
             x=torch.empty(N, S, D, **bf),

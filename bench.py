@@ -62,6 +62,58 @@ def pmc_traffic(kernel_substr, profile="profiles/r1_pmc_summary.txt"):
                 write_kib_raw=vals["WRITE_SIZE"], samples_per_launch=2, source=profile)
 
 
+def filter_microbench(dev):
+    """HBM GB/s of the low-pass kernels at the BASELINE shapes: algorithmic bytes = 2 * planes * H * W *
+    sizeof(dtype) per call.  One video is launch-bound (208 workgroups), so the 8-video batch is reported too."""
+    from alg_amd import lp_utils
+
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    cases = {
+        "down_up_c2_1video_bf16": (torch.randn(1, 13, 16, 60, 90, generator=g).to(torch.bfloat16), "down_up", 0.0, 0, 0.25),
+        "down_up_c2_8videos_bf16": (torch.randn(8, 13, 16, 60, 90, generator=g).to(torch.bfloat16), "down_up", 0.0, 0, 0.25),
+        "down_up_wan480p_f32": (torch.randn(1, 20, 21, 60, 104, generator=g), "down_up", 0.0, 0, 0.4),
+        "down_up_c5_f32": (torch.randn(1, 20, 21, 90, 160, generator=g), "down_up", 0.0, 0, 0.4),
+        "gaussian_wan480p_k9_f32": (torch.randn(1, 20, 21, 60, 104, generator=g), "gaussian_blur", 15.0, 9, 1.0),
+        "gaussian_wan480p_8videos_f32": (torch.randn(8, 20, 21, 60, 104, generator=g), "gaussian_blur", 15.0, 9, 1.0),
+    }
+    for name, (x, kind, sigma, k, f) in cases.items():
+        xd = x.to(dev)
+        for _ in range(3):
+            lp_utils.apply_low_pass_filter(xd, kind, sigma, k, f)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            lp_utils.apply_low_pass_filter(xd, kind, sigma, k, f)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 20
+        nbytes = 2.0 * x.numel() * x.element_size()
+        out[name] = dict(ms=ms, mbytes=nbytes / 1e6, gbs=nbytes / (ms / 1e3) / 1e9, hbm_frac=nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS)
+    return out
+
+
+def cpu_filter_baseline():
+    """the filters on the host cores through the CPU oracle (fp32; ATen's own op for down_up)."""
+    from oracle import loop_oracle, lp_oracle
+    import numpy as np
+
+    g = torch.Generator().manual_seed(5)
+    res = {}
+    x = torch.randn(1, 16, 13, 60, 90, generator=g)
+    loop_oracle.apply_low_pass_filter_torch(x, "down_up", 0.0, 0, 0.25)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        loop_oracle.apply_low_pass_filter_torch(x, "down_up", 0.0, 0, 0.25)
+    res["down_up_c2_f32_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+    w = torch.randn(1, 20, 21, 60, 104, generator=g).numpy()
+    t0 = time.perf_counter()
+    lp_oracle.gaussian_blur(w.astype(np.float32), 9, 15.0, np.float32)
+    res["gaussian_wan480p_k9_f32_ms"] = (time.perf_counter() - t0) * 1e3
+    return res
+
+
 def cpu_baseline(budget_s=30.0):
     """One of the 42 DiT blocks of one sample-forward at the C2 token count, fp32, on the host cores, through the CPU
     oracle; scaled to frames/s of the whole workload (x 42 layers x 102 forwards per 49 frames)."""
@@ -244,8 +296,11 @@ def main():
     }
     if cfg.num_layers != 42:
         out["INVALID"] = "debug run with %d layers" % cfg.num_layers
+    if rank == 0 and world == 1:
+        out["roofline"]["extra"]["filters"] = filter_microbench(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"]["filters"] = cpu_filter_baseline()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

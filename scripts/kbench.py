@@ -46,7 +46,7 @@ def main():
     only = set(filter(None, args.only.split(",")))
     dev = torch.device("cuda:0")
     N, S, D, H, T = args.n, args.S, 3072, 48, 226
-    S_pad = (S + 63) // 64 * 64
+    S_pad = (S + 127) // 128 * 128
     g = torch.Generator(device=dev).manual_seed(0)
     rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g, device=dev) * sc).to(BF)
     y = rn(N, S, D)
