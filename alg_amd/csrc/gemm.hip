@@ -302,7 +302,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
       __builtin_amdgcn_s_barrier();
       const bool dma = kt + 3 < nk && !(abl & 1);
       const int nb_ = (kt + 3) & 3;
-      if (dma && !(abl & 4)) stage(nb_, kt + 3);   // ablation bit 4: burst form (all four DMA right behind the barrier)
+      // ablation bit 16: stagger -- the wm = 1 waves (the SIMD partners of the wm = 0 waves) issue their DMA between
+      // the two MFMA blocks instead of right behind the barrier, so the two waves of a SIMD do not burst together
+      const bool late = (abl & 16) && wm == 1;
+      if (dma && !(abl & 4) && !late) stage(nb_, kt + 3);   // bit 4: spread form (one DMA behind each MFMA pair)
       const bool spread = dma && (abl & 4);
       const unsigned cur = (kt & 3) * STAGE_BYTES, nxt = ((kt + 1) & 3) * STAGE_BYTES;
       const unsigned a1 = a_off1 + cur, b1 = b_off1 + cur, a0n = a_off0 + nxt, b0n = b_off0 + nxt;
@@ -310,6 +313,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
       // (kt, ks0) while (kt, ks1) streams in
       BLOCK(fa0, fb0, fa1, fb1, a1, b1, if (spread) stage_piece(nb_, kt + 3, 0), if (spread) stage_piece(nb_, kt + 3, 1),
             if (spread) stage_piece(nb_, kt + 3, 2), if (spread) stage_piece(nb_, kt + 3, 3));
+      if (dma && late) stage(nb_, kt + 3);
+      __builtin_amdgcn_sched_barrier(0);
       // (kt, ks1) while (kt+1, ks0) streams in
       BLOCK(fa1, fb1, fa0, fb0, a0n, b0n, (void)0, (void)0, (void)0, (void)0);
     }

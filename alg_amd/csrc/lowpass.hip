@@ -64,29 +64,63 @@ __device__ __forceinline__ TapTable carve_taps(char*& p, int n_out, int taps) {
   return t;
 }
 
+// Both 1-D passes give each thread ONE output column (row passes) or ONE plane column (column passes) and let it walk
+// the other axis, so the per-output integer divisions are gone and the tap weights of a row pass sit in registers.
+// The accumulation order is the reference's: acc = s0*w0, then fma over the taps in ascending order.
+constexpr int REG_TAPS = 12;
+
 // dst[r][o] = sum_j w[o][j] * src[r][xmin[o] + j]      (resize along the contiguous axis)
 __device__ __forceinline__ void pass_rows(const float* src, int src_ld, float* dst, int dst_ld, int rows, int n_out,
                                           const TapTable t, int tid, int nthreads) {
-  const int total = rows * n_out;
-  for (int idx = tid; idx < total; idx += nthreads) {
-    const int r = idx / n_out, o = idx - r * n_out;
-    const float* s = src + (size_t)r * src_ld + t.xmin[o];
-    const float* w = t.w + (size_t)o * t.taps;
+  const bool fits = n_out <= nthreads;
+  const int rstep = fits ? nthreads / n_out : 1;
+  const int r0 = fits ? tid / n_out : 0;
+  for (int o = fits ? tid - r0 * n_out : tid; o < n_out; o += nthreads) {
+    if (r0 >= rstep) break;  // leftover threads of the last partial row group
     const int n = t.xsize[o];
-    float acc = n > 0 ? s[0] * w[0] : 0.0f;
-    for (int j = 1; j < n; ++j) acc = fmaf(s[j], w[j], acc);
-    dst[(size_t)r * dst_ld + o] = acc;
+    const float* wp = t.w + (size_t)o * t.taps;
+    const float* s0 = src + t.xmin[o];
+    if (t.taps <= REG_TAPS) {
+      float w[REG_TAPS];
+#pragma unroll
+      for (int j = 0; j < REG_TAPS; ++j) w[j] = j < t.taps ? wp[j] : 0.0f;
+      for (int r = r0; r < rows; r += rstep) {
+        const float* s = s0 + (size_t)r * src_ld;
+        float acc = n > 0 ? s[0] * w[0] : 0.0f;
+#pragma unroll
+        for (int j = 1; j < REG_TAPS; ++j)
+          if (j < n) acc = fmaf(s[j], w[j], acc);
+        dst[(size_t)r * dst_ld + o] = acc;
+      }
+    } else {
+      for (int r = r0; r < rows; r += rstep) {
+        const float* s = s0 + (size_t)r * src_ld;
+        float acc = n > 0 ? s[0] * wp[0] : 0.0f;
+        for (int j = 1; j < n; ++j) acc = fmaf(s[j], wp[j], acc);
+        dst[(size_t)r * dst_ld + o] = acc;
+      }
+    }
   }
 }
 
-// dst[o][c] = sum_j w[o][j] * src[xmin[o] + j][c]      (resize along the strided axis)
-__device__ __forceinline__ float col_tap(const float* src, int src_ld, int c, int o, const TapTable t) {
-  const float* s = src + (size_t)t.xmin[o] * src_ld + c;
-  const float* w = t.w + (size_t)o * t.taps;
-  const int n = t.xsize[o];
-  float acc = n > 0 ? s[0] * w[0] : 0.0f;
-  for (int j = 1; j < n; ++j) acc = fmaf(s[(size_t)j * src_ld], w[j], acc);
-  return acc;
+// out(o, c) = sum_j w[o][j] * src[xmin[o] + j][c]      (resize along the strided axis); `store(o, c, value)`
+template <typename Store>
+__device__ __forceinline__ void pass_cols(const float* src, int src_ld, int cols, int n_out, const TapTable t, int tid,
+                                          int nthreads, Store store) {
+  const bool fits = cols <= nthreads;
+  const int ostep = fits ? nthreads / cols : 1;
+  const int o0 = fits ? tid / cols : 0;
+  for (int c = fits ? tid - o0 * cols : tid; c < cols; c += nthreads) {
+    if (o0 >= ostep) break;
+    for (int o = o0; o < n_out; o += ostep) {
+      const int n = t.xsize[o];
+      const float* s = src + (size_t)t.xmin[o] * src_ld + c;
+      const float* w = t.w + (size_t)o * t.taps;
+      float acc = n > 0 ? s[0] * w[0] : 0.0f;
+      for (int j = 1; j < n; ++j) acc = fmaf(s[(size_t)j * src_ld], w[j], acc);
+      store(o, c, acc);
+    }
+  }
 }
 
 template <typename T>
@@ -119,7 +153,7 @@ __device__ __forceinline__ void load_plane(const T* g, float* lds, int n, int ti
 // down_up
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void down_up_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W,
+__global__ __launch_bounds__(1024) void down_up_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W,
                                                       int h1, int w1, int round_mid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -144,21 +178,14 @@ __global__ __launch_bounds__(256) void down_up_kernel(const T* __restrict__ in, 
   // first interpolate call (lp:53): W pass then H pass
   pass_rows(X, W, T1, w1, H, w1, dw, tid, nt);
   __syncthreads();
-  for (int idx = tid; idx < h1 * w1; idx += nt) {
-    const int o = idx / w1, c = idx - o * w1;
-    float v = col_tap(T1, w1, c, o, dh);
-    T2[idx] = round_mid ? rbf(v) : v;
-  }
+  pass_cols(T1, w1, w1, h1, dh, tid, nt, [&](int o, int c, float v) { T2[o * w1 + c] = round_mid ? rbf(v) : v; });
   __syncthreads();
   // second interpolate call (lp:54): W pass (into the dead X region) then H pass straight to HBM
   float* T3 = X;
   pass_rows(T2, w1, T3, W, h1, W, uw, tid, nt);
   __syncthreads();
-  T* o = out + plane * H * W;
-  for (int idx = tid; idx < H * W; idx += nt) {
-    const int y = idx / W, x = idx - y * W;
-    store_from_float<T>(o, idx, col_tap(T3, W, x, y, uh));
-  }
+  T* optr = out + plane * H * W;
+  pass_cols(T3, W, W, H, uh, tid, nt, [&](int y, int x, float v) { store_from_float<T>(optr, (int64_t)y * W + x, v); });
 }
 
 static size_t down_up_lds_bytes(int H, int W, int h1, int w1) {
@@ -179,7 +206,7 @@ __device__ __forceinline__ int reflect(int i, int n) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gaussian_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W,
+__global__ __launch_bounds__(1024) void gaussian_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W,
                                                        int ksize, float sigma) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -201,32 +228,61 @@ __global__ __launch_bounds__(256) void gaussian_kernel(const T* __restrict__ in,
   __syncthreads();
   if (tid < ksize) g[tid] = __fdiv_rn(g[tid], tot);
   __syncthreads();
-  // W pass (reflect indexing instead of a padded copy)
-  for (int idx = tid; idx < H * W; idx += nt) {
-    const int y = idx / W, x = idx - y * W;
-    const float* row = X + (size_t)y * W;
-    float acc = 0.0f;
-    if (x >= pad && x + pad < W) {
-      for (int j = 0; j < ksize; ++j) acc = fmaf(g[j], row[x - pad + j], acc);
-    } else {
-      for (int j = 0; j < ksize; ++j) acc = fmaf(g[j], row[reflect(x - pad + j, W)], acc);
+  // thread = one column x, walking a strided set of rows (no per-output division); reflect indexing instead of a
+  // padded copy
+  const bool fits = W <= nt;
+  const int ystep = fits ? nt / W : 1;
+  const int y0 = fits ? tid / W : 0;
+  // W pass
+  for (int x = fits ? tid - y0 * W : tid; x < W; x += nt) {
+    if (y0 >= ystep) break;
+    const bool inner = x >= pad && x + pad < W;
+    for (int y = y0; y < H; y += ystep) {
+      const float* row = X + (size_t)y * W;
+      float acc = 0.0f;
+      if (inner) {
+        for (int j = 0; j < ksize; ++j) acc = fmaf(g[j], row[x - pad + j], acc);
+      } else {
+        for (int j = 0; j < ksize; ++j) acc = fmaf(g[j], row[reflect(x - pad + j, W)], acc);
+      }
+      Tm[(size_t)y * W + x] = acc;
     }
-    Tm[idx] = acc;
   }
   __syncthreads();
+  // H pass
   T* o = out + plane * H * W;
-  for (int idx = tid; idx < H * W; idx += nt) {
-    const int y = idx / W, x = idx - y * W;
-    float acc = 0.0f;
-    for (int i = 0; i < ksize; ++i) acc = fmaf(g[i], Tm[(size_t)reflect(y - pad + i, H) * W + x], acc);
-    store_from_float<T>(o, idx, acc);
+  for (int x = fits ? tid - y0 * W : tid; x < W; x += nt) {
+    if (y0 >= ystep) break;
+    for (int y = y0; y < H; y += ystep) {
+      float acc = 0.0f;
+      if (y >= pad && y + pad < H) {
+        const float* col = Tm + (size_t)(y - pad) * W + x;
+        for (int i = 0; i < ksize; ++i) acc = fmaf(g[i], col[(size_t)i * W], acc);
+      } else {
+        for (int i = 0; i < ksize; ++i) acc = fmaf(g[i], Tm[(size_t)reflect(y - pad + i, H) * W + x], acc);
+      }
+      store_from_float<T>(o, (int64_t)y * W + x, acc);
+    }
   }
+}
+
+// threads per plane-workgroup.  Measured (rocprofv3, profiles/): one C2 video (208 planes, a single wave of
+// workgroups) is latency bound -- 1024 threads per plane: 14 us, 256: 24 us; eight videos (1664 planes) are
+// throughput bound and want many small workgroups per CU -- 256 threads: 44 us, 1024: 75 us.
+static int plane_threads(int H, int W, int64_t planes) {
+  const int n = H * W;
+  if (planes > 512) return 256;
+  return n >= 4096 ? 1024 : (n >= 1024 ? 512 : 256);
 }
 
 template <typename K>
 static int set_lds_limit(K kernel, size_t bytes) {
   if (bytes > 160 * 1024) return ALG_ELIMIT;
-  if (bytes > 48 * 1024) {
+  static thread_local const void* last_fn = nullptr;
+  static thread_local size_t last_bytes = 0;
+  if (bytes > 48 * 1024 && !(last_fn == (const void*)kernel && last_bytes >= bytes)) {
+    last_fn = (const void*)kernel;
+    last_bytes = bytes;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", bytes, hipGetErrorString(e));
@@ -262,13 +318,13 @@ extern "C" int alg_down_up(const void* in, void* out, int64_t planes, int H, int
   if (dtype == ALG_F32) {
     rc = set_lds_limit(down_up_kernel<float>, lds);
     if (rc == ALG_OK)
-      hipLaunchKernelGGL(down_up_kernel<float>, dim3((unsigned)planes), dim3(256), lds, s, (const float*)in,
-                         (float*)out, H, W, h1, w1, 0);
+      hipLaunchKernelGGL(down_up_kernel<float>, dim3((unsigned)planes), dim3(plane_threads(H, W, planes)), lds, s,
+                         (const float*)in, (float*)out, H, W, h1, w1, 0);
   } else {
     rc = set_lds_limit(down_up_kernel<bf16_t>, lds);
     if (rc == ALG_OK)
-      hipLaunchKernelGGL(down_up_kernel<bf16_t>, dim3((unsigned)planes), dim3(256), lds, s, (const bf16_t*)in,
-                         (bf16_t*)out, H, W, h1, w1, round_intermediate ? 1 : 0);
+      hipLaunchKernelGGL(down_up_kernel<bf16_t>, dim3((unsigned)planes), dim3(plane_threads(H, W, planes)), lds, s,
+                         (const bf16_t*)in, (bf16_t*)out, H, W, h1, w1, round_intermediate ? 1 : 0);
   }
   if (rc == ALG_ELIMIT) {
     set_error("alg_down_up: plane %dx%d (->%dx%d) needs %zu B of LDS (> 160 KiB); the LDS-resident kernel "
@@ -313,13 +369,13 @@ extern "C" int alg_gaussian_blur(const void* in, void* out, int64_t planes, int 
   if (dtype == ALG_F32) {
     rc = set_lds_limit(gaussian_kernel<float>, lds);
     if (rc == ALG_OK)
-      hipLaunchKernelGGL(gaussian_kernel<float>, dim3((unsigned)planes), dim3(256), lds, s, (const float*)in,
-                         (float*)out, H, W, ksize, sigma);
+      hipLaunchKernelGGL(gaussian_kernel<float>, dim3((unsigned)planes), dim3(plane_threads(H, W, planes)), lds, s,
+                         (const float*)in, (float*)out, H, W, ksize, sigma);
   } else {
     rc = set_lds_limit(gaussian_kernel<bf16_t>, lds);
     if (rc == ALG_OK)
-      hipLaunchKernelGGL(gaussian_kernel<bf16_t>, dim3((unsigned)planes), dim3(256), lds, s, (const bf16_t*)in,
-                         (bf16_t*)out, H, W, ksize, sigma);
+      hipLaunchKernelGGL(gaussian_kernel<bf16_t>, dim3((unsigned)planes), dim3(plane_threads(H, W, planes)), lds, s,
+                         (const bf16_t*)in, (bf16_t*)out, H, W, ksize, sigma);
   }
   if (rc == ALG_ELIMIT) {
     set_error("alg_gaussian_blur: plane %dx%d needs %zu B of LDS (> 160 KiB)", H, W, lds);

@@ -148,7 +148,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=42, help="debug only: fewer layers invalidates the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--filters-only", action="store_true", help="debug: only the low-pass kernel micro-benchmark")
     args = ap.parse_args()
+    if args.filters_only:
+        print(json.dumps(filter_microbench(torch.device("cuda:0"))))
+        return
 
     import alg_amd
     from alg_amd import parallel, weights as W
