@@ -1,12 +1,16 @@
 """alg_amd -- MI355X-native Adaptive Low-pass Guidance (ALG) image-to-video sampler.
 
 Only what the hot path needs: the HIP kernels + C ABI (``csrc/``, ``libalg_hip.so``), and the host-side
-mirror of the reference interface (``lp_utils``, the CogVideoX pipeline / transformer / scheduler).
+mirror of the reference interface (``lp_utils``, the CogVideoX pipeline / transformer / scheduler, and the Wan /
+HunyuanVideo sampler loops with their UniPC / flow-match Euler schedulers).
 """
 from . import lp_utils  # noqa: F401
 from ._lib import AlgHipError, build_library, load_library  # noqa: F401
 from .pipeline_cogvideox_image2video_lowpass import CogVideoXImageToVideoPipeline, CogVideoXPipelineOutput  # noqa: F401
-from .schedulers import CogVideoXDDIMScheduler  # noqa: F401
+from .pipeline_hunyuan_video_image2video_lowpass import HunyuanVideoImageToVideoPipeline  # noqa: F401
+from .pipeline_wan_image2video_lowpass import WanImageToVideoPipeline  # noqa: F401
+from .schedulers import (CogVideoXDDIMScheduler, FlowMatchEulerDiscreteScheduler,  # noqa: F401
+                         UniPCMultistepScheduler)
 from .transformer_cogvideox import CogVideoXTransformer3DModel, CogVideoXTransformerConfig  # noqa: F401
 
 __version__ = "0.1.0"

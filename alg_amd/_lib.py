@@ -22,7 +22,7 @@ GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS = 1, 4
 EXPORTS = (
     "alg_version", "alg_last_error", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16",
     "alg_flash_attn_d64", "alg_layernorm_modulate", "alg_qk_norm_rope", "alg_patchify", "alg_unpatchify",
-    "alg_timestep_embedding",
+    "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast",
 )
 
 
@@ -74,6 +74,12 @@ def load_library():
     lib.alg_gaussian_blur.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p]
     lib.alg_cfg_ddim_step.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_float, c_float, c_float,
                                       c_float, c_float, c_void_p]
+    lib.alg_cfg_combine.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_void_p]
+    lib.alg_lincomb.argtypes = [POINTER(c_void_p), POINTER(c_float), POINTER(c_int), c_int, c_void_p, c_int, c_int64,
+                                c_void_p]
+    lib.alg_concat_cast.argtypes = [POINTER(c_void_p), c_int, POINTER(c_void_p), c_int, c_int] + [c_int64] * 7 + [
+        c_void_p, c_int, c_void_p]
+    lib.alg_unipc_update.argtypes = [c_void_p] * 5 + [c_int64] + [c_float] * 6 + [c_void_p]
     lib.alg_gemm_bf16.argtypes = [POINTER(GemmArgs), c_void_p]
     lib.alg_flash_attn_d64.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
                                        c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]
@@ -166,6 +172,70 @@ def cfg_ddim_step_(pred, latents, n_pass, guidance_scale, sqrt_alpha_t, sqrt_bet
                                  float(guidance_scale), float(sqrt_alpha_t), float(sqrt_beta_t), float(coef_a),
                                  float(coef_b), _stream()), "alg_cfg_ddim_step")
     return latents
+
+
+def cfg_combine(pred, n_pass, guidance_scale):
+    """pred [n_pass * B, ...] -> [B, ...] = u0 + g * (text - u), rounded per op in pred's dtype."""
+    lib = load_library()
+    _dev(pred, "pred")
+    if not pred.is_contiguous() or pred.shape[0] % n_pass:
+        raise AlgHipError("cfg_combine needs a contiguous [n_pass * B, ...] tensor")
+    out = torch.empty((pred.shape[0] // n_pass,) + tuple(pred.shape[1:]), device=pred.device, dtype=pred.dtype)
+    _check(lib.alg_cfg_combine(_ptr(pred), _ptr(out), _dt(pred), n_pass, out.numel(), float(guidance_scale), _stream()),
+           "alg_cfg_combine")
+    return out
+
+
+def lincomb(terms, out_dtype):
+    """sum_i c_i * x_i for 1..4 (coef, tensor) pairs of equal shape -> new tensor of ``out_dtype``."""
+    lib = load_library()
+    xs = [t for _, t in terms]
+    for t in xs:
+        _dev(t, "term")
+        if not t.is_contiguous() or t.shape != xs[0].shape:
+            raise AlgHipError("lincomb needs contiguous tensors of one shape")
+    n = len(xs)
+    out = torch.empty(xs[0].shape, device=xs[0].device, dtype=out_dtype)
+    arr = (c_void_p * n)(*[t.data_ptr() for t in xs])
+    cf = (c_float * n)(*[float(c) for c, _ in terms])
+    dts = (c_int * n)(*[_dt(t) for t in xs])
+    _check(lib.alg_lincomb(arr, cf, dts, n, _ptr(out), ALG_F32 if out_dtype == torch.float32 else ALG_BF16,
+                           out.numel(), _stream()), "alg_lincomb")
+    return out
+
+
+def concat_cast(src0, src1, O, A0, A1, R, s0_ostride, s1_ostride, a1_off, out_dtype):
+    """out[i, o, a, r] = a < A0 ? src0[i][o, a, r] : src1[i][o, a1_off + a - A0, r]; src0/src1: lists of tensors
+    (contiguous device tensors, one per output sample).  Returns a flat [n, O, A0 + A1, R] tensor of out_dtype."""
+    lib = load_library()
+    n = len(src0)
+    for t in list(src0) + list(src1):
+        _dev(t, "concat source")
+        if not t.is_contiguous():
+            raise AlgHipError("concat_cast needs contiguous sources")
+    out = torch.empty((n, O, A0 + A1, R), device=src0[0].device, dtype=out_dtype)
+    a0 = (c_void_p * n)(*[t.data_ptr() for t in src0])
+    a1 = (c_void_p * n)(*[t.data_ptr() for t in src1])
+    _check(lib.alg_concat_cast(a0, _dt(src0[0]), a1, _dt(src1[0]), n, O, A0, A1, R, s0_ostride, s1_ostride, a1_off,
+                               _ptr(out), ALG_F32 if out_dtype == torch.float32 else ALG_BF16, _stream()),
+           "alg_concat_cast")
+    return out
+
+
+def unipc_update(x, m0, m1, m_new, r, c, k, rk=1.0, rho0=0.0, rho_new=0.0):
+    """(r*x - c*m0) - k*(rho0*((m1-m0)/rk) + rho_new*(m_new-m0)) on fp32 tensors; m1 / m_new may be None."""
+    lib = load_library()
+    for t in (x, m0, m1, m_new):
+        if t is None:
+            continue
+        _dev(t, "unipc term")
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != x.shape:
+            raise AlgHipError("unipc_update needs contiguous fp32 tensors of one shape")
+    out = torch.empty_like(x)
+    p = lambda t: None if t is None else _ptr(t)
+    _check(lib.alg_unipc_update(p(x), p(m0), p(m1), p(m_new), _ptr(out), x.numel(), float(r), float(c), float(k),
+                                float(rk), float(rho0), float(rho_new), _stream()), "alg_unipc_update")
+    return out
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=None, batch=1, strideA=0, strideB=0,

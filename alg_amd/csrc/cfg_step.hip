@@ -136,3 +136,214 @@ extern "C" int alg_cfg_ddim_step(const void* pred, int pred_dtype, void* latents
 #undef LAUNCH
   return check_launch("alg_cfg_ddim_step");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Generic loop-body elementwise kernels for the Wan / HunyuanVideo loops, whose schedulers are multi-term linear
+// updates (UniPC, flow-match Euler) and whose CFG combine runs in the model dtype.
+// ---------------------------------------------------------------------------------------------------------------
+namespace alg {
+
+// out = u0 + g * (tx - u) with every intermediate rounded to the prediction dtype (torch eager on bf16 tensors:
+// wan:919-924, hy:1254-1261 combine WITHOUT the .float() the CogVideoX loop has)
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_combine_kernel(const T* __restrict__ pred, T* __restrict__ out, int n_pass,
+                                                          int64_t numel, float g) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const T* p_tx = pred + (int64_t)(n_pass - 1) * numel;
+  const T* p_u = pred + (int64_t)(n_pass - 2) * numel;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < numel; e += stride) {
+    const float tx = load_as_float<T>(p_tx, e), u = load_as_float<T>(p_u, e);
+    const float u0 = n_pass == 3 ? load_as_float<T>(pred, e) : u;
+    float d = __fsub_rn(tx, u);
+    if (sizeof(T) == 2) d = rbf(d);
+    float m = __fmul_rn(g, d);
+    if (sizeof(T) == 2) m = rbf(m);
+    store_from_float<T>(out, e, __fadd_rn(u0, m));
+  }
+}
+
+struct LinTerms {
+  const void* x[4];
+  float c[4];
+  int dt[4];
+  int n;
+};
+
+// out = sum_i c_i * x_i, torch-eager rounding: each product is rounded to its tensor's dtype (scalar * bf16 tensor is
+// a bf16 tensor), the running sum is fp32 (term 0 is the fp32 sample in every caller), left to right, unfused
+template <typename TO>
+__global__ __launch_bounds__(256) void lincomb_kernel(const LinTerms t, TO* __restrict__ out, int64_t numel) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < numel; e += stride) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < t.n) {
+        const float v = t.dt[i] == ALG_BF16 ? bf2f(((const bf16_t*)t.x[i])[e]) : ((const float*)t.x[i])[e];
+        float term = __fmul_rn(t.c[i], v);
+        if (t.dt[i] == ALG_BF16) term = rbf(term);
+        acc = i == 0 ? term : __fadd_rn(acc, term);
+      }
+    }
+    store_from_float<TO>(out, e, acc);
+  }
+}
+
+// UniPC-bh (predict_x0) predictor / corrector update for solver_order <= 2, op order of the published
+// multistep_uni_p_bh_update / multistep_uni_c_bh_update (fp32 tensors, fp32 0-dim scalars):
+//   x_t_ = r * x - c * m0
+//   res  = [has_prev] rho0 * ((m1 - m0) / rk)  (+)  [has_new] rho_new * (m_new - m0)
+//   out  = x_t_ - k * res
+// `tensor / cpu_scalar` on a GPU is ATen's multiply by the fp32 reciprocal (div_true_cuda), reproduced here.
+struct UniPC {
+  float r, c, k, rk, rho0, rho_new;
+  int has_prev, has_new;
+};
+
+__global__ __launch_bounds__(256) void unipc_kernel(const float* __restrict__ x, const float* __restrict__ m0,
+                                                    const float* __restrict__ m1, const float* __restrict__ m_new,
+                                                    float* __restrict__ out, int64_t numel, UniPC u) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < numel; e += stride) {
+    const float a = m0[e];
+    const float xt = __fsub_rn(__fmul_rn(u.r, x[e]), __fmul_rn(u.c, a));
+    float res = 0.0f;
+    if (u.has_prev) res = __fmul_rn(u.rho0, __fmul_rn(__fsub_rn(m1[e], a), u.rk));
+    if (u.has_new) res = __fadd_rn(res, __fmul_rn(u.rho_new, __fsub_rn(m_new[e], a)));
+    out[e] = __fsub_rn(xt, __fmul_rn(u.k, res));
+  }
+}
+
+// CFG batch assembly: out[n, o, a, r] = a < A0 ? src0_n[o, a, r] : src1_n[o, a1_off + a - A0, r], cast to the
+// transformer dtype.  One launch replaces the reference's cat([latents]*n) + cat(..., dim) + .to(dtype) chain
+// (wan:877-889 channel concat: O=1, A=channels; hy:1146-1160 first-frame token replace: O=channels, A=frames).
+struct CatSrc {
+  const void* s0[16];
+  const void* s1[16];
+};
+
+template <typename T0, typename T1, typename TO>
+__global__ __launch_bounds__(256) void concat_cast_kernel(const CatSrc src, TO* __restrict__ out, int O, int A0,
+                                                          int A1, int64_t R, int64_t s0_ostride, int64_t s1_ostride,
+                                                          int a1_off) {
+  const int A = A0 + A1;
+  const int row = blockIdx.y;  // (n, o, a)
+  const int a = row % A, o = (row / A) % O, n = row / (A * O);
+  TO* dst = out + (int64_t)row * R;
+  if (a < A0) {
+    const T0* p = (const T0*)src.s0[n] + (int64_t)o * s0_ostride + (int64_t)a * R;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x)
+      store_from_float<TO>(dst, r, load_as_float<T0>(p, r));
+  } else {
+    const T1* p = (const T1*)src.s1[n] + (int64_t)o * s1_ostride + (int64_t)(a1_off + a - A0) * R;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x)
+      store_from_float<TO>(dst, r, load_as_float<T1>(p, r));
+  }
+}
+
+}  // namespace alg
+
+extern "C" int alg_concat_cast(const void* const* src0, int dtype0, const void* const* src1, int dtype1, int n,
+                               int64_t O, int64_t A0, int64_t A1, int64_t R, int64_t s0_ostride, int64_t s1_ostride,
+                               int64_t a1_off, void* out, int out_dtype, void* stream) {
+  auto okdt = [](int d) { return d == ALG_F32 || d == ALG_BF16; };
+  if (!src0 || !src1 || !out || n < 0 || n > 16 || O < 1 || A0 < 0 || A1 < 0 || R < 0 || a1_off < 0 ||
+      !okdt(dtype0) || !okdt(dtype1) || !okdt(out_dtype) || n * O * (A0 + A1) > 65535) {
+    set_error("alg_concat_cast: bad argument (n=%d O=%lld A0=%lld A1=%lld R=%lld)", n, (long long)O, (long long)A0,
+              (long long)A1, (long long)R);
+    return ALG_EINVAL;
+  }
+  if (n == 0 || R == 0 || A0 + A1 == 0) return ALG_OK;
+  CatSrc cs;
+  for (int i = 0; i < 16; ++i) {
+    cs.s0[i] = i < n ? src0[i] : nullptr;
+    cs.s1[i] = i < n ? src1[i] : nullptr;
+    if (i < n && ((A0 > 0 && !src0[i]) || (A1 > 0 && !src1[i]))) {
+      set_error("alg_concat_cast: source %d is null", i);
+      return ALG_EINVAL;
+    }
+  }
+  int64_t gx = (R + 1023) / 1024;
+  dim3 grid((unsigned)(gx > 64 ? 64 : gx), (unsigned)(n * O * (A0 + A1)));
+  hipStream_t s = (hipStream_t)stream;
+#define CC(T0, T1, TO)                                                                                             \
+  hipLaunchKernelGGL((concat_cast_kernel<T0, T1, TO>), grid, dim3(256), 0, s, cs, (TO*)out, (int)O, (int)A0, (int)A1, \
+                     R, s0_ostride, s1_ostride, (int)a1_off)
+#define CC1(T0, T1)                                                                                                \
+  do {                                                                                                             \
+    if (out_dtype == ALG_F32) CC(T0, T1, float);                                                                   \
+    else CC(T0, T1, bf16_t);                                                                                       \
+  } while (0)
+  if (dtype0 == ALG_F32 && dtype1 == ALG_F32) CC1(float, float);
+  else if (dtype0 == ALG_F32) CC1(float, bf16_t);
+  else if (dtype1 == ALG_F32) CC1(bf16_t, float);
+  else CC1(bf16_t, bf16_t);
+#undef CC1
+#undef CC
+  return check_launch("alg_concat_cast");
+}
+
+extern "C" int alg_unipc_update(const float* x, const float* m0, const float* m1, const float* m_new, float* out,
+                                int64_t numel, float r, float c, float k, float rk, float rho0, float rho_new,
+                                void* stream) {
+  if (!x || !m0 || !out || numel < 0) {
+    set_error("alg_unipc_update: bad argument (numel=%lld)", (long long)numel);
+    return ALG_EINVAL;
+  }
+  if (numel == 0) return ALG_OK;
+  UniPC u{r, c, k, 1.0f / rk, rho0, rho_new, m1 != nullptr, m_new != nullptr};  // u.rk holds the reciprocal
+  int64_t want = (numel + 255) / 256;
+  const unsigned grid = (unsigned)(want > 4096 ? 4096 : want);
+  hipLaunchKernelGGL(unipc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, m0, m1, m_new, out, numel, u);
+  return check_launch("alg_unipc_update");
+}
+
+extern "C" int alg_cfg_combine(const void* pred, void* out, int dtype, int n_pass, int64_t numel, float guidance_scale,
+                               void* stream) {
+  if (numel < 0 || n_pass < 2 || n_pass > 3 || (dtype != ALG_F32 && dtype != ALG_BF16)) {
+    set_error("alg_cfg_combine: bad argument (n_pass=%d numel=%lld dtype=%d)", n_pass, (long long)numel, dtype);
+    return ALG_EINVAL;
+  }
+  if (numel == 0) return ALG_OK;  // empty tensors carry null data pointers
+  if (!pred || !out) {
+    set_error("alg_cfg_combine: null pointer");
+    return ALG_EINVAL;
+  }
+  int64_t want = (numel + 255) / 256;
+  const unsigned grid = (unsigned)(want > 4096 ? 4096 : want);
+  if (dtype == ALG_F32)
+    hipLaunchKernelGGL(cfg_combine_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)pred,
+                       (float*)out, n_pass, numel, guidance_scale);
+  else
+    hipLaunchKernelGGL(cfg_combine_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred,
+                       (bf16_t*)out, n_pass, numel, guidance_scale);
+  return check_launch("alg_cfg_combine");
+}
+
+extern "C" int alg_lincomb(const void* const* xs, const float* coefs, const int* dtypes, int n_terms, void* out,
+                           int out_dtype, int64_t numel, void* stream) {
+  if (!xs || !coefs || !dtypes || !out || n_terms < 1 || n_terms > 4 || numel < 0 ||
+      (out_dtype != ALG_F32 && out_dtype != ALG_BF16)) {
+    set_error("alg_lincomb: bad argument (n_terms=%d numel=%lld)", n_terms, (long long)numel);
+    return ALG_EINVAL;
+  }
+  LinTerms t;
+  t.n = n_terms;
+  for (int i = 0; i < 4; ++i) {
+    t.x[i] = i < n_terms ? xs[i] : nullptr;
+    t.c[i] = i < n_terms ? coefs[i] : 0.0f;
+    t.dt[i] = i < n_terms ? dtypes[i] : ALG_F32;
+    if (i < n_terms && (!xs[i] || (dtypes[i] != ALG_F32 && dtypes[i] != ALG_BF16))) {
+      set_error("alg_lincomb: term %d is null or has an unsupported dtype", i);
+      return ALG_EINVAL;
+    }
+  }
+  if (numel == 0) return ALG_OK;
+  int64_t want = (numel + 255) / 256;
+  const unsigned grid = (unsigned)(want > 4096 ? 4096 : want);
+  if (out_dtype == ALG_F32)
+    hipLaunchKernelGGL(lincomb_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, t, (float*)out, numel);
+  else
+    hipLaunchKernelGGL(lincomb_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, t, (bf16_t*)out, numel);
+  return check_launch("alg_lincomb");
+}

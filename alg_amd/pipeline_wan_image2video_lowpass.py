@@ -1,0 +1,326 @@
+"""Wan 2.1 image-to-video sampler with Adaptive Low-pass Guidance -- the denoising loop, MI355X-native.
+
+Drop-in for the loop of the reference's ``pipeline_wan_image2video_lowpass.WanImageToVideoPipeline``
+(SURVEY.md section 8 row a-5w): same class name, same ``__call__`` keyword arguments and defaults (wan:587-634),
+same ``check_inputs`` errors (wan:318-369), same output object with ``.frames``.
+
+Per step (wan:843-927) this sampler launches, all through the C ABI of ``libalg_hip.so``:
+    * ``prepare_lp`` (wan:472-560): the HIP low-pass filters over the 20-channel condition ``[mask4 | latent16]``,
+      once per *distinct* schedule strength (the reference re-filters every step);
+    * ``alg_concat_cast``: the 2-/3-pass CFG batch ``[latents | condition_p]`` in the transformer dtype in ONE
+      launch (reference: cat([latents]*n), cat(dim=0) of conditions, cat(dim=1), .to(dtype));
+    * the transformer -- an injected object with the diffusers Wan signature (the Wan DiT itself is SURVEY section 8
+      row a-6w, "next");
+    * ``alg_cfg_combine``: ``u0 + g (text - u)`` in the prediction dtype (wan:919-924);
+    * ``UniPCMultistepScheduler.step`` (alg_amd.schedulers): ``alg_lincomb`` + ``alg_unipc_update`` launches.
+
+Once-per-video components outside the hot path (UMT5 text encoder, CLIP image encoder, Wan VAE) are injected
+duck-typed objects; without them pass ``prompt_embeds`` / ``negative_prompt_embeds`` / ``image_embeds`` (reference
+kwargs), the pre-encoded ``image_condition`` (extension kwarg: the ``[B, 20, F, h, w]`` tensor wan:372-468 builds)
+and ``output_type="latent"``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Union
+
+import torch
+
+from . import _lib, lp_utils
+from .schedulers import UniPCMultistepScheduler
+
+
+@dataclass
+class WanPipelineOutput:
+    frames: Any
+
+
+def assemble_channel_concat(latents, cond_groups, out_dtype):
+    """[n_pass * B, C_lat + C_cond, F, H, W] = for pass p, sample b: [latents[b] | cond_groups[p][b]] (wan:877-889)."""
+    B, C, F, H, W = latents.shape
+    Cc = cond_groups[0].shape[1]
+    src0 = [latents[b] for _ in cond_groups for b in range(B)]
+    src1 = [g[b] for g in cond_groups for b in range(B)]
+    R = F * H * W
+    out = _lib.concat_cast(src0, src1, 1, C, Cc, R, C * R, Cc * R, 0, out_dtype)
+    return out.view(len(src0), C + Cc, F, H, W)
+
+
+class WanImageToVideoPipeline:
+    _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]
+
+    def __init__(self, tokenizer=None, text_encoder=None, image_encoder=None, image_processor=None, transformer=None,
+                 vae=None, scheduler=None):
+        self.tokenizer, self.text_encoder = tokenizer, text_encoder
+        self.image_encoder, self.image_processor = image_encoder, image_processor
+        self.transformer, self.vae, self.scheduler = transformer, vae, scheduler
+        self.vae_scale_factor_temporal = 2 ** sum(vae.temperal_downsample) if vae is not None else 4
+        self.vae_scale_factor_spatial = 2 ** len(vae.temperal_downsample) if vae is not None else 8
+        self._device = torch.device("cpu")
+        self._guidance_scale = None
+        self._num_timesteps = None
+        self._current_timestep = None
+        self._attention_kwargs = None
+        self._interrupt = False
+        self._lp_cache = {}
+
+    def to(self, device=None, *args, **kwargs):
+        if device is not None:
+            self._device = torch.device(device)
+        return self
+
+    @property
+    def _execution_device(self):
+        return self._device
+
+    def maybe_free_model_hooks(self):
+        pass
+
+    guidance_scale = property(lambda self: self._guidance_scale)
+    do_classifier_free_guidance = property(lambda self: self._guidance_scale > 1)
+    num_timesteps = property(lambda self: self._num_timesteps)
+    current_timestep = property(lambda self: self._current_timestep)
+    interrupt = property(lambda self: self._interrupt)
+    attention_kwargs = property(lambda self: self._attention_kwargs)
+
+    def check_inputs(self, prompt, negative_prompt, image, height, width, prompt_embeds=None,
+                     negative_prompt_embeds=None, image_embeds=None, callback_on_step_end_tensor_inputs=None):
+        """wan:318-369."""
+        if image is not None and image_embeds is not None:
+            raise ValueError(
+                f"Cannot forward both `image`: {image} and `image_embeds`: {image_embeds}. Please make sure to"
+                " only forward one of the two.")
+        if image is None and image_embeds is None:
+            raise ValueError(
+                "Provide either `image` or `prompt_embeds`. Cannot leave both `image` and `image_embeds` undefined.")
+        if image is not None and not isinstance(image, torch.Tensor) and not hasattr(image, "convert"):
+            raise ValueError(f"`image` has to be of type `torch.Tensor` or `PIL.Image.Image` but is {type(image)}")
+        if height % 16 != 0 or width % 16 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 16 but are {height} and {width}.")
+        if callback_on_step_end_tensor_inputs is not None and not all(
+                k in self._callback_tensor_inputs for k in callback_on_step_end_tensor_inputs):
+            bad = [k for k in callback_on_step_end_tensor_inputs if k not in self._callback_tensor_inputs]
+            raise ValueError(
+                f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}, but found {bad}")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError(
+                f"Cannot forward both `prompt`: {prompt} and `prompt_embeds`: {prompt_embeds}. Please make sure to"
+                " only forward one of the two.")
+        elif negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError(
+                f"Cannot forward both `negative_prompt`: {negative_prompt} and `negative_prompt_embeds`: "
+                f"{negative_prompt_embeds}. Please make sure to only forward one of the two.")
+        elif prompt is None and prompt_embeds is None:
+            raise ValueError(
+                "Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        elif prompt is not None and (not isinstance(prompt, str) and not isinstance(prompt, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        elif negative_prompt is not None and (
+                not isinstance(negative_prompt, str) and not isinstance(negative_prompt, list)):
+            raise ValueError(f"`negative_prompt` has to be of type `str` or `list` but is {type(negative_prompt)}")
+
+    def encode_prompt(self, prompt, negative_prompt=None, do_classifier_free_guidance=True, num_videos_per_prompt=1,
+                      prompt_embeds=None, negative_prompt_embeds=None, max_sequence_length=226, device=None):
+        if (prompt_embeds is None or (do_classifier_free_guidance and negative_prompt_embeds is None)):
+            if self.text_encoder is None:
+                raise _lib.AlgHipError("no text encoder is attached: pass prompt_embeds / negative_prompt_embeds")
+            raise NotImplementedError("UMT5 prompt encoding is outside the hot path (SURVEY section 8 row f-1)")
+        return prompt_embeds.to(device), (None if negative_prompt_embeds is None else negative_prompt_embeds.to(device))
+
+    def prepare_latents(self, image_condition, batch_size, num_channels_latents=16, height=480, width=832,
+                        num_frames=81, dtype=None, device=None, generator=None, latents=None):
+        """wan:372-468 with the VAE-encoded condition supplied: noise latents + shape checks."""
+        f_lat = (num_frames - 1) // self.vae_scale_factor_temporal + 1
+        shape = (batch_size, num_channels_latents, f_lat, height // self.vae_scale_factor_spatial,
+                 width // self.vae_scale_factor_spatial)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(
+                f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            if isinstance(generator, list):
+                latents = torch.cat([torch.randn((1,) + shape[1:], generator=g, device=g.device, dtype=dtype)
+                                     for g in generator]).to(device)
+            else:
+                gdev = generator.device if generator is not None else device
+                latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+        else:
+            latents = latents.to(device=device, dtype=dtype)
+        want = (batch_size, self.vae_scale_factor_temporal + num_channels_latents) + shape[2:]
+        if tuple(image_condition.shape) != want:
+            raise ValueError(f"`image_condition` must have shape {want}, got {tuple(image_condition.shape)}")
+        return latents.contiguous(), image_condition.to(device=device, dtype=dtype).contiguous()
+
+    def prepare_lp(self, lp_filter_type, lp_blur_sigma, lp_blur_kernel_size, lp_resize_factor, generator, num_frames,
+                   use_low_pass_guidance, lp_filter_in_latent, orig_image_latents, orig_image_tensor):
+        """wan:472-560, latent branch: the filter runs per (H, W) plane over the whole ``[mask | latent]`` condition;
+        the reference's temporal-patch padding looks at dim 1 (the 20 channels) and prepends leading channels when
+        that is not a multiple of patch_size[0] -- reproduced as is."""
+        if not use_low_pass_guidance:
+            return None
+        if not lp_filter_in_latent:
+            raise _lib.AlgHipError("lp_filter_in_latent=False re-encodes the filtered image every step and needs the "
+                                   "Wan VAE (SURVEY section 8 row f-1, not built)")
+        out = lp_utils.apply_low_pass_filter(orig_image_latents, lp_filter_type, lp_blur_sigma, lp_blur_kernel_size,
+                                             lp_resize_factor)
+        patch = getattr(getattr(self.transformer, "config", None), "patch_size", None)
+        if patch is not None:
+            rem = out.size(1) % patch[0]
+            if rem != 0:
+                n_pre = min(patch[0] - rem, out.shape[1])
+                out = torch.cat([out[:, :n_pre], out], dim=1)
+        return out.to(dtype=orig_image_latents.dtype)
+
+    @torch.no_grad()
+    def __call__(
+        self,
+        image=None,
+        prompt: Union[str, List[str]] = None,
+        negative_prompt: Union[str, List[str]] = None,
+        height: int = 480,
+        width: int = 832,
+        num_frames: int = 81,
+        num_inference_steps: int = 50,
+        guidance_scale: float = 5.0,
+        num_videos_per_prompt: Optional[int] = 1,
+        generator=None,
+        latents: Optional[torch.Tensor] = None,
+        prompt_embeds: Optional[torch.Tensor] = None,
+        negative_prompt_embeds: Optional[torch.Tensor] = None,
+        image_embeds: Optional[torch.Tensor] = None,
+        last_image: Optional[torch.Tensor] = None,
+        output_type: Optional[str] = "np",
+        return_dict: bool = True,
+        attention_kwargs: Optional[Dict[str, Any]] = None,
+        callback_on_step_end: Optional[Callable] = None,
+        callback_on_step_end_tensor_inputs: List[str] = ["latents"],
+        max_sequence_length: int = 512,
+        use_low_pass_guidance: bool = False,
+        lp_filter_type: str = "none",
+        lp_filter_in_latent: bool = False,
+        lp_blur_sigma: float = 15.0,
+        lp_blur_kernel_size: float = 0.02734375,
+        lp_resize_factor: float = 0.25,
+        lp_strength_schedule_type: str = "none",
+        schedule_blur_kernel_size: bool = False,
+        schedule_interval_start_time: float = 0.0,
+        schedule_interval_end_time: float = 0.05,
+        schedule_linear_start_weight: float = 1.0,
+        schedule_linear_end_weight: float = 0.0,
+        schedule_linear_end_time: float = 0.5,
+        schedule_exp_decay_rate: float = 10.0,
+        # ---- extensions (not in the reference signature) ----
+        image_condition: Optional[torch.Tensor] = None,
+        step_trace: Optional[list] = None,
+    ):
+        self.check_inputs(prompt, negative_prompt, image, height, width, prompt_embeds, negative_prompt_embeds,
+                          image_embeds, callback_on_step_end_tensor_inputs)
+        if num_frames % self.vae_scale_factor_temporal != 1:  # wan:764-769
+            num_frames = num_frames // self.vae_scale_factor_temporal * self.vae_scale_factor_temporal + 1
+        num_frames = max(num_frames, 1)
+        self._guidance_scale = guidance_scale
+        self._attention_kwargs = attention_kwargs
+        self._current_timestep = None
+        self._interrupt = False
+        self._lp_cache = {}
+        device = self._execution_device
+        if device.type != "cuda":
+            raise _lib.AlgHipError("the ALG sampler's hot path is HIP-only: move the pipeline to a GPU "
+                                   "(`pipe.to('cuda')`); there is no CPU fallback")
+        if image_condition is None:
+            raise _lib.AlgHipError("the Wan VAE / CLIP encoders are not built (SURVEY section 8 row f-1): pass the "
+                                   "pre-encoded `image_condition` [B, 20, F, h, w] and `image_embeds`")
+        if not isinstance(self.scheduler, UniPCMultistepScheduler):
+            raise TypeError("this sampler drives alg_amd.schedulers.UniPCMultistepScheduler (HIP step)")
+
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        do_cfg = self.do_classifier_free_guidance
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(
+            prompt, negative_prompt, do_cfg, num_videos_per_prompt, prompt_embeds, negative_prompt_embeds,
+            max_sequence_length, device)
+        tdtype = self.transformer.dtype
+        prompt_embeds = prompt_embeds.to(tdtype)
+        if negative_prompt_embeds is not None:
+            negative_prompt_embeds = negative_prompt_embeds.to(tdtype)
+        image_embeds = image_embeds.to(device).repeat(batch_size, 1, 1).to(tdtype)  # wan:811-812
+
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        timesteps = self.scheduler.timesteps
+        self._num_timesteps = len(timesteps)
+        z_dim = image_condition.shape[1] - self.vae_scale_factor_temporal
+        latents, condition = self.prepare_latents(image_condition, batch_size * num_videos_per_prompt, z_dim, height,
+                                                  width, num_frames, torch.float32, device, generator, latents)
+
+        for i, t in enumerate(timesteps):
+            if self._interrupt:
+                continue
+            self._current_timestep = t
+            strength = None
+            if do_cfg and use_low_pass_guidance:
+                strength = lp_utils.get_lp_strength(
+                    step_index=i, total_steps=num_inference_steps,
+                    lp_strength_schedule_type=lp_strength_schedule_type,
+                    schedule_interval_start_time=schedule_interval_start_time,
+                    schedule_interval_end_time=schedule_interval_end_time,
+                    schedule_linear_start_weight=schedule_linear_start_weight,
+                    schedule_linear_end_weight=schedule_linear_end_weight,
+                    schedule_linear_end_time=schedule_linear_end_time,
+                    schedule_exp_decay_rate=schedule_exp_decay_rate)
+                sigma_i = lp_blur_sigma * strength
+                ksize_i = lp_blur_kernel_size * strength if schedule_blur_kernel_size else lp_blur_kernel_size
+                factor_i = 1.0 - (1.0 - lp_resize_factor) * strength
+                key = (lp_filter_type, sigma_i, ksize_i, type(ksize_i), factor_i)
+                lp_cond = self._lp_cache.get(key) if lp_filter_in_latent else None
+                if lp_cond is None:  # the reference filters every step, also when the result goes unused (wan:866)
+                    lp_cond = self.prepare_lp(lp_filter_type, sigma_i, ksize_i, factor_i, generator, num_frames,
+                                              use_low_pass_guidance, lp_filter_in_latent, condition, image)
+                    self._lp_cache[key] = lp_cond
+                if strength == 0.0:  # wan:879 equivalent to vanilla
+                    groups, embeds = [condition, condition], [negative_prompt_embeds, prompt_embeds]
+                else:
+                    groups = [condition, lp_cond, lp_cond]
+                    embeds = [negative_prompt_embeds, negative_prompt_embeds, prompt_embeds]
+            elif do_cfg:
+                groups, embeds = [condition, condition], [negative_prompt_embeds, prompt_embeds]
+            else:
+                # reference quirk (wan:843-898): without CFG no branch assigns `latent_model_input`
+                raise UnboundLocalError("local variable 'latent_model_input' referenced before assignment "
+                                        "(the Wan ALG loop needs guidance_scale > 1)")
+            latent_model_input = assemble_channel_concat(latents, groups, tdtype)
+            n = latent_model_input.shape[0]
+            timestep = t.expand(n).to(device)
+            noise_pred = self.transformer(
+                hidden_states=latent_model_input, timestep=timestep,
+                encoder_hidden_states=torch.cat(embeds, dim=0),
+                encoder_hidden_states_image=image_embeds.repeat(n, 1, 1) if image_embeds.shape[0] != n else image_embeds,
+                attention_kwargs=attention_kwargs, return_dict=False)[0]
+            # wan:919-924 keys the 3-chunk combine on shape[0] == 3, so the reference's 3-pass step only works for one
+            # video per call (a [3B, ...] prediction would be chunked in two and fail in the scheduler)
+            n_pass = 3 if noise_pred.shape[0] == 3 else 2
+            if n_pass != len(groups):
+                raise ValueError("the Wan ALG loop (3-pass CFG keyed on shape[0] == 3, wan:919) supports one video "
+                                 f"per call; got a batch of {latents.shape[0]}")
+            noise_pred = _lib.cfg_combine(noise_pred.contiguous(), n_pass, guidance_scale)
+            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            if step_trace is not None:
+                step_trace.append((strength, len(groups), n))
+            if callback_on_step_end is not None:
+                pool = {"latents": latents, "prompt_embeds": prompt_embeds,
+                        "negative_prompt_embeds": negative_prompt_embeds}
+                outs = callback_on_step_end(self, i, t, {k: pool[k] for k in callback_on_step_end_tensor_inputs}) or {}
+                latents = outs.pop("latents", latents).contiguous()
+                prompt_embeds = outs.pop("prompt_embeds", prompt_embeds)
+                negative_prompt_embeds = outs.pop("negative_prompt_embeds", negative_prompt_embeds)
+        self._current_timestep = None
+
+        if output_type != "latent":
+            raise _lib.AlgHipError("no Wan VAE is attached to this pipeline: use output_type='latent'")
+        self.maybe_free_model_hooks()
+        if not return_dict:
+            return (latents,)
+        return WanPipelineOutput(frames=latents)

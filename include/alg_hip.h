@@ -65,6 +65,35 @@ int alg_cfg_ddim_step(const void* pred, int pred_dtype, void* latents, int lat_d
                       float guidance_scale, float sqrt_alpha_t, float sqrt_beta_t, float coef_a, float coef_b,
                       void* stream);
 
+/* wan:919-924, hy:1254-1261  CFG combine in the prediction dtype (no .float()): out = u0 + g*(text - u), every
+ * intermediate rounded to `dtype`.  pred [n_pass, numel] (n_pass 2 or 3), out [numel]. */
+int alg_cfg_combine(const void* pred, void* out, int dtype, int n_pass, int64_t numel, float guidance_scale,
+                    void* stream);
+
+/* out = sum_i coefs[i] * xs[i]  (1..4 terms, each ALG_F32 or ALG_BF16).  Rounding follows torch eager: every product
+ * is rounded to its tensor's dtype, the running sum is fp32, left to right, unfused; cast to out_dtype at the end.
+ * Covers FlowMatchEulerDiscreteScheduler.step (hy:1265-1269: sample + (sigma_next - sigma) * v) and UniPC's
+ * convert_model_output (wan:927: sample - sigma * v).
+ * xs, coefs, dtypes are HOST arrays; the pointers inside xs are device pointers. */
+int alg_lincomb(const void* const* xs, const float* coefs, const int* dtypes, int n_terms, void* out, int out_dtype,
+                int64_t numel, void* stream);
+
+/* wan:877-889, hy:1146-1160, 1230  CFG batch assembly in one launch (replaces cat([latents]*n) + cat(dim) + .to()):
+ *   out[i, o, a, r] = a < A0 ? src0[i][o*s0_ostride + a*R + r] : src1[i][o*s1_ostride + (a1_off + a - A0)*R + r]
+ * for i < n (<= 16), o < O, a < A0 + A1, r < R, cast to out_dtype.  src0 / src1 are HOST arrays of n device pointers
+ * (one per output sample -- repeat a pointer to duplicate a sample across CFG passes).
+ *   Wan    (channel concat [latents | condition]):      O=1, A0=16, A1=20, R=F*H*W
+ *   Hunyuan (first-frame token replace [cond | lat 1:]): O=C, A0=cond frames, A1=F-1, R=H*W, a1_off=1 */
+int alg_concat_cast(const void* const* src0, int dtype0, const void* const* src1, int dtype1, int n, int64_t O,
+                    int64_t A0, int64_t A1, int64_t R, int64_t s0_ostride, int64_t s1_ostride, int64_t a1_off,
+                    void* out, int out_dtype, void* stream);
+
+/* wan:927  UniPCMultistepScheduler (bh1/bh2, predict_x0, solver_order <= 2) predictor or corrector update on fp32:
+ *   out = (r*x - c*m0) - k * ( [m1] rho0*((m1 - m0)/rk)  +  [m_new] rho_new*(m_new - m0) )
+ * m1 / m_new may be NULL (order-1 predictor: both NULL; order-1 corrector: m1 NULL). */
+int alg_unipc_update(const float* x, const float* m0, const float* m1, const float* m_new, float* out,
+                     int64_t numel, float r, float c, float k, float rk, float rho0, float rho_new, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Video-DiT forward building blocks (cog:1082-1090 self.transformer(...); the arithmetic is
  * diffusers' CogVideoXTransformer3DModel -- see DESIGN.md).  All activations bf16, fp32 accumulate.

@@ -106,3 +106,126 @@ def alg_denoise_loop(transformer, scheduler, latents, image_latents, prompt_embe
         if trace is not None:
             trace.append((s, two_pass, x.shape[0]))
     return latents
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Wan 2.1 and HunyuanVideo ALG loops (pipeline_wan_image2video_lowpass.py:843-927,
+# pipeline_hunyuan_video_image2video_lowpass.py:1127-1270) -- torch-CPU restatements with the DiT injected.
+# bf16 elementwise ops on CPU round after every op exactly as on the GPU; the only CPU/GPU difference is a 0-dim
+# *tensor* scalar times a bf16 tensor (CPU casts the scalar to bf16 first), which the scheduler oracles avoid by
+# receiving python floats where the pipelines pass python floats (guidance scales).
+# ---------------------------------------------------------------------------------------------------------------------
+def _schedule(i, n, kw):
+    s = lp_oracle.get_lp_strength(i, n, kw.get("lp_strength_schedule_type", "none"),
+                                  kw.get("schedule_interval_start_time", 0.0),
+                                  kw.get("schedule_interval_end_time", 0.05),
+                                  kw.get("schedule_linear_start_weight", 1.0),
+                                  kw.get("schedule_linear_end_weight", 0.0), kw.get("schedule_linear_end_time", 0.5),
+                                  kw.get("schedule_exp_decay_rate", 10.0))
+    sigma, ksize, factor = lp_oracle.modulated_params(s, kw.get("lp_blur_sigma", 15.0),
+                                                      kw.get("lp_blur_kernel_size", 0.02734375),
+                                                      kw.get("lp_resize_factor", 0.25),
+                                                      kw.get("schedule_blur_kernel_size", False))
+    return s, sigma, ksize, factor
+
+
+def wan_denoise_loop(transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds, image_embeds,
+                     num_inference_steps, guidance_scale=5.0, use_low_pass_guidance=True, transformer_dtype=torch.bfloat16,
+                     patch_t=1, trace=None, **kw):
+    """wan:815-927.  latents fp32 [B,16,F,h,w]; condition fp32 [B,20,F,h,w].  ``transformer(x, timestep, ehs,
+    ehs_image)`` -> prediction in transformer_dtype.  ``scheduler``: oracle.sched_oracle.UniPCOracle."""
+    scheduler.set_timesteps(num_inference_steps)
+    do_cfg = guidance_scale > 1
+    for i, t in enumerate(scheduler.timesteps):
+        s = None
+        if do_cfg and use_low_pass_guidance:
+            s, sigma, ksize, factor = _schedule(i, num_inference_steps, kw)
+            lp = apply_low_pass_filter_torch(condition, kw.get("lp_filter_type", "none"), sigma, ksize, factor)
+            rem = lp.size(1) % patch_t                        # wan:549-556 (dim 1 is the channel dim here)
+            if rem != 0:
+                lp = torch.cat([lp[:, :min(patch_t - rem, lp.shape[1])], lp], dim=1)
+            lp = lp.to(condition.dtype)
+            if s == 0.0:
+                x = torch.cat([torch.cat([latents] * 2), torch.cat([condition, condition], dim=0)], dim=1)
+                ehs = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+            else:
+                x = torch.cat([torch.cat([latents] * 3), torch.cat([condition, lp, lp], dim=0)], dim=1)
+                ehs = torch.cat([negative_prompt_embeds, negative_prompt_embeds, prompt_embeds], dim=0)
+        elif do_cfg:
+            x = torch.cat([torch.cat([latents] * 2), torch.cat([condition, condition], dim=0)], dim=1)
+            ehs = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+        else:
+            raise UnboundLocalError("latent_model_input")
+        x = x.to(transformer_dtype)
+        ie = image_embeds.repeat(x.shape[0], 1, 1) if image_embeds.shape[0] != x.shape[0] else image_embeds
+        pred = transformer(x, t.expand(x.shape[0]), ehs, ie)
+        if pred.shape[0] == 3:
+            u0, u, tx = pred.chunk(3)
+            pred = u0 + guidance_scale * (tx - u)
+        else:
+            u, tx = pred.chunk(2)
+            pred = u + guidance_scale * (tx - u)
+        latents = scheduler.step(pred, t, latents)
+        if trace is not None:
+            trace.append((s, 3 if x.shape[0] == 3 * latents.shape[0] else 2, x.shape[0]))
+    return latents
+
+
+def hunyuan_denoise_loop(transformer, scheduler, latents, image_latents, pos, neg, num_inference_steps,
+                         true_cfg_scale=1.0, guidance_scale=1.0, use_low_pass_guidance=False, lp_on_noisy_latent=False,
+                         image_condition_type="token_replace", guidance_embeds=True, transformer_dtype=torch.bfloat16,
+                         patch=2, sigmas=None, trace=None, **kw):
+    """hy:1111-1270.  ``pos`` / ``neg``: (embeds, pooled, mask) triples (neg may be None).  ``transformer(x, timestep,
+    ehs, mask, pooled, guidance)``.  ``scheduler``: oracle.sched_oracle.FlowMatchEulerOracle."""
+    do_true_cfg = true_cfg_scale > 1 and neg is not None
+    sig = np.linspace(1.0, 0.0, num_inference_steps + 1)[:-1] if sigmas is None else sigmas
+    scheduler.set_timesteps(sigmas=sig)
+    n_steps = len(scheduler.timesteps)
+    guidance = None
+    if guidance_embeds:
+        guidance = torch.tensor([guidance_scale] * latents.shape[0], dtype=transformer_dtype) * 1000.0
+
+    def low_passed(i):
+        s, sigma, ksize, factor = _schedule(i, n_steps, kw)
+        lp = apply_low_pass_filter_torch(image_latents, kw.get("lp_filter_type", "none"), sigma, ksize, factor)
+        rem = lp.size(1) % patch                                # hy:780-787 (dim 1 is the channel dim here)
+        if rem != 0:
+            lp = torch.cat([lp[:, :min(patch - rem, lp.shape[1])], lp], dim=1)
+        return s, lp.to(image_latents.dtype)
+
+    for i, t in enumerate(scheduler.timesteps):
+        s = None
+        if do_true_cfg and use_low_pass_guidance:
+            s, lp = low_passed(i)
+            if s == 0.0 or lp_on_noisy_latent:
+                conds = [image_latents, image_latents]
+            else:
+                conds = [image_latents, lp, lp]
+        elif do_true_cfg:
+            conds = [image_latents, image_latents]
+        elif not use_low_pass_guidance:
+            conds = [image_latents]
+        else:
+            s, lp = low_passed(i)
+            conds = [lp]
+        n = len(conds)
+        x = torch.cat([torch.cat(conds, dim=0), torch.cat([latents] * n)[:, :, 1:]], dim=2).to(transformer_dtype)
+        if n == 1:
+            ehs, pooled, mask = pos
+        else:
+            ehs, pooled, mask = (torch.cat([a] * (n - 1) + [b], dim=0) for a, b in zip(neg, pos))
+        pred = transformer(x, t.expand(x.shape[0]).to(transformer_dtype), ehs, mask, pooled, guidance)
+        if pred.shape[0] == 3:
+            u0, u, tx = pred.chunk(3)
+            pred = u0 + true_cfg_scale * (tx - u)
+        elif pred.shape[0] == 2:
+            u, tx = pred.chunk(2)
+            pred = u + true_cfg_scale * (tx - u)
+        if image_condition_type == "latent_concat":
+            latents = scheduler.step(pred, t, latents)
+        else:
+            latents = scheduler.step(pred[:, :, 1:], t, latents[:, :, 1:])
+            latents = torch.cat([image_latents, latents], dim=2)
+        if trace is not None:
+            trace.append((s, n, x.shape[0]))
+    return latents

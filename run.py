@@ -42,8 +42,10 @@ def main(args):
                                                                  cache_dir=args.model_cache_dir)
     elif "Wan" in model_path or "HunyuanVideo" in model_path:
         raise NotImplementedError(
-            "the Wan / HunyuanVideo DiT forwards are the next rows of the build (SURVEY.md section 8f-2); their ALG "
-            "filters, strength schedule and resolution buckets are available in alg_amd.lp_utils")
+            "the Wan / HunyuanVideo DiT forwards are the next rows of the build (SURVEY.md section 8f-2).  Their ALG "
+            "sampler loops are built (alg_amd.WanImageToVideoPipeline / HunyuanVideoImageToVideoPipeline with the HIP "
+            "filters, batch assembly, CFG combine and UniPC / flow-match Euler steps) and take any transformer object "
+            "with the diffusers call signature")
     else:
         raise ValueError(f"unknown model family in model.path: {model_path}")
     pipe.to(device)
