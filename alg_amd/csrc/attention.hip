@@ -84,7 +84,12 @@ __device__ __forceinline__ void mask_tail(f32x16 (&s)[2], int kv0, int S, int h2
 
 // online softmax of one tile's scores -> bf16 P fragments; updates m, l and rescales O when needed
 // NOEXP (measurement only, wrong results): 1 = half of the exp2 replaced by the bare fma, 2 = all of them
-template <bool SKIP, int NOEXP = 0>
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+template <bool B>
+struct BoolC { static constexpr bool value = B; };
+
+// PK: the per-score fma and the row sums are written on float2 so they lower to v_pk_fma_f32 / v_pk_add_f32
+template <bool SKIP, int NOEXP = 0, bool PK = false>
 __device__ __forceinline__ void softmax_tile(const f32x16 (&s)[2], float c, float& m_run, float& l_run,
                                              f32x16 (&o_acc)[2], bf16x8 (&pf)[4]) {
   float mt = fmaxf(s[0][0], s[1][0]);
@@ -103,6 +108,27 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&s)[2], float c, floa
       for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
   }
   const float mc = m_run * c;
+  if (PK) {
+    const f32x2p c2 = {c, c}, mc2 = {mc, mc};
+    f32x2p ps2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2p sv = {s[sub][8 * g + 2 * j], s[sub][8 * g + 2 * j + 1]};
+          const f32x2p x = __builtin_elementwise_fma(sv, c2, -mc2);
+          const f32x2p pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+          ps2 += pv;
+          pk.u[j] = pack_bf2(pv.x, pv.y);
+        }
+        pf[sub * 2 + g] = pk.v;
+      }
+    l_run += ps2.x + ps2.y;
+    return;
+  }
   float psum = 0.0f;
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub)
@@ -227,7 +253,96 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
   const int n_tiles = (S + KVB - 1) / KVB;
   const bool ragged = (S & (KVB - 1)) != 0;
 
-  if (VARIANT < 2 || VARIANT >= 10) {
+  if (VARIANT == 14) {
+    // Explicitly staged fragments.  hipcc's scheduler, squeezed to 128 VGPRs, sinks every ds_read_b128 next to the
+    // MFMA that consumes it (variant 1's PV phase is read / wait / mfma eight times over: ~13 exposed LDS round trips
+    // per tile).  Here the 8 K fragments are fetched in one batch, the first 4 V^T fragments are fetched BEFORE the
+    // softmax and the last 4 while the first 4 PV MFMAs run; sched_barrier fences keep that order; the half-wave max
+    // exchange is a v_permlane32_swap instead of an LDS bpermute; the ragged tail tile is peeled.
+    const int n_loop = ragged ? n_tiles - 1 : n_tiles;
+    stage_k(0, 0);
+    stage_v(0, 0);
+    auto tile = [&](int t, auto masked) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t + 1 < n_tiles) {
+        stage_k((t + 1) & 1, (t + 1) * KVB);
+        stage_v((t + 1) & 1, (t + 1) * KVB);
+      }
+      const char* Ks = k_ring + (t & 1) * ATT_TILE + f.row_off;
+      const char* Vs = v_ring + (t & 1) * ATT_TILE + f.row_off;
+      bf16x8 kf[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        kf[i] = *(const bf16x8*)(Ks + (i >> 2) * 4096 + (((2 * (i & 3) + f.h2) ^ f.sw) * 16));
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 s[2];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+          s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub * 4 + ks], qf[ks], s[sub], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 vf[8];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) vf[kk] = *(const bf16x8*)(Vs + (((2 * kk + f.h2) ^ f.sw) * 16));
+      __builtin_amdgcn_sched_barrier(0);
+      if (masked.value) mask_tail(s, t * KVB, S, h2);
+      // ---- online softmax (per-lane query; the two half-waves exchange the tile max through the VALU) ----
+      float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+      for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
+      {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+        mt = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+      }
+      if (__any(mt > m_run)) {
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+      }
+      const float mc = m_run * c;
+      const f32x2p c2 = {c, c}, mc2 = {mc, mc};
+      f32x2p ps2 = {0.0f, 0.0f};
+      bf16x8 pf[4];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x2p sv = {s[sub][8 * g + 2 * j], s[sub][8 * g + 2 * j + 1]};
+            const f32x2p x = __builtin_elementwise_fma(sv, c2, -mc2);
+            const f32x2p pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+            ps2 += pv;
+            pk.u[j] = pack_bf2(pv.x, pv.y);
+          }
+          pf[sub * 2 + g] = pk.v;
+        }
+      l_run += ps2.x + ps2.y;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) vf[4 + kk] = *(const bf16x8*)(Vs + 4096 + (((2 * kk + f.h2) ^ f.sw) * 16));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk], pf[kk], o_acc[0], 0, 0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[4 + kk], pf[kk], o_acc[1], 0, 0, 0);
+    };
+    for (int t = 0; t < n_loop; ++t) tile(t, BoolC<false>{});
+    if (ragged) tile(n_tiles - 1, BoolC<true>{});
+  } else if (VARIANT < 2 || VARIANT >= 10) {
     // VARIANT >= 16 (measurement only, wrong results, NOT reachable from the C ABI -- instantiate by hand): ablation
     // bits 1 no DMA after tile 0, 2 no LDS fragment reads, 4 no exp2, 8 no per-tile wait + barrier.  Round-1 readings
     // at the C2 shape (ms per 2-sample launch): full 8.75 | no DMA 7.62 | no LDS reads 6.76 | neither 6.10 |
@@ -236,7 +351,10 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
     constexpr int NOEXP = VARIANT == 10 ? 1 : (VARIANT == 11 || (ABL & 4)) ? 2 : 0;
     stage_k(0, 0);
     stage_v(0, 0);
-    for (int t = 0; t < n_tiles; ++t) {
+    constexpr bool PEEL = VARIANT == 13;  // the ragged last tile runs in its own copy of the body: hipcc otherwise
+                                          // if-converts the tail mask into 32 v_cndmask on EVERY tile
+    const int n_loop = (PEEL && ragged) ? n_tiles - 1 : n_tiles;
+    for (int t = 0; t < n_loop; ++t) {
       if (!(ABL & 8) || t == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -247,10 +365,21 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
       }
       f32x16 s[2];
       qk_tile<(ABL & 2) != 0>(k_ring + (t & 1) * ATT_TILE, qf, f, s);
-      if (ragged && t == n_tiles - 1) mask_tail(s, t * KVB, S, h2);
+      if (!PEEL && ragged && t == n_tiles - 1) mask_tail(s, t * KVB, S, h2);
       bf16x8 pf[4];
-      softmax_tile<(VARIANT >= 1), NOEXP>(s, c, m_run, l_run, o_acc, pf);
+      softmax_tile<(VARIANT >= 1), NOEXP, PEEL>(s, c, m_run, l_run, o_acc, pf);
       pv_tile<(ABL & 2) != 0>(v_ring + (t & 1) * ATT_TILE, pf, f, o_acc);
+    }
+    if (PEEL && ragged) {
+      const int t = n_tiles - 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      f32x16 s[2];
+      qk_tile(k_ring + (t & 1) * ATT_TILE, qf, f, s);
+      mask_tail(s, t * KVB, S, h2);
+      bf16x8 pf[4];
+      softmax_tile<true, 0, true>(s, c, m_run, l_run, o_acc, pf);
+      pv_tile(v_ring + (t & 1) * ATT_TILE, pf, f, o_acc);
     }
   } else {
     // K one tile ahead of V: iteration t computes S(t+1) = K(t+1) Q^T, softmax(S(t)), O += V(t)^T P(t)
@@ -744,11 +873,215 @@ __global__ __launch_bounds__(512, 4) void flash_attn_d64_kv128_kernel(const Attn
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant 15/16 "duo": two 32-query streams per wave, staggered so one stream's MFMAs issue BETWEEN the other
+// stream's softmax instructions.  Measured on the box (scripts/micro/*.hip): a wave issues in order, so a cluster of
+// 8 MFMAs holds the wave for 8 x 32 cycles and the VALU work behind it cannot start; across waves the SIMD overlaps
+// an MFMA phase with a VALU phase only partially (4 waves alternating 16 MFMA / 64 v_exp: 61 % matrix-pipe busy), while
+// one wave that interleaves them finely (1 MFMA : 2 v_exp, or 1 : 7 v_fma) keeps the pipe 86-98 % busy.  Per tile:
+//     R1  S_A = K Q_A^T                          (8 MFMA)
+//     R2  S_B = K Q_B^T   ||  softmax(S_A) -> P_A (8 MFMA interleaved with ~125 VALU, sched_group_barrier)
+//     R3  O_A += V^T P_A  ||  softmax(S_B) -> P_B
+//     R4  O_B += V^T P_B
+// Both streams share every K / V^T fragment read (half the LDS traffic per MFMA) and the workgroup stages K/V once
+// per NW*64 queries.  ~230 VGPRs -> 2 waves per SIMD.  The rescale is unconditional (a branch would split the
+// scheduling region); the ragged tail tile runs a masked, non-interleaved copy.
+// ---------------------------------------------------------------------------------------------------------------
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void flash_attn_d64_duo_kernel(const AttnP p) {
+  constexpr int ROUNDS = 8 / NW;
+  __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE];
+  char* const k_ring = smem;
+  char* const v_ring = smem + 2 * ATT_TILE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h2 = lane >> 5;
+
+  const int nbh = p.batch * p.heads;
+  int bh, qb;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int slot = idx / p.q_blocks;
+    qb = idx - slot * p.q_blocks;
+    bh = slot * 8 + xcd;
+    if (bh >= nbh) return;
+  }
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int S = p.S;
+  const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* K = p.k + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
+
+  int q_row[2];
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    q_row[g] = qb * (NW * 64) + wave * 64 + g * 32 + l31;
+    const bf16_t* qp = Q + (int64_t)min(q_row[g], S - 1) * p.q_rs + h2 * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[g][ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+
+  const int srow = tid >> 3;
+  const int sslot = (tid & 7) ^ ((tid >> 4) & 7);
+  const bf16_t* vt_src = VT + (int64_t)srow * p.vt_rs + sslot * 8;
+  auto stage = [&](int slot, int kv0) {
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+      const bf16_t* ks = K + (int64_t)min(kv0 + srow + i * NW * 8, S - 1) * p.q_rs + sslot * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + slot * ATT_TILE + (i * NW + wave) * 1024), 16, 0,
+                                       0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vt_src + (int64_t)i * NW * 8 * p.vt_rs + kv0),
+                                       (lptr_t)(v_ring + slot * ATT_TILE + (i * NW + wave) * 1024), 16, 0, 0);
+    }
+  };
+
+  const int row_off = l31 * 128, sw = (l31 >> 1) & 7;
+  f32x16 o_acc[2][2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o_acc[g][i][e] = 0.0f;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+  const float c = p.scale_log2;
+  const int n_tiles = (S + KVB - 1) / KVB;
+  const bool ragged = (S & (KVB - 1)) != 0;
+
+  // softmax of one stream's tile, branch-free: always rescales (alpha == 1 when the max did not grow)
+  auto softmax = [&](f32x16 (&s)[2], float& m, float& l, f32x16 (&o)[2], bf16x8 (&pf)[4]) {
+    float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
+    {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+      mt = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    const float m_new = fmaxf(m, mt);
+    const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
+    m = m_new;
+    l *= alpha;
+    o[0] *= alpha;
+    o[1] *= alpha;
+    const float mc = m_new * c;
+    const f32x2p c2 = {c, c}, mc2 = {mc, mc};
+    f32x2p ps2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2p sv = {s[sub][8 * g + 2 * j], s[sub][8 * g + 2 * j + 1]};
+          const f32x2p x = __builtin_elementwise_fma(sv, c2, -mc2);
+          const f32x2p pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+          ps2 += pv;
+          pk.u[j] = pack_bf2(pv.x, pv.y);
+        }
+        pf[sub * 2 + g] = pk.v;
+      }
+    l += ps2.x + ps2.y;
+  };
+  auto qk = [&](const bf16x8 (&kf)[8], const bf16x8 (&q)[4], f32x16 (&s)[2]) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[sub][e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub * 4 + ks], q[ks], s[sub], 0, 0, 0);
+  };
+  auto pv = [&](const bf16x8 (&vf)[8], const bf16x8 (&pf)[4], f32x16 (&o)[2]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt * 4 + kk], pf[kk], o[dt], 0, 0, 0);
+  };
+
+  stage(0, 0);
+  auto tile = [&](int t, auto masked) {
+    constexpr bool MASK = decltype(masked)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < n_tiles) stage((t + 1) & 1, (t + 1) * KVB);
+    const char* Ks = k_ring + (t & 1) * ATT_TILE + row_off;
+    const char* Vs = v_ring + (t & 1) * ATT_TILE + row_off;
+    bf16x8 kf[8], vf[8], pfa[4], pfb[4];
+    f32x16 sa[2], sb[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kf[i] = *(const bf16x8*)(Ks + (i >> 2) * 4096 + (((2 * (i & 3) + h2) ^ sw) * 16));
+    __builtin_amdgcn_sched_barrier(0);
+    // R1
+    qk(kf, qf[0], sa);
+    if (MASK) mask_tail(sa, t * KVB, S, h2);
+    __builtin_amdgcn_sched_barrier(0);
+    // R2: QK of stream B between the softmax instructions of stream A; the V^T fragments follow the last K use
+    qk(kf, qf[1], sb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vf[i] = *(const bf16x8*)(Vs + (i >> 2) * 4096 + (((2 * (i & 3) + h2) ^ sw) * 16));
+    softmax(sa, m_run[0], l_run[0], o_acc[0], pfa);
+    if (!MASK) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        SGB(0x008, 1);   // 1 MFMA
+        SGB(0x402, 14);  // 14 VALU / transcendental
+      }
+      SGB(0x100, 8);     // the 8 V^T fragment reads
+      SGB(0x402, 40);    // the rest of the softmax
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (MASK) mask_tail(sb, t * KVB, S, h2);
+    // R3: PV of stream A between the softmax instructions of stream B
+    pv(vf, pfa, o_acc[0]);
+    softmax(sb, m_run[1], l_run[1], o_acc[1], pfb);
+    if (!MASK) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        SGB(0x008, 1);
+        SGB(0x402, 14);
+      }
+      SGB(0x402, 40);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // R4
+    pv(vf, pfb, o_acc[1]);
+  };
+  const int n_loop = ragged ? n_tiles - 1 : n_tiles;
+  for (int t = 0; t < n_loop; ++t) tile(t, BoolC<false>{});
+  if (ragged) tile(n_tiles - 1, BoolC<true>{});
+
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const float l_tot = l_run[g] + __shfl_xor(l_run[g], 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row[g] < S) {
+      bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row[g] * p.o_rs + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          const int d = dt * 32 + 8 * gg + 4 * h2;
+          uint2 v;
+          v.x = pack_bf2(o_acc[g][dt][4 * gg] * inv, o_acc[g][dt][4 * gg + 1] * inv);
+          v.y = pack_bf2(o_acc[g][dt][4 * gg + 2] * inv, o_acc[g][dt][4 * gg + 3] * inv);
+          *(uint2*)(op + d) = v;
+        }
+    }
+  }
+}
+
 // default = the fastest measured variant; ALG_ATTN_VARIANT (read per call) overrides it for A/B runs and tests
 static int attn_variant() {
   const char* e = getenv("ALG_ATTN_VARIANT");
   const int v = e ? atoi(e) : 1;
-  return (v < 0 || v > 12 || v == 10 || v == 11) ? 1 : v;
+  return (v < 0 || v > 16 || v == 10 || v == 11) ? 1 : v;
 }
 
 }  // namespace alg
@@ -777,8 +1110,8 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
   p.batch = batch; p.heads = heads; p.S = S;
   int variant = attn_variant();
   if (variant >= 8 && !vt128) variant = 1;
-  const int nw = (variant == 5 || variant == 7) ? 4 : (variant == 12 ? 16 : 8);
-  const int q_per_wave = (variant == 6 || variant == 7) ? 64 : 32;
+  const int nw = (variant == 5 || variant == 7 || variant == 16) ? 4 : (variant == 12 ? 16 : 8);
+  const int q_per_wave = (variant == 6 || variant == 7 || variant == 15 || variant == 16) ? 64 : 32;
   p.q_blocks = (S + nw * q_per_wave - 1) / (nw * q_per_wave);
   p.q_bs = q_bstride; p.q_rs = q_rstride; p.vt_bs = vt_bstride; p.vt_rs = vt_rstride;
   p.o_bs = o_bstride; p.o_rs = o_rstride;
@@ -796,6 +1129,10 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
     case 6: hipLaunchKernelGGL(flash_attn_d64_q64_kernel<8>, g, blk, 0, s, p); break;
     case 7: hipLaunchKernelGGL(flash_attn_d64_q64_kernel<4>, g, blk, 0, s, p); break;
     case 12: hipLaunchKernelGGL((flash_attn_d64_kernel<1, 16>), g, blk, 0, s, p); break;
+    case 13: hipLaunchKernelGGL((flash_attn_d64_kernel<13, 8>), g, blk, 0, s, p); break;
+    case 14: hipLaunchKernelGGL((flash_attn_d64_kernel<14, 8>), g, blk, 0, s, p); break;
+    case 15: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<8>, g, blk, 0, s, p); break;
+    case 16: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<4>, g, blk, 0, s, p); break;
     case 8: hipLaunchKernelGGL(flash_attn_d64_kv128_kernel<false>, g, blk, 0, s, p); break;
     case 9: hipLaunchKernelGGL(flash_attn_d64_kv128_kernel<true>, g, blk, 0, s, p); break;
     default: hipLaunchKernelGGL(flash_attn_d64_lean_kernel<true>, g, blk, 0, s, p); break;

@@ -24,9 +24,11 @@
 namespace alg {
 
 constexpr int BM = 256, BN = 256;
-constexpr int GEMM_THREADS = 512;
 constexpr int GEMM_LDS = 128 * 1024;
 constexpr int GROUP_M = 8;
+
+template <int V>
+struct IntC { static constexpr int value = V; };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -52,11 +54,17 @@ __device__ __forceinline__ void unpack4(const uint2 v, float (&f)[4]) {
 
 // ACT: ALG_ACT_*; RES: residual (+ optional gate) epilogue; PIPE: staging pipeline (see header).  All compile-time
 // so the 128-accumulator epilogue stays fully unrolled with static register indexing.
-template <int ACT, bool RES, int PIPE>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_args p, int m_tiles, int n_tiles,
+template <int ACT, bool RES, int PIPE, int WNW = 4>
+__global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_args p, int m_tiles, int n_tiles,
                                                                  int group_m) {
-  constexpr int BK = PIPE ? 32 : 64;
-  constexpr int NSTAGE = PIPE ? 4 : 2;
+  constexpr int GEMM_THREADS = 2 * WNW * 64;  // 512 (8 waves, 128x64 each) or 256 (4 waves, 128x128 each)
+  constexpr int NT = BN / WNW / 32;           // 32-column MFMA tiles per wave: 2 or 4
+  static_assert(WNW == 4 || (WNW == 2 && (PIPE == 0 || PIPE == 5)), "the 4-wave layout is only built on the 2-stage ring");
+  static_assert(PIPE != 6 || WNW == 4, "the ping-pong schedule is an 8-wave schedule");
+  constexpr bool BK64 = PIPE == 0 || PIPE == 5 || PIPE == 6;
+  constexpr bool PP = PIPE == 6;  // ping-pong: a wave owns 2 x 64 rows (one piece per A half-tile) x 2 x 32 columns
+  constexpr int BK = BK64 ? 64 : 32;
+  constexpr int NSTAGE = BK64 ? 2 : 4;
   constexpr int ROW_BYTES = BK * 2;                // 64 or 128
   constexpr int SLOTS = ROW_BYTES / 16;            // 4 or 8 sixteen-byte slots per tile row
   constexpr int TILE_BYTES = BM * ROW_BYTES;       // one operand tile of one stage
@@ -69,7 +77,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WNW, wn = wave % WNW;
 
   // ---- workgroup -> (batch, m_tile, n_tile): XCD-contiguous, grouped along M ----
   int wg;
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
   // tile row r, logical slot s lives at physical slot s ^ swz(r); the thread that fills physical slot (tid % SLOTS)
   // of row r therefore fetches logical slot (tid % SLOTS) ^ swz(r).  swz(r) only depends on tid (see below).
   const int srow = tid / SLOTS;
-  const int sw_src = PIPE ? ((tid >> 4) & 3) : ((tid >> 4) & 7);   // PIPE1: (r >> 2) & 3, PIPE0: (r >> 1) & 7
+  const int sw_src = !BK64 ? ((tid >> 4) & 3) : ((tid >> 4) & 7);   // PIPE1: (r >> 2) & 3, PIPE0: (r >> 1) & 7
   const int sslot = (tid & (SLOTS - 1)) ^ sw_src;
   const bf16_t* a_src[LD_PER_OP];
   const bf16_t* b_src[LD_PER_OP];
@@ -114,10 +122,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
     char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < LD_PER_OP; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + kt * BK), (lptr_t)(base + (i * 512 + wave * 64) * 16), 16,
-                                       0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + kt * BK),
+                                       (lptr_t)(base + (i * GEMM_THREADS + wave * 64) * 16), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + kt * BK),
-                                       (lptr_t)(base + TILE_BYTES + (i * 512 + wave * 64) * 16), 16, 0, 0);
+                                       (lptr_t)(base + TILE_BYTES + (i * GEMM_THREADS + wave * 64) * 16), 16, 0, 0);
     }
   };
 
@@ -127,60 +135,64 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
     const int i = w >> 1;
     if (w & 1)
       __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + kt * BK),
-                                       (lptr_t)(base + TILE_BYTES + (i * 512 + wave * 64) * 16), 16, 0, 0);
+                                       (lptr_t)(base + TILE_BYTES + (i * GEMM_THREADS + wave * 64) * 16), 16, 0, 0);
     else
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + kt * BK), (lptr_t)(base + (i * 512 + wave * 64) * 16), 16,
-                                       0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + kt * BK),
+                                       (lptr_t)(base + (i * GEMM_THREADS + wave * 64) * 16), 16, 0, 0);
   };
 
   // ---- fragment read offsets ----
   const int l31 = lane & 31, h2 = lane >> 5;
-  const int sw = PIPE ? ((l31 >> 2) & 3) : ((l31 >> 1) & 7);
+  const int sw = !BK64 ? ((l31 >> 2) & 3) : ((l31 >> 1) & 7);
   const int a_row_off = (wm * 128 + l31) * ROW_BYTES;   // + mt*32*ROW_BYTES
-  const int b_row_off = (wn * 64 + l31) * ROW_BYTES;    // + nt*32*ROW_BYTES
+  const int b_row_off = (wn * (NT * 32) + l31) * ROW_BYTES;    // + nt*32*ROW_BYTES
+  // ping-pong mapping: m-tiles 0,1 sit in A half-tile 0 (block rows wm*64 ..), m-tiles 2,3 in half-tile 1 (128 + wm*64 ..);
+  // n-tile 0 in B half-tile 0 (block cols wn*32 ..), n-tile 1 in half-tile 1 (128 + wn*32 ..)
+  auto pp_a_row = [&](int mt) { return ((mt >> 1) * 128 + wm * 64 + (mt & 1) * 32 + l31) * ROW_BYTES; };
+  auto pp_b_row = [&](int nt) { return (nt * 128 + wn * 32 + l31) * ROW_BYTES; };
 
-  f32x16 acc[4][2];  // acc[mt][nt] holds the TRANSPOSED 32x32 tile: D[n][m]
+  f32x16 acc[4][NT];  // acc[mt][nt] holds the TRANSPOSED 32x32 tile: D[n][m]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
   // Fragments are double-buffered in registers: the 6 ds_read_b128 of k-step ks+1 are issued BEFORE the 8 MFMAs
   // of k-step ks (pinned with sched_barrier: hipcc otherwise sinks the reads behind the MFMAs to save VGPRs and
   // every k-step then eats a full LDS round trip at s_waitcnt lgkmcnt(0)).
-  auto load_frags = [&](const char* As, const char* Bs, int ks, bf16x8 (&af)[4], bf16x8 (&bfr)[2]) {
+  auto load_frags = [&](const char* As, const char* Bs, int ks, bf16x8 (&af)[4], bf16x8 (&bfr)[NT]) {
     const int so = ((2 * ks + h2) ^ sw) * 16;
     // B fragments first: the MFMA order below (mt outer, nt inner) then needs the reads in exactly issue order, so
     // the counted lgkmcnt waits hipcc emits leave the later reads in flight under the earlier MFMAs
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) bfr[nt] = *(const bf16x8*)(Bs + b_row_off + nt * 32 * ROW_BYTES + so);
+    for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf16x8*)(Bs + b_row_off + nt * 32 * ROW_BYTES + so);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) af[mt] = *(const bf16x8*)(As + a_row_off + mt * 32 * ROW_BYTES + so);
   };
-  auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[2]) {
+  auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[NT]) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
   };
   auto compute = [&](int buf) {
     const char* As = smem + buf * STAGE_BYTES;
     const char* Bs = As + TILE_BYTES;
     constexpr int KS = BK / 16;
-    bf16x8 af0[4], bf0[2], af1[4], bf1[2];
+    bf16x8 af0[4], bf0[NT], af1[4], bf1[NT];
     load_frags(As, Bs, 0, af0, bf0);
     // interleave: one ds_read of the NEXT k-step behind each of the first six MFMAs of the current one (an MFMA
     // occupies the matrix pipe for 32 cycles but the wave's issue slot for only 4, so the reads go out under it)
     auto interleave = [&]() {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < 4 + NT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - (4 + NT), 0);
     };
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
   };
 
   const int nk = p.K / BK;
-  if (PIPE == 0) {
+  if constexpr (PIPE == 0) {
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -209,7 +221,154 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
       if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
       compute(kt & 1);
     }
-  } else if (PIPE == 2) {
+  } else if constexpr (PIPE == 6) {
+    // 8-wave ping-pong over half-tiles (the guide's 256^2 8-phase structure, restated for 32x32x16 C^T tiles).
+    //   * waves 0-3 (wm = 0) and 4-7 (wm = 1) share SIMDs pairwise and run HALF A PHASE apart (one extra barrier up
+    //     front for wm = 1, one at the end for wm = 0): while one group sits in its 8-MFMA section the other issues
+    //     its fragment reads and DMA -- the matrix pipe of every SIMD always has exactly one wave feeding it;
+    //   * a phase = [ds_reads + one half-tile of DMA] lgkmcnt(0) barrier [8 MFMA = one 64x32 quadrant x K 64] barrier;
+    //     4 phases per K-tile: (A0,B0) (A0,B1) (A1,B1) (A1,B0); A0/A1 and B0/B1 come from DIFFERENT half-tiles, so a
+    //     K-tile is consumed half-tile by half-tile and restaged the same way, 7 half-tiles ahead:
+    //         phase p0 stages B0 of K-tile t+1;  p1: A0 of t+2;  p2: B1 of t+2;  p3: A1 of t+2 and waits vmcnt(6)
+    //     (everything of K-tile t+1 has landed, three half-tiles of t+2 stay in flight -- the queue never drains);
+    //   * RAW: the wait sits before p3's first barrier, K-tile t+1 is first read in the next phase (after the barrier
+    //     both groups have passed).  WAR: every fragment read is retired (lgkmcnt(0)) before the barrier that precedes
+    //     the other group's -- and a phase later its own -- restage of that half-tile.
+    auto stage_half = [&](int kt, int kind) {  // kind: 0 = A rows 0..127, 1 = A rows 128..255, 2/3 = B likewise
+      char* base = smem + (kt & 1) * STAGE_BYTES + (kind >> 1) * TILE_BYTES;
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = (kind & 1) * 2 + ii;
+        const bf16_t* src = ((kind >> 1) ? b_src[i] : a_src[i]) + kt * BK;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * GEMM_THREADS + wave * 64) * 16), 16, 0, 0);
+      }
+    };
+    bf16x8 af[2][4], b0f[4], b1f[4];
+    auto load_a = [&](const char* As, int half) {
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          af[m2][ks] = *(const bf16x8*)(As + pp_a_row(half * 2 + m2) + (((2 * ks + h2) ^ sw) * 16));
+    };
+    auto load_b = [&](const char* Bs, int half, bf16x8 (&bf)[4]) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bf[ks] = *(const bf16x8*)(Bs + pp_b_row(half) + (((2 * ks + h2) ^ sw) * 16));
+    };
+    auto quad = [&](int mh, int nt, const bf16x8 (&bf)[4]) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+          acc[mh * 2 + m2][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks], af[m2][ks], acc[mh * 2 + m2][nt], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto enter_mfma = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto leave_mfma = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // prologue: K-tile 0 (A0, B1, A1, B0) and the first three half-tiles of K-tile 1
+    stage_half(0, 0); stage_half(0, 3); stage_half(0, 1); stage_half(0, 2);
+    if (nk > 1) {
+      stage_half(1, 0); stage_half(1, 3); stage_half(1, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier behind group 0
+    for (int t = 0; t < nk; ++t) {
+      const char* As = smem + (t & 1) * STAGE_BYTES;
+      const char* Bs = As + TILE_BYTES;
+      // p0: (A0, B0)
+      load_a(As, 0);
+      load_b(Bs, 0, b0f);
+      if (t + 1 < nk) stage_half(t + 1, 2);
+      enter_mfma();
+      quad(0, 0, b0f);
+      leave_mfma();
+      // p1: (A0, B1)
+      load_b(Bs, 1, b1f);
+      if (t + 2 < nk) stage_half(t + 2, 0);
+      enter_mfma();
+      quad(0, 1, b1f);
+      leave_mfma();
+      // p2: (A1, B1)
+      load_a(As, 1);
+      if (t + 2 < nk) stage_half(t + 2, 3);
+      enter_mfma();
+      quad(1, 1, b1f);
+      leave_mfma();
+      // p3: (A1, B0); the wait that publishes K-tile t+1
+      if (t + 2 < nk) {
+        stage_half(t + 2, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      enter_mfma();
+      quad(1, 0, b0f);
+      leave_mfma();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+  } else if constexpr (PIPE == 5) {
+    // 2-stage BK = 64 ring for ONE wave per SIMD (4 waves x 128x128): nothing else hides a stall, so the fragment
+    // pipeline runs across the barrier.  The barrier of stage kt+1 sits BEFORE the last k-step's MFMAs of stage kt:
+    // by then every fragment of stage kt is in registers, so the buffer can be handed to the DMA of stage kt+2 and the
+    // first fragments of stage kt+1 are read under those 16 MFMAs.
+    bf16x8 af0[4], bf0[NT], af1[4], bf1[NT];
+    auto il = [&](int n_ds) {  // one DS read (or DMA issue) behind each of the first n MFMAs of a 4*NT MFMA group
+#pragma unroll
+      for (int i = 0; i < 4 + NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - (4 + NT), 0);
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nk > 1) stage(1, 1);
+    load_frags(smem, smem + TILE_BYTES, 0, af0, bf0);
+    __builtin_amdgcn_sched_barrier(0);
+    auto steps012 = [&](const char* As) {
+      const char* Bs = As + TILE_BYTES;
+      load_frags(As, Bs, 1, af1, bf1);
+      mma(af0, bf0);
+      il(0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(As, Bs, 2, af0, bf0);
+      mma(af1, bf1);
+      il(0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(As, Bs, 3, af1, bf1);
+      mma(af0, bf0);
+      il(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      steps012(smem + (kt & 1) * STAGE_BYTES);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < nk) stage(kt & 1, kt + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      const char* An = smem + ((kt + 1) & 1) * STAGE_BYTES;
+      load_frags(An, An + TILE_BYTES, 0, af0, bf0);
+      mma(af1, bf1);
+      il(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    steps012(smem + ((nk - 1) & 1) * STAGE_BYTES);
+    mma(af1, bf1);
+  } else if constexpr (PIPE == 2) {
     // 4-deep BK = 32 ring whose fragment pipeline runs ACROSS the barrier: at the top of iteration kt, stage kt+1 is
     // already landed and visible, so the first fragments of stage kt+1 are read under the last MFMAs of stage kt and
     // the matrix pipe never waits for an LDS round trip after a barrier.  The barrier itself only (a) publishes
@@ -224,11 +383,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
     load_frags(smem, smem + TILE_BYTES, 0, af0, bf0);
     auto interleave = [&]() {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < 4 + NT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - (4 + NT), 0);
     };
     for (int kt = 0; kt < nk - 1; ++kt) {
       // stage kt+1 landed (only stage kt+2 may still be in flight)
@@ -256,7 +415,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
       __builtin_amdgcn_sched_barrier(0);
       mma(af1, bf1);
     }
-  } else if (PIPE == 3) {
+  } else if constexpr (PIPE == 3) {
     // PIPE 2's schedule with the LDS side taken out of hipcc's hands: hipcc guards every 8-MFMA block with
     // s_waitcnt lgkmcnt(0), i.e. it waits for the six fragment reads it issued two MFMAs earlier.  Here the ds_reads
     // are inline asm (invisible to its scoreboard) and the waits are COUNTED: LDS returns in order, so
@@ -360,18 +519,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
   bf16_t* Cb = (bf16_t*)p.C + (int64_t)b * p.strideC;
   const int ldc = (int)p.ldc, ldr = (int)p.ldr;
   const bool n_vec = (p.N & 3) == 0;  // whole quads are either inside or outside N
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int row = m0 + wm * 128 + mt * 32 + l31;
+  // one 32-row band per call with a compile-time index: with 256 accumulators hipcc stops fully unrolling a 4-deep mt
+  // loop and the dynamically indexed accumulator array then lives in scratch (64 scratch stores per K-iteration)
+  auto epilogue_band = [&](auto mt_c) {
+    constexpr int mt = decltype(mt_c)::value;
+    const int row = PP ? m0 + (mt >> 1) * 128 + wm * 64 + (mt & 1) * 32 + l31 : m0 + wm * 128 + mt * 32 + l31;
     const bool row_ok = row < p.M;
     const int rowc = row_ok ? row : p.M - 1;
     const float brow = (bias && bias_row) ? bf2f(bias[rowc]) : 0.0f;
     const bool seg1 = row >= p.seg_split;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 64 + nt * 32 + 8 * g + 4 * h2;
+        const int n = PP ? n0 + nt * 128 + wn * 32 + 8 * g + 4 * h2 : n0 + wn * (NT * 32) + nt * 32 + 8 * g + 4 * h2;
         if (n_vec) {
           if (n < p.N) {
             float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f}, rv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -413,13 +574,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(const alg_gemm_
         }
       }
     }
-  }
+  };
+  epilogue_band(IntC<0>{});
+  epilogue_band(IntC<1>{});
+  epilogue_band(IntC<2>{});
+  epilogue_band(IntC<3>{});
 }
 
 static int gemm_pipe() {
   const char* e = getenv("ALG_GEMM_PIPE");
   const int v = e ? atoi(e) : 0;
-  return (v < 0 || v > 3) ? 0 : v;
+  return (v < 0 || v > 6) ? 0 : v;
 }
 
 static int gemm_group_m() {
@@ -433,14 +598,14 @@ static int gemm_group_m() {
 
 using namespace alg;
 
-template <int PIPE>
+template <int PIPE, int WNW = 4>
 static int launch_gemm(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[4] = {(const void*)gemm_bf16_kernel<ALG_ACT_NONE, true, PIPE>,
-                          (const void*)gemm_bf16_kernel<ALG_ACT_GELU_TANH, false, PIPE>,
-                          (const void*)gemm_bf16_kernel<ALG_ACT_SILU, false, PIPE>,
-                          (const void*)gemm_bf16_kernel<ALG_ACT_NONE, false, PIPE>};
+    const void* fns[4] = {(const void*)gemm_bf16_kernel<ALG_ACT_NONE, true, PIPE, WNW>,
+                          (const void*)gemm_bf16_kernel<ALG_ACT_GELU_TANH, false, PIPE, WNW>,
+                          (const void*)gemm_bf16_kernel<ALG_ACT_SILU, false, PIPE, WNW>,
+                          (const void*)gemm_bf16_kernel<ALG_ACT_NONE, false, PIPE, WNW>};
     for (const void* fn : fns) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
       if (e != hipSuccess) {
@@ -450,17 +615,20 @@ static int launch_gemm(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t
     }
     attr_set = true;
   }
-  const dim3 grid((unsigned)nwg), block(GEMM_THREADS);
+  const dim3 grid((unsigned)nwg), block(2 * WNW * 64);
   const int gm = gemm_group_m();
   if (a->R) {
-    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, true, PIPE>), grid, block, GEMM_LDS, s, *a, m_tiles, n_tiles, gm);
+    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, true, PIPE, WNW>), grid, block, GEMM_LDS, s, *a, m_tiles,
+                       n_tiles, gm);
   } else if (a->act == ALG_ACT_GELU_TANH) {
-    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_GELU_TANH, false, PIPE>), grid, block, GEMM_LDS, s, *a, m_tiles,
+    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_GELU_TANH, false, PIPE, WNW>), grid, block, GEMM_LDS, s, *a, m_tiles,
                        n_tiles, gm);
   } else if (a->act == ALG_ACT_SILU) {
-    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_SILU, false, PIPE>), grid, block, GEMM_LDS, s, *a, m_tiles, n_tiles, gm);
+    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_SILU, false, PIPE, WNW>), grid, block, GEMM_LDS, s, *a, m_tiles,
+                       n_tiles, gm);
   } else {
-    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, false, PIPE>), grid, block, GEMM_LDS, s, *a, m_tiles, n_tiles, gm);
+    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, false, PIPE, WNW>), grid, block, GEMM_LDS, s, *a, m_tiles,
+                       n_tiles, gm);
   }
   return check_launch("alg_gemm_bf16");
 }
@@ -525,6 +693,9 @@ extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) {
     case 0: return launch_gemm<0>(a, m_tiles, n_tiles, nwg, s);
     case 1: return launch_gemm<1>(a, m_tiles, n_tiles, nwg, s);
     case 2: return launch_gemm<2>(a, m_tiles, n_tiles, nwg, s);
+    case 4: return launch_gemm<0, 2>(a, m_tiles, n_tiles, nwg, s);  // 4 waves x 128x128
+    case 5: return launch_gemm<5, 2>(a, m_tiles, n_tiles, nwg, s);  // + fragment pipeline across the barrier
+    case 6: return launch_gemm<6>(a, m_tiles, n_tiles, nwg, s);     // 8-wave ping-pong over half-tiles
     default: return launch_gemm<3>(a, m_tiles, n_tiles, nwg, s);
   }
 }

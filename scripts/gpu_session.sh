@@ -22,7 +22,7 @@ for w in $WHAT; do
       timeout 1800 python bench.py > $O/bench_full.json 2> $O/bench_full.err
       echo "bench exit $?"; tail -c 4000 $O/bench_full.json; tail -5 $O/bench_full.err ;;
     kbench)
-      for v in 1 8 9; do
+      for v in ${ATTN_VARIANTS:-1 13}; do
         echo "== ALG_ATTN_VARIANT=$v" | tee -a $O/kbench.log
         ALG_ATTN_VARIANT=$v timeout 600 python scripts/kbench.py --only attn --check 2>&1 | grep -v amdgpu.ids | tee -a $O/kbench.log
       done
