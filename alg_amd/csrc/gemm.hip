@@ -59,9 +59,9 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
                                                                  int group_m) {
   constexpr int GEMM_THREADS = 2 * WNW * 64;  // 512 (8 waves, 128x64 each) or 256 (4 waves, 128x128 each)
   constexpr int NT = BN / WNW / 32;           // 32-column MFMA tiles per wave: 2 or 4
-  static_assert(WNW == 4 || (WNW == 2 && (PIPE == 0 || PIPE == 5)), "the 4-wave layout is only built on the 2-stage ring");
+  static_assert(WNW == 4 || (WNW == 2 && (PIPE == 0 || PIPE == 5 || PIPE == 7)), "the 4-wave layout is only built on the 2-stage ring");
   static_assert(PIPE != 6 || WNW == 4, "the ping-pong schedule is an 8-wave schedule");
-  constexpr bool BK64 = PIPE == 0 || PIPE == 5 || PIPE == 6;
+  constexpr bool BK64 = PIPE == 0 || PIPE == 5 || PIPE == 6 || PIPE == 7;
   constexpr bool PP = PIPE == 6;  // ping-pong: a wave owns 2 x 64 rows (one piece per A half-tile) x 2 x 32 columns
   constexpr int BK = BK64 ? 64 : 32;
   constexpr int NSTAGE = BK64 ? 2 : 4;
@@ -318,6 +318,98 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
       leave_mfma();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
+  } else if constexpr (PIPE == 7) {
+    // 4 waves x 128x128, ONE wave per SIMD, everything behind an MFMA.  Per K-tile a wave issues 64 MFMAs, 32 fragment
+    // reads and 16 DMA instructions; nothing else can hide a stall, so each memory instruction sits in the issue shadow
+    // of an MFMA (an MFMA holds the matrix pipe 32 cycles but the issue port 4):
+    //     step 0: MFMA(ks0) + reads(ks1) + second half of the DMA of stage kt+1
+    //     step 1: MFMA(ks1) + reads(ks2)        step 2: MFMA(ks2) + reads(ks3)
+    //     vmcnt(0) lgkmcnt(0) barrier        (stage kt+1 published; every wave holds all fragments of stage kt)
+    //     step 3: MFMA(ks3) + reads(ks0 of stage kt+1) + first half of the DMA of stage kt+2 into the freed buffer
+    // The loop body is branch-free (first / steady / last-but-one / last iterations are separate copies) so the whole
+    // K-tile is one scheduling region.
+    constexpr int NDMA = 2 * LD_PER_OP;  // 16
+    bf16x8 af0[4], bf0[NT], af1[4], bf1[NT];
+    auto il_ds = [&]() {  // 8 DS reads behind the first 8 MFMAs, then the other 8 MFMAs
+#pragma unroll
+      for (int i = 0; i < 4 + NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - (4 + NT), 0);
+    };
+    auto il_ds_dma = [&]() {  // 8 DS reads behind MFMAs 0-7, 8 DMA issues behind MFMAs 8-15
+#pragma unroll
+      for (int i = 0; i < 4 + NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NDMA / 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    };
+    auto iter = [&](int kt, auto dma0_c, auto bar_c, auto dma3_c) {
+      constexpr bool DMA0 = decltype(dma0_c)::value, BAR = decltype(bar_c)::value, DMA3 = decltype(dma3_c)::value;
+      const char* As = smem + (kt & 1) * STAGE_BYTES;
+      const char* Bs = As + TILE_BYTES;
+      load_frags(As, Bs, 1, af1, bf1);
+      mma(af0, bf0);
+      if (DMA0) {
+#pragma unroll
+        for (int w = NDMA / 2; w < NDMA; ++w) stage_piece((kt + 1) & 1, kt + 1, w);
+        il_ds_dma();
+      } else {
+        il_ds();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(As, Bs, 2, af0, bf0);
+      mma(af1, bf1);
+      il_ds();
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(As, Bs, 3, af1, bf1);
+      mma(af0, bf0);
+      il_ds();
+      __builtin_amdgcn_sched_barrier(0);
+      if (BAR) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* An = smem + ((kt + 1) & 1) * STAGE_BYTES;
+        load_frags(An, An + TILE_BYTES, 0, af0, bf0);
+        mma(af1, bf1);
+        if (DMA3) {
+#pragma unroll
+          for (int w = 0; w < NDMA / 2; ++w) stage_piece(kt & 1, kt + 2, w);
+          il_ds_dma();
+        } else {
+          il_ds();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        mma(af1, bf1);
+      }
+    };
+    using T = IntC<1>;
+    using F = IntC<0>;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nk > 1) stage(1, 1);
+    load_frags(smem, smem + TILE_BYTES, 0, af0, bf0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nk == 1) {
+      iter(0, F{}, F{}, F{});
+    } else if (nk == 2) {
+      iter(0, F{}, T{}, F{});
+      iter(1, F{}, F{}, F{});
+    } else {
+      iter(0, F{}, T{}, T{});                                    // stage 1 went out whole in the prologue
+      for (int kt = 1; kt + 2 < nk; ++kt) iter(kt, T{}, T{}, T{});
+      iter(nk - 2, T{}, T{}, F{});
+      iter(nk - 1, F{}, F{}, F{});
+    }
   } else if constexpr (PIPE == 5) {
     // 2-stage BK = 64 ring for ONE wave per SIMD (4 waves x 128x128): nothing else hides a stall, so the fragment
     // pipeline runs across the barrier.  The barrier of stage kt+1 sits BEFORE the last k-step's MFMAs of stage kt:
@@ -583,8 +675,8 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
 
 static int gemm_pipe() {
   const char* e = getenv("ALG_GEMM_PIPE");
-  const int v = e ? atoi(e) : 0;
-  return (v < 0 || v > 6) ? 0 : v;
+  const int v = e ? atoi(e) : 6;  // default: 8-wave ping-pong over half-tiles (fastest measured)
+  return (v < 0 || v > 7) ? 6 : v;
 }
 
 static int gemm_group_m() {
@@ -696,6 +788,7 @@ extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) {
     case 4: return launch_gemm<0, 2>(a, m_tiles, n_tiles, nwg, s);  // 4 waves x 128x128
     case 5: return launch_gemm<5, 2>(a, m_tiles, n_tiles, nwg, s);  // + fragment pipeline across the barrier
     case 6: return launch_gemm<6>(a, m_tiles, n_tiles, nwg, s);     // 8-wave ping-pong over half-tiles
+    case 7: return launch_gemm<7, 2>(a, m_tiles, n_tiles, nwg, s);  // 4 waves, every memory op behind an MFMA
     default: return launch_gemm<3>(a, m_tiles, n_tiles, nwg, s);
   }
 }
