@@ -23,9 +23,16 @@
 //   3/4  "lean" softmax (pre-scaled Q, -m folded into the accumulator chain, packed row sums) -- see below
 //   5  variant 1 with 4-wave workgroups;  6/7  64 queries per wave (8 / 4 waves per workgroup)
 //   8/9  two KV tiles per barrier (9: + s_setprio around the MFMA clusters);  12  16-wave workgroups
-// Measured on MI355X at the C2 shape (2 x 48 heads x 17,776 tokens, profiles/): 1: 850-915 TFLOP/s (default),
-// 0: 875, 2: 830, 3: 867, 4: 861, 5: 836, 6: 804, 7: 599, 8: 899, 9: 893, 12: 860 -- every restructuring that trades occupancy (4 waves per
-// SIMD at 110 VGPRs) for less VALU, less LDS traffic or more ILP loses; the variants stay selectable for A/B runs.
+//   13  variant 1 with the ragged tail tile peeled (no per-tile v_cndmask) and packed fma / row sums (-30 % VALU)
+//   14  13 + explicitly staged fragments (8 K reads in one batch, V^T reads issued before / under the softmax) and a
+//       v_permlane32_swap max exchange: no exposed LDS round trip left in the loop
+//   15/16  "duo": two 32-query streams per wave sharing every fragment read, one stream's MFMAs interleaved with the
+//       other's softmax by sched_group_barrier (8 / 4 waves per workgroup)
+// Measured on MI355X at the C2 shape (2 x 48 heads x 17,776 tokens, profiles/): 1: 860-915 TFLOP/s (default),
+// 0: 875, 2: 830, 3: 867, 4: 861, 5: 836, 6: 804, 7: 599, 8: 899, 9: 893, 12: 860, 13: 880, 14: 865, 15: 835, 16: 875.
+// All of them sit at 1225-1330 W with the clock pulled down to 1.9-2.2 GHz (profiles/r1_power_and_issue_rates.txt):
+// the kernel is bound by energy per FLOP under the package power cap, so variants that only remove stalls or issue
+// slots gain clock, not time.  The variants stay selectable (ALG_ATTN_VARIANT) for A/B runs and parity tests.
 #include <stdlib.h>
 
 #include "common.h"

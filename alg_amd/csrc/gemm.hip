@@ -1,17 +1,19 @@
 // bf16 GEMM for the DiT linears on gfx950 MFMA:  C = R + gate * act(A @ B^T + bias).
 //
 // Shape of the design (MI355X-first, 64-wide waves):
-//   * 256x256 output tile per workgroup, 8 waves as 2(M) x 4(N); each wave owns 128x64 = 4x2 tiles of
-//     v_mfma_f32_32x32x16_bf16 (128 fp32 accumulators per lane).  The MFMA is issued as (B-fragment, A-fragment),
-//     i.e. it produces C^T tiles: a lane then holds 4 CONSECUTIVE output columns of one row per register quad,
-//     so the epilogue loads bias/gate/residual and stores C with 8-byte accesses (32 stores per lane, not 128).
+//   * 256x256 output tile per workgroup, v_mfma_f32_32x32x16_bf16 issued as (B-fragment, A-fragment), i.e. it produces
+//     C^T tiles: a lane then holds 4 CONSECUTIVE output columns of one row per register quad, so the epilogue loads
+//     bias/gate/residual and stores C with 8-byte accesses.
 //   * A and B (both K-contiguous: activations [M][K], nn.Linear weights [N][K]) stream L2 -> LDS with 16-byte
-//     global_load_lds (no VGPR round trip) through a 128 KiB ring:
-//        PIPE 2 (default): 4 stages of BK = 32, counted s_waitcnt vmcnt(4) + raw s_barrier, and a register fragment
-//                pipeline that runs across the barrier (stage kt+1 is already visible while stage kt is multiplied),
-//                so the matrix pipe never waits for an LDS round trip after a barrier;
-//        PIPE 1: same ring, fragments re-started after every barrier, two stages kept in flight;
-//        PIPE 0: 2 stages of BK = 64, drain + barrier per K-tile.   (1 and 0 are kept for A/B measurements)
+//     global_load_lds (no VGPR round trip) through 128 KiB of LDS.  Schedules (ALG_GEMM_PIPE, measured in
+//     profiles/r1_power_and_issue_rates.txt; all are kept for A/B runs and are covered by the parity tests):
+//        PIPE 6 (default): 8 waves, 2-stage BK = 64 buffer staged by half-tiles; the two wave groups that share a SIMD
+//                run half a phase apart (ping-pong): 8 MFMAs of one wave cover the partner's fragment reads and DMA
+//                issue; counted vmcnt(6), the DMA queue never drains;
+//        PIPE 0: 8 waves x 128x64, 2 stages of BK = 64, drain + barrier per K-tile;
+//        PIPE 1/2/3: 4 stages of BK = 32 (plain / fragment pipeline across the barrier / asm ds_reads + counted lgkmcnt);
+//        PIPE 4/5/7: 4 waves x 128x128 (one wave per SIMD, 1/3 fewer fragment reads per MFMA): naive / fragment
+//                pipeline across the barrier / every memory instruction in the issue shadow of an MFMA.
 //   * LDS-DMA writes lane-linear, so the bank swizzle lives on the per-lane SOURCE address; the matching XOR is
 //     applied on the ds_read_b128 fragment reads, which are conflict free (measured SQ_LDS_BANK_CONFLICT = 0).
 //   * workgroup ids are remapped so each XCD (private 4 MiB L2) walks a contiguous run of tiles, grouped

@@ -285,6 +285,9 @@ def main():
                     launches=len(ms.get("attn", [])),
                     mean_launch_ms=(sum(ms["attn"]) / len(ms["attn"])) if ms.get("attn") else None, extra=extra)
     flops_total = (attn_flops_total + sum(gemm_flops.values()) * total_samples * cfg.num_layers)
+    # measured on this chip (profiles/r1_power_and_issue_rates.txt): a register-only MFMA loop on random bf16 operands
+    # sustains 1765 TFLOP/s under the 1400 W package cap -- the matrix-pipe ceiling for real data; `peak` stays the guide's
+    roofline["extra"]["mfma_sustained_random_operands_tflops"] = 1765.0
     roofline["extra"]["whole_step_mfma_frac"] = flops_total * world / elapsed / 1e12 / MFMA_PEAK_TFLOPS / world
 
     out = {
