@@ -22,7 +22,7 @@ GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS = 1, 4
 EXPORTS = (
     "alg_version", "alg_last_error", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16",
     "alg_flash_attn_d64", "alg_layernorm_modulate", "alg_qk_norm_rope", "alg_patchify", "alg_unpatchify",
-    "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast",
+    "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128",
 )
 
 
@@ -79,6 +79,7 @@ def load_library():
                                 c_void_p]
     lib.alg_concat_cast.argtypes = [POINTER(c_void_p), c_int, POINTER(c_void_p), c_int, c_int] + [c_int64] * 7 + [
         c_void_p, c_int, c_void_p]
+    lib.alg_flash_attn_d128.argtypes = [c_void_p] * 4 + [c_int] * 4 + [c_int64] * 8 + [c_float, c_void_p]
     lib.alg_unipc_update.argtypes = [c_void_p] * 5 + [c_int64] + [c_float] * 6 + [c_void_p]
     lib.alg_gemm_bf16.argtypes = [POINTER(GemmArgs), c_void_p]
     lib.alg_flash_attn_d64.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
@@ -220,6 +221,18 @@ def concat_cast(src0, src1, O, A0, A1, R, s0_ostride, s1_ostride, a1_off, out_dt
                                _ptr(out), ALG_F32 if out_dtype == torch.float32 else ALG_BF16, _stream()),
            "alg_concat_cast")
     return out
+
+
+def flash_attn_d128(q, k, vt, o, batch, heads, Sq, Skv, q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs, scale,
+                    q_off=0, k_off=0, vt_off=0, o_off=0):
+    """softmax(q k^T * scale) v for head_dim 128; strides / offsets in elements (see include/alg_hip.h)."""
+    lib = load_library()
+    for t in (q, k, vt, o):
+        _dev(t, "attention operand")
+    at = lambda t, off: c_void_p(t.data_ptr() + 2 * off)
+    _check(lib.alg_flash_attn_d128(at(q, q_off), at(k, k_off), at(vt, vt_off), at(o, o_off), batch, heads, Sq, Skv, q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs, float(scale),
+                                   _stream()), "alg_flash_attn_d128")
+    return o
 
 
 def unipc_update(x, m0, m1, m_new, r, c, k, rk=1.0, rho0=0.0, rho_new=0.0):

@@ -136,6 +136,18 @@ int alg_flash_attn_d64(const void* q, const void* k, const void* vt, void* o, in
                        int64_t q_bstride, int64_t q_rstride, int64_t vt_bstride, int64_t vt_rstride,
                        int64_t o_bstride, int64_t o_rstride, float scale, void* stream);
 
+/* wan:910-917 (WanTransformer3DModel self- and cross-attention, head_dim 128; diffusers WanAttnProcessor SDPA)
+ * Same contract as alg_flash_attn_d64 with head_dim 128 and separate query / key lengths:
+ *   q : element (b, s, h, d) at q + b*q_bstride + s*q_rstride + h*128 + d,  s < Sq
+ *   k : likewise with k_bstride / k_rstride, s < Skv
+ *   vt: V transposed, element (b, h, d, s) at vt + b*vt_bstride + (h*128 + d)*vt_rstride + perm(s), perm swaps index
+ *       bits 2 and 3 (what alg_gemm_bf16 writes with ALG_GEMM_PERMUTE_COLS); vt_rstride >= Skv rounded up to 64 and the
+ *       padding columns must hold finite values (they are multiplied by p = 0)
+ *   o : element (b, s, h, d) at o + b*o_bstride + s*o_rstride + h*128 + d */
+int alg_flash_attn_d128(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq, int Skv,
+                        int64_t q_bstride, int64_t q_rstride, int64_t k_bstride, int64_t k_rstride, int64_t vt_bstride,
+                        int64_t vt_rstride, int64_t o_bstride, int64_t o_rstride, float scale, void* stream);
+
 /* y = LayerNorm(x; weight, bias, eps) * (1 + scale[seg]) + shift[seg]       (CogVideoXLayerNormZero / AdaLayerNorm)
  * x, y: [batch][rows][D] bf16, rows contiguous, batch strides x_bstride / y_bstride (elements);
  * weight/bias: [D] bf16 (may be NULL);

@@ -88,6 +88,17 @@ def main():
         "qk_norm_rope": (lambda: _lib.qk_norm_rope_(qk, nq[0], nq[1], nq[2], nq[3], cos, sin, N, S, H, T, 1e-6),
                          2.0 * N * S * 2 * D * 2, "byte"),
     }
+    if "attn128" in only:  # Wan-480p self-attention shape: N x 40 heads x 32,760 tokens x 128
+        Sw, Hw = 32760, 40
+        Dw = Hw * 128
+        Sw_pad = (Sw + 63) // 64 * 64
+        qw, kw = rn(N, Sw, Dw), rn(N, Sw, Dw)
+        vtw = torch.zeros(N, Dw, Sw_pad, dtype=BF, device=dev)
+        vtw[:, :, :Sw] = rn(N, Dw, Sw)
+        ow = torch.empty(N, Sw, Dw, dtype=BF, device=dev)
+        cases["attn128"] = (lambda: _lib.flash_attn_d128(qw, kw, vtw, ow, N, Hw, Sw, Sw, Sw * Dw, Dw, Sw * Dw, Dw,
+                                                         Dw * Sw_pad, Sw_pad, Sw * Dw, Dw, 128 ** -0.5),
+                            4.0 * N * Hw * Sw * Sw * 128, "flop")
     res = {}
     for name, (fn, work, kind) in cases.items():
         if only and name not in only:
