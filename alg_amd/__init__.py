@@ -12,5 +12,6 @@ from .pipeline_wan_image2video_lowpass import WanImageToVideoPipeline  # noqa: F
 from .schedulers import (CogVideoXDDIMScheduler, FlowMatchEulerDiscreteScheduler,  # noqa: F401
                          UniPCMultistepScheduler)
 from .transformer_cogvideox import CogVideoXTransformer3DModel, CogVideoXTransformerConfig  # noqa: F401
+from .transformer_wan import WanTransformer3DModel, WanTransformerConfig  # noqa: F401
 
 __version__ = "0.1.0"

@@ -17,12 +17,14 @@ LIB_PATH = os.path.join(_HERE, "libalg_hip.so")
 
 ALG_F32, ALG_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
-GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS = 1, 4
+GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS, GEMM_GATE_F32 = 1, 4, 8
 
 EXPORTS = (
     "alg_version", "alg_last_error", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16",
     "alg_flash_attn_d64", "alg_layernorm_modulate", "alg_qk_norm_rope", "alg_patchify", "alg_unpatchify",
-    "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128",
+    "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128", "alg_layernorm_mod_f32", "alg_rmsnorm_rope",
+    "alg_wan_modulation", "alg_patchify3d", "alg_unpatchify3d", "alg_timestep_embedding_f32", "alg_linear_f32",
+    "alg_gelu_erf",
 )
 
 
@@ -80,6 +82,14 @@ def load_library():
     lib.alg_concat_cast.argtypes = [POINTER(c_void_p), c_int, POINTER(c_void_p), c_int, c_int] + [c_int64] * 7 + [
         c_void_p, c_int, c_void_p]
     lib.alg_flash_attn_d128.argtypes = [c_void_p] * 4 + [c_int] * 4 + [c_int64] * 8 + [c_float, c_void_p]
+    lib.alg_layernorm_mod_f32.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]
+    lib.alg_rmsnorm_rope.argtypes = [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]
+    lib.alg_wan_modulation.argtypes = [c_void_p] * 3 + [c_int] * 5 + [c_void_p]
+    lib.alg_patchify3d.argtypes = [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]
+    lib.alg_unpatchify3d.argtypes = [c_void_p, c_int64, c_void_p] + [c_int] * 7 + [c_void_p]
+    lib.alg_timestep_embedding_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
+    lib.alg_linear_f32.argtypes = [c_void_p] * 6 + [c_int] * 4 + [c_void_p]
+    lib.alg_gelu_erf.argtypes = [c_void_p, c_int64, c_void_p]
     lib.alg_unipc_update.argtypes = [c_void_p] * 5 + [c_int64] + [c_float] * 6 + [c_void_p]
     lib.alg_gemm_bf16.argtypes = [POINTER(GemmArgs), c_void_p]
     lib.alg_flash_attn_d64.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
@@ -187,8 +197,8 @@ def cfg_combine(pred, n_pass, guidance_scale):
     return out
 
 
-def lincomb(terms, out_dtype):
-    """sum_i c_i * x_i for 1..4 (coef, tensor) pairs of equal shape -> new tensor of ``out_dtype``."""
+def lincomb(terms, out_dtype, out=None):
+    """sum_i c_i * x_i for 1..4 (coef, tensor) pairs of equal shape -> tensor of ``out_dtype`` (``out`` may alias a term)."""
     lib = load_library()
     xs = [t for _, t in terms]
     for t in xs:
@@ -196,7 +206,10 @@ def lincomb(terms, out_dtype):
         if not t.is_contiguous() or t.shape != xs[0].shape:
             raise AlgHipError("lincomb needs contiguous tensors of one shape")
     n = len(xs)
-    out = torch.empty(xs[0].shape, device=xs[0].device, dtype=out_dtype)
+    if out is None:
+        out = torch.empty(xs[0].shape, device=xs[0].device, dtype=out_dtype)
+    elif out.dtype != out_dtype or out.shape != xs[0].shape or not out.is_contiguous():
+        raise AlgHipError("lincomb: `out` must be a contiguous tensor of the requested dtype and shape")
     arr = (c_void_p * n)(*[t.data_ptr() for t in xs])
     cf = (c_float * n)(*[float(c) for c, _ in terms])
     dts = (c_int * n)(*[_dt(t) for t in xs])
@@ -235,6 +248,58 @@ def flash_attn_d128(q, k, vt, o, batch, heads, Sq, Skv, q_bs, q_rs, k_bs, k_rs, 
     return o
 
 
+def _p(t, off=0):
+    """device pointer of tensor t advanced by off ELEMENTS (None -> NULL)."""
+    if t is None:
+        return c_void_p(0)
+    _dev(t, "tensor")
+    return c_void_p(t.data_ptr() + off * t.element_size())
+
+
+def layernorm_mod_f32(x, y, weight, bias, scale, shift, mod_bstride, batch, rows, D, eps, scale_off=0, shift_off=0):
+    _check(load_library().alg_layernorm_mod_f32(_p(x), _p(y), _p(weight), _p(bias), _p(scale, scale_off),
+                                                _p(shift, shift_off), mod_bstride, batch, rows, D, float(eps), _stream()),
+           "alg_layernorm_mod_f32")
+    return y
+
+
+def rmsnorm_rope_(x, weight, cos, sin, x_rstride, batch, rows, D, eps, x_off=0):
+    _check(load_library().alg_rmsnorm_rope(_p(x, x_off), _p(weight), _p(cos), _p(sin), x_rstride, batch, rows, D,
+                                           float(eps), _stream()), "alg_rmsnorm_rope")
+    return x
+
+
+def wan_modulation(table, vec, out, layers, batch, J, D, vec_per_j):
+    _check(load_library().alg_wan_modulation(_p(table), _p(vec), _p(out), layers, batch, J, D, int(vec_per_j), _stream()),
+           "alg_wan_modulation")
+    return out
+
+
+def patchify3d(x, out, n, C, F, H, W, ph, pw, Kpad):
+    _check(load_library().alg_patchify3d(_p(x), _p(out), n, C, F, H, W, ph, pw, Kpad, _stream()), "alg_patchify3d")
+    return out
+
+
+def unpatchify3d(x, ldin, out, n, C, F, H, W, ph, pw):
+    _check(load_library().alg_unpatchify3d(_p(x), ldin, _p(out), n, C, F, H, W, ph, pw, _stream()), "alg_unpatchify3d")
+    return out
+
+
+def timestep_embedding_f32(t, out, n, dim):
+    _check(load_library().alg_timestep_embedding_f32(_p(t), _p(out), n, dim, _stream()), "alg_timestep_embedding_f32")
+    return out
+
+
+def linear_f32(x, W, b, y, y_bf16, y_silu_bf16, M, N, K, act=0):
+    _check(load_library().alg_linear_f32(_p(x), _p(W), _p(b), _p(y), _p(y_bf16), _p(y_silu_bf16), M, N, K, act, _stream()),
+           "alg_linear_f32")
+
+
+def gelu_erf_(x):
+    _check(load_library().alg_gelu_erf(_p(x), x.numel(), _stream()), "alg_gelu_erf")
+    return x
+
+
 def unipc_update(x, m0, m1, m_new, r, c, k, rk=1.0, rho0=0.0, rho_new=0.0):
     """(r*x - c*m0) - k*(rho0*((m1-m0)/rk) + rho_new*(m_new-m0)) on fp32 tensors; m1 / m_new may be None."""
     lib = load_library()
@@ -262,7 +327,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=None, b
     args.C = C.data_ptr() + 2 * c_off
     args.bias = bias.data_ptr() if bias is not None else None
     args.R = (R.data_ptr() + 2 * r_off) if R is not None else None
-    args.gate = (gate.data_ptr() + 2 * gate_off) if gate is not None else None
+    args.gate = (gate.data_ptr() + gate.element_size() * gate_off) if gate is not None else None
     args.lda, args.ldb, args.ldc, args.ldr = lda, ldb, ldc, ldr
     args.strideA, args.strideB, args.strideC, args.strideR, args.strideGate = strideA, strideB, strideC, strideR, strideGate
     args.M, args.N, args.K, args.batch = M, N, K, batch

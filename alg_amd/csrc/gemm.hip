@@ -610,6 +610,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
   const bf16_t* gate = (RES && p.gate) ? (const bf16_t*)p.gate + (int64_t)b * p.strideGate : nullptr;
   const bool bias_row = p.flags & ALG_GEMM_BIAS_PER_ROW;
   const bool perm = p.flags & ALG_GEMM_PERMUTE_COLS;
+  const bool gate_f32 = RES && p.gate && (p.flags & ALG_GEMM_GATE_F32);  // Wan: fp32 gate, one rounding at the end
   bf16_t* Cb = (bf16_t*)p.C + (int64_t)b * p.strideC;
   const int ldc = (int)p.ldc, ldr = (int)p.ldr;
   const bool n_vec = (p.N & 3) == 0;  // whole quads are either inside or outside N
@@ -631,14 +632,21 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
           if (n < p.N) {
             float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f}, rv[4] = {0.f, 0.f, 0.f, 0.f};
             if (bias && !bias_row) unpack4(*(const uint2*)(bias + n), bv);
-            if (RES && gate) unpack4(*(const uint2*)(gate + (seg1 ? p.N : 0) + n), gv);
+            if (RES && gate) {
+              if (gate_f32) {
+                const float4 g4 = *(const float4*)((const float*)p.gate + (int64_t)b * p.strideGate + (seg1 ? p.N : 0) + n);
+                gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+              } else {
+                unpack4(*(const uint2*)(gate + (seg1 ? p.N : 0) + n), gv);
+              }
+            }
             if (RES) unpack4(*(const uint2*)(R + rowc * ldr + n), rv);
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               float x = rbf(acc[mt][nt][4 * g + i] + bv[i] + brow);  // nn.Linear returns a bf16 tensor
               if (ACT != ALG_ACT_NONE) x = rbf(act_apply(x, ACT));
-              if (RES) x = rv[i] + rbf(gv[i] * x);
+              if (RES) x = gate_f32 ? rv[i] + gv[i] * x : rv[i] + rbf(gv[i] * x);
               v[i] = x;
             }
             if (row_ok) {
@@ -658,8 +666,13 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
               float x = rbf(acc[mt][nt][4 * g + i] + ((bias && !bias_row) ? bf2f(bias[nn]) : 0.0f) + brow);
               if (ACT != ALG_ACT_NONE) x = rbf(act_apply(x, ACT));
               if (RES) {
-                const float gg = gate ? bf2f(gate[(seg1 ? p.N : 0) + nn]) : 1.0f;
-                x = bf2f(R[rowc * ldr + nn]) + rbf(gg * x);
+                if (gate_f32) {
+                  x = bf2f(R[rowc * ldr + nn]) +
+                      ((const float*)p.gate)[(int64_t)b * p.strideGate + (seg1 ? p.N : 0) + nn] * x;
+                } else {
+                  const float gg = gate ? bf2f(gate[(seg1 ? p.N : 0) + nn]) : 1.0f;
+                  x = bf2f(R[rowc * ldr + nn]) + rbf(gg * x);
+                }
               }
               const int nc = perm ? ((nn & ~12) | ((nn & 4) << 1) | ((nn & 8) >> 1)) : nn;
               Cb[row * ldc + nc] = f2bf(x);
@@ -770,7 +783,8 @@ extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) {
     const bool bad = (a->ldc & 3) || (a->strideC & 3) || ((uintptr_t)a->C & 7) ||
                      (a->bias && !(a->flags & ALG_GEMM_BIAS_PER_ROW) && ((uintptr_t)a->bias & 7)) ||
                      (a->R && ((a->ldr & 3) || (a->strideR & 3) || ((uintptr_t)a->R & 7))) ||
-                     (a->gate && ((a->strideGate & 3) || ((uintptr_t)a->gate & 7)));
+                     (a->gate && ((a->strideGate & 3) ||
+                                  ((uintptr_t)a->gate & ((a->flags & ALG_GEMM_GATE_F32) ? 15 : 7))));
     if (bad) {
       set_error("alg_gemm_bf16: C/bias/R/gate must be 8-byte aligned with ldc/ldr/strides multiples of 4 elements");
       return ALG_EINVAL;

@@ -105,6 +105,8 @@ int alg_unipc_update(const float* x, const float* m0, const float* m1, const flo
 
 #define ALG_GEMM_BIAS_PER_ROW 1   /* bias indexed by output row (used for the transposed V projection) */
 #define ALG_GEMM_PERMUTE_COLS 4   /* store column n at n with bits 2 and 3 swapped (MFMA k-order for V^T) */
+#define ALG_GEMM_GATE_F32 8       /* gate is float32 and C = bf16(R + gate * bf16(acc + bias)) with ONE final rounding
+                                     (WanTransformerBlock: (x.float() + out * gate_msa).type_as(x)) */
 
 typedef struct alg_gemm_args {
   const void* A;      /* [batch][M][K] bf16, row stride lda, batch stride strideA (elements) */
@@ -147,6 +149,48 @@ int alg_flash_attn_d64(const void* q, const void* k, const void* vt, void* o, in
 int alg_flash_attn_d128(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq, int Skv,
                         int64_t q_bstride, int64_t q_rstride, int64_t k_bstride, int64_t k_rstride, int64_t vt_bstride,
                         int64_t vt_rstride, int64_t o_bstride, int64_t o_rstride, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Wan 2.1 DiT building blocks (diffusers WanTransformer3DModel; call site wan:910-917)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* WanTransformerBlock norm1/norm2/norm3, norm_out:  y = bf16( FP32LayerNorm(x) [* weight + bias] [* (1 + scale[b]) +
+ * shift[b]] ), the whole chain in fp32.  x, y: [batch][rows][D] bf16 contiguous; weight/bias: [D] float32 or NULL;
+ * scale/shift: float32 vectors of batch b at scale + b*mod_bstride (NULL = no modulation).  Register-resident rows when
+ * D % 512 == 0 (D/512 in {1,2,3,4,6,8,10,12}), a strided three-pass kernel otherwise. */
+int alg_layernorm_mod_f32(const void* x, void* y, const float* weight, const float* bias, const float* scale,
+                          const float* shift, int64_t mod_bstride, int batch, int rows, int D, float eps, void* stream);
+
+/* WanAttnProcessor norm_q / norm_k (RMSNorm across all heads) + rotary embedding, in place:
+ *   x = rope( bf16( bf16(x * rsqrt(mean(x^2) + eps)) * weight ) ),  x: [batch*rows] rows of D bf16 at stride x_rstride;
+ * rope multiplies the interleaved pairs (2j, 2j+1) of every 128-wide head by cos/sin[token][j] (fp32 tables [rows][64],
+ * token = row % rows); cos_tab NULL = no rope (cross-attention q, text / image k). */
+int alg_rmsnorm_rope(void* x, const void* weight, const float* cos_tab, const float* sin_tab, int64_t x_rstride,
+                     int batch, int rows, int D, float eps, void* stream);
+
+/* out[l][b][j][d] = table[l][j][d] + float(vec[b][(vec_per_j ? j*D : 0) + d]):  (scale_shift_table + temb.float()) of
+ * every block in one launch (J = 6, vec = timestep_proj), and of the output head (J = 2, vec = temb). */
+int alg_wan_modulation(const float* table, const void* vec, float* out, int layers, int batch, int J, int D,
+                       int vec_per_j, void* stream);
+
+/* Conv3d(kernel = stride = (1, ph, pw)) patch gather: out[n][(f, gy, gx)][c*ph*pw + py*pw + px] = in[n][c][f][..][..],
+ * row length Kpad >= C*ph*pw (zero padded so the patch-embed GEMM sees K % 64 == 0). */
+int alg_patchify3d(const void* in, void* out, int n, int C, int F, int H, int W, int ph, int pw, int Kpad, void* stream);
+
+/* proj_out rows [n][(f, gy, gx)][(py*pw + px)*C + c] (row stride ldin) -> [n][C][F][H][W] bf16. */
+int alg_unpatchify3d(const void* in, int64_t ldin, void* out, int n, int C, int F, int H, int W, int ph, int pw,
+                     void* stream);
+
+/* Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0) in float32: out[n][dim] = [cos | sin]. */
+int alg_timestep_embedding_f32(const float* t, float* out, int n, int dim, void* stream);
+
+/* float32 linear for the modules diffusers keeps in fp32 (time_embedder): y = act(x W^T + b), x [M][K], W [N][K];
+ * act 0 none, 1 SiLU.  Any of y (fp32), y_bf16 (= bf16(y)), y_silu_bf16 (= bf16(silu(bf16(y)))) may be NULL. */
+int alg_linear_f32(const float* x, const float* W, const float* b, float* y, void* y_bf16, void* y_silu_bf16, int M,
+                   int N, int K, int act, void* stream);
+
+/* exact (erf) GELU in place on bf16 (WanImageEmbedding feed-forward). */
+int alg_gelu_erf(void* x, int64_t numel, void* stream);
 
 /* y = LayerNorm(x; weight, bias, eps) * (1 + scale[seg]) + shift[seg]       (CogVideoXLayerNormZero / AdaLayerNorm)
  * x, y: [batch][rows][D] bf16, rows contiguous, batch strides x_bstride / y_bstride (elements);

@@ -1,0 +1,235 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (plain torch, fp32 by default) of the Wan 2.1 image-to-video DiT forward
+that pipeline_wan_image2video_lowpass.py:910-917 calls.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+may import it.
+
+The module lives in the `diffusers` dependency (requirements.txt pins git @ be2fb77dc164083bf8f033874066c96bc0a75a11,
+not in /root/reference, not installable here): WanTransformer3DModel / WanTransformerBlock / WanAttnProcessor2_0 /
+WanTimeTextImageEmbedding / WanRotaryPosEmbed.  Restated from the published architecture; PARITY UNPINNED (no golden
+vector of the real class can be produced in this image).  State-dict names follow diffusers so a real checkpoint maps
+1:1 (alg_amd.transformer_wan.WanTransformer3DModel loads the same names).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class WanConfig:
+    patch_size: tuple = (1, 2, 2)
+    num_attention_heads: int = 40
+    attention_head_dim: int = 128
+    in_channels: int = 36
+    out_channels: int = 16
+    text_dim: int = 4096
+    freq_dim: int = 256
+    ffn_dim: int = 13824
+    num_layers: int = 40
+    cross_attn_norm: bool = True
+    eps: float = 1e-6
+    image_dim: int = 1280
+    added_kv_proj_dim: int = 5120
+    rope_max_seq_len: int = 1024
+
+    @property
+    def dim(self):
+        return self.num_attention_heads * self.attention_head_dim
+
+
+def param_shapes(cfg: WanConfig):
+    """name -> (shape, dtype) with the dtypes diffusers keeps after from_pretrained(torch_dtype=bf16):
+    _keep_in_fp32_modules = time_embedder, scale_shift_table, norm1/2/3."""
+    D, Ff = cfg.dim, cfg.ffn_dim
+    pt, ph, pw = cfg.patch_size
+    bf, f32 = torch.bfloat16, torch.float32
+    s = {"patch_embedding.weight": ((D, cfg.in_channels, pt, ph, pw), bf), "patch_embedding.bias": ((D,), bf)}
+    ce = "condition_embedder."
+    s[ce + "time_embedder.linear_1.weight"] = ((D, cfg.freq_dim), f32)
+    s[ce + "time_embedder.linear_1.bias"] = ((D,), f32)
+    s[ce + "time_embedder.linear_2.weight"] = ((D, D), f32)
+    s[ce + "time_embedder.linear_2.bias"] = ((D,), f32)
+    s[ce + "time_proj.weight"] = ((6 * D, D), bf)
+    s[ce + "time_proj.bias"] = ((6 * D,), bf)
+    s[ce + "text_embedder.linear_1.weight"] = ((D, cfg.text_dim), bf)
+    s[ce + "text_embedder.linear_1.bias"] = ((D,), bf)
+    s[ce + "text_embedder.linear_2.weight"] = ((D, D), bf)
+    s[ce + "text_embedder.linear_2.bias"] = ((D,), bf)
+    if cfg.image_dim is not None:
+        I = cfg.image_dim
+        s[ce + "image_embedder.norm1.weight"] = ((I,), bf)
+        s[ce + "image_embedder.norm1.bias"] = ((I,), bf)
+        s[ce + "image_embedder.ff.net.0.proj.weight"] = ((I, I), bf)
+        s[ce + "image_embedder.ff.net.0.proj.bias"] = ((I,), bf)
+        s[ce + "image_embedder.ff.net.2.weight"] = ((D, I), bf)
+        s[ce + "image_embedder.ff.net.2.bias"] = ((D,), bf)
+        s[ce + "image_embedder.norm2.weight"] = ((D,), bf)
+        s[ce + "image_embedder.norm2.bias"] = ((D,), bf)
+    for l in range(cfg.num_layers):
+        b = f"blocks.{l}."
+        s[b + "scale_shift_table"] = ((1, 6, D), f32)
+        for a in ("attn1", "attn2"):
+            names = ["to_q", "to_k", "to_v", "to_out.0"]
+            if a == "attn2" and cfg.added_kv_proj_dim is not None:
+                names += ["add_k_proj", "add_v_proj"]
+            for n in names:
+                s[b + f"{a}.{n}.weight"] = ((D, D), bf)
+                s[b + f"{a}.{n}.bias"] = ((D,), bf)
+            s[b + f"{a}.norm_q.weight"] = ((D,), bf)
+            s[b + f"{a}.norm_k.weight"] = ((D,), bf)
+            if a == "attn2" and cfg.added_kv_proj_dim is not None:
+                s[b + f"{a}.norm_added_k.weight"] = ((D,), bf)
+        if cfg.cross_attn_norm:
+            s[b + "norm2.weight"] = ((D,), f32)
+            s[b + "norm2.bias"] = ((D,), f32)
+        s[b + "ffn.net.0.proj.weight"] = ((Ff, D), bf)
+        s[b + "ffn.net.0.proj.bias"] = ((Ff,), bf)
+        s[b + "ffn.net.2.weight"] = ((D, Ff), bf)
+        s[b + "ffn.net.2.bias"] = ((D,), bf)
+    s["scale_shift_table"] = ((1, 2, D), f32)
+    s["proj_out.weight"] = ((cfg.out_channels * pt * ph * pw, D), bf)
+    s["proj_out.bias"] = ((cfg.out_channels * pt * ph * pw,), bf)
+    return s
+
+
+def init_weights(cfg: WanConfig, seed=0):
+    """Seeded synthetic state dict (values representable in the stored dtype)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, (shape, dt) in param_shapes(cfg).items():
+        if name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or name.endswith("norm_added_k.weight") \
+                or (name.endswith("weight") and len(shape) == 1):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif "scale_shift_table" in name:
+            t = torch.randn(shape, generator=g) / shape[-1] ** 0.5
+        elif name.endswith("bias"):
+            t = 0.02 * torch.randn(shape, generator=g)
+        else:
+            fan_in = math.prod(shape[1:])
+            t = torch.randn(shape, generator=g) / fan_in ** 0.5
+        sd[name] = t.to(dt)
+    return sd
+
+
+def rope_tables(cfg: WanConfig, F_, H, W):
+    """WanRotaryPosEmbed: complex frequencies per (f, h, w) token -> (cos, sin) [S, 64] float64."""
+    d = cfg.attention_head_dim
+    pt, ph, pw = cfg.patch_size
+    h_dim = w_dim = 2 * (d // 6)
+    t_dim = d - h_dim - w_dim
+    tabs = []
+    for dim in (t_dim, h_dim, w_dim):
+        freqs = 1.0 / (10000.0 ** (torch.arange(0, dim, 2, dtype=torch.float64)[: dim // 2] / dim))
+        tabs.append(torch.outer(torch.arange(cfg.rope_max_seq_len, dtype=torch.float64), freqs))
+    ppf, pph, ppw = F_ // pt, H // ph, W // pw
+    ang = torch.cat([tabs[0][:ppf].view(ppf, 1, 1, -1).expand(ppf, pph, ppw, -1),
+                     tabs[1][:pph].view(1, pph, 1, -1).expand(ppf, pph, ppw, -1),
+                     tabs[2][:ppw].view(1, 1, ppw, -1).expand(ppf, pph, ppw, -1)], dim=-1).reshape(ppf * pph * ppw, -1)
+    return torch.cos(ang), torch.sin(ang)
+
+
+def _ln(x, w=None, b=None, eps=1e-6):
+    return F.layer_norm(x.float(), (x.shape[-1],), None if w is None else w.float(), None if b is None else b.float(), eps)
+
+
+def _rms(x, w, eps, dt):
+    """diffusers RMSNorm: fp32 variance, x * rsqrt -> cast to the weight dtype -> * weight."""
+    var = x.float().pow(2).mean(-1, keepdim=True)
+    y = (x.float() * torch.rsqrt(var + eps)).to(dt)
+    return y * w.to(dt)
+
+
+def _rope(x, cos, sin):
+    """x [B, H, S, 128]: complex product of interleaved pairs with (cos + i sin), evaluated in float64."""
+    xr = x.to(torch.float64).unflatten(3, (-1, 2))
+    a, b = xr[..., 0], xr[..., 1]
+    out = torch.stack([a * cos - b * sin, a * sin + b * cos], dim=-1).flatten(3, 4)
+    return out.type_as(x)
+
+
+def _sdpa(q, k, v, heads):
+    B, Sq, D = q.shape
+    d = D // heads
+    qh, kh, vh = (t.view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    o = torch.softmax(qh.float() @ kh.float().transpose(-1, -2) / math.sqrt(d), dim=-1) @ vh.float()
+    return o.transpose(1, 2).reshape(B, Sq, D).to(q.dtype)
+
+
+def wan_forward(cfg: WanConfig, sd, hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image,
+                dtype=torch.float32, collect=None):
+    """hidden_states [B, 36, F, H, W]; timestep [B]; text [B, 512, 4096]; image [B, 257, 1280] or None.
+    ``dtype`` is the activation dtype (float32: the mathematical reference; bfloat16: the reference's rounding points)."""
+    W_ = lambda n: sd[n].to(dtype) if sd[n].dtype != torch.float32 or "time_embedder" not in n else sd[n]
+    lin = lambda x, n: F.linear(x, W_(n + ".weight"), W_(n + ".bias"))
+    B, C, F_, H, Wd = hidden_states.shape
+    pt, ph, pw = cfg.patch_size
+    D, heads = cfg.dim, cfg.num_attention_heads
+    cos, sin = rope_tables(cfg, F_, H, Wd)
+    x = F.conv3d(hidden_states.to(dtype), W_("patch_embedding.weight"), W_("patch_embedding.bias"), stride=cfg.patch_size)
+    x = x.flatten(2).transpose(1, 2)
+    ce = "condition_embedder."
+    half = cfg.freq_dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    emb = timestep.float()[:, None] * torch.exp(exponent)[None]
+    emb = torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)             # flip_sin_to_cos
+    temb = F.linear(F.silu(F.linear(emb, sd[ce + "time_embedder.linear_1.weight"],
+                                    sd[ce + "time_embedder.linear_1.bias"])),
+                    sd[ce + "time_embedder.linear_2.weight"], sd[ce + "time_embedder.linear_2.bias"]).to(dtype)
+    timestep_proj = lin(F.silu(temb), ce + "time_proj").unflatten(1, (6, -1))
+    ehs = lin(F.gelu(lin(encoder_hidden_states.to(dtype), ce + "text_embedder.linear_1"), approximate="tanh"),
+              ce + "text_embedder.linear_2")
+    n_img = 0
+    if encoder_hidden_states_image is not None:
+        im = encoder_hidden_states_image.to(dtype)
+        im = _ln(im, sd[ce + "image_embedder.norm1.weight"], sd[ce + "image_embedder.norm1.bias"], 1e-5).to(dtype)
+        im = lin(F.gelu(lin(im, ce + "image_embedder.ff.net.0.proj")), ce + "image_embedder.ff.net.2")
+        im = _ln(im, sd[ce + "image_embedder.norm2.weight"], sd[ce + "image_embedder.norm2.bias"], 1e-5).to(dtype)
+        ehs = torch.cat([im, ehs], dim=1)
+        n_img = im.shape[1]
+    if collect is not None:
+        collect["temb"], collect["timestep_proj"], collect["ehs"], collect["x0"] = temb, timestep_proj, ehs, x
+    for l in range(cfg.num_layers):
+        b = f"blocks.{l}."
+        mod = sd[b + "scale_shift_table"] + timestep_proj.float()
+        sh1, sc1, g1, sh2, sc2, g2 = mod.chunk(6, dim=1)
+        # self-attention
+        n = (_ln(x, eps=cfg.eps) * (1 + sc1) + sh1).to(dtype)
+        q = _rms(lin(n, b + "attn1.to_q"), sd[b + "attn1.norm_q.weight"], cfg.eps, dtype)
+        k = _rms(lin(n, b + "attn1.to_k"), sd[b + "attn1.norm_k.weight"], cfg.eps, dtype)
+        v = lin(n, b + "attn1.to_v")
+        rp = lambda t: _rope(t.view(B, -1, heads, D // heads).transpose(1, 2), cos, sin).transpose(1, 2).reshape(B, -1, D)
+        a = lin(_sdpa(rp(q), rp(k), v, heads), b + "attn1.to_out.0")
+        x = (x.float() + a * g1).to(dtype)
+        # cross-attention (image tokens first, text last)
+        n = _ln(x, sd.get(b + "norm2.weight"), sd.get(b + "norm2.bias"), cfg.eps).to(dtype) if cfg.cross_attn_norm else x
+        q = _rms(lin(n, b + "attn2.to_q"), sd[b + "attn2.norm_q.weight"], cfg.eps, dtype)
+        txt = ehs[:, n_img:]
+        k = _rms(lin(txt, b + "attn2.to_k"), sd[b + "attn2.norm_k.weight"], cfg.eps, dtype)
+        v = lin(txt, b + "attn2.to_v")
+        o = _sdpa(q, k, v, heads)
+        if n_img:
+            img = ehs[:, :n_img]
+            ki = _rms(lin(img, b + "attn2.add_k_proj"), sd[b + "attn2.norm_added_k.weight"], cfg.eps, dtype)
+            vi = lin(img, b + "attn2.add_v_proj")
+            o = o + _sdpa(q, ki, vi, heads)
+        x = x + lin(o, b + "attn2.to_out.0")
+        # feed-forward
+        n = (_ln(x, eps=cfg.eps) * (1 + sc2) + sh2).to(dtype)
+        f = lin(F.gelu(lin(n, b + "ffn.net.0.proj"), approximate="tanh"), b + "ffn.net.2")
+        x = (x.float() + f.float() * g2).to(dtype)
+        if collect is not None:
+            collect[f"block{l}"] = x
+    shift, scale = (sd["scale_shift_table"] + temb.unsqueeze(1)).chunk(2, dim=1)
+    x = (_ln(x, eps=cfg.eps) * (1 + scale) + shift).to(dtype)
+    x = lin(x, "proj_out")
+    x = x.reshape(B, F_ // pt, H // ph, Wd // pw, pt, ph, pw, -1).permute(0, 7, 1, 4, 2, 5, 3, 6)
+    return x.flatten(6, 7).flatten(4, 5).flatten(2, 3)
+
+
+def flops_per_forward(cfg: WanConfig, S, n_text=512, n_img=257):
+    D, Ff, L = cfg.dim, cfg.ffn_dim, cfg.num_layers
+    lin = 2 * S * (4 * D * D + 2 * D * D + 2 * D * Ff) + 2 * (n_text + n_img) * 2 * D * D
+    attn = 4 * S * S * D + 4 * S * (n_text + n_img) * D
+    return L * (lin + attn)

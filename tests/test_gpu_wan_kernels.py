@@ -56,3 +56,98 @@ def test_flash_attn_d128_rejects_bad_arguments():
     with pytest.raises(_lib.AlgHipError):
         _lib.flash_attn_d128(q.cpu(), q, q, q.clone(), 1, 1, 64, 64, 64 * 128, 128, 64 * 128, 128, 128 * 64, 64,
                              64 * 128, 128, 0.1)
+
+
+@pytest.mark.parametrize("D,affine,mod", [(512, False, True), (5120, True, False), (1280, True, False), (1024, True, True)])
+def test_layernorm_mod_f32(D, affine, mod):
+    B, S = 2, 37
+    x = _rand((B, S, D), 5)
+    g = torch.Generator().manual_seed(6)
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV) if affine else None
+    b = (0.1 * torch.randn(D, generator=g)).to(DEV) if affine else None
+    modv = torch.randn(B, 6, D, generator=g).to(DEV) * 0.3
+    y = torch.empty_like(x)
+    _lib.layernorm_mod_f32(x, y, w, b, modv if mod else None, modv if mod else None, 6 * D, B, S, D, 1e-6,
+                           scale_off=D, shift_off=2 * D)
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), w, b, 1e-6)
+    if mod:
+        ref = ref * (1 + modv[:, 1:2]) + modv[:, 2:3]
+    ref = ref.to(BF)
+    assert (y.float() - ref.float()).abs().max().item() <= 2.0 ** -6          # one bf16 ulp at |y| < 4
+    assert (y != ref).float().mean().item() < 0.01
+
+
+@pytest.mark.parametrize("D,rope", [(512, True), (5120, True), (512, False)])
+def test_rmsnorm_rope(D, rope):
+    B, S = 2, 29
+    x = _rand((B, S, 2 * D), 7)
+    w = _rand((D,), 8, 0.1) + 1
+    g = torch.Generator().manual_seed(9)
+    ang = torch.rand(S, 64, generator=g, dtype=torch.float64) * 6.0
+    cos, sin = torch.cos(ang), torch.sin(ang)
+    y = x.clone()
+    _lib.rmsnorm_rope_(y, w, cos.float().to(DEV) if rope else None, sin.float().to(DEV) if rope else None, 2 * D, B, S, D,
+                       1e-6, x_off=D)  # the k half of a fused [q | k] buffer
+    xs = x[:, :, D:]
+    var = xs.float().pow(2).mean(-1, keepdim=True)
+    ref = (xs.float() * torch.rsqrt(var + 1e-6)).to(BF) * w
+    if rope:
+        r = ref.to(torch.float64).view(B, S, D // 128, 64, 2)
+        c, s_ = cos.to(DEV)[None, :, None, :], sin.to(DEV)[None, :, None, :]
+        ref = torch.stack([r[..., 0] * c - r[..., 1] * s_, r[..., 0] * s_ + r[..., 1] * c], dim=-1).reshape(B, S, D).to(BF)
+    assert torch.equal(y[:, :, :D], x[:, :, :D])          # the q half is untouched
+    got = y[:, :, D:]
+    assert (got.float() - ref.float()).abs().max().item() <= 2.0 ** -5
+    assert (got != ref).float().mean().item() < 0.02
+
+
+def test_patchify_unpatchify_modulation_linear():
+    N, C, F, H, W = 2, 36, 3, 8, 12
+    x = _rand((N, C, F, H, W), 10)
+    S = F * (H // 2) * (W // 2)
+    out = torch.empty(N, S, 192, dtype=BF, device=DEV)
+    _lib.patchify3d(x, out, N, C, F, H, W, 2, 2, 192)
+    ref = x.view(N, C, F, H // 2, 2, W // 2, 2).permute(0, 2, 3, 5, 1, 4, 6).reshape(N, S, 144)
+    assert torch.equal(out[:, :, :144], ref) and not out[:, :, 144:].any()
+    tok = _rand((N, S, 64), 11)
+    img = torch.empty(N, 16, F, H, W, dtype=BF, device=DEV)
+    _lib.unpatchify3d(tok, 64, img, N, 16, F, H, W, 2, 2)
+    ref = tok.reshape(N, F, H // 2, W // 2, 1, 2, 2, 16).permute(0, 7, 1, 4, 2, 5, 3, 6).flatten(6, 7).flatten(4, 5).flatten(2, 3)
+    assert torch.equal(img, ref)
+    g = torch.Generator().manual_seed(12)
+    table = torch.randn(3, 6, 512, generator=g).to(DEV)
+    vec = _rand((N, 6 * 512), 13)
+    mod = torch.empty(3, N, 6, 512, device=DEV)
+    _lib.wan_modulation(table, vec, mod, 3, N, 6, 512, True)
+    assert torch.equal(mod, table[:, None] + vec.float().view(1, N, 6, 512))
+    t = torch.tensor([999.0, 12.0], device=DEV)
+    emb = torch.empty(2, 256, device=DEV)
+    _lib.timestep_embedding_f32(t, emb, 2, 256)
+    freq = torch.exp(-math.log(10000.0) * torch.arange(128, dtype=torch.float32, device=DEV) / 128)
+    a = t[:, None] * freq[None]
+    assert torch.allclose(emb, torch.cat([torch.cos(a), torch.sin(a)], dim=-1), atol=2e-4)
+    Wt, bt = torch.randn(64, 256, generator=g).to(DEV) / 16, torch.randn(64, generator=g).to(DEV)
+    y, ybf, ysl = torch.empty(2, 64, device=DEV), torch.empty(2, 64, dtype=BF, device=DEV), torch.empty(2, 64, dtype=BF, device=DEV)
+    _lib.linear_f32(emb, Wt, bt, y, ybf, ysl, 2, 64, 256, act=0)
+    ref = emb @ Wt.t() + bt
+    assert torch.allclose(y, ref, atol=1e-5)
+    assert torch.equal(ybf, y.to(BF))
+    assert (ysl.float() - torch.nn.functional.silu(y.to(BF)).float()).abs().max().item() <= 2.0 ** -7
+    z = _rand((5, 77), 14)
+    ref = torch.nn.functional.gelu(z.float()).to(BF)
+    _lib.gelu_erf_(z)
+    assert (z.float() - ref.float()).abs().max().item() <= 2.0 ** -7
+
+
+def test_gemm_fp32_gate_epilogue():
+    B, S, D, K = 2, 300, 512, 256
+    a, wgt, bias, r = _rand((B, S, K), 15), _rand((D, K), 16, 0.06), _rand((D,), 17, 0.1), _rand((B, S, D), 18)
+    g = torch.Generator().manual_seed(19)
+    gate = torch.randn(B, 6, D, generator=g).to(DEV)
+    c = r.clone()
+    _lib.gemm(a, wgt, c, S, D, K, K, K, D, bias=bias, R=c, ldr=D, gate=gate, gate_off=2 * D, strideGate=6 * D, batch=B,
+              strideA=S * K, strideC=S * D, strideR=S * D, seg_split=1 << 30, flags=_lib.GEMM_GATE_F32)
+    lin = (a.float() @ wgt.float().t() + bias.float()).to(BF)
+    ref = (r.float() + lin.float() * gate[:, 2:3]).to(BF)
+    assert (c.float() - ref.float()).abs().max().item() <= 2.0 ** -5
+    assert (c != ref).float().mean().item() < 0.02
