@@ -189,6 +189,27 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const LinTerms t, TO* __re
   }
 }
 
+// all-bf16 fast path (the text + image cross-attention sum of the Wan DiT runs over 670 MB): 16-byte accesses
+__global__ __launch_bounds__(256) void lincomb_bf16x8_kernel(const LinTerms t, bf16_t* __restrict__ out, int64_t nvec) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i8 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i8 < nvec; i8 += stride) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < t.n) {
+        float v[8];
+        load8<bf16_t>((const bf16_t*)t.x[i], i8 * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float term = rbf(__fmul_rn(t.c[i], v[k]));
+          acc[k] = i == 0 ? term : __fadd_rn(acc[k], term);
+        }
+      }
+    }
+    store8<bf16_t>(out, i8 * 8, acc);
+  }
+}
+
 // UniPC-bh (predict_x0) predictor / corrector update for solver_order <= 2, op order of the published
 // multistep_uni_p_bh_update / multistep_uni_c_bh_update (fp32 tensors, fp32 0-dim scalars):
 //   x_t_ = r * x - c * m0
@@ -339,6 +360,14 @@ extern "C" int alg_lincomb(const void* const* xs, const float* coefs, const int*
     }
   }
   if (numel == 0) return ALG_OK;
+  bool all_bf16 = out_dtype == ALG_BF16 && numel % 8 == 0 && ((uintptr_t)out & 15) == 0;
+  for (int i = 0; i < n_terms; ++i) all_bf16 = all_bf16 && dtypes[i] == ALG_BF16 && ((uintptr_t)xs[i] & 15) == 0;
+  if (all_bf16) {
+    const int64_t nvec = numel / 8, wantv = (nvec + 255) / 256;
+    hipLaunchKernelGGL(lincomb_bf16x8_kernel, dim3((unsigned)(wantv > 8192 ? 8192 : wantv)), dim3(256), 0,
+                       (hipStream_t)stream, t, (bf16_t*)out, nvec);
+    return check_launch("alg_lincomb");
+  }
   int64_t want = (numel + 255) / 256;
   const unsigned grid = (unsigned)(want > 4096 ? 4096 : want);
   if (out_dtype == ALG_F32)

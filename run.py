@@ -18,7 +18,8 @@ import torch
 import yaml
 
 from alg_amd import (CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, CogVideoXTransformer3DModel,
-                     CogVideoXTransformerConfig)
+                     CogVideoXTransformerConfig, UniPCMultistepScheduler, WanImageToVideoPipeline, WanTransformer3DModel,
+                     WanTransformerConfig)
 from alg_amd.lp_utils import get_hunyuan_video_size  # noqa: F401  (kept importable here, as in the reference)
 
 logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s", stream=sys.stdout)
@@ -40,12 +41,20 @@ def main(args):
         else:
             pipe = CogVideoXImageToVideoPipeline.from_pretrained(model_path, torch_dtype=model_dtype,
                                                                  cache_dir=args.model_cache_dir)
-    elif "Wan" in model_path or "HunyuanVideo" in model_path:
+    elif "Wan" in model_path:
+        # run.py:63: UniPC with flow_shift 3.0 for 480p, 5.0 otherwise (the reference compares height with the STRING '480',
+        # which never matches an int from YAML, so it always lands on 5.0 -- reproduced)
+        flow_shift = 3.0 if config["generation"]["height"] == "480" else 5.0
+        if args.synthetic:
+            transformer = WanTransformer3DModel.from_synthetic(WanTransformerConfig(), device=device)
+        else:
+            transformer = WanTransformer3DModel.from_pretrained(model_path, device=device)
+        pipe = WanImageToVideoPipeline(transformer=transformer, scheduler=UniPCMultistepScheduler(flow_shift=flow_shift))
+    elif "HunyuanVideo" in model_path:
         raise NotImplementedError(
-            "the Wan / HunyuanVideo DiT forwards are the next rows of the build (SURVEY.md section 8f-2).  Their ALG "
-            "sampler loops are built (alg_amd.WanImageToVideoPipeline / HunyuanVideoImageToVideoPipeline with the HIP "
-            "filters, batch assembly, CFG combine and UniPC / flow-match Euler steps) and take any transformer object "
-            "with the diffusers call signature")
+            "the HunyuanVideo DiT forward is the next row of the build (SURVEY.md section 8f-2).  Its ALG sampler loop is "
+            "built (alg_amd.HunyuanVideoImageToVideoPipeline: HIP filters, batch assembly, CFG combine, flow-match Euler) "
+            "and takes any transformer object with the diffusers call signature")
     else:
         raise ValueError(f"unknown model family in model.path: {model_path}")
     pipe.to(device)
@@ -60,9 +69,21 @@ def main(args):
 
     if args.synthetic:
         g = torch.Generator().manual_seed(42)
-        pipe_kwargs["prompt_embeds"] = torch.randn(1, 226, 4096, generator=g).to(model_dtype)
-        pipe_kwargs["negative_prompt_embeds"] = torch.randn(1, 226, 4096, generator=g).to(model_dtype)
-        pipe_kwargs["image_latents"] = (torch.randn(1, 1, 16, 60, 90, generator=g) * 0.7).to(model_dtype)
+        if "Wan" in model_path:
+            gen = config.get("generation", {})
+            h, w_, nf = gen.get("height", 480), gen.get("width", 832), gen.get("num_frames", 81)
+            f_lat = (nf - 1) // 4 + 1
+            pipe_kwargs["prompt_embeds"] = torch.randn(1, 512, 4096, generator=g).to(model_dtype)
+            pipe_kwargs["negative_prompt_embeds"] = torch.randn(1, 512, 4096, generator=g).to(model_dtype)
+            pipe_kwargs["image_embeds"] = torch.randn(1, 257, 1280, generator=g).to(model_dtype)
+            cond = torch.randn(1, 20, f_lat, h // 8, w_ // 8, generator=g) * 0.7
+            cond[:, :4] = 0.0
+            cond[:, :4, 0] = 1.0                      # first-frame mask channels (wan:444-456)
+            pipe_kwargs["image_condition"] = cond
+        else:
+            pipe_kwargs["prompt_embeds"] = torch.randn(1, 226, 4096, generator=g).to(model_dtype)
+            pipe_kwargs["negative_prompt_embeds"] = torch.randn(1, 226, 4096, generator=g).to(model_dtype)
+            pipe_kwargs["image_latents"] = (torch.randn(1, 1, 16, 60, 90, generator=g) * 0.7).to(model_dtype)
         pipe_kwargs["output_type"] = "latent"
     else:
         from PIL import Image

@@ -230,3 +230,12 @@ def test_hunyuan_loop_matches_oracle(true_cfg, alg, noisy):
     err = (got - want).abs().max().item()
     assert err <= 2.0 ** -6, err
     assert (got != want).float().mean().item() < 0.01
+
+
+def test_lincomb_bf16_vector_path_and_aliasing():
+    a, b = _rand((4, 4096), 90, BF).to(DEV), _rand((4, 4096), 91, BF).to(DEV)
+    want = a + b
+    got = _lib.lincomb([(1.0, a), (1.0, b)], BF, out=a)   # in place on the first term (Wan cross-attention sum)
+    assert got is a and torch.equal(a, want)
+    c = _rand((3, 1000), 92, BF).to(DEV)
+    assert torch.equal(_lib.lincomb([(0.5, c), (-2.0, c)], BF), (0.5 * c + (-2.0) * c))
