@@ -198,3 +198,24 @@ def test_loop_branch_table_oracle():
     assert sum(1 for _, tp, _ in trace if not tp) == 12
     trace, _ = run(10, use_low_pass_guidance=False)
     assert all(n == 2 for _, _, n in trace)
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """The drop-in boundary is a C ABI: include/alg_hip.h must compile as C (no C++/torch types) and a C program must
+    link against libalg_hip.so and resolve every declared entry point (no compute call: there is no GPU here)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    header = open(os.path.join(ROOT, "include", "alg_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(alg_[a-z0-9_]+)\s*\(", header)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "alg_hip.h"\n#include <stdio.h>\nint main(void) {\n  const void* fns[] = {%s};\n'
+                   '  printf("%%d %%d\\n", (int)(sizeof(fns) / sizeof(fns[0])), alg_version());\n  return fns[0] == 0;\n}\n'
+                   % ", ".join("(const void*)%s" % n for n in names))
+    lib_dir = os.path.join(ROOT, "alg_amd")
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", lib_dir, "-lalg_hip", "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == len(names) and int(out[1]) > 0
