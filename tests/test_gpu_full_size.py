@@ -124,3 +124,26 @@ def test_sampler_full_latent_size_one_layer(device):
     assert sum(n for _, _, n in trace) == 102 and [n for _, _, n in trace[:3]] == [3, 3, 2]
     assert [s for s, _, _ in trace[:3]] == [1.0, 1.0, 0.0]
     assert len(pipe._lp_cache) == 2  # factor 0.25 (filtered once) and factor 1.0 (identity: the input object itself)
+
+
+def test_wan_self_attention_full_size_properties():
+    """Wan-480p self-attention shape (40 heads x 32,760 tokens x 128): size-independent properties -- softmax rows sum to
+    one (V = 1 -> O = 1) and with K = 0 every query returns the mean of V."""
+    from alg_amd import _lib
+    S, H = 32760, 4                      # 4 of the 40 heads: same kernel path, 10x less memory
+    D = H * 128
+    s_pad = (S + 63) // 64 * 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.randn(1, S, D, generator=g, device="cuda").to(torch.bfloat16)
+    k = torch.randn(1, S, D, generator=g, device="cuda").to(torch.bfloat16)
+    vt = torch.zeros(1, D, s_pad, dtype=torch.bfloat16, device="cuda")
+    vt[:, :, :S] = 1.0
+    o = torch.empty(1, S, D, dtype=torch.bfloat16, device="cuda")
+    args = (1, H, S, S, S * D, D, S * D, D, D * s_pad, s_pad, S * D, D, 128 ** -0.5)
+    _lib.flash_attn_d128(q, k, vt, o, *args)
+    assert (o.float() - 1.0).abs().max().item() <= 2.0 ** -7
+    v = torch.randn(1, D, S, generator=g, device="cuda").to(torch.bfloat16)
+    vt[:, :, :S] = v
+    _lib.flash_attn_d128(q, torch.zeros_like(k), vt, o, *args)
+    mean = v.float().mean(dim=2)          # the kv permutation inside 16-blocks does not change a mean
+    assert (o.float() - mean[:, None, :]).abs().max().item() <= 3e-3
