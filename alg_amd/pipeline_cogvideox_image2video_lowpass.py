@@ -16,7 +16,8 @@ What runs where
 Components that are once-per-video and outside the hot path (text encoder, VAE, video post-processing;
 SURVEY.md section 8f "next" rows) are injected duck-typed objects, exactly as diffusers registers them; when
 they are absent the caller passes ``prompt_embeds`` / ``negative_prompt_embeds`` (reference kwargs) and
-``image_latents`` (extension kwarg) and asks for ``output_type="latent"``.
+``image_latents`` (extension kwarg) and asks for ``output_type="latent"``.  ``cfg_split=`` (extension kwarg, an
+``alg_amd.parallel.CFGPairSplit``) evaluates the cond / uncond passes of one video on two GPUs.
 """
 from __future__ import annotations
 
@@ -410,6 +411,7 @@ class CogVideoXImageToVideoPipeline:
         schedule_exp_decay_rate: float = 10.0,
         image_latents: Optional[torch.Tensor] = None,
         step_trace: Optional[list] = None,
+        cfg_split=None,
     ) -> Union[CogVideoXPipelineOutput, Tuple]:
         """Keyword-compatible with the reference ``__call__`` (cog:727-774); ``image_latents`` and ``step_trace``
         are extensions (VAE bypass; per-step (strength, two_pass, n_forward) log for tests)."""
@@ -529,7 +531,16 @@ class CogVideoXImageToVideoPipeline:
             conds = [g[b:b + 1] for g in cond_groups for b in range(B)]
             lat_in = latents if B == 1 else torch.cat([latents] * n_pass, dim=0)
             ts = torch.full((n_pass * B,), int(t), dtype=torch.float32)
-            noise_pred = self.transformer.forward_assembled(lat_in, conds, embeds, ts, image_rotary_emb)
+            if cfg_split is not None and n_pass > 1:
+                # alg_amd.parallel.CFGPairSplit: this rank evaluates its share of the CFG passes, one all-reduce merges
+                # the predictions; combine + step below run identically on both ranks of the pair
+                rows = [p_ * B + b for p_ in cfg_split.my_passes(n_pass) for b in range(B)]
+                lat_l = latents if B == 1 else torch.cat([latents] * (len(rows) // B), dim=0)
+                local = self.transformer.forward_assembled(lat_l, [conds[r] for r in rows], embeds[rows].contiguous(),
+                                                           ts[:len(rows)], image_rotary_emb)
+                noise_pred = cfg_split.merge(local, n_pass, B)
+            else:
+                noise_pred = self.transformer.forward_assembled(lat_in, conds, embeds, ts, image_rotary_emb)
             gs = guidance_scale
             if do_cfg and not use_low_pass_guidance and use_dynamic_cfg:  # cog:1105-1108
                 gs = 1 + guidance_scale * (

@@ -212,6 +212,7 @@ class WanImageToVideoPipeline:
         # ---- extensions (not in the reference signature) ----
         image_condition: Optional[torch.Tensor] = None,
         step_trace: Optional[list] = None,
+        cfg_split=None,
     ):
         self.check_inputs(prompt, negative_prompt, image, height, width, prompt_embeds, negative_prompt_embeds,
                           image_embeds, callback_on_step_end_tensor_inputs)
@@ -294,11 +295,21 @@ class WanImageToVideoPipeline:
             latent_model_input = assemble_channel_concat(latents, groups, tdtype)
             n = latent_model_input.shape[0]
             timestep = t.expand(n).to(device)
-            noise_pred = self.transformer(
-                hidden_states=latent_model_input, timestep=timestep,
-                encoder_hidden_states=torch.cat(embeds, dim=0),
-                encoder_hidden_states_image=image_embeds.repeat(n, 1, 1) if image_embeds.shape[0] != n else image_embeds,
-                attention_kwargs=attention_kwargs, return_dict=False)[0]
+            ehs = torch.cat(embeds, dim=0)
+            ehs_img = image_embeds.repeat(n, 1, 1) if image_embeds.shape[0] != n else image_embeds
+            if cfg_split is not None:
+                # alg_amd.parallel.CFGPairSplit: this rank's share of the CFG passes, one all-reduce merges the predictions
+                B_ = latents.shape[0]
+                rows = [p_ * B_ + b for p_ in cfg_split.my_passes(len(groups)) for b in range(B_)]
+                local = self.transformer(hidden_states=latent_model_input[rows].contiguous(), timestep=timestep[:len(rows)],
+                                         encoder_hidden_states=ehs[rows].contiguous(),
+                                         encoder_hidden_states_image=ehs_img[rows].contiguous(),
+                                         attention_kwargs=attention_kwargs, return_dict=False)[0]
+                noise_pred = cfg_split.merge(local.contiguous(), len(groups), B_)
+            else:
+                noise_pred = self.transformer(
+                    hidden_states=latent_model_input, timestep=timestep, encoder_hidden_states=ehs,
+                    encoder_hidden_states_image=ehs_img, attention_kwargs=attention_kwargs, return_dict=False)[0]
             # wan:919-924 keys the 3-chunk combine on shape[0] == 3, so the reference's 3-pass step only works for one
             # video per call (a [3B, ...] prediction would be chunked in two and fail in the scheduler)
             n_pass = 3 if noise_pred.shape[0] == 3 else 2

@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=42, help="debug only: fewer layers invalidates the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cfg-split", action="store_true",
+                    help="opt-in: cond/uncond CFG passes of one video on a pair of GPUs (latency mode, one all-reduce per step)")
     ap.add_argument("--filters-only", action="store_true", help="debug: only the low-pass kernel micro-benchmark")
     args = ap.parse_args()
     if args.filters_only:
@@ -179,7 +181,14 @@ def main():
     timesteps = sched.timesteps
 
     # per-rank synthetic video inputs (seed 42 + rank, run.py:94 uses 42)
-    g = torch.Generator().manual_seed(42 + rank)
+    split = None
+    if args.cfg_split:
+        # BASELINE config 5 style: the cond / uncond CFG passes of ONE video on a pair of GPUs (one small all-reduce per
+        # step); pairs are independent videos.  Opt-in: the default bench is pure data parallelism over videos.
+        if world % 2:
+            raise SystemExit("--cfg-split needs an even number of GPUs")
+        split = parallel.CFGPairSplit.from_world()
+    g = torch.Generator().manual_seed(42 + (rank // 2 if split else rank))
     F_lat, C, Hh, Ww = 13, 16, 60, 90
     latents0 = torch.randn(1, F_lat, C, Hh, Ww, generator=g).to(dev, torch.bfloat16)
     image_latents = torch.zeros(1, F_lat, C, Hh, Ww, device=dev, dtype=torch.bfloat16)
@@ -212,7 +221,16 @@ def main():
         conds = [lp, lp] if two_pass else [image_latents, lp, lp]
         n = len(conds)
         ts = torch.full((n,), float(t), device=dev)
-        pred = model.forward_assembled(latents, conds, emb2 if two_pass else emb3, ts, rope)
+        if split is not None:
+            rows = split.my_passes(n)
+            emb = emb2 if two_pass else emb3
+            local = model.forward_assembled(latents, [conds[r] for r in rows], emb[rows].contiguous(), ts[:len(rows)],
+                                            rope)
+            pred = split.merge(local, n, 1)
+            n_local = len(rows)
+        else:
+            pred = model.forward_assembled(latents, conds, emb2 if two_pass else emb3, ts, rope)
+            n_local = n
         if prof is not None:
             e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e2.record()
@@ -220,7 +238,7 @@ def main():
         if prof is not None:
             e3.record()
             prof.setdefault("cfg_step_%d" % n, []).append((e2, e3))
-        return n
+        return n_local
 
     for i in range(args.warmup):
         one_step(i, None)
@@ -244,7 +262,8 @@ def main():
     elapsed = parallel.max_over_ranks(elapsed, dev)
     finite = bool(torch.isfinite(latents.float()).all().item())
 
-    frames = C2["frames"] * args.steps / C2["steps"] * world
+    n_videos_parallel = world // 2 if split else world
+    frames = C2["frames"] * args.steps / C2["steps"] * n_videos_parallel
     value = frames / elapsed
 
     # ---- per-kernel rooflines from the HIP events of the timed region --------------------------------------
@@ -297,8 +316,8 @@ def main():
         "dtype": "bf16", "data": "synthetic (seeded random-init weights at CogVideoX-5B-I2V shapes, seeded latents/embeddings)",
         "config": {"workload": "BASELINE config 2: CogVideoX-5B-I2V bf16, 49 frames @ 480x720, 50 steps, ALG interval "
                                "down_up (resize_factor 0.25, interval [0, 0.04]), guidance 6.0; one video per GPU",
-                   "layers": cfg.num_layers, "tokens": S, "dit_sample_forwards": forwards, "parallelism": "dp%d" % world,
-                   "videos": args.steps / C2["steps"] * world},
+                   "layers": cfg.num_layers, "tokens": S, "dit_sample_forwards": forwards, "parallelism": ("cfgpair2xdp%d" % (world // 2)) if split else ("dp%d" % world),
+                   "videos": args.steps / C2["steps"] * n_videos_parallel},
         "seconds": elapsed, "finite": finite, "roofline": roofline,
     }
     if cfg.num_layers != 42:

@@ -126,3 +126,64 @@ def test_sampler_schedules_and_filter_cache(device):
     with pytest.raises(alg_amd.AlgHipError):  # no VAE attached -> cannot decode
         pipe(image_latents=first, prompt_embeds=pe, negative_prompt_embeds=ne, height=64, width=96, num_frames=9,
              num_inference_steps=1)
+
+
+class _ThreadPair:
+    """Stands in for alg_amd.parallel.CFGPairSplit on ONE GPU: the two 'ranks' are threads with their own model
+    instance (own workspace); merge() is the all-reduce, done through a shared dict and a barrier."""
+
+    def __init__(self):
+        import threading
+        self.barrier = threading.Barrier(2)
+        self.box = {}
+
+    def rank(self, pair_rank):
+        from alg_amd.parallel import CFGPairSplit
+        outer = self
+
+        class _Rank(CFGPairSplit):
+            def all_reduce(self, t):
+                outer.box[self.pair_rank] = t.clone()
+                outer.barrier.wait()
+                t.copy_(outer.box[0] + outer.box[1])
+                outer.barrier.wait()
+        return _Rank(group=None, pair_rank=pair_rank)
+
+
+def test_cfg_pair_split_reproduces_the_single_gpu_sampler(device):
+    """cond / uncond passes of one video on two 'ranks' (threads): both must end on the bits of the unsplit sampler --
+    the DiT kernels are batch-consistent and the merged prediction is exact."""
+    import threading
+    g = torch.Generator().manual_seed(43)
+    Fr, C, H, W = 3, 8, 8, 12
+    latents = torch.randn(1, Fr, C, H, W, generator=g).to(BF)
+    first = (torch.randn(1, 1, C, H, W, generator=g) * 0.7).to(BF)
+    pe, ne = torch.randn(1, 10, 128, generator=g).to(BF), torch.randn(1, 10, 128, generator=g).to(BF)
+    kw = dict(image=None, image_latents=first, latents=latents, prompt_embeds=pe, negative_prompt_embeds=ne, height=H * 8,
+              width=W * 8, num_frames=9, output_type="latent", lp_filter_in_latent=True, num_inference_steps=4,
+              guidance_scale=6.0, use_low_pass_guidance=True, lp_filter_type="down_up", lp_resize_factor=0.25,
+              lp_strength_schedule_type="interval", schedule_interval_start_time=0.0, schedule_interval_end_time=0.3)
+
+    def pipe():
+        _, _, model = make_pair(device, seed=5)
+        return CogVideoXImageToVideoPipeline(transformer=model, scheduler=CogVideoXDDIMScheduler()).to(device)
+
+    trace = []
+    ref = pipe()(step_trace=trace, **kw).frames
+    assert sorted(set(n for _, _, n in trace)) == [2, 3]       # both the 3-pass and the 2-pass split are exercised
+    pair, outs, errs = _ThreadPair(), {}, []
+
+    def run(r):
+        try:
+            outs[r] = pipe()(cfg_split=pair.rank(r), **kw).frames
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            pair.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    assert torch.equal(outs[0], ref) and torch.equal(outs[1], ref)

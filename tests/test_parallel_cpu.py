@@ -88,3 +88,48 @@ def test_yaml_schema_matches_call_signature():
                   schedule_exp_decay_rate=10.0, max_sequence_length=226, output_type="pil", eta=0.0)
     for k, v in expect.items():
         assert sig[k].default == v, k
+
+
+def _cfg_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_distributed(backend="gloo")
+    split = parallel.CFGPairSplit.from_world()
+    ok = True
+    for n_pass, batch in ((2, 1), (3, 1), (3, 2)):
+        g = torch.Generator().manual_seed(7 + n_pass + batch)
+        full = torch.randn(n_pass * batch, 4, 3, 5, generator=g).to(torch.bfloat16)   # what one GPU would compute
+        mine = split.my_passes(n_pass)
+        local = torch.cat([full[p * batch:(p + 1) * batch] for p in mine])
+        merged = split.merge(local, n_pass, batch)
+        ok = ok and torch.equal(merged, full)
+    out.put((rank, split.pair_rank, split.my_passes(2), split.my_passes(3), ok))
+    dist.destroy_process_group()
+
+
+def test_cfg_pair_split_exchange():
+    """The cond / uncond branches of one video on two ranks: pass assignment covers every pass exactly once and the
+    one-collective merge reproduces the full prediction bit-exactly on both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cfg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == (0, 0, [0], [0, 1], True)
+    assert res[1] == (1, 1, [1], [2], True)
+
+
+def test_yaml_schema_matches_wan_call_signature():
+    from alg_amd import WanImageToVideoPipeline
+    params = set(inspect.signature(WanImageToVideoPipeline.__call__).parameters)
+    for name in os.listdir(os.path.join(ROOT, "configs")):
+        if name.startswith("wan"):
+            with open(os.path.join(ROOT, "configs", name)) as f:
+                cfg = yaml.safe_load(f)
+            for key in {**cfg.get("generation", {}), **cfg.get("alg", {})}:
+                assert key in params, (name, key)
