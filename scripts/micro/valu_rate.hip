@@ -47,6 +47,21 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
       REP16(asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n"
                          "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n"
                          : "+v"(acc0), "+v"(acc1), "+v"(fa), "+v"(fb), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (OP == 10) {  // mfma + 7 v_pk_fma behind each: does packed fp32 share the matrix datapath?
+      REP16(asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n"
+                         "v_pk_fma_f32 %4, %4, %4, %4\n v_pk_fma_f32 %5, %5, %5, %5\n v_pk_fma_f32 %6, %6, %6, %6\n v_pk_fma_f32 %7, %7, %7, %7\n"
+                         "v_pk_fma_f32 %4, %4, %4, %4\n v_pk_fma_f32 %5, %5, %5, %5\n v_pk_fma_f32 %6, %6, %6, %6\n"
+                         : "+v"(acc0), "+v"(acc1), "+v"(fa), "+v"(fb), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));)
+    } else if (OP == 11) {  // mfma + 7 v_max3
+      REP16(asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n"
+                         "v_max3_f32 %4, %4, %5, %6\n v_max3_f32 %5, %5, %6, %7\n v_max3_f32 %6, %6, %7, %4\n v_max3_f32 %7, %7, %4, %5\n"
+                         "v_max3_f32 %4, %4, %5, %6\n v_max3_f32 %5, %5, %6, %7\n v_max3_f32 %6, %6, %7, %4\n"
+                         : "+v"(acc0), "+v"(acc1), "+v"(fa), "+v"(fb), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (OP == 12) {  // mfma + 7 v_cvt_pk_bf16_f32
+      REP16(asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n"
+                         "v_cvt_pk_bf16_f32 %4, %4, %5\n v_cvt_pk_bf16_f32 %5, %5, %6\n v_cvt_pk_bf16_f32 %6, %6, %7\n v_cvt_pk_bf16_f32 %7, %7, %4\n"
+                         "v_cvt_pk_bf16_f32 %4, %4, %5\n v_cvt_pk_bf16_f32 %5, %5, %6\n v_cvt_pk_bf16_f32 %6, %6, %7\n"
+                         : "+v"(acc0), "+v"(acc1), "+v"(fa), "+v"(fb), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
     } else if (OP == 8) {  // v_pk_add_f32
       REP16(asm volatile("v_pk_add_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_add_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3"
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));)
@@ -97,6 +112,9 @@ int main() {
     run<5>("mfma_32x32x16_bf16", 64, w);
     run<6>("mfma + 7 fma (per group)", 16, w);
     run<7>("mfma + 2 exp (per group)", 16, w);
+    run<10>("mfma + 7 pk_fma (per group)", 16, w);
+    run<11>("mfma + 7 max3 (per group)", 16, w);
+    run<12>("mfma + 7 cvt_pk_bf16 (per group)", 16, w);
   }
   return 0;
 }
