@@ -2,7 +2,7 @@
 
 Only what the hot path needs: the HIP kernels + C ABI (``csrc/``, ``libalg_hip.so``), and the host-side
 mirror of the reference interface (``lp_utils``, the CogVideoX pipeline / transformer / scheduler, and the Wan /
-HunyuanVideo sampler loops with their UniPC / flow-match Euler schedulers).
+HunyuanVideo samplers with their DiT forwards and UniPC / flow-match Euler schedulers).
 """
 from . import lp_utils  # noqa: F401
 from ._lib import AlgHipError, build_library, load_library  # noqa: F401
@@ -12,6 +12,7 @@ from .pipeline_wan_image2video_lowpass import WanImageToVideoPipeline  # noqa: F
 from .schedulers import (CogVideoXDDIMScheduler, FlowMatchEulerDiscreteScheduler,  # noqa: F401
                          UniPCMultistepScheduler)
 from .transformer_cogvideox import CogVideoXTransformer3DModel, CogVideoXTransformerConfig  # noqa: F401
+from .transformer_hunyuan_video import HunyuanVideoTransformer3DModel, HunyuanVideoTransformerConfig  # noqa: F401
 from .transformer_wan import WanTransformer3DModel, WanTransformerConfig  # noqa: F401
 
 __version__ = "0.1.0"

@@ -17,14 +17,14 @@ LIB_PATH = os.path.join(_HERE, "libalg_hip.so")
 
 ALG_F32, ALG_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
-GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS, GEMM_GATE_F32 = 1, 4, 8
+GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS, GEMM_GATE_F32, GEMM_GATE_SEG_STRIDE = 1, 4, 8, 16
 
 EXPORTS = (
     "alg_version", "alg_last_error", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16",
     "alg_flash_attn_d64", "alg_layernorm_modulate", "alg_qk_norm_rope", "alg_patchify", "alg_unpatchify",
     "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128", "alg_layernorm_mod_f32", "alg_rmsnorm_rope",
     "alg_wan_modulation", "alg_patchify3d", "alg_unpatchify3d", "alg_timestep_embedding_f32", "alg_linear_f32",
-    "alg_gelu_erf",
+    "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu",
 )
 
 
@@ -40,6 +40,7 @@ class GemmArgs(Structure):
         ("strideGate", c_int64),
         ("M", c_int32), ("N", c_int32), ("K", c_int32), ("batch", c_int32),
         ("seg_split", c_int32), ("act", c_int32), ("flags", c_int32),
+        ("gate_seg_stride", c_int64),
     ]
 
 
@@ -86,7 +87,12 @@ def load_library():
     lib.alg_rmsnorm_rope.argtypes = [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]
     lib.alg_wan_modulation.argtypes = [c_void_p] * 3 + [c_int] * 5 + [c_void_p]
     lib.alg_patchify3d.argtypes = [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]
-    lib.alg_unpatchify3d.argtypes = [c_void_p, c_int64, c_void_p] + [c_int] * 7 + [c_void_p]
+    lib.alg_unpatchify3d.argtypes = [c_void_p, c_int64, c_void_p] + [c_int] * 8 + [c_void_p]
+    lib.alg_layernorm_modulate_seg.argtypes = [c_void_p] * 6 + [c_int64, c_int64, c_int, c_int, c_int, c_int64, c_int64,
+                                               c_int, c_float, c_void_p]
+    lib.alg_headnorm_rope.argtypes = [c_void_p] * 4 + [c_int64, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]
+    lib.alg_masked_mean.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.alg_silu.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
     lib.alg_timestep_embedding_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.alg_linear_f32.argtypes = [c_void_p] * 6 + [c_int] * 4 + [c_void_p]
     lib.alg_gelu_erf.argtypes = [c_void_p, c_int64, c_void_p]
@@ -280,9 +286,38 @@ def patchify3d(x, out, n, C, F, H, W, ph, pw, Kpad):
     return out
 
 
-def unpatchify3d(x, ldin, out, n, C, F, H, W, ph, pw):
-    _check(load_library().alg_unpatchify3d(_p(x), ldin, _p(out), n, C, F, H, W, ph, pw, _stream()), "alg_unpatchify3d")
+def unpatchify3d(x, ldin, out, n, C, F, H, W, ph, pw, channel_major=False):
+    _check(load_library().alg_unpatchify3d(_p(x), ldin, _p(out), n, C, F, H, W, ph, pw, int(channel_major), _stream()),
+           "alg_unpatchify3d")
     return out
+
+
+def layernorm_modulate_seg(x, y, weight, bias, scale, shift, mod_bstride, seg_stride, batch, rows, D, seg_split, eps,
+                           x_bstride=None, y_bstride=None, x_off=0, y_off=0, scale_off=0, shift_off=0):
+    """alg_layernorm_modulate with an explicit distance between the two row segments' modulation vectors."""
+    x_bstride = rows * D if x_bstride is None else x_bstride
+    y_bstride = rows * D if y_bstride is None else y_bstride
+    _check(load_library().alg_layernorm_modulate_seg(_p(x, x_off), _p(y, y_off), _p(weight), _p(bias), _p(scale, scale_off),
+                                                     _p(shift, shift_off), mod_bstride, seg_stride, batch, rows, D,
+                                                     x_bstride, y_bstride, seg_split, float(eps), _stream()),
+           "alg_layernorm_modulate_seg")
+    return y
+
+
+def headnorm_rope_(x, weight, cos, sin, x_rstride, x_bstride, batch, rows, heads, rope_tokens, eps, x_off=0):
+    _check(load_library().alg_headnorm_rope(_p(x, x_off), _p(weight), _p(cos), _p(sin), x_rstride, x_bstride, batch, rows,
+                                            heads, rope_tokens, float(eps), _stream()), "alg_headnorm_rope")
+    return x
+
+
+def masked_mean(x, valid, out, batch, L, D):
+    _check(load_library().alg_masked_mean(_p(x), _p(valid), _p(out), batch, L, D, _stream()), "alg_masked_mean")
+    return out
+
+
+def silu(x, y):
+    _check(load_library().alg_silu(_p(x), _p(y), x.numel(), _stream()), "alg_silu")
+    return y
 
 
 def timestep_embedding_f32(t, out, n, dim):
@@ -318,14 +353,17 @@ def unipc_update(x, m0, m1, m_new, r, c, k, rk=1.0, rho0=0.0, rho_new=0.0):
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=None, batch=1, strideA=0, strideB=0,
          strideC=0, strideR=0, strideGate=0, seg_split=0, act=ACT_NONE, flags=0, a_off=0, b_off=0, c_off=0, r_off=0,
-         gate_off=0):
+         gate_off=0, gate_seg_stride=None, bias_off=0):
     """Raw pointer-level GEMM: C = R + gate * act(A @ B^T + bias); offsets in elements."""
     lib = load_library()
     args = GemmArgs()
     args.A = A.data_ptr() + 2 * a_off
     args.B = B.data_ptr() + 2 * b_off
     args.C = C.data_ptr() + 2 * c_off
-    args.bias = bias.data_ptr() if bias is not None else None
+    args.bias = (bias.data_ptr() + 2 * bias_off) if bias is not None else None
+    if gate_seg_stride is not None:
+        flags |= GEMM_GATE_SEG_STRIDE
+        args.gate_seg_stride = gate_seg_stride
     args.R = (R.data_ptr() + 2 * r_off) if R is not None else None
     args.gate = (gate.data_ptr() + gate.element_size() * gate_off) if gate is not None else None
     args.lda, args.ldb, args.ldc, args.ldr = lda, ldb, ldc, ldr

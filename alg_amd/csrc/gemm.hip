@@ -610,6 +610,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
   const bf16_t* gate = (RES && p.gate) ? (const bf16_t*)p.gate + (int64_t)b * p.strideGate : nullptr;
   const bool bias_row = p.flags & ALG_GEMM_BIAS_PER_ROW;
   const bool perm = p.flags & ALG_GEMM_PERMUTE_COLS;
+  const int64_t gate_seg = (p.flags & ALG_GEMM_GATE_SEG_STRIDE) ? p.gate_seg_stride : p.N;
   const bool gate_f32 = RES && p.gate && (p.flags & ALG_GEMM_GATE_F32);  // Wan: fp32 gate, one rounding at the end
   bf16_t* Cb = (bf16_t*)p.C + (int64_t)b * p.strideC;
   const int ldc = (int)p.ldc, ldr = (int)p.ldr;
@@ -634,10 +635,10 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
             if (bias && !bias_row) unpack4(*(const uint2*)(bias + n), bv);
             if (RES && gate) {
               if (gate_f32) {
-                const float4 g4 = *(const float4*)((const float*)p.gate + (int64_t)b * p.strideGate + (seg1 ? p.N : 0) + n);
+                const float4 g4 = *(const float4*)((const float*)p.gate + (int64_t)b * p.strideGate + (seg1 ? gate_seg : 0) + n);
                 gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
               } else {
-                unpack4(*(const uint2*)(gate + (seg1 ? p.N : 0) + n), gv);
+                unpack4(*(const uint2*)(gate + (seg1 ? gate_seg : 0) + n), gv);
               }
             }
             if (RES) unpack4(*(const uint2*)(R + rowc * ldr + n), rv);
@@ -668,9 +669,9 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
               if (RES) {
                 if (gate_f32) {
                   x = bf2f(R[rowc * ldr + nn]) +
-                      ((const float*)p.gate)[(int64_t)b * p.strideGate + (seg1 ? p.N : 0) + nn] * x;
+                      ((const float*)p.gate)[(int64_t)b * p.strideGate + (seg1 ? gate_seg : 0) + nn] * x;
                 } else {
-                  const float gg = gate ? bf2f(gate[(seg1 ? p.N : 0) + nn]) : 1.0f;
+                  const float gg = gate ? bf2f(gate[(seg1 ? gate_seg : 0) + nn]) : 1.0f;
                   x = bf2f(R[rowc * ldr + nn]) + rbf(gg * x);
                 }
               }

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ 
                                                      const bf16_t* __restrict__ scale,
                                                      const bf16_t* __restrict__ shift, int64_t mod_bs,
                                                      int64_t x_bs, int64_t y_bs, int64_t total_rows, int rows,
-                                                     int seg_split, float eps) {
+                                                     int seg_split, int64_t seg_stride, float eps) {
   constexpr int D = ITERS * 512;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ 
       q = fmaf(d, d, q);
     }
   const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
-  const bf16_t* sc = scale ? scale + (int64_t)bidx * mod_bs + (int64_t)seg * D : nullptr;
-  const bf16_t* sh = shift ? shift + (int64_t)bidx * mod_bs + (int64_t)seg * D : nullptr;
+  const bf16_t* sc = scale ? scale + (int64_t)bidx * mod_bs + (int64_t)seg * seg_stride : nullptr;
+  const bf16_t* sh = shift ? shift + (int64_t)bidx * mod_bs + (int64_t)seg * seg_stride : nullptr;
   bf16_t* yr = y + (int64_t)bidx * y_bs + (int64_t)r * D;
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
@@ -160,7 +160,15 @@ extern "C" int alg_layernorm_modulate(const void* x, void* y, const void* weight
                                       const void* scale, const void* shift, int64_t mod_bstride, int batch, int rows,
                                       int D, int64_t x_bstride, int64_t y_bstride, int seg_split, float eps,
                                       void* stream) {
-  if (!x || !y || batch <= 0 || rows <= 0 || D <= 0) {
+  return alg_layernorm_modulate_seg(x, y, weight, bias, scale, shift, mod_bstride, D, batch, rows, D, x_bstride, y_bstride,
+                                    seg_split, eps, stream);
+}
+
+extern "C" int alg_layernorm_modulate_seg(const void* x, void* y, const void* weight, const void* bias,
+                                          const void* scale, const void* shift, int64_t mod_bstride,
+                                          int64_t seg_stride, int batch, int rows, int D, int64_t x_bstride,
+                                          int64_t y_bstride, int seg_split, float eps, void* stream) {
+  if (!x || !y || batch <= 0 || rows <= 0 || D <= 0 || seg_stride % 8) {
     set_error("alg_layernorm_modulate: bad argument (batch=%d rows=%d D=%d)", batch, rows, D);
     return ALG_EINVAL;
   }
@@ -185,7 +193,7 @@ extern "C" int alg_layernorm_modulate(const void* x, void* y, const void* weight
   case I:                                                                                                           \
     hipLaunchKernelGGL(ln_mod_kernel<I>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,                  \
                        (const bf16_t*)weight, (const bf16_t*)bias, (const bf16_t*)scale, (const bf16_t*)shift,      \
-                       mod_bstride, x_bstride, y_bstride, total, rows, seg_split, eps);                                                   \
+                       mod_bstride, x_bstride, y_bstride, total, rows, seg_split, seg_stride, eps);                                                   \
     break;
   switch (D / 512) {
     LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void patchify3d_kernel(const bf16_t* __restric
 // out[n][c][f][gy*ph + py][gx*pw + px] = in[n][(f, gy, gx)][(py*pw + px)*C + c]
 __global__ __launch_bounds__(256) void unpatchify3d_kernel(const bf16_t* __restrict__ in, int64_t ldin,
                                                            bf16_t* __restrict__ out, int N, int C, int F, int H, int W,
-                                                           int ph, int pw) {
+                                                           int ph, int pw, int channel_major) {
   const int gh = H / ph, gw = W / pw;
   const int64_t total = (int64_t)N * C * F * H * W;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void unpatchify3d_kernel(const bf16_t* __restr
     const int n = (int)(t / C);
     const int gx = xw / pw, px = xw % pw, gy = yh / ph, py = yh % ph;
     const int64_t tok = ((int64_t)n * F + f) * gh * gw + (int64_t)gy * gw + gx;
-    out[e] = in[tok * ldin + (py * pw + px) * C + c];
+    out[e] = in[tok * ldin + (channel_major ? c * ph * pw + py * pw + px : (py * pw + px) * C + c)];
   }
 }
 
@@ -372,7 +372,7 @@ extern "C" int alg_patchify3d(const void* in, void* out, int n, int C, int F, in
 }
 
 extern "C" int alg_unpatchify3d(const void* in, int64_t ldin, void* out, int n, int C, int F, int H, int W, int ph, int pw,
-                                void* stream) {
+                                int channel_major, void* stream) {
   if (n < 0 || C <= 0 || F <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || H % ph || W % pw || ldin < C * ph * pw) {
     set_error("alg_unpatchify3d: bad shape");
     return ALG_EINVAL;
@@ -384,7 +384,7 @@ extern "C" int alg_unpatchify3d(const void* in, int64_t ldin, void* out, int n, 
   }
   const int64_t total = (int64_t)n * C * F * H * W;
   hipLaunchKernelGGL(wan::unpatchify3d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)in, ldin, (bf16_t*)out, n, C, F, H, W, ph, pw);
+                     (const bf16_t*)in, ldin, (bf16_t*)out, n, C, F, H, W, ph, pw, channel_major);
   return check_launch("alg_unpatchify3d");
 }
 

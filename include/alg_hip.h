@@ -105,6 +105,7 @@ int alg_unipc_update(const float* x, const float* m0, const float* m1, const flo
 
 #define ALG_GEMM_BIAS_PER_ROW 1   /* bias indexed by output row (used for the transposed V projection) */
 #define ALG_GEMM_PERMUTE_COLS 4   /* store column n at n with bits 2 and 3 swapped (MFMA k-order for V^T) */
+#define ALG_GEMM_GATE_SEG_STRIDE 16 /* gate[1] sits gate_seg_stride elements after gate[0] instead of N */
 #define ALG_GEMM_GATE_F32 8       /* gate is float32 and C = bf16(R + gate * bf16(acc + bias)) with ONE final rounding
                                      (WanTransformerBlock: (x.float() + out * gate_msa).type_as(x)) */
 
@@ -121,6 +122,7 @@ typedef struct alg_gemm_args {
   int32_t seg_split;
   int32_t act;        /* ALG_ACT_* applied to (acc + bias) */
   int32_t flags;      /* ALG_GEMM_* */
+  int64_t gate_seg_stride; /* with ALG_GEMM_GATE_SEG_STRIDE: elements between gate[0] and gate[1] (default N; 0 = one gate) */
 } alg_gemm_args;
 
 /* C = R + gate * act(A @ B^T + bias)   (bias optional; either act or the residual(+gate) form).  K % 64 == 0, lda/ldb % 8 == 0,
@@ -151,6 +153,22 @@ int alg_flash_attn_d128(const void* q, const void* k, const void* vt, void* o, i
                         int64_t vt_rstride, int64_t o_bstride, int64_t o_rstride, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * HunyuanVideo DiT building blocks (diffusers HunyuanVideoTransformer3DModel; call site hy:1243-1252)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* HunyuanVideoAttnProcessor2_0 qk norm (RMSNorm over each 128-wide head, weight [128]) + rotary embedding, in place:
+ * row r of batch b = heads*128 bf16 at x + b*x_bstride + r*x_rstride; rope = x*cos + rot(x)*sin on interleaved pairs
+ * with fp32 tables [rope_tokens][128], applied to rows r < rope_tokens only (latent tokens; text tokens follow them). */
+int alg_headnorm_rope(void* x, const void* weight, const float* cos_tab, const float* sin_tab, int64_t x_rstride,
+                      int64_t x_bstride, int batch, int rows, int heads, int rope_tokens, float eps, void* stream);
+
+/* HunyuanVideoTokenRefiner pooled prompt: out[b][d] = mean over the first valid[b] tokens of x[b][.][d] (bf16). */
+int alg_masked_mean(const void* x, const int* valid, void* out, int batch, int L, int D, void* stream);
+
+/* y = silu(x) on bf16 (AdaLayerNormZero: linear(silu(emb))). */
+int alg_silu(const void* x, void* y, int64_t numel, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Wan 2.1 DiT building blocks (diffusers WanTransformer3DModel; call site wan:910-917)
  * ------------------------------------------------------------------------------------------------ */
 
@@ -177,9 +195,10 @@ int alg_wan_modulation(const float* table, const void* vec, float* out, int laye
  * row length Kpad >= C*ph*pw (zero padded so the patch-embed GEMM sees K % 64 == 0). */
 int alg_patchify3d(const void* in, void* out, int n, int C, int F, int H, int W, int ph, int pw, int Kpad, void* stream);
 
-/* proj_out rows [n][(f, gy, gx)][(py*pw + px)*C + c] (row stride ldin) -> [n][C][F][H][W] bf16. */
+/* proj_out rows (row stride ldin) -> [n][C][F][H][W] bf16; the row holds (py*pw + px)*C + c (Wan, channel_major = 0) or
+ * c*ph*pw + py*pw + px (HunyuanVideo, channel_major = 1). */
 int alg_unpatchify3d(const void* in, int64_t ldin, void* out, int n, int C, int F, int H, int W, int ph, int pw,
-                     void* stream);
+                     int channel_major, void* stream);
 
 /* Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0) in float32: out[n][dim] = [cos | sin]. */
 int alg_timestep_embedding_f32(const float* t, float* out, int n, int dim, void* stream);
@@ -200,6 +219,11 @@ int alg_gelu_erf(void* x, int64_t numel, void* stream);
 int alg_layernorm_modulate(const void* x, void* y, const void* weight, const void* bias, const void* scale,
                            const void* shift, int64_t mod_bstride, int batch, int rows, int D, int64_t x_bstride,
                            int64_t y_bstride, int seg_split, float eps, void* stream);
+/* same with an explicit distance (elements) between the two segments' vectors (seg_stride = D above; 0 = one vector for
+ * all rows).  HunyuanVideo token_replace: rows < seg_split (first-frame tokens) take the timestep-0 modulation. */
+int alg_layernorm_modulate_seg(const void* x, void* y, const void* weight, const void* bias, const void* scale,
+                               const void* shift, int64_t mod_bstride, int64_t seg_stride, int batch, int rows, int D,
+                               int64_t x_bstride, int64_t y_bstride, int seg_split, float eps, void* stream);
 
 /* In place on qk: [batch][S][2][heads][64] bf16 (q then k per token):
  * per-head LayerNorm(64) with (wq,bq) / (wk,bk), then RoPE (cos/sin fp32 [S - text_len][64], interleaved-pair
