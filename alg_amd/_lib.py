@@ -40,7 +40,7 @@ class GemmArgs(Structure):
         ("strideGate", c_int64),
         ("M", c_int32), ("N", c_int32), ("K", c_int32), ("batch", c_int32),
         ("seg_split", c_int32), ("act", c_int32), ("flags", c_int32),
-        ("gate_seg_stride", c_int64),
+        ("gate_seg_stride", c_int64), ("perm_col0", c_int32), ("reserved0", c_int32),
     ]
 
 
@@ -353,7 +353,7 @@ def unipc_update(x, m0, m1, m_new, r, c, k, rk=1.0, rho0=0.0, rho_new=0.0):
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=None, batch=1, strideA=0, strideB=0,
          strideC=0, strideR=0, strideGate=0, seg_split=0, act=ACT_NONE, flags=0, a_off=0, b_off=0, c_off=0, r_off=0,
-         gate_off=0, gate_seg_stride=None, bias_off=0):
+         gate_off=0, gate_seg_stride=None, bias_off=0, perm_col0=0):
     """Raw pointer-level GEMM: C = R + gate * act(A @ B^T + bias); offsets in elements."""
     lib = load_library()
     args = GemmArgs()
@@ -370,6 +370,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=None, b
     args.strideA, args.strideB, args.strideC, args.strideR, args.strideGate = strideA, strideB, strideC, strideR, strideGate
     args.M, args.N, args.K, args.batch = M, N, K, batch
     args.seg_split, args.act, args.flags = seg_split, act, flags
+    args.perm_col0 = perm_col0
     _check(lib.alg_gemm_bf16(ctypes.byref(args), _stream()), "alg_gemm_bf16")
 
 

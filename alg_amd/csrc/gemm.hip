@@ -614,7 +614,11 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
   const bool gate_f32 = RES && p.gate && (p.flags & ALG_GEMM_GATE_F32);  // Wan: fp32 gate, one rounding at the end
   bf16_t* Cb = (bf16_t*)p.C + (int64_t)b * p.strideC;
   const int ldc = (int)p.ldc, ldr = (int)p.ldr;
-  const bool n_vec = (p.N & 3) == 0;  // whole quads are either inside or outside N
+  // PERMUTE_COLS with a column origin (perm_col0: this GEMM fills columns [col0, col0 + N) of a wider permuted V^T row,
+  // HunyuanVideo's [latents; text] joint sequence): the bit swap acts on the JOINT index, so the quad shortcut only
+  // holds when col0 is a multiple of 16; otherwise take the element-wise path
+  const int col0 = perm ? p.perm_col0 : 0;
+  const bool n_vec = (p.N & 3) == 0 && (col0 & 15) == 0;  // whole quads are either inside or outside N
   // one 32-row band per call with a compile-time index: with 256 accumulators hipcc stops fully unrolling a 4-deep mt
   // loop and the dynamically indexed accumulator array then lives in scratch (64 scratch stores per K-iteration)
   auto epilogue_band = [&](auto mt_c) {
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
             }
             if (row_ok) {
               // PERMUTE_COLS swaps index bits 2 and 3: quad (g, h2) lands where (h2, g & 1) says
-              const int nc = perm ? ((n & ~12) | (h2 << 3) | ((g & 1) << 2)) : n;
+              const int nc = perm ? col0 + ((n & ~12) | (h2 << 3) | ((g & 1) << 2)) : n;
               uint2 o;
               o.x = pack_bf2(v[0], v[1]);
               o.y = pack_bf2(v[2], v[3]);
@@ -675,7 +679,8 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
                   x = bf2f(R[rowc * ldr + nn]) + rbf(gg * x);
                 }
               }
-              const int nc = perm ? ((nn & ~12) | ((nn & 4) << 1) | ((nn & 8) >> 1)) : nn;
+              const int nj = nn + col0;
+              const int nc = perm ? ((nj & ~12) | ((nj & 4) << 1) | ((nj & 8) >> 1)) : nn;
               Cb[row * ldc + nc] = f2bf(x);
             }
           }

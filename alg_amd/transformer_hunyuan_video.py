@@ -306,8 +306,8 @@ class HunyuanVideoTransformer3DModel:
             raise ValueError("this checkpoint has a guidance embedder: pass `guidance`")
         D, M, heads = cfg.dim, int(cfg.dim * cfg.mlp_ratio), cfg.num_attention_heads
         S, first = F_ * (H // p) * (W // p), (H // p) * (W // p)
-        if S % 16:
-            raise NotImplementedError("the joint [latents; text] V^T layout needs a multiple of 16 latent tokens")
+        if S % 4:
+            raise NotImplementedError("the joint [latents; text] layout needs a multiple of 4 latent tokens")
         L = encoder_hidden_states.shape[1]
         ws = self._workspace(N, S, L)
         J, dev = ws.J, self.device
@@ -417,7 +417,7 @@ class HunyuanVideoTransformer3DModel:
             G(Lw.v[0], ws.y, ws.vt, D, S, D, D, D, ws.J_pad, bias=Lw.v[1], batch=N, strideB=J * D, strideC=D * ws.J_pad,
               flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
             G(Lw.v_c[0], ws.y, ws.vt, D, L, D, D, D, ws.J_pad, bias=Lw.v_c[1], batch=N, strideB=J * D,
-              strideC=D * ws.J_pad, b_off=S * D, c_off=S, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
+              strideC=D * ws.J_pad, b_off=S * D, perm_col0=S, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
             # latent rows: norm_q / norm_k + rope; prompt rows: norm_added_q / norm_added_k, no rope
             _lib.headnorm_rope_(ws.qk, Lw.nq, cos, sin, 2 * D, J * 2 * D, N, S, heads, S, 1e-6)
             _lib.headnorm_rope_(ws.qk, Lw.nk, cos, sin, 2 * D, J * 2 * D, N, S, heads, S, 1e-6, x_off=D)

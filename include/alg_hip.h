@@ -123,6 +123,9 @@ typedef struct alg_gemm_args {
   int32_t act;        /* ALG_ACT_* applied to (acc + bias) */
   int32_t flags;      /* ALG_GEMM_* */
   int64_t gate_seg_stride; /* with ALG_GEMM_GATE_SEG_STRIDE: elements between gate[0] and gate[1] (default N; 0 = one gate) */
+  int32_t perm_col0;  /* with ALG_GEMM_PERMUTE_COLS: output column n is joint column perm_col0 + n of a wider permuted row
+                         (C points at joint column 0); 0 for a stand-alone V^T */
+  int32_t reserved0;
 } alg_gemm_args;
 
 /* C = R + gate * act(A @ B^T + bias)   (bias optional; either act or the residual(+gate) form).  K % 64 == 0, lda/ldb % 8 == 0,

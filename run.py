@@ -18,8 +18,9 @@ import torch
 import yaml
 
 from alg_amd import (CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, CogVideoXTransformer3DModel,
-                     CogVideoXTransformerConfig, UniPCMultistepScheduler, WanImageToVideoPipeline, WanTransformer3DModel,
-                     WanTransformerConfig)
+                     CogVideoXTransformerConfig, FlowMatchEulerDiscreteScheduler, HunyuanVideoImageToVideoPipeline,
+                     HunyuanVideoTransformer3DModel, HunyuanVideoTransformerConfig, UniPCMultistepScheduler,
+                     WanImageToVideoPipeline, WanTransformer3DModel, WanTransformerConfig)
 from alg_amd.lp_utils import get_hunyuan_video_size  # noqa: F401  (kept importable here, as in the reference)
 
 logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s", stream=sys.stdout)
@@ -51,10 +52,15 @@ def main(args):
             transformer = WanTransformer3DModel.from_pretrained(model_path, device=device)
         pipe = WanImageToVideoPipeline(transformer=transformer, scheduler=UniPCMultistepScheduler(flow_shift=flow_shift))
     elif "HunyuanVideo" in model_path:
-        raise NotImplementedError(
-            "the HunyuanVideo DiT forward is the next row of the build (SURVEY.md section 8f-2).  Its ALG sampler loop is "
-            "built (alg_amd.HunyuanVideoImageToVideoPipeline: HIP filters, batch assembly, CFG combine, flow-match Euler) "
-            "and takes any transformer object with the diffusers call signature")
+        if args.synthetic:
+            transformer = HunyuanVideoTransformer3DModel.from_synthetic(HunyuanVideoTransformerConfig(), device=device)
+        else:
+            transformer = HunyuanVideoTransformer3DModel.from_pretrained(model_path, device=device)
+        # run.py:82-86: from_config(flow_shift=model.flow_shift, invert_sigmas=model.flow_reverse); `flow_shift` is not a
+        # parameter of FlowMatchEulerDiscreteScheduler, the checkpoint's own shift (7.0 for HunyuanVideo-I2V) stays in force
+        scheduler = FlowMatchEulerDiscreteScheduler(shift=7.0, flow_shift=config["model"].get("flow_shift"),
+                                                    invert_sigmas=bool(config["model"].get("flow_reverse", False)))
+        pipe = HunyuanVideoImageToVideoPipeline(transformer=transformer, scheduler=scheduler)
     else:
         raise ValueError(f"unknown model family in model.path: {model_path}")
     pipe.to(device)
@@ -69,7 +75,21 @@ def main(args):
 
     if args.synthetic:
         g = torch.Generator().manual_seed(42)
-        if "Wan" in model_path:
+        if "HunyuanVideo" in model_path:
+            nominal = type("Img", (), {"size": (1280, 720)})()           # stands in for the 16:9 input image
+            h, w_ = get_hunyuan_video_size(config["video"]["resolution"], nominal)   # run.py:112-113
+            pipe_kwargs["height"], pipe_kwargs["width"] = h, w_
+            n_tok, n_valid = 256, 48
+            mask = torch.cat([torch.ones(1, n_valid), torch.zeros(1, n_tok - n_valid)], dim=1)
+            pipe_kwargs["prompt_embeds"] = torch.randn(1, n_tok, 4096, generator=g).to(model_dtype)
+            pipe_kwargs["pooled_prompt_embeds"] = torch.randn(1, 768, generator=g).to(model_dtype)
+            pipe_kwargs["prompt_attention_mask"] = mask
+            pipe_kwargs["negative_prompt_embeds"] = torch.randn(1, n_tok, 4096, generator=g).to(model_dtype)
+            pipe_kwargs["negative_pooled_prompt_embeds"] = torch.randn(1, 768, generator=g).to(model_dtype)
+            pipe_kwargs["negative_prompt_attention_mask"] = mask.clone()
+            pipe_kwargs["negative_prompt"] = None
+            pipe_kwargs["image_latents"] = torch.randn(1, 16, 1, h // 8, w_ // 8, generator=g) * 0.7
+        elif "Wan" in model_path:
             gen = config.get("generation", {})
             h, w_, nf = gen.get("height", 480), gen.get("width", 832), gen.get("num_frames", 81)
             f_lat = (nf - 1) // 4 + 1

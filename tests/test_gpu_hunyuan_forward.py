@@ -97,6 +97,19 @@ def test_hunyuan_forward_small(mode):
     assert rel(out2[0].cpu(), ref[0]) < 3e-2
 
 
+def test_hunyuan_forward_latent_tokens_not_a_multiple_of_16():
+    """Bucketed resolutions give per-frame token counts like 836: the prompt's V^T columns then start inside a 16-group
+    of the permuted joint layout (alg_gemm_bf16 perm_col0)."""
+    cfg, ocfg = small(num_layers=2, num_single_layers=2)
+    sd = hy_oracle.init_weights(ocfg, seed=11)
+    model = HunyuanVideoTransformer3DModel(cfg, sd, device=DEV)
+    x, txt, mask, pooled = inputs(2, 3, 12, 20, 22, (22, 5), 12)       # 3 x 6 x 10 = 180 latent tokens, 180 % 16 = 4
+    t = torch.tensor([500.0, 500.0])
+    ref = hy_oracle.hy_forward(ocfg, {k: v.float() for k, v in sd.items()}, x.float(), t, txt.float(), mask, pooled.float())
+    out = model(x.to(DEV), t.to(DEV), txt.to(DEV), mask.to(DEV).to(BF), pooled.to(DEV), return_dict=False)[0]
+    assert rel(out.cpu(), ref) < 3e-2
+
+
 def test_hunyuan_alg_sampler_with_hip_dit():
     """hy:1127-1270 end to end with true CFG + ALG: HIP filters, first-frame token replace assembly, HIP DiT, combine,
     flow-match Euler -- vs the loop oracle driving the fp32 oracle DiT."""
