@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libalg_hip.so")
+LIB_PATH = os.environ.get("ALG_HIP_LIB") or os.path.join(_HERE, "libalg_hip.so")  # env override: A/B builds
 
 ALG_F32, ALG_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
