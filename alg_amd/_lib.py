@@ -24,7 +24,7 @@ EXPORTS = (
     "alg_flash_attn_d64", "alg_layernorm_modulate", "alg_qk_norm_rope", "alg_patchify", "alg_unpatchify",
     "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128", "alg_layernorm_mod_f32", "alg_rmsnorm_rope",
     "alg_wan_modulation", "alg_patchify3d", "alg_unpatchify3d", "alg_timestep_embedding_f32", "alg_linear_f32",
-    "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu",
+    "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu", "alg_gemm_fp8", "alg_quantize_fp8_rows",
 )
 
 
@@ -41,6 +41,7 @@ class GemmArgs(Structure):
         ("M", c_int32), ("N", c_int32), ("K", c_int32), ("batch", c_int32),
         ("seg_split", c_int32), ("act", c_int32), ("flags", c_int32),
         ("gate_seg_stride", c_int64), ("perm_col0", c_int32), ("reserved0", c_int32),
+        ("a_scale", c_void_p), ("b_scale", c_void_p), ("strideAScale", c_int64), ("strideBScale", c_int64),
     ]
 
 
@@ -93,6 +94,8 @@ def load_library():
     lib.alg_headnorm_rope.argtypes = [c_void_p] * 4 + [c_int64, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]
     lib.alg_masked_mean.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.alg_silu.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
+    lib.alg_gemm_fp8.argtypes = [POINTER(GemmArgs), c_void_p]
+    lib.alg_quantize_fp8_rows.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p]
     lib.alg_timestep_embedding_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.alg_linear_f32.argtypes = [c_void_p] * 6 + [c_int] * 4 + [c_void_p]
     lib.alg_gelu_erf.argtypes = [c_void_p, c_int64, c_void_p]
@@ -353,12 +356,19 @@ def unipc_update(x, m0, m1, m_new, r, c, k, rk=1.0, rho0=0.0, rho_new=0.0):
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=None, batch=1, strideA=0, strideB=0,
          strideC=0, strideR=0, strideGate=0, seg_split=0, act=ACT_NONE, flags=0, a_off=0, b_off=0, c_off=0, r_off=0,
-         gate_off=0, gate_seg_stride=None, bias_off=0, perm_col0=0):
-    """Raw pointer-level GEMM: C = R + gate * act(A @ B^T + bias); offsets in elements."""
+         gate_off=0, gate_seg_stride=None, bias_off=0, perm_col0=0, a_scale=None, b_scale=None, strideAScale=0,
+         strideBScale=0, a_scale_off=0, b_scale_off=0):
+    """Raw pointer-level GEMM: C = R + gate * act(A @ B^T + bias); offsets in elements.  With a_scale / b_scale (float32
+    row scales) A and B are OCP e4m3 bytes and the call goes to alg_gemm_fp8."""
     lib = load_library()
     args = GemmArgs()
-    args.A = A.data_ptr() + 2 * a_off
-    args.B = B.data_ptr() + 2 * b_off
+    fp8 = a_scale is not None
+    args.A = A.data_ptr() + A.element_size() * a_off
+    args.B = B.data_ptr() + B.element_size() * b_off
+    if fp8:
+        args.a_scale = a_scale.data_ptr() + 4 * a_scale_off
+        args.b_scale = b_scale.data_ptr() + 4 * b_scale_off
+        args.strideAScale, args.strideBScale = strideAScale, strideBScale
     args.C = C.data_ptr() + 2 * c_off
     args.bias = (bias.data_ptr() + 2 * bias_off) if bias is not None else None
     if gate_seg_stride is not None:
@@ -371,7 +381,18 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=None, b
     args.M, args.N, args.K, args.batch = M, N, K, batch
     args.seg_split, args.act, args.flags = seg_split, act, flags
     args.perm_col0 = perm_col0
-    _check(lib.alg_gemm_bf16(ctypes.byref(args), _stream()), "alg_gemm_bf16")
+    if fp8:
+        _check(lib.alg_gemm_fp8(ctypes.byref(args), _stream()), "alg_gemm_fp8")
+    else:
+        _check(lib.alg_gemm_bf16(ctypes.byref(args), _stream()), "alg_gemm_bf16")
+
+
+def quantize_fp8_rows(x, q, scale, rows, K, x_rstride=None, x_off=0, q_off=0, scale_off=0):
+    """Row-wise OCP e4m3 quantisation: q (uint8 / float8 bytes), scale (float32) filled in place."""
+    x_rstride = K if x_rstride is None else x_rstride
+    _check(load_library().alg_quantize_fp8_rows(_p(x, x_off), x_rstride, _p(q, q_off), _p(scale, scale_off), rows, K,
+                                                _stream()), "alg_quantize_fp8_rows")
+    return q, scale
 
 
 def flash_attn_d64(q, k, vt, o, batch, heads, S, q_bstride, q_rstride, vt_bstride, vt_rstride, o_bstride, o_rstride,

@@ -9,6 +9,7 @@ constexpr int BM = 256, BN = 256;
 int launch_gemm_p0(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p7(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
+int launch_gemm_p6_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 static int gemm_pipe() {
   const char* e = getenv("ALG_GEMM_PIPE");
   const int v = e ? atoi(e) : 6;  // default: 8-wave ping-pong over half-tiles (fastest measured)
@@ -18,7 +19,7 @@ static int gemm_pipe() {
 
 using namespace alg;
 
-extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) {
+static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
   if (!a || !a->A || !a->B || !a->C) {
     set_error("alg_gemm_bf16: null argument");
     return ALG_EINVAL;
@@ -27,13 +28,18 @@ extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) {
     set_error("alg_gemm_bf16: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
     return ALG_EINVAL;
   }
-  if (a->K % 64 != 0) {
-    set_error("alg_gemm_bf16: K=%d must be a multiple of 64", a->K);
+  if (a->K % (fp8 ? 128 : 64) != 0) {
+    set_error("alg_gemm_%s: K=%d must be a multiple of %d", fp8 ? "fp8" : "bf16", a->K, fp8 ? 128 : 64);
     return ALG_EINVAL;
   }
-  if (a->lda % 8 || a->ldb % 8 || a->strideA % 8 || a->strideB % 8 || ((uintptr_t)a->A & 15) ||
+  const int al = fp8 ? 16 : 8;  // elements per 16 bytes
+  if (a->lda % al || a->ldb % al || a->strideA % al || a->strideB % al || ((uintptr_t)a->A & 15) ||
       ((uintptr_t)a->B & 15)) {
-    set_error("alg_gemm_bf16: A/B must be 16-byte aligned with lda/ldb/strides multiples of 8 elements");
+    set_error("alg_gemm: A/B must be 16-byte aligned with lda/ldb/strides multiples of 16 bytes");
+    return ALG_EINVAL;
+  }
+  if (fp8 && (!a->a_scale || !a->b_scale || ((uintptr_t)a->b_scale & 15) || (a->strideBScale & 3))) {
+    set_error("alg_gemm_fp8: a_scale / b_scale are required (b_scale 16-byte aligned)");
     return ALG_EINVAL;
   }
   if (a->act < ALG_ACT_NONE || a->act > ALG_ACT_SILU) {
@@ -75,9 +81,14 @@ extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) {
     return ALG_ELIMIT;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (fp8) return launch_gemm_p6_fp8(a, m_tiles, n_tiles, nwg, s);
   switch (gemm_pipe()) {
     case 0: return launch_gemm_p0(a, m_tiles, n_tiles, nwg, s);   // 2-stage ring, 8 waves
     case 7: return launch_gemm_p7(a, m_tiles, n_tiles, nwg, s);   // 4 waves, every memory op behind an MFMA
     default: return launch_gemm_p6(a, m_tiles, n_tiles, nwg, s);  // 8-wave ping-pong over half-tiles
   }
 }
+
+extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) { return gemm_entry(a, stream, false); }
+
+extern "C" int alg_gemm_fp8(const alg_gemm_args* a, void* stream) { return gemm_entry(a, stream, true); }

@@ -25,6 +25,8 @@
 //   * edge tiles: source rows are clamped (min(row, M-1)), stores are guarded -- no padding contract.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace alg {
@@ -68,18 +70,25 @@ __device__ __forceinline__ void unpack4(const uint2 v, float (&f)[4]) {
 
 // ACT: ALG_ACT_*; RES: residual (+ optional gate) epilogue; PIPE: staging pipeline (see header).  All compile-time
 // so the 128-accumulator epilogue stays fully unrolled with static register indexing.
-template <int ACT, bool RES, int PIPE, int WNW = 4>
+// FP8: both operands are OCP e4m3 bytes with one float32 scale per row (A: a_scale[M], B: b_scale[N]); a tile row is
+// still 128 bytes (BK = 128), so staging, swizzle and fragment reads are unchanged; every 16-byte fragment feeds two
+// v_mfma_f32_32x32x16_fp8_fp8 (its low and high 8 bytes -- A and B use the same k order, so any order is a valid
+// contraction order) and the epilogue multiplies the fp32 accumulator by a_scale[row] * b_scale[col].
+template <int ACT, bool RES, int PIPE, int WNW = 4, bool FP8 = false>
 __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_args p, int m_tiles, int n_tiles,
                                                                  int group_m) {
+  static_assert(!FP8 || PIPE == 6, "the fp8 operands are built on the ping-pong schedule");
+  typedef typename std::conditional<FP8, uint8_t, bf16_t>::type elem_t;
+  constexpr int EPS = 16 / (int)sizeof(elem_t);  // elements per 16-byte slot
   constexpr int GEMM_THREADS = 2 * WNW * 64;  // 512 (8 waves, 128x64 each) or 256 (4 waves, 128x128 each)
   constexpr int NT = BN / WNW / 32;           // 32-column MFMA tiles per wave: 2 or 4
   static_assert(PIPE == 0 || PIPE == 6 || PIPE == 7, "schedules built: 0 (2-stage ring), 6 (ping-pong), 7 (4-wave interleaved)");
   static_assert((PIPE == 7) == (WNW == 2), "PIPE 7 is the 4-wave layout, the others run 8 waves");
   constexpr bool BK64 = true;
   constexpr bool PP = PIPE == 6;  // ping-pong: a wave owns 2 x 64 rows (one piece per A half-tile) x 2 x 32 columns
-  constexpr int BK = BK64 ? 64 : 32;
-  constexpr int NSTAGE = BK64 ? 2 : 4;
-  constexpr int ROW_BYTES = BK * 2;                // 64 or 128
+  constexpr int BK = FP8 ? 128 : 64;
+  constexpr int NSTAGE = 2;
+  constexpr int ROW_BYTES = BK * (int)sizeof(elem_t);   // 128
   constexpr int SLOTS = ROW_BYTES / 16;            // 4 or 8 sixteen-byte slots per tile row
   constexpr int TILE_BYTES = BM * ROW_BYTES;       // one operand tile of one stage
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;
@@ -114,8 +123,8 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
   const int m0 = (first_m + t % gsize) * BM;
   const int n0 = (t / gsize) * BN;
 
-  const bf16_t* A = (const bf16_t*)p.A + (int64_t)b * p.strideA;
-  const bf16_t* B = (const bf16_t*)p.B + (int64_t)b * p.strideB;
+  const elem_t* A = (const elem_t*)p.A + (int64_t)b * p.strideA;
+  const elem_t* B = (const elem_t*)p.B + (int64_t)b * p.strideB;
 
   // ---- per-thread DMA sources: LD_PER_OP rows of A and of B, one 16-B slot each ----
   // tile row r, logical slot s lives at physical slot s ^ swz(r); the thread that fills physical slot (tid % SLOTS)
@@ -123,14 +132,14 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
   const int srow = tid / SLOTS;
   const int sw_src = !BK64 ? ((tid >> 4) & 3) : ((tid >> 4) & 7);   // PIPE1: (r >> 2) & 3, PIPE0: (r >> 1) & 7
   const int sslot = (tid & (SLOTS - 1)) ^ sw_src;
-  const bf16_t* a_src[LD_PER_OP];
-  const bf16_t* b_src[LD_PER_OP];
+  const elem_t* a_src[LD_PER_OP];
+  const elem_t* b_src[LD_PER_OP];
 #pragma unroll
   for (int i = 0; i < LD_PER_OP; ++i) {
     const int r = i * ROWS_PER_LD + srow;
     const int am = (abl & 8) ? 0 : m0, bn = (abl & 8) ? 0 : n0;  // ablation bit 8: every tile streams tile (0, 0)
-    a_src[i] = A + (int64_t)min(am + r, p.M - 1) * p.lda + sslot * 8;
-    b_src[i] = B + (int64_t)min(bn + r, p.N - 1) * p.ldb + sslot * 8;
+    a_src[i] = A + (int64_t)min(am + r, p.M - 1) * p.lda + sslot * EPS;
+    b_src[i] = B + (int64_t)min(bn + r, p.N - 1) * p.ldb + sslot * EPS;
   }
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE_BYTES;
@@ -165,6 +174,18 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
   auto pp_a_row = [&](int mt) { return ((mt >> 1) * 128 + wm * 64 + (mt & 1) * 32 + l31) * ROW_BYTES; };
   auto pp_b_row = [&](int nt) { return (nt * 128 + wn * 32 + l31) * ROW_BYTES; };
 
+  // acc += B-fragment x A-fragment over the 16 bytes both lanes hold (bf16: 8 k values; fp8: 16 k values in two MFMAs)
+  auto fma_frag = [](const bf16x8 bfrag, const bf16x8 afrag, f32x16 c) -> f32x16 {
+    if constexpr (FP8) {
+      typedef long l2 __attribute__((ext_vector_type(2)));
+      const l2 bq = __builtin_bit_cast(l2, bfrag), aq = __builtin_bit_cast(l2, afrag);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(bq[0], aq[0], c, 0, 0, 0);
+      return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(bq[1], aq[1], c, 0, 0, 0);
+    } else {
+      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag, afrag, c, 0, 0, 0);
+    }
+  };
+
   f32x16 acc[4][NT];  // acc[mt][nt] holds the TRANSPOSED 32x32 tile: D[n][m]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -190,7 +211,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = fma_frag(bfr[nt], af[mt], acc[mt][nt]);
   };
   auto compute = [&](int buf) {
     const char* As = smem + buf * STAGE_BYTES;
@@ -253,7 +274,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
         const int i = (kind & 1) * 2 + ii;
-        const bf16_t* src = ((kind >> 1) ? b_src[i] : a_src[i]) + kt * BK;
+        const elem_t* src = ((kind >> 1) ? b_src[i] : a_src[i]) + kt * BK;
         if (kind >> 1)
           __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * GEMM_THREADS + wave * 64) * 16), 16, 0, ALG_AUX_B);
         else
@@ -278,7 +299,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2)
-          acc[mh * 2 + m2][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks], af[m2][ks], acc[mh * 2 + m2][nt], 0, 0, 0);
+          acc[mh * 2 + m2][nt] = fma_frag(bf[ks], af[m2][ks], acc[mh * 2 + m2][nt]);
       __builtin_amdgcn_s_setprio(0);
     };
     auto enter_mfma = [&]() {
@@ -454,6 +475,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
     const int rowc = row_ok ? row : p.M - 1;
     const float brow = (bias && bias_row) ? bf2f(bias[rowc]) : 0.0f;
     const bool seg1 = row >= p.seg_split;
+    const float a_sc = FP8 ? p.a_scale[(int64_t)b * p.strideAScale + rowc] : 1.0f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -472,10 +494,16 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
               }
             }
             if (RES) unpack4(*(const uint2*)(R + rowc * ldr + n), rv);
+            float sv[4] = {1.f, 1.f, 1.f, 1.f};
+            if (FP8) {
+              const float4 s4 = *(const float4*)(p.b_scale + (int64_t)b * p.strideBScale + n);
+              sv[0] = s4.x * a_sc; sv[1] = s4.y * a_sc; sv[2] = s4.z * a_sc; sv[3] = s4.w * a_sc;
+            }
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              float x = rbf(acc[mt][nt][4 * g + i] + bv[i] + brow);  // nn.Linear returns a bf16 tensor
+              const float dot = FP8 ? acc[mt][nt][4 * g + i] * sv[i] : acc[mt][nt][4 * g + i];
+              float x = rbf(dot + bv[i] + brow);  // nn.Linear returns a bf16 tensor
               if (ACT != ALG_ACT_NONE) x = rbf(act_apply(x, ACT));
               if (RES) x = gate_f32 ? rv[i] + gv[i] * x : rv[i] + rbf(gv[i] * x);
               v[i] = x;
@@ -494,7 +522,9 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
           for (int i = 0; i < 4; ++i) {
             const int nn = n + i;
             if (nn < p.N && row_ok) {
-              float x = rbf(acc[mt][nt][4 * g + i] + ((bias && !bias_row) ? bf2f(bias[nn]) : 0.0f) + brow);
+              const float dot = FP8 ? acc[mt][nt][4 * g + i] * (a_sc * p.b_scale[(int64_t)b * p.strideBScale + nn])
+                                    : acc[mt][nt][4 * g + i];
+              float x = rbf(dot + ((bias && !bias_row) ? bf2f(bias[nn]) : 0.0f) + brow);
               if (ACT != ALG_ACT_NONE) x = rbf(act_apply(x, ACT));
               if (RES) {
                 if (gate_f32) {
@@ -537,14 +567,14 @@ inline int gemm_group_m() {
 
 using namespace alg;
 
-template <int PIPE, int WNW = 4>
+template <int PIPE, int WNW = 4, bool FP8 = false>
 int launch_gemm(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[4] = {(const void*)gemm_bf16_kernel<ALG_ACT_NONE, true, PIPE, WNW>,
-                          (const void*)gemm_bf16_kernel<ALG_ACT_GELU_TANH, false, PIPE, WNW>,
-                          (const void*)gemm_bf16_kernel<ALG_ACT_SILU, false, PIPE, WNW>,
-                          (const void*)gemm_bf16_kernel<ALG_ACT_NONE, false, PIPE, WNW>};
+    const void* fns[4] = {(const void*)gemm_bf16_kernel<ALG_ACT_NONE, true, PIPE, WNW, FP8>,
+                          (const void*)gemm_bf16_kernel<ALG_ACT_GELU_TANH, false, PIPE, WNW, FP8>,
+                          (const void*)gemm_bf16_kernel<ALG_ACT_SILU, false, PIPE, WNW, FP8>,
+                          (const void*)gemm_bf16_kernel<ALG_ACT_NONE, false, PIPE, WNW, FP8>};
     for (const void* fn : fns) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
       if (e != hipSuccess) {
@@ -557,16 +587,16 @@ int launch_gemm(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, h
   const dim3 grid((unsigned)nwg), block(2 * WNW * 64);
   const int gm = gemm_group_m();
   if (a->R) {
-    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, true, PIPE, WNW>), grid, block, GEMM_LDS, s, *a, m_tiles,
+    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, true, PIPE, WNW, FP8>), grid, block, GEMM_LDS, s, *a, m_tiles,
                        n_tiles, gm);
   } else if (a->act == ALG_ACT_GELU_TANH) {
-    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_GELU_TANH, false, PIPE, WNW>), grid, block, GEMM_LDS, s, *a, m_tiles,
+    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_GELU_TANH, false, PIPE, WNW, FP8>), grid, block, GEMM_LDS, s, *a, m_tiles,
                        n_tiles, gm);
   } else if (a->act == ALG_ACT_SILU) {
-    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_SILU, false, PIPE, WNW>), grid, block, GEMM_LDS, s, *a, m_tiles,
+    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_SILU, false, PIPE, WNW, FP8>), grid, block, GEMM_LDS, s, *a, m_tiles,
                        n_tiles, gm);
   } else {
-    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, false, PIPE, WNW>), grid, block, GEMM_LDS, s, *a, m_tiles,
+    hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, false, PIPE, WNW, FP8>), grid, block, GEMM_LDS, s, *a, m_tiles,
                        n_tiles, gm);
   }
   return check_launch("alg_gemm_bf16");

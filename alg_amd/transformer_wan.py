@@ -135,7 +135,11 @@ def synthetic_state_dict(cfg, seed=1234, device="cuda"):
 class WanTransformer3DModel:
     dtype = BF
 
-    def __init__(self, config: WanTransformerConfig, weights: dict, device="cuda"):
+    def __init__(self, config: WanTransformerConfig, weights: dict, device="cuda", fp8=False):
+        """``fp8=True`` (BASELINE config 5): the seven large linears of every block run on the fp8 MFMA -- weights are
+        quantised once to OCP e4m3 with one scale per output channel, activations per token right before each GEMM
+        (alg_quantize_fp8_rows); norms, attention, embedders and the residual stream stay bf16 / fp32."""
+        self.fp8 = bool(fp8)
         if config.qk_norm != "rms_norm_across_heads" or config.attention_head_dim != 128:
             raise NotImplementedError("the Wan DiT path is built for rms_norm_across_heads and head_dim 128")
         if tuple(config.patch_size)[0] != 1:
@@ -200,6 +204,13 @@ class WanTransformer3DModel:
                 L.cnak = bf(b + "attn2.norm_added_k.weight")
             L.f1_w, L.f1_b = bf(b + "ffn.net.0.proj.weight"), bf(b + "ffn.net.0.proj.bias")
             L.f2_w, L.f2_b = bf(b + "ffn.net.2.weight"), bf(b + "ffn.net.2.bias")
+            if self.fp8:
+                for name in ("wqk", "wv", "wo", "cq_w", "co_w", "f1_w", "f2_w"):
+                    wt = getattr(L, name)
+                    q = torch.empty(wt.shape, dtype=torch.uint8, device=dev)
+                    sc = torch.empty(wt.shape[0], dtype=torch.float32, device=dev)
+                    _lib.quantize_fp8_rows(wt, q, sc, wt.shape[0], wt.shape[1])
+                    setattr(L, name, (q, sc))          # the bf16 copy is dropped: half the weight memory
             self.blocks.append(L)
         self.w = w
         self._ws = {}
@@ -208,12 +219,12 @@ class WanTransformer3DModel:
 
     # ---- construction ------------------------------------------------------------------------------------------------
     @classmethod
-    def from_synthetic(cls, config=None, seed=1234, device="cuda"):
+    def from_synthetic(cls, config=None, seed=1234, device="cuda", fp8=False):
         config = config or WanTransformerConfig()
-        return cls(config, synthetic_state_dict(config, seed=seed, device=device), device=device)
+        return cls(config, synthetic_state_dict(config, seed=seed, device=device), device=device, fp8=fp8)
 
     @classmethod
-    def from_pretrained(cls, path, subfolder="transformer", torch_dtype=BF, device="cuda", **_):
+    def from_pretrained(cls, path, subfolder="transformer", torch_dtype=BF, device="cuda", fp8=False, **_):
         """Load a diffusers-format checkpoint directory (config.json + *.safetensors) from local disk."""
         from safetensors.torch import load_file
         root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
@@ -228,7 +239,7 @@ class WanTransformer3DModel:
         sd = {}
         for shard in sorted(glob.glob(os.path.join(root, "*.safetensors"))):
             sd.update(load_file(shard))
-        return cls(cfg, sd, device=device)
+        return cls(cfg, sd, device=device, fp8=fp8)
 
     def to(self, *args, **kwargs):
         return self
@@ -285,6 +296,9 @@ class WanTransformer3DModel:
             ws.h = e(N, S, Ff)
             ws.o2 = e(N, S, D)
             ws.tok = e(N, S, self.w.out_w.shape[0])
+            if self.fp8:
+                ws.q8 = e(N * S, max(D, Ff), dt=torch.uint8)      # e4m3 copy of the current GEMM input
+                ws.q8s = e(N * S, dt=torch.float32)
             ws.temb_f32 = e(N, cfg.freq_dim, dt=torch.float32)
             ws.t1 = e(N, D, dt=torch.float32)
             ws.temb, ws.temb_silu = e(N, D), e(N, D)
@@ -353,28 +367,45 @@ class WanTransformer3DModel:
             _lib.layernorm_mod_f32(ws.img_p, ws.img, w.in2_w, w.in2_b, None, None, 0, N, n_img, D, 1e-5)
 
         mod_bs = 6 * D
+
+        def lin(name, A, Wt, C, M_, N_, K_, lda, ldc, requant=True, **kw):
+            """C = epilogue(A @ W^T): bf16, or e4m3 operands when the block weights are quantised (A is re-quantised per
+            token unless the previous call already left its e4m3 copy in the workspace)."""
+            if not self.fp8:
+                return T(name, G, A, Wt, C, M_, N_, K_, lda, K_, ldc, **kw)
+            if requant:
+                T("quant", _lib.quantize_fp8_rows, A, ws.q8, ws.q8s, N * S, K_, x_rstride=lda)
+            sa = kw.pop("strideA", 0)
+            return T(name, G, ws.q8, Wt[0], C, M_, N_, K_, K_, K_, ldc, a_scale=ws.q8s, b_scale=Wt[1],
+                     strideA=(S * K_ if sa else 0), strideAScale=(S if sa else 0), **kw)
+
         for li, L in enumerate(self.blocks):
             m0 = li * N * 6 * D  # element offset of this block's [N, 6, D] modulation: shift, scale, gate, c_shift, c_scale, c_gate
             # ---- self-attention ----
             T("ln_mod", _lib.layernorm_mod_f32, ws.x, ws.y, None, None, ws.mod, ws.mod, mod_bs, N, S, D, cfg.eps,
               scale_off=m0 + D, shift_off=m0)
-            T("gemm_qk", G, ws.y, L.wqk, ws.qk, N * S, 2 * D, D, D, D, 2 * D, bias=L.bqk)
-            T("gemm_vt", G, L.wv, ws.y, ws.vt, D, S, D, D, D, S_pad, bias=L.bv, batch=N, strideB=S * D,
-              strideC=D * S_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
+            lin("gemm_qk", ws.y, L.wqk, ws.qk, N * S, 2 * D, D, D, 2 * D, bias=L.bqk)
+            if self.fp8:   # V^T: the weight is the A operand, the (already quantised) tokens are B
+                T("gemm_vt", G, L.wv[0], ws.q8, ws.vt, D, S, D, D, D, S_pad, bias=L.bv, batch=N, strideB=S * D,
+                  strideC=D * S_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS, a_scale=L.wv[1],
+                  b_scale=ws.q8s, strideBScale=S)
+            else:
+                T("gemm_vt", G, L.wv, ws.y, ws.vt, D, S, D, D, D, S_pad, bias=L.bv, batch=N, strideB=S * D,
+                  strideC=D * S_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
             T("rms_rope", _lib.rmsnorm_rope_, ws.qk, L.nq, cos, sin, 2 * D, N, S, D, cfg.eps)
             T("rms_rope", _lib.rmsnorm_rope_, ws.qk, L.nk, cos, sin, 2 * D, N, S, D, cfg.eps, x_off=D)
             T("attn_self", _lib.flash_attn_d128, ws.qk, ws.qk, ws.vt, ws.att, N, heads, S, S, S * 2 * D, 2 * D,
               S * 2 * D, 2 * D, D * S_pad, S_pad, S * D, D, scale, k_off=D)
-            T("gemm_out", G, ws.att, L.wo, ws.x, S, D, D, D, D, D, bias=L.bo, R=ws.x, ldr=D, gate=ws.mod,
-              gate_off=m0 + 2 * D, strideGate=mod_bs, batch=N, strideA=S * D, strideC=S * D, strideR=S * D,
-              seg_split=1 << 30, flags=_lib.GEMM_GATE_F32)
+            lin("gemm_out", ws.att, L.wo, ws.x, S, D, D, D, D, bias=L.bo, R=ws.x, ldr=D, gate=ws.mod,
+                gate_off=m0 + 2 * D, strideGate=mod_bs, batch=N, strideA=S * D, strideC=S * D, strideR=S * D,
+                seg_split=1 << 30, flags=_lib.GEMM_GATE_F32)
             # ---- cross-attention: image tokens and text tokens attend separately, outputs are added ----
             if cfg.cross_attn_norm:
                 T("ln_mod", _lib.layernorm_mod_f32, ws.x, ws.y, L.n2w, L.n2b, None, None, 0, N, S, D, cfg.eps)
                 yc = ws.y
             else:
                 yc = ws.x
-            T("gemm_cq", G, yc, L.cq_w, ws.qc, N * S, D, D, D, D, D, bias=L.cq_b)
+            lin("gemm_cq", yc, L.cq_w, ws.qc, N * S, D, D, D, D, bias=L.cq_b)
             T("rms_rope", _lib.rmsnorm_rope_, ws.qc, L.cnq, None, None, D, N, S, D, cfg.eps)
             G(ws.txt, L.ck_w, ws.kt, N * n_txt, D, D, D, D, D, bias=L.ck_b)
             _lib.rmsnorm_rope_(ws.kt, L.cnk, None, None, D, N, n_txt, D, cfg.eps)
@@ -390,14 +421,14 @@ class WanTransformer3DModel:
                 T("attn_cross", _lib.flash_attn_d128, ws.qc, ws.ki, ws.vti, ws.o2, N, heads, S, n_img, S * D, D, n_img * D,
                   D, D * ws.img_pad, ws.img_pad, S * D, D, scale)
                 T("add", _lib.lincomb, [(1.0, ws.att), (1.0, ws.o2)], BF, out=ws.att)
-            T("gemm_cout", G, ws.att, L.co_w, ws.x, N * S, D, D, D, D, D, bias=L.co_b, R=ws.x, ldr=D)
+            lin("gemm_cout", ws.att, L.co_w, ws.x, N * S, D, D, D, D, bias=L.co_b, R=ws.x, ldr=D)
             # ---- feed-forward ----
             T("ln_mod", _lib.layernorm_mod_f32, ws.x, ws.y, None, None, ws.mod, ws.mod, mod_bs, N, S, D, cfg.eps,
               scale_off=m0 + 4 * D, shift_off=m0 + 3 * D)
-            T("gemm_ff1", G, ws.y, L.f1_w, ws.h, N * S, Ff, D, D, D, Ff, bias=L.f1_b, act=_lib.ACT_GELU_TANH)
-            T("gemm_ff2", G, ws.h, L.f2_w, ws.x, S, D, Ff, Ff, Ff, D, bias=L.f2_b, R=ws.x, ldr=D, gate=ws.mod,
-              gate_off=m0 + 5 * D, strideGate=mod_bs, batch=N, strideA=S * Ff, strideC=S * D, strideR=S * D,
-              seg_split=1 << 30, flags=_lib.GEMM_GATE_F32)
+            lin("gemm_ff1", ws.y, L.f1_w, ws.h, N * S, Ff, D, D, Ff, bias=L.f1_b, act=_lib.ACT_GELU_TANH)
+            lin("gemm_ff2", ws.h, L.f2_w, ws.x, S, D, Ff, Ff, D, bias=L.f2_b, R=ws.x, ldr=D, gate=ws.mod,
+                gate_off=m0 + 5 * D, strideGate=mod_bs, batch=N, strideA=S * Ff, strideC=S * D, strideR=S * D,
+                seg_split=1 << 30, flags=_lib.GEMM_GATE_F32)
 
         # ---- output head ----
         _lib.layernorm_mod_f32(ws.x, ws.y, None, None, ws.mod_out, ws.mod_out, 2 * D, N, S, D, cfg.eps, scale_off=D,

@@ -126,11 +126,23 @@ typedef struct alg_gemm_args {
   int32_t perm_col0;  /* with ALG_GEMM_PERMUTE_COLS: output column n is joint column perm_col0 + n of a wider permuted row
                          (C points at joint column 0); 0 for a stand-alone V^T */
   int32_t reserved0;
+  const float* a_scale; /* alg_gemm_fp8 only: one scale per row of A, [batch][M] at batch stride strideAScale */
+  const float* b_scale; /* alg_gemm_fp8 only: one scale per row of B, [batch][N] at batch stride strideBScale (0 = shared) */
+  int64_t strideAScale, strideBScale;
 } alg_gemm_args;
 
 /* C = R + gate * act(A @ B^T + bias)   (bias optional; either act or the residual(+gate) form).  K % 64 == 0, lda/ldb % 8 == 0,
  * A and B 16-byte aligned.  M and N are arbitrary (edge tiles clamp loads and guard stores). */
 int alg_gemm_bf16(const alg_gemm_args* args, void* stream);
+
+/* BASELINE config 5 (fp8 weights on the CDNA4 fp8 MFMA): same contract and epilogues with A and B holding OCP e4m3 bytes
+ * (lda / ldb / strides in elements = bytes) and per-row float32 scales: C = epilogue(a_scale[m] * b_scale[n] * (A @ B^T)).
+ * K % 128 == 0.  Operands come from alg_quantize_fp8_rows (activations: per token, weights: per output channel). */
+int alg_gemm_fp8(const alg_gemm_args* args, void* stream);
+
+/* Row-wise dynamic quantisation to OCP e4m3: scale[r] = max|x[r]| / 448 (1 if the row is zero), q = e4m3(x / scale).
+ * x: rows of K bf16 at stride x_rstride (elements); q: rows of K bytes, contiguous; scale: [rows] float32. */
+int alg_quantize_fp8_rows(const void* x, int64_t x_rstride, void* q, float* scale, int64_t rows, int K, void* stream);
 
 /* Full (unmasked) softmax attention, head_dim 64.
  *   q, k : bf16, element (b, s, h, d) at  base + b*q_bstride + s*q_rstride + h*64 + d   (same strides for k)

@@ -88,6 +88,20 @@ def main():
         "qk_norm_rope": (lambda: _lib.qk_norm_rope_(qk, nq[0], nq[1], nq[2], nq[3], cos, sin, N, S, H, T, 1e-6),
                          2.0 * N * S * 2 * D * 2, "byte"),
     }
+    if "gemm_fp8" in only:  # Wan ff2 shape with e4m3 operands (BASELINE config 5): N x 32,760 x 13824 -> 5120
+        Sw, Dw, Fw = 32760, 5120, 13824
+        hq = torch.randint(0, 255, (N * Sw, Fw), dtype=torch.uint8, device=dev)
+        wq = torch.randint(0, 255, (Dw, Fw), dtype=torch.uint8, device=dev)
+        # keep the bytes finite e4m3 (0x7f / 0xff are NaN)
+        hq[hq == 0x7f] = 0x3f; hq[hq == 0xff] = 0xbf; wq[wq == 0x7f] = 0x3f; wq[wq == 0xff] = 0xbf
+        sa, sb = torch.rand(N * Sw, device=dev) * 1e-3, torch.rand(Dw, device=dev) * 1e-3
+        xo = torch.empty(N * Sw, Dw, dtype=BF, device=dev)
+        hb, wb = rn(N * Sw, Fw), rn(Dw, Fw, sc=0.02)
+        cases["gemm_fp8"] = (lambda: G(hq, wq, xo, N * Sw, Dw, Fw, Fw, Fw, Dw, a_scale=sa, b_scale=sb),
+                             2.0 * N * Sw * Dw * Fw, "flop")
+        cases["gemm_bf16_same_shape"] = (lambda: G(hb, wb, xo, N * Sw, Dw, Fw, Fw, Fw, Dw), 2.0 * N * Sw * Dw * Fw, "flop")
+        qx, qs = torch.empty(N * Sw, Fw, dtype=torch.uint8, device=dev), torch.empty(N * Sw, device=dev)
+        cases["quantize_fp8"] = (lambda: _lib.quantize_fp8_rows(hb, qx, qs, N * Sw, Fw), 3.0 * N * Sw * Fw, "byte")
     if "attn128" in only:  # Wan-480p self-attention shape: N x 40 heads x 32,760 tokens x 128
         Sw, Hw = 32760, 40
         Dw = Hw * 128

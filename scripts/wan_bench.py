@@ -24,11 +24,12 @@ def main():
     ap.add_argument("--frames", type=int, default=21)
     ap.add_argument("--height", type=int, default=60)
     ap.add_argument("--width", type=int, default=104)
+    ap.add_argument("--fp8", action="store_true", help="BASELINE config 5: e4m3 block linears on the fp8 MFMA")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = WanTransformerConfig(num_layers=a.layers)
     t0 = time.time()
-    model = WanTransformer3DModel.from_synthetic(cfg, device=dev)
+    model = WanTransformer3DModel.from_synthetic(cfg, device=dev, fp8=a.fp8)
     torch.cuda.synchronize()
     print("weights ready in %.1f s, %.1f GB allocated" % (time.time() - t0, torch.cuda.memory_allocated() / 1e9), flush=True)
     g = torch.Generator(device=dev).manual_seed(0)
@@ -54,7 +55,7 @@ def main():
              "gemm_cq": 2.0 * N * S * D * D, "gemm_cout": 2.0 * N * S * D * D, "gemm_ff1": 2.0 * N * S * D * Ff,
              "gemm_ff2": 2.0 * N * S * D * Ff, "attn_self": 4.0 * N * S * S * D, "attn_cross": 4.0 * N * S * (512 + 257) * D / 2}
     total_flop = L * (sum(v for k, v in flops.items() if k != "attn_cross") + 2 * flops["attn_cross"])
-    res = {"ms_per_forward": round(ms, 2), "samples": N, "tokens": S, "layers": L,
+    res = {"ms_per_forward": round(ms, 2), "fp8": a.fp8, "samples": N, "tokens": S, "layers": L,
            "tflops_whole_forward": round(total_flop / ms / 1e9, 1), "kernels": {}}
     for name, evs in sorted(model.profile.items()):
         tms = sum(x0.elapsed_time(x1) for x0, x1 in evs) / a.iters

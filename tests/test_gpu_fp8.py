@@ -1,0 +1,83 @@
+"""GPU parity of the fp8 (OCP e4m3) operand path of BASELINE config 5: the row quantiser against torch's float8_e4m3fn
+cast, the fp8 GEMM against an fp32 matmul of the de-quantised operands (products of e4m3 values are exact in fp32)."""
+import pytest
+import torch
+
+from alg_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+F8 = torch.float8_e4m3fn
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(DEV)
+
+
+def quant(x):
+    rows, K = x.shape
+    q = torch.empty(rows, K, dtype=torch.uint8, device=DEV)
+    s = torch.empty(rows, dtype=torch.float32, device=DEV)
+    _lib.quantize_fp8_rows(x, q, s, rows, K)
+    return q, s
+
+
+@pytest.mark.parametrize("rows,K", [(5, 512), (300, 5120), (7, 1152)])
+def test_quantize_fp8_rows_matches_torch(rows, K):
+    x = _rand((rows, K), 1, 3.0)
+    x[0] = 0                                           # an all-zero row keeps scale 1
+    q, s = quant(x)
+    amax = x.float().abs().amax(dim=1)
+    want_s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    assert torch.allclose(s, want_s, rtol=1e-6)
+    want_q = (x.float() * (1.0 / want_s)[:, None]).clamp(-448, 448).to(F8)
+    assert torch.equal(q.view(F8).float(), want_q.float())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (1000, 640, 1152), (33, 64, 128)])
+def test_gemm_fp8_matches_dequantised_matmul(M, N, K):
+    a, w, bias = _rand((M, K), 2), _rand((N, K), 3, 0.05), _rand((N,), 4, 0.1)
+    qa, sa = quant(a)
+    qw, sw = quant(w)
+    c = torch.empty(M, N, dtype=BF, device=DEV)
+    _lib.gemm(qa, qw, c, M, N, K, K, K, N, bias=bias, a_scale=sa, b_scale=sw)
+    ref = (qa.view(F8).float() * sa[:, None]) @ (qw.view(F8).float() * sw[:, None]).t() + bias.float()
+    ref = ref.to(BF)
+    assert (c.float() - ref.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, ref.float().abs().max().item())
+    assert (c != ref).float().mean().item() < 0.02
+    # and the quantisation itself stays within the e4m3 error budget of the bf16 product
+    full = (a.float() @ w.float().t() + bias.float())
+    assert ((c.float() - full).norm() / full.norm()).item() < 0.06
+
+
+def test_gemm_fp8_epilogues():
+    """Residual + fp32 gate (Wan), GELU, transposed / permuted V^T store -- the epilogues the Wan DiT uses."""
+    B, S, D, K = 2, 200, 512, 256
+    a, w, bias = _rand((B, S, K), 5), _rand((D, K), 6, 0.06), _rand((D,), 7, 0.1)
+    qa, sa = quant(a.view(B * S, K))
+    qw, sw = quant(w)
+    deq = lambda q, s: q.view(F8).float() * s[:, None]
+    lin = (deq(qa, sa) @ deq(qw, sw).t() + bias.float()).to(BF).view(B, S, D)
+    r = _rand((B, S, D), 8)
+    g = torch.Generator().manual_seed(9)
+    gate = torch.randn(B, 6, D, generator=g).to(DEV)
+    c = r.clone()
+    _lib.gemm(qa, qw, c, S, D, K, K, K, D, bias=bias, R=c, ldr=D, gate=gate, gate_off=2 * D, strideGate=6 * D, batch=B,
+              strideA=S * K, strideC=S * D, strideR=S * D, seg_split=1 << 30, flags=_lib.GEMM_GATE_F32, a_scale=sa,
+              b_scale=sw, strideAScale=S)
+    ref = (r.float() + lin.float() * gate[:, 2:3]).to(BF)
+    assert (c.float() - ref.float()).abs().max().item() <= 2.0 ** -5
+    h = torch.empty(B * S, D, dtype=BF, device=DEV)
+    _lib.gemm(qa, qw, h, B * S, D, K, K, K, D, bias=bias, act=_lib.ACT_GELU_TANH, a_scale=sa, b_scale=sw)
+    ref = torch.nn.functional.gelu(lin.float(), approximate="tanh").to(BF).view(B * S, D)
+    assert (h.float() - ref.float()).abs().max().item() <= 2.0 ** -5
+    # V^T: weights as the A operand (rows = channels), tokens as B; bias per row; kv index bits 2 and 3 swapped
+    s_pad = 256
+    vt = torch.zeros(B, D, s_pad, dtype=BF, device=DEV)
+    _lib.gemm(qw, qa, vt, D, S, K, K, K, s_pad, bias=bias, batch=B, strideB=S * K, strideC=D * s_pad,
+              flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS, a_scale=sw, b_scale=sa, strideBScale=S)
+    perm = torch.tensor([(i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1) for i in range(s_pad)], device=DEV)
+    got = vt[:, :, perm[:S]].transpose(1, 2)
+    assert (got.float() - lin.float()).abs().max().item() <= 2.0 ** -5
