@@ -47,9 +47,9 @@ def main(args):
         # which never matches an int from YAML, so it always lands on 5.0 -- reproduced)
         flow_shift = 3.0 if config["generation"]["height"] == "480" else 5.0
         if args.synthetic:
-            transformer = WanTransformer3DModel.from_synthetic(WanTransformerConfig(), device=device)
+            transformer = WanTransformer3DModel.from_synthetic(WanTransformerConfig(), device=device, fp8=args.fp8)
         else:
-            transformer = WanTransformer3DModel.from_pretrained(model_path, device=device)
+            transformer = WanTransformer3DModel.from_pretrained(model_path, device=device, fp8=args.fp8)
         pipe = WanImageToVideoPipeline(transformer=transformer, scheduler=UniPCMultistepScheduler(flow_shift=flow_shift))
     elif "HunyuanVideo" in model_path:
         if args.synthetic:
@@ -134,6 +134,8 @@ if __name__ == "__main__":
     parser.add_argument("--prompt", type=str, default="a red double decker bus driving down a street")
     parser.add_argument("--output_path", type=str, default="output.mp4")
     parser.add_argument("--model_cache_dir", type=str, default=None)
+    parser.add_argument("--fp8", action="store_true",
+                        help="extension (BASELINE config 5, Wan): e4m3 block linears on the fp8 MFMA")
     parser.add_argument("--synthetic", action="store_true",
                         help="extension: seeded synthetic weights/inputs (no checkpoint, text encoder or VAE needed)")
     main(parser.parse_args())
