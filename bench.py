@@ -300,9 +300,13 @@ def main():
     extra["time_share"] = {k: round(sum(v) / 1e3 / elapsed, 4) for k, v in ms.items()}
     attn_tflops = attn_flops_total / attn_time_total / 1e12 if attn_time_total > 0 else 0.0
     roofline = dict(bound="mfma", kernel="flash_attn_d64_kernel", achieved=attn_tflops, peak=MFMA_PEAK_TFLOPS,
-                    unit="TFLOP/s", frac=attn_tflops / MFMA_PEAK_TFLOPS, traffic=pmc_traffic("flash_attn_d64_kernel"),
+                    unit="TFLOP/s", frac=attn_tflops / MFMA_PEAK_TFLOPS, traffic=None,
                     launches=len(ms.get("attn", [])),
                     mean_launch_ms=(sum(ms["attn"]) / len(ms["attn"])) if ms.get("attn") else None, extra=extra)
+    tr = pmc_traffic("flash_attn_d64_kernel")
+    if tr is not None:  # `traffic` = HBM bytes per launch (PMC, corrected); how it was derived goes next to it
+        roofline["traffic"] = tr["bytes_per_launch"]
+        roofline["traffic_detail"] = tr
     flops_total = (attn_flops_total + sum(gemm_flops.values()) * total_samples * cfg.num_layers)
     # measured on this chip (profiles/r1_power_and_issue_rates.txt): a register-only MFMA loop on random bf16 operands
     # sustains 1765 TFLOP/s under the 1400 W package cap -- the matrix-pipe ceiling for real data; `peak` stays the guide's
