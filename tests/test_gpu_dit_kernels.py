@@ -226,3 +226,26 @@ def test_patchify_unpatchify_timestep(device):
     _lib.timestep_embedding(t.to(device), emb, 3, 512, True)
     ref = dit_oracle.timestep_sinusoid(t, 512, True, 0)
     assert (emb.float().cpu() - ref).abs().max() <= 8e-3  # bf16 output of values in [-1, 1]
+
+
+def test_pingpong_gemm_race_screen(monkeypatch):
+    """The default GEMM schedule keeps LDS-DMA loads in flight across barriers (counted vmcnt): an ordering bug would show
+    as rare wrong tiles.  Its output must equal the drain-and-barrier schedule bit for bit (same K order), over random
+    shapes and repeated runs of a large one."""
+    import random
+    rng = random.Random(1)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    cases = [(rng.randint(1, 3000), rng.randint(1, 300) * 4, rng.randint(1, 48) * 64) for _ in range(40)]
+    cases += [(17776, 3072, 3072)] * 4
+    for M, N, K in cases:
+        a = torch.randn(M, K, generator=g, device="cuda").to(BF)
+        w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(BF)
+        outs = {}
+        for pipe in ("0", "6", "6", "6"):
+            monkeypatch.setenv("ALG_GEMM_PIPE", pipe)
+            c = torch.empty(M, N, dtype=BF, device="cuda")
+            _lib.gemm(a, w, c, M, N, K, K, K, N)
+            if pipe in outs:
+                assert torch.equal(c, outs["0"]), (M, N, K)
+            outs.setdefault(pipe, c)
+        assert torch.equal(outs["6"], outs["0"]), (M, N, K)
