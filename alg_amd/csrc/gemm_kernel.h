@@ -466,6 +466,118 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
   // holds when col0 is a multiple of 16; otherwise take the element-wise path
   const int col0 = perm ? p.perm_col0 : 0;
   const bool n_vec = (p.N & 3) == 0 && (col0 & 15) == 0;  // whole quads are either inside or outside N
+  // ---- coalesced epilogue of the ping-pong schedule: transpose through LDS ----
+  // In the C^T accumulator layout a lane owns 4 consecutive columns of ONE row, so a wave's direct store instruction
+  // touches 32 rows x 16 bytes: measured per-tile overhead 16 us (stores only) to 29 us (+ residual loads) against 77 us of
+  // main loop at K = 3072.  After the K-loop the 128 KiB of LDS are free: every wave parks its 128x64 bf16 sub-tile
+  // (after bias / scale / activation, exactly the bf16 value nn.Linear returns) in its own 16 KiB, reads it back with
+  // 16 bytes per lane along rows, and applies gate / residual and stores with 16-byte accesses -- 64 contiguous bytes per
+  // row segment instead of 16.  Bank-conflict-free both ways (chunk XOR (row >> 2) & 3).  Needs 16-byte aligned rows of
+  // C / R / gate and N % 8 == 0; anything else takes the element-exact path below.
+  if constexpr (PP) {
+    const bool staged = (p.N & 7) == 0 && (ldc & 7) == 0 && (p.strideC & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 &&
+                        (col0 & 15) == 0 && !(abl & 32) &&
+                        (!RES || ((ldr & 7) == 0 && (p.strideR & 7) == 0 && (((uintptr_t)p.R) & 15) == 0)) &&
+                        (!(RES && p.gate) || ((p.strideGate & 7) == 0 && (gate_seg & 7) == 0 && (((uintptr_t)p.gate) & 15) == 0));
+    if (staged) {
+      char* const my = smem + wave * 16384;
+      auto park_band = [&](auto mt_c) {
+        constexpr int mt = decltype(mt_c)::value;
+        const int row = m0 + (mt >> 1) * 128 + wm * 64 + (mt & 1) * 32 + l31;
+        const int rowc = row < p.M ? row : p.M - 1;
+        const float brow = (bias && bias_row) ? bf2f(bias[rowc]) : 0.0f;
+        const float a_sc = FP8 ? p.a_scale[(int64_t)b * p.strideAScale + rowc] : 1.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = n0 + nt * 128 + wn * 32 + 8 * g + 4 * h2;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f};
+            if (n < p.N) {
+              if (bias && !bias_row) unpack4(*(const uint2*)(bias + n), bv);
+              if (FP8) {
+                const float4 s4 = *(const float4*)(p.b_scale + (int64_t)b * p.strideBScale + n);
+                sv[0] = s4.x * a_sc; sv[1] = s4.y * a_sc; sv[2] = s4.z * a_sc; sv[3] = s4.w * a_sc;
+              }
+            }
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float dot = FP8 ? acc[mt][nt][4 * g + i] * sv[i] : acc[mt][nt][4 * g + i];
+              float x = rbf(dot + bv[i] + brow);
+              if (ACT != ALG_ACT_NONE) x = rbf(act_apply(x, ACT));
+              v[i] = x;
+            }
+            uint2 o;
+            o.x = pack_bf2(v[0], v[1]);
+            o.y = pack_bf2(v[2], v[3]);
+            *(uint2*)(my + (mt * 2 + nt) * 2048 + l31 * 64 + ((g ^ ((l31 >> 2) & 3)) * 16) + h2 * 8) = o;
+          }
+      };
+      park_band(IntC<0>{});
+      park_band(IntC<1>{});
+      park_band(IntC<2>{});
+      park_band(IntC<3>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave reads back only what it wrote itself
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int blk = it >> 1, mt = blk >> 1, nt = blk & 1;
+        const int rr = (it & 1) * 16 + (lane >> 2), ch = lane & 3;
+        const uint4 raw = *(const uint4*)(my + blk * 2048 + rr * 64 + ((ch ^ ((rr >> 2) & 3)) * 16));
+        const int row = m0 + (mt >> 1) * 128 + wm * 64 + (mt & 1) * 32 + rr;
+        const int c0 = n0 + nt * 128 + wn * 32 + ch * 8;
+        if (row < p.M && c0 < p.N) {
+          uint4 outv = raw;
+          if (RES) {
+            float x[8], r[8], gq[8];
+            const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+            const uint4 rraw = *(const uint4*)(R + row * ldr + c0);
+            const uint32_t ru[4] = {rraw.x, rraw.y, rraw.z, rraw.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              x[2 * k] = __uint_as_float(u[k] << 16);
+              x[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u);
+              r[2 * k] = __uint_as_float(ru[k] << 16);
+              r[2 * k + 1] = __uint_as_float(ru[k] & 0xffff0000u);
+              gq[2 * k] = gq[2 * k + 1] = 1.0f;
+            }
+            const bool seg1 = row >= p.seg_split;
+            if (gate) {
+              if (gate_f32) {
+                const float* gp = (const float*)p.gate + (int64_t)b * p.strideGate + (seg1 ? gate_seg : 0) + c0;
+                const float4 g0 = *(const float4*)gp, g1 = *(const float4*)(gp + 4);
+                gq[0] = g0.x; gq[1] = g0.y; gq[2] = g0.z; gq[3] = g0.w; gq[4] = g1.x; gq[5] = g1.y; gq[6] = g1.z; gq[7] = g1.w;
+              } else {
+                const uint4 graw = *(const uint4*)(gate + (seg1 ? gate_seg : 0) + c0);
+                const uint32_t gu[4] = {graw.x, graw.y, graw.z, graw.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  gq[2 * k] = __uint_as_float(gu[k] << 16);
+                  gq[2 * k + 1] = __uint_as_float(gu[k] & 0xffff0000u);
+                }
+              }
+            }
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = gate_f32 ? r[k] + gq[k] * x[k] : r[k] + rbf(gq[k] * x[k]);
+            outv.x = pack_bf2(y[0], y[1]); outv.y = pack_bf2(y[2], y[3]);
+            outv.z = pack_bf2(y[4], y[5]); outv.w = pack_bf2(y[6], y[7]);
+          }
+          bf16_t* crow = Cb + row * ldc;
+          if (perm) {
+            // columns c0..c0+3 (bit 2 = 0) and c0+4..c0+7 (bit 2 = 1) swap bit 2 with bit 3 = (c0 >> 3) & 1
+            const int base = col0 + (c0 & ~12), b3 = (c0 >> 3) & 1;
+            *(uint2*)(crow + base + (b3 << 2)) = make_uint2(outv.x, outv.y);
+            *(uint2*)(crow + base + 8 + (b3 << 2)) = make_uint2(outv.z, outv.w);
+          } else {
+            *(uint4*)(crow + c0) = outv;
+          }
+        }
+      }
+      return;
+    }
+  }
+
   // one 32-row band per call with a compile-time index: with 256 accumulators hipcc stops fully unrolling a 4-deep mt
   // loop and the dynamically indexed accumulator array then lives in scratch (64 scratch stores per K-iteration)
   auto epilogue_band = [&](auto mt_c) {
