@@ -9,7 +9,7 @@ from ._lib import AlgHipError, build_library, load_library  # noqa: F401
 from .pipeline_cogvideox_image2video_lowpass import CogVideoXImageToVideoPipeline, CogVideoXPipelineOutput  # noqa: F401
 from .pipeline_hunyuan_video_image2video_lowpass import HunyuanVideoImageToVideoPipeline  # noqa: F401
 from .pipeline_wan_image2video_lowpass import WanImageToVideoPipeline  # noqa: F401
-from .schedulers import (CogVideoXDDIMScheduler, FlowMatchEulerDiscreteScheduler,  # noqa: F401
+from .schedulers import (CogVideoXDDIMScheduler, CogVideoXDPMScheduler, FlowMatchEulerDiscreteScheduler,  # noqa: F401
                          UniPCMultistepScheduler)
 from .transformer_cogvideox import CogVideoXTransformer3DModel, CogVideoXTransformerConfig  # noqa: F401
 from .transformer_hunyuan_video import HunyuanVideoTransformer3DModel, HunyuanVideoTransformerConfig  # noqa: F401

@@ -29,7 +29,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 import torch
 
 from . import _lib, lp_utils
-from .schedulers import CogVideoXDDIMScheduler
+from .schedulers import CogVideoXDDIMScheduler, CogVideoXDPMScheduler
 from .transformer_cogvideox import CogVideoXTransformer3DModel
 
 
@@ -482,6 +482,8 @@ class CogVideoXImageToVideoPipeline:
                             "(fused HIP step); other components are not wired yet")
         if eta != 0.0:
             raise NotImplementedError("eta > 0 is not used by the ALG configs")
+        is_dpm = isinstance(self.scheduler, CogVideoXDPMScheduler)
+        old_pred_original_sample = None  # cog:998
 
         B = latents.shape[0]
         for i, t in enumerate(timesteps):
@@ -546,7 +548,17 @@ class CogVideoXImageToVideoPipeline:
                 gs = 1 + guidance_scale * (
                     (1 - math.cos(math.pi * ((num_inference_steps - int(t)) / num_inference_steps) ** 5.0)) / 2)
                 self._guidance_scale = gs
-            self.scheduler.fused_cfg_step_(noise_pred, latents, n_pass, gs, t)
+            if is_dpm:
+                # cog:1091-1123, DPM branch: float(); CFG combine in fp32; the two-output step; cast back
+                pred32 = noise_pred.float()
+                if n_pass > 1:
+                    pred32 = _lib.cfg_combine(pred32, n_pass, gs)
+                new_lat, old_pred_original_sample = self.scheduler.step(
+                    pred32, old_pred_original_sample, t, timesteps[i - 1] if i > 0 else None, latents,
+                    generator=generator, return_dict=False)
+                latents = _lib.lincomb([(1.0, new_lat)], dtype)
+            else:
+                self.scheduler.fused_cfg_step_(noise_pred, latents, n_pass, gs, t)
             if step_trace is not None:
                 step_trace.append((strength, bool(two_pass), n_pass * B))
             if callback_on_step_end is not None:

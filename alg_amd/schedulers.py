@@ -310,3 +310,51 @@ class UniPCMultistepScheduler:
             self.lower_order_nums += 1
         self._step_index += 1
         return SimpleNamespace(prev_sample=out) if return_dict else (out,)
+
+
+class CogVideoXDPMScheduler(CogVideoXDDIMScheduler):
+    """CogVideoXDPMScheduler as the reference loop drives it (cog:1111-1122: the second ``step`` signature, returning
+    ``(prev_sample, pred_original_sample)``): SDE-DPM-Solver++ (2M) in the log-SNR variable over the same alpha tables
+    as the DDIM scheduler, fresh noise in the sample's dtype every step.  Host scalars in float64; the per-element
+    updates are ``alg_lincomb`` launches with torch-eager rounding (a 0-dim fp64 scalar times a bf16 tensor is a bf16
+    tensor, the running sum is fp32); the noise comes from ``torch.randn`` on the generator's device (plumbing)."""
+
+    def multipliers(self, timestep, timestep_back):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' first")
+        t = int(timestep)
+        prev = t - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        lam = lambda a: ((a / (1 - a)) ** 0.5).log()
+        h = lam(a_prev) - lam(a_t)
+        m1 = ((1 - a_prev) / (1 - a_t)) ** 0.5 * (-h).exp()
+        m2 = (-2 * h).expm1() * a_prev ** 0.5
+        mn = (1 - a_prev) ** 0.5 * (1 - (-2 * h).exp()) ** 0.5
+        m3 = m4 = None
+        if timestep_back is not None:
+            r = (lam(a_t) - lam(self.alphas_cumprod[int(timestep_back)])) / h
+            m3, m4 = 1 + 1 / (2 * r), 1 / (2 * r)
+        f = lambda v: None if v is None else float(v)
+        return f(a_t ** 0.5), f((1 - a_t) ** 0.5), f(m1), f(m2), f(m3), f(m4), f(mn), prev
+
+    def step(self, model_output, old_pred_original_sample, timestep, timestep_back, sample, eta=0.0,
+             use_clipped_model_output=False, generator=None, variance_noise=None, return_dict=False):
+        sa, sb, m1, m2, m3, m4, mn, prev = self.multipliers(timestep, timestep_back)
+        sample = sample.contiguous()
+
+        def noise():
+            gdev = generator.device if generator is not None else sample.device
+            return torch.randn(sample.shape, generator=generator, device=gdev, dtype=sample.dtype).to(sample.device)
+
+        x0 = _lib.lincomb([(sa, sample), (-sb, model_output.contiguous())], torch.float32)
+        if old_pred_original_sample is None or prev < 0:
+            out = _lib.lincomb([(m1, sample), (-m2, x0), (mn, noise())], torch.float32)
+        else:
+            first = noise()  # the published step draws (and discards) the first-order noise before the second-order one
+            del first
+            d = _lib.lincomb([(m3, x0), (-m4, old_pred_original_sample.contiguous())], torch.float32)
+            out = _lib.lincomb([(m1, sample), (-m2, d), (mn, noise())], torch.float32)
+        if not return_dict:
+            return out, x0
+        return SimpleNamespace(prev_sample=out, pred_original_sample=x0)

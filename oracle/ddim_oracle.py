@@ -69,3 +69,46 @@ class DDIMOracle:
         sa, sb, ca, cb = self.coefficients(timestep)
         x0 = sa * sample - sb * model_output
         return ca * sample + cb * x0
+
+
+class DPMOracle(DDIMOracle):
+    """CogVideoXDPMScheduler (cog:1114-1122: ``step(model_output, old_pred_original_sample, timestep, timestep_back,
+    sample, generator=)`` -> (prev_sample, pred_original_sample)): second-order SDE-DPM-Solver++ in the log-SNR variable,
+    fresh Gaussian noise in the sample's dtype every step, first-order on the first and last step.  Same tables as the
+    DDIM scheduler.  PARITY UNPINNED (diffusers @ be2fb77, absent)."""
+
+    def _variables(self, a_t, a_prev, a_back):
+        lamb = ((a_t / (1 - a_t)) ** 0.5).log()
+        lamb_next = ((a_prev / (1 - a_prev)) ** 0.5).log()
+        h = lamb_next - lamb
+        r = None
+        if a_back is not None:
+            lamb_prev = ((a_back / (1 - a_back)) ** 0.5).log()
+            r = (lamb - lamb_prev) / h
+        return h, r
+
+    def multipliers(self, timestep, timestep_back):
+        t = int(timestep)
+        prev = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        a_back = self.alphas_cumprod[int(timestep_back)] if timestep_back is not None else None
+        h, r = self._variables(a_t, a_prev, a_back)
+        m1 = ((1 - a_prev) / (1 - a_t)) ** 0.5 * (-h).exp()
+        m2 = (-2 * h).expm1() * a_prev ** 0.5
+        m_noise = (1 - a_prev) ** 0.5 * (1 - (-2 * h).exp()) ** 0.5
+        m3 = m4 = None
+        if r is not None:
+            m3, m4 = 1 + 1 / (2 * r), 1 / (2 * r)
+        return a_t ** 0.5, (1 - a_t) ** 0.5, m1, m2, m3, m4, m_noise, prev
+
+    def step(self, model_output, old_pred_original_sample, timestep, timestep_back, sample, generator=None):
+        sa, sb, m1, m2, m3, m4, mn, prev = self.multipliers(timestep, timestep_back)
+        x0 = sa * sample - sb * model_output
+        noise = torch.randn(sample.shape, generator=generator, dtype=sample.dtype)
+        prev_sample = m1 * sample - m2 * x0 + mn * noise
+        if old_pred_original_sample is None or prev < 0:
+            return prev_sample, x0
+        denoised_d = m3 * x0 - m4 * old_pred_original_sample
+        noise = torch.randn(sample.shape, generator=generator, dtype=sample.dtype)
+        return m1 * sample - m2 * denoised_d + mn * noise, x0

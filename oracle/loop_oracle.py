@@ -57,7 +57,7 @@ def alg_denoise_loop(transformer, scheduler, latents, image_latents, prompt_embe
                      lp_strength_schedule_type="interval", schedule_blur_kernel_size=False,
                      schedule_interval_start_time=0.0, schedule_interval_end_time=0.05,
                      schedule_linear_start_weight=1.0, schedule_linear_end_weight=0.0, schedule_linear_end_time=0.5,
-                     schedule_exp_decay_rate=10.0, image_rotary_emb=None, trace=None):
+                     schedule_exp_decay_rate=10.0, image_rotary_emb=None, trace=None, generator=None):
     """Returns final latents [B,F,C,H,W].  ``transformer(hidden_states, encoder_hidden_states, timestep,
     image_rotary_emb)`` -> noise prediction.  ``trace`` (list) receives per-step
     (strength, two_pass, n_forward) for branch-table tests."""
@@ -72,6 +72,7 @@ def alg_denoise_loop(transformer, scheduler, latents, image_latents, prompt_embe
         pe3 = pe2 = prompt_embeds
     scheduler.set_timesteps(num_inference_steps)
     latents = latents * scheduler.init_noise_sigma
+    old_pred_original_sample = None                     # cog:998, only used by the DPM scheduler branch
     for i, t in enumerate(scheduler.timesteps):
         two_pass = True
         if do_cfg and use_low_pass_guidance:
@@ -102,7 +103,13 @@ def alg_denoise_loop(transformer, scheduler, latents, image_latents, prompt_embe
         elif do_cfg:
             u, tx = pred.chunk(2)
             pred = u + guidance_scale * (tx - u)  # cog:1096-1097 / 1109
-        latents = scheduler.step(pred, t, latents).to(dtype)  # cog:1112, 1123
+        if hasattr(scheduler, "multipliers"):             # CogVideoXDPMScheduler: the second step signature (cog:1114-1122)
+            latents, old_pred_original_sample = scheduler.step(
+                pred, old_pred_original_sample, t, scheduler.timesteps[i - 1] if i > 0 else None, latents,
+                generator=generator)
+            latents = latents.to(dtype)
+        else:
+            latents = scheduler.step(pred, t, latents).to(dtype)  # cog:1112, 1123
         if trace is not None:
             trace.append((s, two_pass, x.shape[0]))
     return latents

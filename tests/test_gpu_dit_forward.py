@@ -187,3 +187,33 @@ def test_cfg_pair_split_reproduces_the_single_gpu_sampler(device):
         t.join(timeout=300)
     assert not errs, errs
     assert torch.equal(outs[0], ref) and torch.equal(outs[1], ref)
+
+
+def test_alg_sampler_with_dpm_scheduler(device):
+    """cog:1111-1122: the CogVideoXDPMScheduler branch (two-output step, fresh noise each step) vs the loop oracle
+    driving oracle.ddim_oracle.DPMOracle on the same CPU generator stream."""
+    from alg_amd import CogVideoXDPMScheduler
+    ocfg, w, model = make_pair(device, seed=5)
+    pipe = CogVideoXImageToVideoPipeline(transformer=model, scheduler=CogVideoXDPMScheduler()).to(device)
+    g = torch.Generator().manual_seed(44)
+    Fr, C, H, W = 3, 8, 8, 12
+    # fp32-exact inputs in bf16 so both sides see the same values; latents are bf16 in the reference loop
+    latents = torch.randn(1, Fr, C, H, W, generator=g).to(BF)
+    first = (torch.randn(1, 1, C, H, W, generator=g) * 0.7).to(BF)
+    pe, ne = torch.randn(1, 10, 128, generator=g).to(BF), torch.randn(1, 10, 128, generator=g).to(BF)
+    kw = dict(num_inference_steps=4, guidance_scale=6.0, use_low_pass_guidance=True, lp_filter_type="down_up",
+              lp_resize_factor=0.25, lp_strength_schedule_type="interval", schedule_interval_start_time=0.0,
+              schedule_interval_end_time=0.3)
+    out = pipe(image=None, image_latents=first, latents=latents, prompt_embeds=pe, negative_prompt_embeds=ne,
+               height=H * 8, width=W * 8, num_frames=9, output_type="latent", lp_filter_in_latent=True,
+               generator=torch.Generator().manual_seed(7), **kw).frames
+    cond = torch.zeros(1, Fr, C, H, W)
+    cond[:, :1] = first.float()
+    rope = dit_oracle.rope_tables(ocfg, H * 8, W * 8, Fr)
+    tf = lambda x, e, ts, r: dit_oracle.dit_forward(ocfg, w, x, e, ts, r)
+    # the oracle keeps bf16 latents like the reference loop (the noise is drawn in the latents' dtype)
+    ref = loop_oracle.alg_denoise_loop(tf, ddim_oracle.DPMOracle(), latents, cond.to(BF), pe, ne,
+                                       image_rotary_emb=rope, generator=torch.Generator().manual_seed(7), **kw)
+    assert out.dtype == BF and torch.isfinite(out.float()).all()
+    r = rel(out.float().cpu(), ref.float())
+    assert r < 5e-2, r

@@ -219,3 +219,27 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
                     "-L", lib_dir, "-lalg_hip", "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert int(out[0]) == len(names) and int(out[1]) > 0
+
+
+def test_dpm_scheduler_scalars_match_the_oracle():
+    """CogVideoXDPMScheduler (the second step signature, cog:1114-1122): host multipliers vs the oracle's, and the
+    first / last step fall back to first order."""
+    from alg_amd.schedulers import CogVideoXDPMScheduler
+    from oracle.ddim_oracle import DPMOracle
+    p, o = CogVideoXDPMScheduler(), DPMOracle()
+    p.set_timesteps(50)
+    o.set_timesteps(50)
+    assert torch.equal(p.timesteps, o.timesteps)
+    ts = o.timesteps
+    for i in (0, 1, 2, 25, 48):
+        a = o.multipliers(ts[i], ts[i - 1] if i else None)
+        b = p.multipliers(ts[i], ts[i - 1] if i else None)
+        assert a[7] == b[7]
+        for x, y in zip(a[:7], b[:7]):
+            assert (x is None and y is None) or abs(float(x) - y) <= 1e-12 * max(1.0, abs(y))
+    assert p.multipliers(ts[0], None)[4] is None                      # no history on the first step
+    assert p.multipliers(ts[49], ts[48])[7] < 0                       # last step: prev_timestep < 0 -> first order
+    x = torch.randn(1, 2, 3, generator=torch.Generator().manual_seed(0))
+    g = torch.Generator().manual_seed(1)
+    nxt, x0 = o.step(torch.zeros_like(x), None, ts[49], ts[48], x, generator=g)
+    assert torch.allclose(nxt, x0)                                    # alpha_prev = 1: the last step returns x0 (no noise)
