@@ -16,8 +16,9 @@ Per step (wan:843-927) this sampler launches, all through the C ABI of ``libalg_
 
 Once-per-video components outside the hot path (UMT5 text encoder, CLIP image encoder, Wan VAE) are injected
 duck-typed objects; without them pass ``prompt_embeds`` / ``negative_prompt_embeds`` / ``image_embeds`` (reference
-kwargs), the pre-encoded ``image_condition`` (extension kwarg: the ``[B, 20, F, h, w]`` tensor wan:372-468 builds)
-and ``output_type="latent"``.
+kwargs), the pre-encoded ``image_condition`` (extension kwarg: the ``[B, 20, F, h, w]`` tensor wan:372-468 builds) or
+just the normalised VAE latents of the condition video as ``latent_condition`` ``[B, 16, F, h, w]`` (the mask channels are
+then built here, wan:439-456), and ``output_type="latent"``.
 """
 from __future__ import annotations
 
@@ -44,6 +45,23 @@ def assemble_channel_concat(latents, cond_groups, out_dtype):
     R = F * H * W
     out = _lib.concat_cast(src0, src1, 1, C, Cc, R, C * R, Cc * R, 0, out_dtype)
     return out.view(len(src0), C + Cc, F, H, W)
+
+
+def build_wan_condition(latent_condition, num_frames, vae_scale_factor_temporal=4, has_last_image=False):
+    """wan:439-456: the 20-channel condition ``[mask4 | latent16]`` from the (normalised) VAE latents of the padded
+    condition video ``[B, 16, F_lat, h, w]``.  The mask marks the conditioning frames in PIXEL time (first frame, plus the
+    last one for first-last-frame checkpoints), the first frame's flag is repeated 4 times, and groups of 4 pixel frames
+    fold into the channel dimension.  Once per video; plain tensor plumbing."""
+    B, _, f_lat, h, w = latent_condition.shape
+    mask = torch.ones(B, 1, num_frames, h, w)
+    if has_last_image:
+        mask[:, :, 1:num_frames - 1] = 0
+    else:
+        mask[:, :, 1:] = 0
+    first = torch.repeat_interleave(mask[:, :, 0:1], dim=2, repeats=vae_scale_factor_temporal)
+    mask = torch.concat([first, mask[:, :, 1:]], dim=2)
+    mask = mask.view(B, -1, vae_scale_factor_temporal, h, w).transpose(1, 2)
+    return torch.concat([mask.to(latent_condition.device, latent_condition.dtype), latent_condition], dim=1)
 
 
 class WanImageToVideoPipeline:
@@ -211,6 +229,7 @@ class WanImageToVideoPipeline:
         schedule_exp_decay_rate: float = 10.0,
         # ---- extensions (not in the reference signature) ----
         image_condition: Optional[torch.Tensor] = None,
+        latent_condition: Optional[torch.Tensor] = None,
         step_trace: Optional[list] = None,
         cfg_split=None,
     ):
@@ -228,6 +247,9 @@ class WanImageToVideoPipeline:
         if device.type != "cuda":
             raise _lib.AlgHipError("the ALG sampler's hot path is HIP-only: move the pipeline to a GPU "
                                    "(`pipe.to('cuda')`); there is no CPU fallback")
+        if image_condition is None and latent_condition is not None:
+            image_condition = build_wan_condition(latent_condition.float(), num_frames, self.vae_scale_factor_temporal,
+                                                  has_last_image=last_image is not None)
         if image_condition is None:
             raise _lib.AlgHipError("the Wan VAE / CLIP encoders are not built (SURVEY section 8 row f-1): pass the "
                                    "pre-encoded `image_condition` [B, 20, F, h, w] and `image_embeds`")

@@ -183,3 +183,16 @@ def test_hunyuan_pipeline_boundary_without_gpu():
         pipe(prompt_embeds=pe, prompt_template={})
     with pytest.raises(_lib.AlgHipError, match="HIP-only"):
         pipe(prompt_embeds=pe)
+
+
+def test_wan_condition_builder():
+    """wan:439-456: [mask4 | latent16]; only the first latent frame carries the 4 mask flags (plus the last one for
+    first-last-frame conditioning)."""
+    from alg_amd.pipeline_wan_image2video_lowpass import build_wan_condition
+    lat = torch.randn(2, 16, 21, 6, 8)
+    c = build_wan_condition(lat, 81)
+    assert c.shape == (2, 20, 21, 6, 8) and torch.equal(c[:, 4:], lat)
+    assert bool((c[:, :4, 0] == 1).all()) and bool((c[:, :4, 1:] == 0).all())
+    c2 = build_wan_condition(lat, 81, has_last_image=True)
+    assert bool((c2[:, :4, 0] == 1).all()) and bool((c2[:, :4, 1:20] == 0).all())
+    assert bool((c2[:, 3, 20] == 1).all()) and bool((c2[:, :3, 20] == 0).all())   # pixel frame 80 = last slot of group 20
