@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 import torch
 
@@ -25,6 +25,8 @@ EXPORTS = (
     "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128", "alg_layernorm_mod_f32", "alg_rmsnorm_rope",
     "alg_wan_modulation", "alg_patchify3d", "alg_unpatchify3d", "alg_timestep_embedding_f32", "alg_linear_f32",
     "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu", "alg_gemm_fp8", "alg_quantize_fp8_rows",
+    "alg_conv_cl_bf16", "alg_vae_groupnorm_workspace", "alg_vae_groupnorm_stats", "alg_vae_spatial_norm", "alg_vae_upsample",
+    "alg_vae_pack_latent", "alg_vae_unpack_video",
 )
 
 
@@ -40,9 +42,15 @@ class GemmArgs(Structure):
         ("strideGate", c_int64),
         ("M", c_int32), ("N", c_int32), ("K", c_int32), ("batch", c_int32),
         ("seg_split", c_int32), ("act", c_int32), ("flags", c_int32),
-        ("gate_seg_stride", c_int64), ("perm_col0", c_int32), ("reserved0", c_int32),
+        ("gate_seg_stride", c_int64), ("perm_col0", c_int32), ("conv_cin_log2", c_int32),
         ("a_scale", c_void_p), ("b_scale", c_void_p), ("strideAScale", c_int64), ("strideBScale", c_int64),
+        ("conv_wp", c_int32), ("conv_hpwp", c_int32),
     ]
+
+
+class VaeGeom(Structure):
+    _fields_ = [(n, c_int32) for n in ("frames", "H", "W", "C", "first_len", "seg_len", "lat_first_single", "lat_rate",
+                                       "lat_scale", "lat_h", "lat_w")]
 
 
 _lib = None
@@ -95,6 +103,14 @@ def load_library():
     lib.alg_masked_mean.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.alg_silu.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
     lib.alg_gemm_fp8.argtypes = [POINTER(GemmArgs), c_void_p]
+    lib.alg_conv_cl_bf16.argtypes = [c_void_p] * 5 + [c_int] * 6 + [c_void_p]
+    lib.alg_vae_groupnorm_workspace.argtypes = [POINTER(VaeGeom)]
+    lib.alg_vae_groupnorm_workspace.restype = c_int64
+    lib.alg_vae_groupnorm_stats.argtypes = [c_void_p, POINTER(VaeGeom), c_float, c_void_p, c_void_p, c_void_p]
+    lib.alg_vae_spatial_norm.argtypes = [c_void_p] * 6 + [POINTER(VaeGeom), c_int, c_void_p]
+    lib.alg_vae_upsample.argtypes = [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]
+    lib.alg_vae_pack_latent.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]
+    lib.alg_vae_unpack_video.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.alg_quantize_fp8_rows.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p]
     lib.alg_timestep_embedding_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.alg_linear_f32.argtypes = [c_void_p] * 6 + [c_int] * 4 + [c_void_p]
@@ -321,6 +337,57 @@ def masked_mean(x, valid, out, batch, L, D):
 def silu(x, y):
     _check(load_library().alg_silu(_p(x), _p(y), x.numel(), _stream()), "alg_silu")
     return y
+
+
+def conv_cl(x, w, bias, res, y, frames, Hp, Wp, Cin, Cout, kt, x_off=0, y_off=0, res_off=0):
+    """alg_conv_cl_bf16 on flat bf16 buffers (offsets in elements)."""
+    _check(load_library().alg_conv_cl_bf16(_p(x, x_off), _p(w), _p(bias), _p(res, res_off), _p(y, y_off), frames, Hp, Wp,
+                                           Cin, Cout, kt, _stream()), "alg_conv_cl_bf16")
+    return y
+
+
+def vae_geom(**kw):
+    g = VaeGeom()
+    for k, v in kw.items():
+        setattr(g, k, v)
+    return g
+
+
+def vae_groupnorm_workspace(g):
+    n = load_library().alg_vae_groupnorm_workspace(byref(g))
+    if n < 0:
+        _check(1, "alg_vae_groupnorm_workspace")
+    return n
+
+
+def vae_groupnorm_stats(x, g, eps, workspace, stats):
+    _check(load_library().alg_vae_groupnorm_stats(_p(x), byref(g), eps, _p(workspace), _p(stats), _stream()),
+           "alg_vae_groupnorm_stats")
+    return stats
+
+
+def vae_spatial_norm(x, stats, gamma, beta, zyb, out, g, silu=True):
+    _check(load_library().alg_vae_spatial_norm(_p(x), _p(stats), _p(gamma), _p(beta), _p(zyb), _p(out), byref(g),
+                                               int(silu), _stream()), "alg_vae_spatial_norm")
+    return out
+
+
+def vae_upsample(x, out, frames_out, H, W, C, compress_time, first_single):
+    _check(load_library().alg_vae_upsample(_p(x), _p(out), frames_out, H, W, C, int(compress_time), int(first_single),
+                                           _stream()), "alg_vae_upsample")
+    return out
+
+
+def vae_pack_latent(z, c_stride, frame_stride, out, frames, h, w, channels, scale, z_off=0):
+    _check(load_library().alg_vae_pack_latent(_p(z, z_off), c_stride, frame_stride, _p(out), frames, h, w, channels, scale,
+                                              _stream()), "alg_vae_pack_latent")
+    return out
+
+
+def vae_unpack_video(x, out, frames, H, W, to_uint8=False):
+    _check(load_library().alg_vae_unpack_video(_p(x), _p(out), frames, H, W, int(to_uint8), _stream()),
+           "alg_vae_unpack_video")
+    return out
 
 
 def timestep_embedding_f32(t, out, n, dim):

@@ -10,6 +10,7 @@ int launch_gemm_p0(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg
 int launch_gemm_p6(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p7(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
+int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 static int gemm_pipe() {
   const char* e = getenv("ALG_GEMM_PIPE");
   const int v = e ? atoi(e) : 6;  // default: 8-wave ping-pong over half-tiles (fastest measured)
@@ -74,6 +75,17 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
       return ALG_EINVAL;
     }
   }
+  if (a->conv_wp) {
+    const int cl = a->conv_cin_log2;
+    const int taps = (cl >= 6 && cl <= 12) ? a->K >> cl : 0;
+    if (fp8 || (taps != 9 && taps != 27) || (taps << cl) != a->K || a->lda != (1 << cl) || a->conv_wp < 3 ||
+        a->conv_hpwp < 3 * a->conv_wp || a->act != ALG_ACT_NONE ||
+        (2ll * a->conv_hpwp + 2ll * a->conv_wp + 2) * a->lda >= (1ll << 31)) {
+      set_error("alg_gemm_bf16: bad convolution addressing (cin_log2=%d K=%d lda=%lld wp=%d hpwp=%d)", cl, a->K,
+                (long long)a->lda, a->conv_wp, a->conv_hpwp);
+      return ALG_EINVAL;
+    }
+  }
   const int m_tiles = (a->M + BM - 1) / BM, n_tiles = (a->N + BN - 1) / BN;
   const int64_t nwg = (int64_t)m_tiles * n_tiles * a->batch;
   if (nwg > 0x7fffffff) {
@@ -82,6 +94,7 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
   }
   hipStream_t s = (hipStream_t)stream;
   if (fp8) return launch_gemm_p6_fp8(a, m_tiles, n_tiles, nwg, s);
+  if (a->conv_wp) return launch_gemm_p6_conv(a, m_tiles, n_tiles, nwg, s);
   switch (gemm_pipe()) {
     case 0: return launch_gemm_p0(a, m_tiles, n_tiles, nwg, s);   // 2-stage ring, 8 waves
     case 7: return launch_gemm_p7(a, m_tiles, n_tiles, nwg, s);   // 4 waves, every memory op behind an MFMA
@@ -92,3 +105,22 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
 extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) { return gemm_entry(a, stream, false); }
 
 extern "C" int alg_gemm_fp8(const alg_gemm_args* a, void* stream) { return gemm_entry(a, stream, true); }
+
+// AutoencoderKLCogVideoX convolutions (CogVideoXCausalConv3d k = 3, upsampler Conv2d k = 3) as one GEMM launch over the
+// padded grid: output row r = (y, x) of frame t reads input rows r + dt*Hp*Wp + dy*Wp + dx of frame t.
+extern "C" int alg_conv_cl_bf16(const void* x, const void* w, const void* bias, const void* res, void* y, int frames,
+                                int Hp, int Wp, int Cin, int Cout, int kt, void* stream) {
+  if (frames <= 0 || Hp < 3 || Wp < 3 || (kt != 1 && kt != 3) || Cin < 64 || (Cin & (Cin - 1)) || Cout <= 0 || (Cout & 3)) {
+    set_error("alg_conv_cl_bf16: bad shape frames=%d Hp=%d Wp=%d Cin=%d Cout=%d kt=%d (Cin a power of two >= 64, Cout %% 4 == 0)",
+              frames, Hp, Wp, Cin, Cout, kt);
+    return ALG_EINVAL;
+  }
+  alg_gemm_args a = {};
+  a.A = x, a.B = w, a.C = y, a.bias = bias, a.R = res;
+  a.lda = Cin, a.ldb = (int64_t)kt * 9 * Cin, a.ldc = Cout, a.ldr = Cout;
+  a.strideA = (int64_t)Hp * Wp * Cin, a.strideB = 0, a.strideC = (int64_t)Hp * Wp * Cout, a.strideR = a.strideC;
+  a.M = Hp * Wp, a.N = Cout, a.K = kt * 9 * Cin, a.batch = frames;
+  a.act = ALG_ACT_NONE;
+  a.conv_cin_log2 = __builtin_ctz((unsigned)Cin), a.conv_wp = Wp, a.conv_hpwp = Hp * Wp;
+  return gemm_entry(&a, stream, false);
+}

@@ -74,10 +74,14 @@ __device__ __forceinline__ void unpack4(const uint2 v, float (&f)[4]) {
 // still 128 bytes (BK = 128), so staging, swizzle and fragment reads are unchanged; every 16-byte fragment feeds two
 // v_mfma_f32_32x32x16_fp8_fp8 (its low and high 8 bytes -- A and B use the same k order, so any order is a valid
 // contraction order) and the epilogue multiplies the fp32 accumulator by a_scale[row] * b_scale[col].
-template <int ACT, bool RES, int PIPE, int WNW = 4, bool FP8 = false>
+// CONV: A is a zero-padded channels-last volume and K runs over (tap, channel): k-tile kt reads rows shifted by the
+// tap's (dt, dy, dx) -- a constant row offset over the padded grid, so an implicit-GEMM convolution costs one scalar
+// offset per k-tile and nothing else (see alg_gemm_args.conv_*).
+template <int ACT, bool RES, int PIPE, int WNW = 4, bool FP8 = false, bool CONV = false>
 __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_args p, int m_tiles, int n_tiles,
                                                                  int group_m) {
   static_assert(!FP8 || PIPE == 6, "the fp8 operands are built on the ping-pong schedule");
+  static_assert(!CONV || (PIPE == 6 && !FP8), "the convolution addressing is built on the bf16 ping-pong schedule");
   typedef typename std::conditional<FP8, uint8_t, bf16_t>::type elem_t;
   constexpr int EPS = 16 / (int)sizeof(elem_t);  // elements per 16-byte slot
   constexpr int GEMM_THREADS = 2 * WNW * 64;  // 512 (8 waves, 128x64 each) or 256 (4 waves, 128x128 each)
@@ -141,6 +145,17 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
     a_src[i] = A + (int64_t)min(am + r, p.M - 1) * p.lda + sslot * EPS;
     b_src[i] = B + (int64_t)min(bn + r, p.N - 1) * p.ldb + sslot * EPS;
   }
+  // element offset of k-tile kt within a row of A (uniform: scalar ALU only)
+  auto a_koff = [&](int kt) -> int {
+    if constexpr (CONV) {
+      const int cl = p.conv_cin_log2 - 6;  // log2(k-tiles per tap)
+      const int tap = kt >> cl;
+      const int dt = tap / 9, r9 = tap - dt * 9, dy = r9 / 3, dx = r9 - dy * 3;
+      return (dt * p.conv_hpwp + dy * p.conv_wp + dx) * (int)p.lda + (kt & ((1 << cl) - 1)) * BK;
+    } else {
+      return kt * BK;
+    }
+  };
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
         const int i = (kind & 1) * 2 + ii;
-        const elem_t* src = ((kind >> 1) ? b_src[i] : a_src[i]) + kt * BK;
+        const elem_t* src = (kind >> 1) ? b_src[i] + kt * BK : a_src[i] + a_koff(kt);
         if (kind >> 1)
           __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * GEMM_THREADS + wave * 64) * 16), 16, 0, ALG_AUX_B);
         else

@@ -125,10 +125,12 @@ typedef struct alg_gemm_args {
   int64_t gate_seg_stride; /* with ALG_GEMM_GATE_SEG_STRIDE: elements between gate[0] and gate[1] (default N; 0 = one gate) */
   int32_t perm_col0;  /* with ALG_GEMM_PERMUTE_COLS: output column n is joint column perm_col0 + n of a wider permuted row
                          (C points at joint column 0); 0 for a stand-alone V^T */
-  int32_t reserved0;
+  int32_t conv_cin_log2; /* implicit-GEMM convolution (alg_conv_bf16 sets these; 0 = plain GEMM): log2 of the channels per tap */
   const float* a_scale; /* alg_gemm_fp8 only: one scale per row of A, [batch][M] at batch stride strideAScale */
   const float* b_scale; /* alg_gemm_fp8 only: one scale per row of B, [batch][N] at batch stride strideBScale (0 = shared) */
   int64_t strideAScale, strideBScale;
+  int32_t conv_wp;   /* rows of A between vertically adjacent taps (padded width) */
+  int32_t conv_hpwp; /* rows of A between temporally adjacent taps (padded height * padded width) */
 } alg_gemm_args;
 
 /* C = R + gate * act(A @ B^T + bias)   (bias optional; either act or the residual(+gate) form).  K % 64 == 0, lda/ldb % 8 == 0,
@@ -166,6 +168,56 @@ int alg_flash_attn_d64(const void* q, const void* k, const void* vt, void* o, in
 int alg_flash_attn_d128(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq, int Skv,
                         int64_t q_bstride, int64_t q_rstride, int64_t k_bstride, int64_t k_rstride, int64_t vt_bstride,
                         int64_t vt_rstride, int64_t o_bstride, int64_t o_rstride, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * AutoencoderKLCogVideoX decoder (diffusers; call site cog:428-433 `frames = self.vae.decode(latents).sample`)
+ * Activations are channels-last bf16 over a padded grid (Hp, Wp) = (H + 2, W + 2):
+ *   padded  [T + 2][Hp][Wp][C]  zero borders, frames 0 and 1 repeat frame 0 (causal padding)  -- convolution input
+ *   virtual [T][Hp][Wp][C]      rows with y >= H or x >= W are don't-care                      -- convolution output
+ * ------------------------------------------------------------------------------------------------ */
+
+/* CogVideoXCausalConv3d (kt = 3: 3x3x3, first frame repeated twice in front, zero spatial padding) and the upsamplers'
+ * Conv2d 3x3 (kt = 1), as one implicit-GEMM launch on the MFMA GEMM kernel:
+ *   x : padded input [frames + kt - 1][Hp][Wp][Cin], readable for 2*Wp + 2 rows past its end
+ *   w : [Cout][kt*9][Cin] bf16 (tap-major (dt, dy, dx), channels innermost);  bias: [Cout] or NULL
+ *   y : virtual output [frames][Hp][Wp][Cout];  res: optional residual in y's layout, y = res + conv (may alias y)
+ * Cin a power of two >= 64 (pad thinner inputs with zero channels), Cout % 4 == 0. */
+int alg_conv_cl_bf16(const void* x, const void* w, const void* bias, const void* res, void* y, int frames, int Hp,
+                     int Wp, int Cin, int Cout, int kt, void* stream);
+
+typedef struct alg_vae_geom {
+  int32_t frames, H, W, C;     /* activation extent; C a power of two in [128, 2048] (32 groups) */
+  int32_t first_len, seg_len;  /* GroupNorm segments in frames: [0, first_len), then seg_len each -- the published decoder
+                                  normalises each batch of latent frames (3 first, then 2) on its own */
+  int32_t lat_first_single;    /* frame t came from latent frame (t ? 1 + (t-1)/lat_rate : 0) if set, else t/lat_rate */
+  int32_t lat_rate, lat_scale; /* temporal and spatial upsampling factors relative to the latent */
+  int32_t lat_h, lat_w;        /* latent grid (the conditioning tensor is padded: [L + 2][lat_h + 2][lat_w + 2][2C]) */
+} alg_vae_geom;
+
+/* GroupNorm(32 groups) statistics of a virtual-layout activation per (segment, group): stats[seg][32][2] = (mean, rstd).
+ * Deterministic (fixed-order partial sums, final reduction in double).  workspace: alg_vae_groupnorm_workspace() bytes. */
+int64_t alg_vae_groupnorm_workspace(const alg_vae_geom* g);
+int alg_vae_groupnorm_stats(const void* x, const alg_vae_geom* g, float eps, void* workspace, float* stats, void* stream);
+
+/* CogVideoXSpatialNorm3D (+ SiLU): out = act(GroupNorm(x) * conv_y(zq) + conv_b(zq)), virtual -> padded.  zyb holds
+ * [conv_y(zq) | conv_b(zq)] (2C channels) at latent resolution in the padded latent layout; each tensor op rounds to bf16
+ * as the eager reference does. */
+int alg_vae_spatial_norm(const void* x, const float* stats, const void* gamma, const void* beta, const void* zyb,
+                         void* out, const alg_vae_geom* g, int silu, void* stream);
+
+/* CogVideoXUpsample3D nearest-neighbour part: virtual [T][H+2][W+2][C] -> padded [frames_out][2H+2][2W+2][C] (no time
+ * padding, the convolution that follows is 2-D); compress_time doubles every frame but the first (first_single) . */
+int alg_vae_upsample(const void* x, void* out, int frames_out, int H, int W, int C, int compress_time, int first_single,
+                     void* stream);
+
+/* cog:429-430: z element (c, l, y, x) at z + c*c_stride + l*frame_stride + y*w + x, times `scale` (1 / scaling_factor,
+ * one bf16 rounding) -> padded [frames + 2][h + 2][w + 2][64] with channels >= `channels` zero. */
+int alg_vae_pack_latent(const void* z, int64_t c_stride, int64_t frame_stride, void* out, int frames, int h, int w,
+                        int channels, float scale, void* stream);
+
+/* virtual [frames][H+2][W+2][4] (RGB + pad channel) -> bf16 [3][frames][H][W] (decode().sample) or, with to_uint8, the
+ * writer's uint8 [frames][H][W][3] (VideoProcessor.postprocess_video + run:121-125). */
+int alg_vae_unpack_video(const void* x, void* out, int frames, int H, int W, int to_uint8, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HunyuanVideo DiT building blocks (diffusers HunyuanVideoTransformer3DModel; call site hy:1243-1252)
