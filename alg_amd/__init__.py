@@ -2,9 +2,10 @@
 
 Only what the hot path needs: the HIP kernels + C ABI (``csrc/``, ``libalg_hip.so``), and the host-side
 mirror of the reference interface (``lp_utils``, the CogVideoX pipeline / transformer / scheduler, and the Wan /
-HunyuanVideo samplers with their DiT forwards and UniPC / flow-match Euler schedulers).
+HunyuanVideo samplers with their DiT forwards and UniPC / flow-match Euler schedulers, the CogVideoX VAE decoder).
 """
 from . import lp_utils  # noqa: F401
+from .autoencoder_kl_cogvideox import AutoencoderKLCogVideoX, AutoencoderKLCogVideoXConfig  # noqa: F401
 from ._lib import AlgHipError, build_library, load_library  # noqa: F401
 from .pipeline_cogvideox_image2video_lowpass import CogVideoXImageToVideoPipeline, CogVideoXPipelineOutput  # noqa: F401
 from .pipeline_hunyuan_video_image2video_lowpass import HunyuanVideoImageToVideoPipeline  # noqa: F401

@@ -44,7 +44,7 @@ class GemmArgs(Structure):
         ("seg_split", c_int32), ("act", c_int32), ("flags", c_int32),
         ("gate_seg_stride", c_int64), ("perm_col0", c_int32), ("conv_cin_log2", c_int32),
         ("a_scale", c_void_p), ("b_scale", c_void_p), ("strideAScale", c_int64), ("strideBScale", c_int64),
-        ("conv_wp", c_int32), ("conv_hpwp", c_int32),
+        ("conv_wp", c_int32), ("conv_hpwp", c_int32), ("conv_kw", c_int32), ("reserved1", c_int32),
     ]
 
 
@@ -103,7 +103,7 @@ def load_library():
     lib.alg_masked_mean.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.alg_silu.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
     lib.alg_gemm_fp8.argtypes = [POINTER(GemmArgs), c_void_p]
-    lib.alg_conv_cl_bf16.argtypes = [c_void_p] * 5 + [c_int] * 6 + [c_void_p]
+    lib.alg_conv_cl_bf16.argtypes = [c_void_p] * 5 + [c_int] * 7 + [c_void_p]
     lib.alg_vae_groupnorm_workspace.argtypes = [POINTER(VaeGeom)]
     lib.alg_vae_groupnorm_workspace.restype = c_int64
     lib.alg_vae_groupnorm_stats.argtypes = [c_void_p, POINTER(VaeGeom), c_float, c_void_p, c_void_p, c_void_p]
@@ -339,11 +339,21 @@ def silu(x, y):
     return y
 
 
-def conv_cl(x, w, bias, res, y, frames, Hp, Wp, Cin, Cout, kt, x_off=0, y_off=0, res_off=0):
-    """alg_conv_cl_bf16 on flat bf16 buffers (offsets in elements)."""
+def conv_cl(x, w, bias, res, y, frames, Hp, Wp, Cin, Cout, kt, pair=False, x_off=0, y_off=0, res_off=0):
+    """alg_conv_cl_bf16 on flat bf16 buffers (offsets in elements); pair: w / bias in the two-voxel packing."""
     _check(load_library().alg_conv_cl_bf16(_p(x, x_off), _p(w), _p(bias), _p(res, res_off), _p(y, y_off), frames, Hp, Wp,
-                                           Cin, Cout, kt, _stream()), "alg_conv_cl_bf16")
+                                           Cin, Cout, kt, int(pair), _stream()), "alg_conv_cl_bf16")
     return y
+
+
+def pack_conv_pair(w, bias, taps_t):
+    """[Cout][taps_t*9][Cin] / [Cout] -> the two-voxel packing of alg_conv_cl_bf16: [2*Cout][taps_t*12][Cin] / [2*Cout]."""
+    co = w.shape[0]
+    w = w.reshape(co, taps_t, 3, 3, -1)
+    wp = w.new_zeros(2, co, taps_t, 3, 4, w.shape[-1])
+    wp[0, :, :, :, 0:3] = w
+    wp[1, :, :, :, 1:4] = w
+    return wp.reshape(2 * co, -1).contiguous(), torch.cat([bias, bias]).contiguous()
 
 
 def vae_geom(**kw):

@@ -150,7 +150,7 @@ class AutoencoderKLCogVideoX:
             raise KeyError("missing decoder weights: %s ..." % missing[:3])
         dev, bf = self.device, torch.bfloat16
 
-        def conv_w(name, cin_pad=None, cout_pad=None):
+        def conv_w(name, cin_pad=None, cout_pad=None, pair_ok=False):
             w = sd[name + ".weight"].to(torch.float32)
             if tuple(w.shape) != tuple(shapes[name + ".weight"]):
                 raise ValueError("%s: shape %s, expected %s" % (name, tuple(w.shape), shapes[name + ".weight"]))
@@ -162,13 +162,17 @@ class AutoencoderKLCogVideoX:
             if cout_pad and cout_pad > co:
                 w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cout_pad - co))
                 b = torch.nn.functional.pad(b, (0, cout_pad - co))
-            return w.reshape(w.shape[0], -1).contiguous().to(dev, bf), b.contiguous().to(dev, bf)
+            w, b = w.reshape(w.shape[0], -1).contiguous().to(dev, bf), b.contiguous().to(dev, bf)
+            if pair_ok and w.shape[0] == 128:
+                # 128 output channels fill half of the 256-column GEMM tile: pack two neighbouring voxels per GEMM row
+                return _lib.pack_conv_pair(w, b, 3) + (True,)
+            return w, b, False
 
         W = {}
 
         def snorm(name):
-            wy, by = conv_w(name + ".conv_y.conv", cin_pad=64)
-            wb, bb = conv_w(name + ".conv_b.conv", cin_pad=64)
+            wy, by, _ = conv_w(name + ".conv_y.conv", cin_pad=64)
+            wb, bb, _ = conv_w(name + ".conv_b.conv", cin_pad=64)
             W[name] = (sd[name + ".norm_layer.weight"].to(dev, bf).contiguous(),
                        sd[name + ".norm_layer.bias"].to(dev, bf).contiguous(),
                        torch.cat([wy, wb], 0).contiguous(), torch.cat([by, bb], 0).contiguous())
@@ -176,8 +180,8 @@ class AutoencoderKLCogVideoX:
         for name, ci, co in self._resnets():
             snorm(name + ".norm1")
             snorm(name + ".norm2")
-            W[name + ".conv1"] = conv_w(name + ".conv1.conv")
-            W[name + ".conv2"] = conv_w(name + ".conv2.conv")
+            W[name + ".conv1"] = conv_w(name + ".conv1.conv", pair_ok=True)
+            W[name + ".conv2"] = conv_w(name + ".conv2.conv", pair_ok=True)
             if ci != co:
                 W[name + ".conv_shortcut"] = conv_w(name + ".conv_shortcut")
         W["decoder.conv_in"] = conv_w("decoder.conv_in.conv", cin_pad=64)
@@ -219,17 +223,17 @@ class AutoencoderKLCogVideoX:
         stats = torch.empty(nseg * 64, device=self.device, dtype=torch.float32)
         self._mark("gn_stats")
         _lib.vae_groupnorm_stats(x, g, self.config.norm_eps, ws, stats)
-        out = self._buf((lv.T + 2) * lv.rows, C, slack_rows=2 * lv.Wp + 2)
+        out = self._buf((lv.T + 2) * lv.rows, C, slack_rows=2 * lv.Wp + 4)
         self._mark("spatial_norm")
         _lib.vae_spatial_norm(x, stats, gamma, beta, zyb, out, g, silu=True)
         return out
 
     def _conv(self, xpad, name, lv, Cin, Cout, res=None, out=None, kt=3, frames=None):
-        w, b = self.w[name]
+        w, b, pair = self.w[name]
         frames = lv.T if frames is None else frames
         out = self._buf(frames * lv.rows, Cout) if out is None else out
         self._mark("conv%d_%d" % (Cin, Cout))
-        _lib.conv_cl(xpad, w, b, res, out, frames, lv.Hp, lv.Wp, Cin, Cout, kt)
+        _lib.conv_cl(xpad, w, b, res, out, frames, lv.Hp, lv.Wp, Cin, Cout, kt, pair=pair)
         return out
 
     def _resnet(self, h, name, ci, co, lv, zpad, lat):
@@ -239,7 +243,7 @@ class AutoencoderKLCogVideoX:
         n = self._spatial_norm(c1, co, lv, name + ".norm2", zpad, lat)
         del c1
         if ci != co:
-            w, b = self.w[name + ".conv_shortcut"]
+            w, b, _ = self.w[name + ".conv_shortcut"]
             res = self._buf(lv.T * lv.rows, co)
             self._mark("shortcut")
             _lib.gemm(h, w, res, lv.rows, co, ci, ci, ci, co, bias=b, batch=lv.T, strideA=lv.rows * ci,
@@ -253,7 +257,7 @@ class AutoencoderKLCogVideoX:
         rev = list(reversed(c.block_out_channels))
         lat = (L, h, w)
         lv = _Level(L, h, w, 1, 1)
-        zpad = self._buf((L + 2) * lv.rows, 64, slack_rows=2 * lv.Wp + 2)
+        zpad = self._buf((L + 2) * lv.rows, 64, slack_rows=2 * lv.Wp + 4)
         self._mark("pack")
         _lib.vae_pack_latent(z, c_stride, frame_stride, zpad, L, h, w, c.latent_channels, scale, z_off=z_off)
         hcur = self._conv(zpad, "decoder.conv_in", lv, 64, rev[0])
@@ -270,7 +274,7 @@ class AutoencoderKLCogVideoX:
             if i != len(rev) - 1:
                 compress = i < levels
                 nxt = _Level(L, h, w, lv.rate * (2 if compress else 1), lv.scale * 2)
-                up = self._buf(nxt.T * nxt.rows, ch, slack_rows=2 * nxt.Wp + 2)
+                up = self._buf(nxt.T * nxt.rows, ch, slack_rows=2 * nxt.Wp + 4)
                 self._mark("upsample")
                 _lib.vae_upsample(hcur, up, nxt.T, lv.H, lv.W, ch, compress, lv.single)
                 hcur = self._conv(up, "decoder.up_blocks.%d.upsamplers.0" % i, nxt, ch, ch, kt=1)

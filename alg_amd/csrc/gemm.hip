@@ -78,9 +78,11 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
   if (a->conv_wp) {
     const int cl = a->conv_cin_log2;
     const int taps = (cl >= 6 && cl <= 12) ? a->K >> cl : 0;
-    if (fp8 || (taps != 9 && taps != 27) || (taps << cl) != a->K || a->lda != (1 << cl) || a->conv_wp < 3 ||
+    const int kw = a->conv_kw;
+    if (fp8 || (kw != 3 && kw != 4) || (taps != 3 * kw && taps != 9 * kw) || (taps << cl) != a->K ||
+        a->lda != ((int64_t)(kw - 2) << cl) || a->conv_wp < 3 ||
         a->conv_hpwp < 3 * a->conv_wp || a->act != ALG_ACT_NONE ||
-        (2ll * a->conv_hpwp + 2ll * a->conv_wp + 2) * a->lda >= (1ll << 31)) {
+        ((2ll * a->conv_hpwp + 2ll * a->conv_wp + 3) << cl) >= (1ll << 31)) {
       set_error("alg_gemm_bf16: bad convolution addressing (cin_log2=%d K=%d lda=%lld wp=%d hpwp=%d)", cl, a->K,
                 (long long)a->lda, a->conv_wp, a->conv_hpwp);
       return ALG_EINVAL;
@@ -109,18 +111,20 @@ extern "C" int alg_gemm_fp8(const alg_gemm_args* a, void* stream) { return gemm_
 // AutoencoderKLCogVideoX convolutions (CogVideoXCausalConv3d k = 3, upsampler Conv2d k = 3) as one GEMM launch over the
 // padded grid: output row r = (y, x) of frame t reads input rows r + dt*Hp*Wp + dy*Wp + dx of frame t.
 extern "C" int alg_conv_cl_bf16(const void* x, const void* w, const void* bias, const void* res, void* y, int frames,
-                                int Hp, int Wp, int Cin, int Cout, int kt, void* stream) {
-  if (frames <= 0 || Hp < 3 || Wp < 3 || (kt != 1 && kt != 3) || Cin < 64 || (Cin & (Cin - 1)) || Cout <= 0 || (Cout & 3)) {
+                                int Hp, int Wp, int Cin, int Cout, int kt, int pair, void* stream) {
+  if (frames <= 0 || Hp < 3 || Wp < 3 || (kt != 1 && kt != 3) || Cin < 64 || (Cin & (Cin - 1)) || Cout <= 0 || (Cout & 3) ||
+      (pair && (((Hp * Wp) & 1) || Cout > 128))) {
     set_error("alg_conv_cl_bf16: bad shape frames=%d Hp=%d Wp=%d Cin=%d Cout=%d kt=%d (Cin a power of two >= 64, Cout %% 4 == 0)",
               frames, Hp, Wp, Cin, Cout, kt);
     return ALG_EINVAL;
   }
   alg_gemm_args a = {};
   a.A = x, a.B = w, a.C = y, a.bias = bias, a.R = res;
-  a.lda = Cin, a.ldb = (int64_t)kt * 9 * Cin, a.ldc = Cout, a.ldr = Cout;
+  const int vox = pair ? 2 : 1, kw = pair ? 4 : 3;  // voxels per GEMM row, taps along x
+  a.lda = (int64_t)vox * Cin, a.ldb = (int64_t)kt * 3 * kw * Cin, a.ldc = (int64_t)vox * Cout, a.ldr = a.ldc;
   a.strideA = (int64_t)Hp * Wp * Cin, a.strideB = 0, a.strideC = (int64_t)Hp * Wp * Cout, a.strideR = a.strideC;
-  a.M = Hp * Wp, a.N = Cout, a.K = kt * 9 * Cin, a.batch = frames;
+  a.M = Hp * Wp / vox, a.N = vox * Cout, a.K = kt * 3 * kw * Cin, a.batch = frames;
   a.act = ALG_ACT_NONE;
-  a.conv_cin_log2 = __builtin_ctz((unsigned)Cin), a.conv_wp = Wp, a.conv_hpwp = Hp * Wp;
+  a.conv_cin_log2 = __builtin_ctz((unsigned)Cin), a.conv_wp = Wp, a.conv_hpwp = Hp * Wp, a.conv_kw = kw;
   return gemm_entry(&a, stream, false);
 }

@@ -150,8 +150,11 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
     if constexpr (CONV) {
       const int cl = p.conv_cin_log2 - 6;  // log2(k-tiles per tap)
       const int tap = kt >> cl;
-      const int dt = tap / 9, r9 = tap - dt * 9, dy = r9 / 3, dx = r9 - dy * 3;
-      return (dt * p.conv_hpwp + dy * p.conv_wp + dx) * (int)p.lda + (kt & ((1 << cl) - 1)) * BK;
+      // taps run (dt, dy, dx) with dx < conv_kw: 3, or 4 when two neighbouring voxels share one A row (see alg_conv_cl_bf16)
+      const bool k4 = p.conv_kw == 4;
+      const int dt = k4 ? tap / 12 : tap / 9, r9 = tap - dt * (k4 ? 12 : 9);
+      const int dy = k4 ? r9 >> 2 : r9 / 3, dx = r9 - dy * (k4 ? 4 : 3);
+      return ((dt * p.conv_hpwp + dy * p.conv_wp + dx) << p.conv_cin_log2) + (kt & ((1 << cl) - 1)) * BK;
     } else {
       return kt * BK;
     }

@@ -307,6 +307,9 @@ class CogVideoXImageToVideoPipeline:
         """reference cog:428-433."""
         if self.vae is None:
             raise _lib.AlgHipError("no VAE is attached to this pipeline: use output_type='latent'")
+        if hasattr(self.vae, "decode_latents"):
+            # the HIP decoder takes the sampler's [B, F, C, h, w] layout and applies 1 / scaling_factor while packing
+            return self.vae.decode_latents(latents.contiguous())
         z = latents.permute(0, 2, 1, 3, 4)
         return self.vae.decode(1 / self.vae_scaling_factor_image * z).sample
 
@@ -575,6 +578,12 @@ class CogVideoXImageToVideoPipeline:
 
         if output_type == "latent":
             video = latents
+        elif output_type in ("pil", "uint8") and hasattr(self.vae, "decode_latents"):
+            # decode + postprocess_video + the writer's uint8 conversion (run:121-125) end in one kernel: [B, F, H, W, 3]
+            video = self.vae.decode_latents(latents.contiguous(), to_uint8=True)
+            if output_type == "pil":
+                from PIL import Image
+                video = [[Image.fromarray(f) for f in vid] for vid in video.cpu().numpy()]
         else:
             video = self.decode_latents(latents)
             video = self.postprocess_video(video, output_type)
@@ -584,11 +593,12 @@ class CogVideoXImageToVideoPipeline:
         return CogVideoXPipelineOutput(frames=video)
 
     def postprocess_video(self, video, output_type="pil"):
-        """Minimal VideoProcessor.postprocess_video: [B, C, F, H, W] in [-1, 1] -> 'pt' | 'np' | 'pil'."""
-        v = (video.float() / 2 + 0.5).clamp(0, 1)
+        """VideoProcessor.postprocess_video (cog:1148): [B, C, F, H, W] in [-1, 1] -> 'pt' | 'np' | 'pil'; the
+        denormalisation runs in the video's dtype, as the tensor ops of the published processor do."""
+        v = (video * 0.5 + 0.5).clamp(0, 1)
         if output_type == "pt":
             return v.permute(0, 2, 1, 3, 4)
-        arr = v.permute(0, 2, 3, 4, 1).cpu().numpy()  # [B, F, H, W, C]
+        arr = v.permute(0, 2, 3, 4, 1).cpu().float().numpy()  # [B, F, H, W, C]
         if output_type == "np":
             return arr
         if output_type == "pil":

@@ -131,6 +131,8 @@ typedef struct alg_gemm_args {
   int64_t strideAScale, strideBScale;
   int32_t conv_wp;   /* rows of A between vertically adjacent taps (padded width) */
   int32_t conv_hpwp; /* rows of A between temporally adjacent taps (padded height * padded width) */
+  int32_t conv_kw;   /* taps along x: 3, or 4 when one A row holds two neighbouring voxels (lda = 2 * channels) */
+  int32_t reserved1;
 } alg_gemm_args;
 
 /* C = R + gate * act(A @ B^T + bias)   (bias optional; either act or the residual(+gate) form).  K % 64 == 0, lda/ldb % 8 == 0,
@@ -181,9 +183,13 @@ int alg_flash_attn_d128(const void* q, const void* k, const void* vt, void* o, i
  *   x : padded input [frames + kt - 1][Hp][Wp][Cin], readable for 2*Wp + 2 rows past its end
  *   w : [Cout][kt*9][Cin] bf16 (tap-major (dt, dy, dx), channels innermost);  bias: [Cout] or NULL
  *   y : virtual output [frames][Hp][Wp][Cout];  res: optional residual in y's layout, y = res + conv (may alias y)
- * Cin a power of two >= 64 (pad thinner inputs with zero channels), Cout % 4 == 0. */
+ * Cin a power of two >= 64 (pad thinner inputs with zero channels), Cout % 4 == 0.
+ * pair != 0 (Cout <= 128; the GEMM tile is 256 columns wide): one GEMM row produces TWO neighbouring voxels, so a
+ * 128-channel convolution fills the tile: w is then [2*Cout][kt*3*4][Cin] with rows [0, Cout) = the kernel at dx 0..2
+ * (dx 3 zero) and rows [Cout, 2*Cout) = the kernel at dx 1..3 (dx 0 zero), bias is [2*Cout] (the bias twice), Hp*Wp must
+ * be even, and x must be readable for 2*Wp + 3 rows past its end.  Same results, 4/3 of the useful MFMA work instead of 2x. */
 int alg_conv_cl_bf16(const void* x, const void* w, const void* bias, const void* res, void* y, int frames, int Hp,
-                     int Wp, int Cin, int Cout, int kt, void* stream);
+                     int Wp, int Cin, int Cout, int kt, int pair, void* stream);
 
 typedef struct alg_vae_geom {
   int32_t frames, H, W, C;     /* activation extent; C a power of two in [128, 2048] (32 groups) */

@@ -17,7 +17,7 @@ import sys
 import torch
 import yaml
 
-from alg_amd import (CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, CogVideoXTransformer3DModel,
+from alg_amd import (AutoencoderKLCogVideoX, CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, CogVideoXTransformer3DModel,
                      CogVideoXTransformerConfig, FlowMatchEulerDiscreteScheduler, HunyuanVideoImageToVideoPipeline,
                      HunyuanVideoTransformer3DModel, HunyuanVideoTransformerConfig, UniPCMultistepScheduler,
                      WanImageToVideoPipeline, WanTransformer3DModel, WanTransformerConfig)
@@ -38,7 +38,8 @@ def main(args):
     if "CogVideoX" in model_path:
         if args.synthetic:
             transformer = CogVideoXTransformer3DModel.from_synthetic(CogVideoXTransformerConfig(), device=device)
-            pipe = CogVideoXImageToVideoPipeline(transformer=transformer, scheduler=CogVideoXDDIMScheduler())
+            vae = AutoencoderKLCogVideoX.from_synthetic(device=device)   # decoder only: cog:427-433 runs on HIP
+            pipe = CogVideoXImageToVideoPipeline(transformer=transformer, scheduler=CogVideoXDDIMScheduler(), vae=vae)
         else:
             pipe = CogVideoXImageToVideoPipeline.from_pretrained(model_path, torch_dtype=model_dtype,
                                                                  cache_dir=args.model_cache_dir)
@@ -104,7 +105,7 @@ def main(args):
             pipe_kwargs["prompt_embeds"] = torch.randn(1, 226, 4096, generator=g).to(model_dtype)
             pipe_kwargs["negative_prompt_embeds"] = torch.randn(1, 226, 4096, generator=g).to(model_dtype)
             pipe_kwargs["image_latents"] = (torch.randn(1, 1, 16, 60, 90, generator=g) * 0.7).to(model_dtype)
-        pipe_kwargs["output_type"] = "latent"
+        pipe_kwargs["output_type"] = "latent" if getattr(pipe, "vae", None) is None else "pil"
     else:
         from PIL import Image
         pipe_kwargs["image"] = Image.open(args.image_path).convert("RGB")

@@ -23,7 +23,7 @@ def _padded(x, time_pad):
         x = torch.cat([x[:, :, :1]] * time_pad + [x], dim=2)
     x = F.pad(x, (1, 1, 1, 1))
     flat = x[0].permute(1, 2, 3, 0).contiguous().bfloat16().reshape(-1)
-    return torch.cat([flat, torch.zeros((2 * (W + 2) + 2) * C, dtype=torch.bfloat16)]).to(_dev())
+    return torch.cat([flat, torch.zeros((2 * (W + 2) + 4) * C, dtype=torch.bfloat16)]).to(_dev())
 
 
 def _virtual(x, fill=7.0):
@@ -36,11 +36,13 @@ def _from_virtual(buf, T, H, W, C):
     return buf.reshape(T, H + 2, W + 2, C)[:, :H, :W].permute(3, 0, 1, 2).float().cpu()
 
 
-@pytest.mark.parametrize("Cin,Cout,kt,res", [(64, 128, 3, False), (128, 128, 3, True), (256, 128, 3, False),
-                                             (512, 256, 3, True), (128, 4, 3, False), (256, 256, 1, False)])
-def test_conv_cl_matches_conv3d(Cin, Cout, kt, res):
+@pytest.mark.parametrize("Cin,Cout,kt,res,pair", [
+    (64, 128, 3, False, False), (128, 128, 3, True, False), (256, 128, 3, False, False), (512, 256, 3, True, False),
+    (128, 4, 3, False, False), (256, 256, 1, False, False), (128, 128, 3, True, True), (256, 128, 3, False, True),
+    (128, 128, 1, False, True), (128, 4, 3, False, True)])
+def test_conv_cl_matches_conv3d(Cin, Cout, kt, res, pair):
     g = torch.Generator().manual_seed(Cin + Cout + kt)
-    T, H, W = 5, 9, 13
+    T, H, W = 5, 8 if pair else 9, 13
     x = torch.randn(1, Cin, T, H, W, generator=g).bfloat16().float()
     w = (torch.randn(Cout, Cin, kt, 3, 3, generator=g) / (Cin * kt * 9) ** 0.5).bfloat16().float()
     b = torch.randn(Cout, generator=g).bfloat16().float()
@@ -50,8 +52,11 @@ def test_conv_cl_matches_conv3d(Cin, Cout, kt, res):
     if res:
         want = want + r
     wp = w.reshape(Cout, Cin, -1).permute(0, 2, 1).reshape(Cout, -1).contiguous().bfloat16().to(_dev())
+    bp = b.bfloat16().to(_dev())
+    if pair:
+        wp, bp = _lib.pack_conv_pair(wp, bp, kt)
     y = _virtual(r) if res else torch.full((T * (H + 2) * (W + 2) * Cout,), 3.0, dtype=torch.bfloat16, device=_dev())
-    _lib.conv_cl(_padded(x, kt - 1), wp, b.bfloat16().to(_dev()), y if res else None, y, T, H + 2, W + 2, Cin, Cout, kt)
+    _lib.conv_cl(_padded(x, kt - 1), wp, bp, y if res else None, y, T, H + 2, W + 2, Cin, Cout, kt, pair=pair)
     got = _from_virtual(y, T, H, W, Cout)
     # fp32 accumulation, one bf16 rounding of the result: 2^-8 relative of the magnitude
     assert (got - want[0]).abs().max().item() <= 2.0 ** -7 * want.abs().max().item()
@@ -199,3 +204,32 @@ def test_decoder_batch_of_two():
     both = vae.decode_latents(lat2.to(_dev()))
     assert torch.equal(both[0], vae.decode_latents(lat.to(_dev()))[0])
     assert torch.equal(both[1], vae.decode_latents(lat.flip(1).contiguous().to(_dev()))[0])
+
+
+def test_pipeline_decodes_through_the_hip_vae():
+    """cog:1142-1148: with a VAE attached the CogVideoX pipeline returns frames; 'pt' goes through decode_latents +
+    postprocess_video, 'uint8' (extension) / 'pil' through the fused writer kernel -- same pixels."""
+    from alg_amd import CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline
+    from alg_amd.transformer_cogvideox import CogVideoXTransformer3DModel, CogVideoXTransformerConfig
+    from oracle import dit_oracle
+    dev = _dev()
+    small = dict(num_attention_heads=8, attention_head_dim=64, in_channels=32, out_channels=16, num_layers=1,
+                 time_embed_dim=64, text_embed_dim=128, max_text_seq_length=10, sample_width=6, sample_height=4,
+                 sample_frames=9, patch_size=2)
+    w = dit_oracle.init_weights(dit_oracle.DiTConfig(**small), seed=4, std=0.05, randomize_affine=True)
+    tr = CogVideoXTransformer3DModel(CogVideoXTransformerConfig(**small), {k: v.bfloat16() for k, v in w.items()}, device=dev)
+    vae = AutoencoderKLCogVideoX.from_synthetic(AutoencoderKLCogVideoXConfig(layers_per_block=0), seed=5, device=dev)
+    pipe = CogVideoXImageToVideoPipeline(transformer=tr, scheduler=CogVideoXDDIMScheduler(), vae=vae).to(dev)
+    g = torch.Generator().manual_seed(1)
+    kw = dict(image=None, prompt_embeds=torch.randn(1, 10, 128, generator=g).bfloat16(),
+              negative_prompt_embeds=torch.randn(1, 10, 128, generator=g).bfloat16(),
+              image_latents=(torch.randn(1, 1, 16, 4, 6, generator=g) * 0.7).bfloat16(), height=32, width=48,
+              num_frames=9, num_inference_steps=2, use_low_pass_guidance=False)
+    pt = pipe(**kw, generator=torch.Generator().manual_seed(2), output_type="pt").frames
+    u8 = pipe(**kw, generator=torch.Generator().manual_seed(2), output_type="uint8").frames
+    pil = pipe(**kw, generator=torch.Generator().manual_seed(2), output_type="pil").frames
+    assert pt.shape == (1, 9, 3, 32, 48) and u8.shape == (1, 9, 32, 48, 3) and u8.dtype == torch.uint8
+    want = (pt[0].permute(0, 2, 3, 1).float().cpu().numpy() * 255).round().astype("uint8")
+    assert (u8[0].cpu().numpy() == want).all()
+    import numpy as np
+    assert len(pil[0]) == 9 and (np.asarray(pil[0][3]) == want[3]).all()

@@ -125,7 +125,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.alg_version() == 100
-    assert ctypes.sizeof(alg_amd._lib.GemmArgs) == 6 * 8 + 9 * 8 + 7 * 4 + 4 + 8 + 8 + 4 * 8 + 8  # struct alg_gemm_args (+pad, gate_seg_stride, perm_col0/conv_cin_log2, fp8 scales, conv_wp/conv_hpwp)
+    assert ctypes.sizeof(alg_amd._lib.GemmArgs) == 6 * 8 + 9 * 8 + 7 * 4 + 4 + 8 + 8 + 4 * 8 + 16  # struct alg_gemm_args (+pad, gate_seg_stride, perm_col0/conv_cin_log2, fp8 scales, conv_wp/conv_hpwp/conv_kw/reserved)
 
 
 def test_c_abi_argument_errors_without_gpu():

@@ -37,13 +37,20 @@ def test_weight_packing_is_tap_major_channels_last():
     vae = AutoencoderKLCogVideoX(cfg, device="cpu")
     sd = vae_oracle.synthetic_state_dict(vae_oracle.VAEConfig(layers_per_block=0), seed=3)
     vae.load_state_dict(sd)
-    w, b = vae.w["decoder.up_blocks.3.resnets.0.conv1"]
+    w, b, pair = vae.w["decoder.up_blocks.2.resnets.0.conv1"]
+    ref = sd["decoder.up_blocks.2.resnets.0.conv1.conv.weight"]
+    assert w.shape == (256, 27 * 256) and w.dtype == torch.bfloat16 and not pair
+    assert torch.equal(w.float().reshape(256, 3, 3, 3, 256)[5, 2, 0, 1], ref[5, :, 2, 0, 1])
+    # 128 output channels: two neighbouring voxels per GEMM row, kernel at dx 0..2 for the first, dx 1..3 for the second
+    w, b, pair = vae.w["decoder.up_blocks.3.resnets.0.conv1"]
     ref = sd["decoder.up_blocks.3.resnets.0.conv1.conv.weight"]
-    assert w.shape == (128, 27 * 256) and w.dtype == torch.bfloat16
-    assert torch.equal(w.float().reshape(128, 3, 3, 3, 256)[5, 2, 0, 1], ref[5, :, 2, 0, 1])
-    w, b = vae.w["decoder.conv_in"]
+    assert pair and w.shape == (256, 36 * 256) and b.shape == (256,) and torch.equal(b[:128], b[128:])
+    w5 = w.float().reshape(2, 128, 3, 3, 4, 256)
+    assert torch.equal(w5[0, 7, 1, 2, 0:3], ref[7, :, 1, 2, :].T) and bool((w5[0, :, :, :, 3] == 0).all())
+    assert torch.equal(w5[1, 7, 1, 2, 1:4], ref[7, :, 1, 2, :].T) and bool((w5[1, :, :, :, 0] == 0).all())
+    w, b, _ = vae.w["decoder.conv_in"]
     assert w.shape == (512, 27 * 64) and bool((w.reshape(512, 27, 64)[:, :, 16:] == 0).all())
-    w, b = vae.w["decoder.conv_out"]
+    w, b, _ = vae.w["decoder.conv_out"]
     assert w.shape == (4, 27 * 128) and bool((w[3] == 0).all()) and b[3] == 0
     gamma, beta, wyb, byb = vae.w["decoder.norm_out"]
     assert wyb.shape == (256, 64) and byb.shape == (256,)
