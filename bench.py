@@ -141,6 +141,26 @@ def cpu_baseline(budget_s=30.0):
                 seconds_sampled=dt, flops_sampled=dit_oracle.flops_per_forward(cfg, tokens))
 
 
+def vae_decode_microbench(dev, latents, loop_seconds_per_video):
+    """The step after the loop (cog:427-433): CogVideoX VAE decode of the final latents to uint8 frames,
+    outside the timed region and NOT part of `value` (BASELINE's metric counts the denoising loop); reported so the
+    end-to-end figure is on record."""
+    from alg_amd.autoencoder_kl_cogvideox import AutoencoderKLCogVideoX
+    vae = AutoencoderKLCogVideoX.from_synthetic(device=dev)
+    z = (latents.float() * 0.3).to(torch.bfloat16).contiguous()
+    frames = vae.decode_latents(z, to_uint8=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        vae.decode_latents(z, to_uint8=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    n = int(frames.shape[1])
+    return {"ms_per_video": round(ms, 1), "frames": n, "conv_tflop": 312.98, "tflops": round(312.98 / ms * 1e3, 1),
+            "frames_per_s_loop_plus_decode": round(n / (loop_seconds_per_video + ms / 1e3), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,6 +348,7 @@ def main():
         out["INVALID"] = "debug run with %d layers" % cfg.num_layers
     if rank == 0 and world == 1:
         out["roofline"]["extra"]["filters"] = filter_microbench(dev)
+        out["roofline"]["extra"]["vae_decode"] = vae_decode_microbench(dev, latents, elapsed / args.steps * C2["steps"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
         out["cpu_baseline"]["filters"] = cpu_filter_baseline()
