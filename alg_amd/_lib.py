@@ -26,7 +26,8 @@ EXPORTS = (
     "alg_wan_modulation", "alg_patchify3d", "alg_unpatchify3d", "alg_timestep_embedding_f32", "alg_linear_f32",
     "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu", "alg_gemm_fp8", "alg_quantize_fp8_rows",
     "alg_conv_cl_bf16", "alg_vae_groupnorm_workspace", "alg_vae_groupnorm_stats", "alg_vae_spatial_norm", "alg_vae_upsample",
-    "alg_vae_pack_latent", "alg_vae_unpack_video",
+    "alg_vae_pack_latent", "alg_vae_unpack_video", "alg_vae_group_norm", "alg_vae_pad", "alg_vae_repitch",
+    "alg_vae_unpack_planes",
 )
 
 
@@ -108,6 +109,10 @@ def load_library():
     lib.alg_vae_groupnorm_workspace.restype = c_int64
     lib.alg_vae_groupnorm_stats.argtypes = [c_void_p, POINTER(VaeGeom), c_float, c_void_p, c_void_p, c_void_p]
     lib.alg_vae_spatial_norm.argtypes = [c_void_p] * 6 + [POINTER(VaeGeom), c_int, c_void_p]
+    lib.alg_vae_group_norm.argtypes = [c_void_p] * 5 + [POINTER(VaeGeom), c_int, c_void_p]
+    lib.alg_vae_pad.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]
+    lib.alg_vae_repitch.argtypes = [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]
+    lib.alg_vae_unpack_planes.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]
     lib.alg_vae_upsample.argtypes = [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]
     lib.alg_vae_pack_latent.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]
     lib.alg_vae_unpack_video.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
@@ -339,11 +344,37 @@ def silu(x, y):
     return y
 
 
-def conv_cl(x, w, bias, res, y, frames, Hp, Wp, Cin, Cout, kt, pair=False, x_off=0, y_off=0, res_off=0):
-    """alg_conv_cl_bf16 on flat bf16 buffers (offsets in elements); pair: w / bias in the two-voxel packing."""
+CONV_PLAIN, CONV_PAIR, CONV_STRIDE2 = 0, 1, 2
+
+
+def conv_cl(x, w, bias, res, y, frames, Hp, Wp, Cin, Cout, kt, pair=False, stride2=False, x_off=0, y_off=0, res_off=0):
+    """alg_conv_cl_bf16 on flat bf16 buffers (offsets in elements); pair: w / bias in the two-voxel packing; stride2: the
+    downsampler convolution (output rows at the input's pitch)."""
+    mode = CONV_STRIDE2 if stride2 else (CONV_PAIR if pair else CONV_PLAIN)
     _check(load_library().alg_conv_cl_bf16(_p(x, x_off), _p(w), _p(bias), _p(res, res_off), _p(y, y_off), frames, Hp, Wp,
-                                           Cin, Cout, kt, int(pair), _stream()), "alg_conv_cl_bf16")
+                                           Cin, Cout, kt, mode, _stream()), "alg_conv_cl_bf16")
     return y
+
+
+def vae_group_norm(x, stats, gamma, beta, out, g, silu=True):
+    _check(load_library().alg_vae_group_norm(_p(x), _p(stats), _p(gamma), _p(beta), _p(out), byref(g), int(silu),
+                                             _stream()), "alg_vae_group_norm")
+    return out
+
+
+def vae_pad(x, out, frames, H, W, C):
+    _check(load_library().alg_vae_pad(_p(x), _p(out), frames, H, W, C, _stream()), "alg_vae_pad")
+    return out
+
+
+def vae_repitch(x, out, frames, H, W, C, src_rows, src_wp):
+    _check(load_library().alg_vae_repitch(_p(x), _p(out), frames, H, W, C, src_rows, src_wp, _stream()), "alg_vae_repitch")
+    return out
+
+
+def vae_unpack_planes(x, out, frames, H, W, C):
+    _check(load_library().alg_vae_unpack_planes(_p(x), _p(out), frames, H, W, C, _stream()), "alg_vae_unpack_planes")
+    return out
 
 
 def pack_conv_pair(w, bias, taps_t):

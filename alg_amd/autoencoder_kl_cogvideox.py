@@ -44,6 +44,31 @@ class DecoderOutput:
     sample: torch.Tensor
 
 
+class DiagonalGaussianDistribution:
+    """diffusers' posterior object: moments [B, 2C, ...] -> mean, logvar clamped to [-30, 20], std = exp(0.5 logvar);
+    `sample` draws the noise like `randn_tensor` (on the generator's device, then moved), in the moments' dtype."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+
+    def sample(self, generator=None):
+        gdev = generator.device if generator is not None else self.mean.device
+        noise = torch.randn(self.mean.shape, generator=generator, device=gdev, dtype=self.mean.dtype).to(self.mean.device)
+        return self.mean + self.std * noise
+
+    def mode(self):
+        return self.mean
+
+
+@dataclass
+class AutoencoderKLOutput:
+    latent_dist: DiagonalGaussianDistribution
+
+
 class _Level:
     """Geometry of one resolution level for a video of L latent frames."""
 
@@ -78,16 +103,19 @@ class AutoencoderKLCogVideoX:
 
     # ---- weights -------------------------------------------------------------------------------------------------
     @classmethod
-    def from_synthetic(cls, config=None, seed=0, device="cuda"):
+    def from_synthetic(cls, config=None, seed=0, device="cuda", encoder=False):
         """Seeded random weights at the published shapes (no checkpoint is reachable from this environment)."""
         self = cls(config, device=device)
         c = self.config
         g = torch.Generator().manual_seed(seed)
         sd = {}
-        for name, shape in self.param_shapes().items():
-            if name.endswith("norm_layer.weight"):
+        shapes = dict(self.param_shapes())
+        if encoder:
+            shapes.update(self.encoder_param_shapes())
+        for name, shape in shapes.items():
+            if name.split(".")[-2] in ("norm_layer", "norm1", "norm2", "norm_out") and name.endswith(".weight"):
                 t = 1.0 + 0.1 * torch.randn(shape, generator=g)
-            elif name.endswith("norm_layer.bias"):
+            elif name.split(".")[-2] in ("norm_layer", "norm1", "norm2", "norm_out"):
                 t = 0.1 * torch.randn(shape, generator=g)
             elif name.endswith(".bias"):
                 t = 0.05 * torch.randn(shape, generator=g)
@@ -100,6 +128,40 @@ class AutoencoderKLCogVideoX:
             sd[name] = t.bfloat16()
         self.load_state_dict(sd)
         return self
+
+    def encoder_param_shapes(self):
+        """diffusers names / shapes of the encoder (plain GroupNorm, stride-2 downsamplers, 2 x latent moments out)."""
+        c = self.config
+        boc = list(c.block_out_channels)
+        out = {}
+
+        def conv3(name, ci, co):
+            out[name + ".conv.weight"], out[name + ".conv.bias"] = (co, ci, 3, 3, 3), (co,)
+
+        for name, ci, co in self._encoder_resnets():
+            out[name + ".norm1.weight"], out[name + ".norm1.bias"] = (ci,), (ci,)
+            conv3(name + ".conv1", ci, co)
+            out[name + ".norm2.weight"], out[name + ".norm2.bias"] = (co,), (co,)
+            conv3(name + ".conv2", co, co)
+            if ci != co:
+                out[name + ".conv_shortcut.weight"], out[name + ".conv_shortcut.bias"] = (co, ci, 1, 1, 1), (co,)
+        conv3("encoder.conv_in", c.in_channels, boc[0])
+        for i, ch in enumerate(boc[:-1]):
+            out["encoder.down_blocks.%d.downsamplers.0.conv.weight" % i] = (ch, ch, 3, 3)
+            out["encoder.down_blocks.%d.downsamplers.0.conv.bias" % i] = (ch,)
+        out["encoder.norm_out.weight"], out["encoder.norm_out.bias"] = (boc[-1],), (boc[-1],)
+        conv3("encoder.conv_out", boc[-1], 2 * c.latent_channels)
+        return out
+
+    def _encoder_resnets(self):
+        c = self.config
+        boc = list(c.block_out_channels)
+        out, prev = [], boc[0]
+        for i, ch in enumerate(boc):
+            for j in range(c.layers_per_block):
+                out.append(("encoder.down_blocks.%d.resnets.%d" % (i, j), prev if j == 0 else ch, ch))
+            prev = ch
+        return out + [("encoder.mid_block.resnets.%d" % j, boc[-1], boc[-1]) for j in range(2)]
 
     def param_shapes(self):
         c = self.config
@@ -148,6 +210,13 @@ class AutoencoderKLCogVideoX:
         missing = [k for k in shapes if k not in sd]
         if missing and strict:
             raise KeyError("missing decoder weights: %s ..." % missing[:3])
+        enc_shapes = self.encoder_param_shapes()
+        has_encoder = any(k.startswith("encoder.") for k in sd)
+        if has_encoder:
+            missing = [k for k in enc_shapes if k not in sd]
+            if missing:
+                raise KeyError("missing encoder weights: %s ..." % missing[:3])
+            shapes = dict(shapes, **enc_shapes)
         dev, bf = self.device, torch.bfloat16
 
         def conv_w(name, cin_pad=None, cout_pad=None, pair_ok=False):
@@ -189,6 +258,22 @@ class AutoencoderKLCogVideoX:
             W["decoder.up_blocks.%d.upsamplers.0" % i] = conv_w("decoder.up_blocks.%d.upsamplers.0.conv" % i)
         snorm("decoder.norm_out")
         W["decoder.conv_out"] = conv_w("decoder.conv_out.conv", cout_pad=4)
+        if has_encoder:
+            for name, ci, co in self._encoder_resnets():
+                for n in (".norm1", ".norm2"):
+                    W[name + n] = (sd[name + n + ".weight"].to(dev, bf).contiguous(),
+                                   sd[name + n + ".bias"].to(dev, bf).contiguous())
+                W[name + ".conv1"] = conv_w(name + ".conv1.conv", pair_ok=True)
+                W[name + ".conv2"] = conv_w(name + ".conv2.conv", pair_ok=True)
+                if ci != co:
+                    W[name + ".conv_shortcut"] = conv_w(name + ".conv_shortcut")
+            W["encoder.conv_in"] = conv_w("encoder.conv_in.conv", cin_pad=64, pair_ok=True)
+            for i in range(len(self.config.block_out_channels) - 1):
+                W["encoder.down_blocks.%d.downsamplers.0" % i] = conv_w("encoder.down_blocks.%d.downsamplers.0.conv" % i)
+            W["encoder.norm_out"] = (sd["encoder.norm_out.weight"].to(dev, bf).contiguous(),
+                                     sd["encoder.norm_out.bias"].to(dev, bf).contiguous())
+            W["encoder.conv_out"] = conv_w("encoder.conv_out.conv")
+        self.has_encoder = has_encoder
         self.w = W
         return self
 
@@ -210,13 +295,18 @@ class AutoencoderKLCogVideoX:
                              lat_w=lat[2])
 
     def _spatial_norm(self, x, C, lv, name, zpad, lat):
-        """virtual x [T][Hp][Wp][C] -> padded silu(GroupNorm(x) * conv_y(zq) + conv_b(zq)) [T + 2][Hp][Wp][C]."""
-        gamma, beta, wyb, byb = self.w[name]
-        L, h, w = lat
-        zrows = (L + 2) * (h + 2) * (w + 2)
-        zyb = self._buf(zrows, 2 * C)
-        self._mark("zq_gemm")
-        _lib.gemm(zpad, wyb, zyb, zrows, 2 * C, 64, 64, 64, 2 * C, bias=byb)
+        """virtual x [T][Hp][Wp][C] -> padded silu(GroupNorm(x) * conv_y(zq) + conv_b(zq)) [T + 2][Hp][Wp][C]; without a
+        latent (`zpad` None: the encoder) plain silu(GroupNorm(x))."""
+        if zpad is None:
+            gamma, beta = self.w[name]
+            lat = (1, lv.H, lv.W)
+        else:
+            gamma, beta, wyb, byb = self.w[name]
+            L, h, w = lat
+            zrows = (L + 2) * (h + 2) * (w + 2)
+            zyb = self._buf(zrows, 2 * C)
+            self._mark("zq_gemm")
+            _lib.gemm(zpad, wyb, zyb, zrows, 2 * C, 64, 64, 64, 2 * C, bias=byb)
         g = self._geom(lv, C, lat)
         ws = torch.empty(_lib.vae_groupnorm_workspace(g) // 4, device=self.device, dtype=torch.float32)
         nseg = 1 if lv.T <= lv.first_len else 1 + -(-(lv.T - lv.first_len) // lv.seg_len)
@@ -225,7 +315,10 @@ class AutoencoderKLCogVideoX:
         _lib.vae_groupnorm_stats(x, g, self.config.norm_eps, ws, stats)
         out = self._buf((lv.T + 2) * lv.rows, C, slack_rows=2 * lv.Wp + 4)
         self._mark("spatial_norm")
-        _lib.vae_spatial_norm(x, stats, gamma, beta, zyb, out, g, silu=True)
+        if zpad is None:
+            _lib.vae_group_norm(x, stats, gamma, beta, out, g, silu=True)
+        else:
+            _lib.vae_spatial_norm(x, stats, gamma, beta, zyb, out, g, silu=True)
         return out
 
     def _conv(self, xpad, name, lv, Cin, Cout, res=None, out=None, kt=3, frames=None):
@@ -291,6 +384,60 @@ class AutoencoderKLCogVideoX:
         _lib.vae_unpack_video(rgb, out, lv.T, lv.H, lv.W, to_uint8)
         self._mark("end")
         return out
+
+    def _encode_one(self, x, x_off, H, W):
+        """One image [3][1][H][W] -> moments planes [2 * latent][1][H/8][W/8] (AutoencoderKLCogVideoX._encode, one frame)."""
+        c = self.config
+        boc = list(c.block_out_channels)
+        lv = _Level(1, H, W, 1, 1)
+        xpad = self._buf(3 * lv.rows, 64, slack_rows=2 * lv.Wp + 4)
+        _lib.vae_pack_latent(x, H * W, H * W, xpad, 1, H, W, c.in_channels, 1.0, z_off=x_off)
+        h = self._conv(xpad, "encoder.conv_in", lv, 64, boc[0])
+        resnets = self._encoder_resnets()
+        k = 0
+        for i, ch in enumerate(boc):
+            for _ in range(c.layers_per_block):
+                name, ci, co = resnets[k]
+                k += 1
+                h = self._resnet(h, name, ci, co, lv, None, None)
+            if i != len(boc) - 1:
+                # CogVideoXDownsample3D on one frame: no temporal pooling; pad (0, 1, 0, 1) + Conv2d k3 s2
+                pad = self._buf(3 * lv.rows, ch, slack_rows=2 * lv.Wp + 4)
+                _lib.vae_pad(h, pad, 1, lv.H, lv.W, ch)
+                w, b, _ = self.w["encoder.down_blocks.%d.downsamplers.0" % i]
+                m = lv.H // 2 * lv.Wp
+                wide = self._buf(m, ch)
+                _lib.conv_cl(pad, w, b, None, wide, 1, lv.Hp, lv.Wp, ch, ch, 1, stride2=True, x_off=2 * lv.rows * ch)
+                nxt = _Level(1, lv.H // 2, lv.W // 2, 1, 1)
+                h = self._buf(nxt.rows, ch)
+                _lib.vae_repitch(wide, h, 1, nxt.H, nxt.W, ch, m, lv.Wp)
+                lv = nxt
+        for name, ci, co in resnets[k:]:
+            h = self._resnet(h, name, ci, co, lv, None, None)
+        n = self._spatial_norm(h, boc[-1], lv, "encoder.norm_out", None, None)
+        mom = self._conv(n, "encoder.conv_out", lv, boc[-1], 2 * c.latent_channels)
+        out = torch.empty(2 * c.latent_channels, 1, lv.H, lv.W, device=self.device, dtype=torch.bfloat16)
+        _lib.vae_unpack_planes(mom, out, 1, lv.H, lv.W, 2 * c.latent_channels)
+        return out
+
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """`AutoencoderKLCogVideoX.encode` for single frames -- the only use the reference makes of it (cog:388-391 the
+        conditioning image, cog:645 the filtered image of the pixel-space ALG branch): x [B, 3, 1, H, W] bf16 in [-1, 1]
+        -> `.latent_dist` (DiagonalGaussianDistribution over [B, 16, 1, H/8, W/8])."""
+        if not getattr(self, "has_encoder", False):
+            raise _lib.AlgHipError("this AutoencoderKLCogVideoX was loaded without encoder weights")
+        if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 5 and x.is_contiguous()):
+            raise _lib.AlgHipError("AutoencoderKLCogVideoX.encode: a contiguous 5-D bfloat16 device tensor is required "
+                                   "(HIP-only path)")
+        B, C, T, H, W = x.shape
+        down = 2 ** (len(self.config.block_out_channels) - 1)
+        if T != 1 or C != self.config.in_channels or H % down or W % down:
+            raise ValueError("encode() takes single frames [B, %d, 1, H, W] with H, W multiples of %d (video encoding -- "
+                             "temporal pooling, 8-frame batches -- is not used by the ALG pipelines and not built)"
+                             % (self.config.in_channels, down))
+        mom = torch.stack([self._encode_one(x, b * C * H * W, H, W) for b in range(B)])
+        dist = DiagonalGaussianDistribution(mom)
+        return AutoencoderKLOutput(latent_dist=dist) if return_dict else (dist,)
 
     def _run(self, z, scale, to_uint8, layout):
         if not (z.is_cuda and z.dtype == torch.bfloat16 and z.dim() == 5 and z.is_contiguous()):

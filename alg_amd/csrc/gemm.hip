@@ -80,7 +80,7 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
     const int taps = (cl >= 6 && cl <= 12) ? a->K >> cl : 0;
     const int kw = a->conv_kw;
     if (fp8 || (kw != 3 && kw != 4) || (taps != 3 * kw && taps != 9 * kw) || (taps << cl) != a->K ||
-        a->lda != ((int64_t)(kw - 2) << cl) || a->conv_wp < 3 ||
+        (a->lda != ((int64_t)(kw - 2) << cl) && !(kw == 3 && a->lda == (2ll << cl))) || a->conv_wp < 3 ||
         a->conv_hpwp < 3 * a->conv_wp || a->act != ALG_ACT_NONE ||
         ((2ll * a->conv_hpwp + 2ll * a->conv_wp + 3) << cl) >= (1ll << 31)) {
       set_error("alg_gemm_bf16: bad convolution addressing (cin_log2=%d K=%d lda=%lld wp=%d hpwp=%d)", cl, a->K,
@@ -111,9 +111,11 @@ extern "C" int alg_gemm_fp8(const alg_gemm_args* a, void* stream) { return gemm_
 // AutoencoderKLCogVideoX convolutions (CogVideoXCausalConv3d k = 3, upsampler Conv2d k = 3) as one GEMM launch over the
 // padded grid: output row r = (y, x) of frame t reads input rows r + dt*Hp*Wp + dy*Wp + dx of frame t.
 extern "C" int alg_conv_cl_bf16(const void* x, const void* w, const void* bias, const void* res, void* y, int frames,
-                                int Hp, int Wp, int Cin, int Cout, int kt, int pair, void* stream) {
+                                int Hp, int Wp, int Cin, int Cout, int kt, int mode, void* stream) {
+  const bool pair = mode == ALG_CONV_PAIR, down = mode == ALG_CONV_STRIDE2;
   if (frames <= 0 || Hp < 3 || Wp < 3 || (kt != 1 && kt != 3) || Cin < 64 || (Cin & (Cin - 1)) || Cout <= 0 || (Cout & 3) ||
-      (pair && (((Hp * Wp) & 1) || Cout > 128))) {
+      mode < 0 || mode > ALG_CONV_STRIDE2 || (pair && (((Hp * Wp) & 1) || Cout > 128)) ||
+      (down && (kt != 1 || (Hp & 1) || (Wp & 1)))) {
     set_error("alg_conv_cl_bf16: bad shape frames=%d Hp=%d Wp=%d Cin=%d Cout=%d kt=%d (Cin a power of two >= 64, Cout %% 4 == 0)",
               frames, Hp, Wp, Cin, Cout, kt);
     return ALG_EINVAL;
@@ -126,5 +128,13 @@ extern "C" int alg_conv_cl_bf16(const void* x, const void* w, const void* bias, 
   a.M = Hp * Wp / vox, a.N = vox * Cout, a.K = kt * 3 * kw * Cin, a.batch = frames;
   a.act = ALG_ACT_NONE;
   a.conv_cin_log2 = __builtin_ctz((unsigned)Cin), a.conv_wp = Wp, a.conv_hpwp = Hp * Wp, a.conv_kw = kw;
+  if (down) {
+    // CogVideoXDownsample3D: pad (0, 1, 0, 1), Conv2d k3 s2 p0: output (Y, X) reads unpadded (2Y + dy, 2X + dx) = padded
+    // rows (Wp + 1) + 2 (Y Wp + X) + dy Wp + dx: GEMM row m = Y Wp + X over the INPUT's pitch, two voxels apart
+    a.A = (const bf16_t*)x + (int64_t)(Wp + 1) * Cin;
+    a.lda = 2ll * Cin;
+    a.M = (Hp - 2) / 2 * Wp;
+    a.strideC = a.strideR = (int64_t)a.M * Cout;
+  }
   return gemm_entry(&a, stream, false);
 }

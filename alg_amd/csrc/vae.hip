@@ -88,7 +88,9 @@ __global__ __launch_bounds__(64) void gn_final_kernel(const float* __restrict__ 
 // new_f = GroupNorm(f) * conv_y(zq) + conv_b(zq), then the block's nonlinearity; every tensor op of the reference rounds
 // to bf16, so this does too.  zyb holds [conv_y(zq) | conv_b(zq)] at LATENT resolution in the latent's padded layout
 // (a 1x1x1 convolution commutes with the nearest-neighbour interpolation the reference applies to zq first).
-template <bool SILU>
+// MODE 2: the spatial norm above; MODE 1: plain GroupNorm (the encoder's norms); MODE 0: no arithmetic, just the
+// virtual -> padded re-layout (the encoder's downsamplers convolve the un-normalised activation).
+template <int MODE, bool SILU>
 __global__ __launch_bounds__(256) void spatial_norm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats,
                                                            const bf16_t* __restrict__ gamma,
                                                            const bf16_t* __restrict__ beta,
@@ -104,10 +106,13 @@ __global__ __launch_bounds__(256) void spatial_norm_kernel(const bf16_t* __restr
     return;
   }
   const bf16_t* xrow = x + ((int64_t)t * Hp + y) * Wp * g.C;
-  const float* st = stats + segment_of(g, t) * 64;
-  const int lt = latent_frame(g, t), ly = y / g.lat_scale;
-  const int lhp = g.lat_h + 2, lwp = g.lat_w + 2;
-  const bf16_t* zrow = zyb + (((int64_t)(lt + 2) * lhp + ly + 1) * lwp + 1) * (2 * g.C);
+  const float* st = MODE ? stats + segment_of(g, t) * 64 : nullptr;
+  const bf16_t* zrow = nullptr;
+  if (MODE == 2) {
+    const int lt = latent_frame(g, t), ly = y / g.lat_scale;
+    const int lhp = g.lat_h + 2, lwp = g.lat_w + 2;
+    zrow = zyb + (((int64_t)(lt + 2) * lhp + ly + 1) * lwp + 1) * (2 * g.C);
+  }
   const int gs = g.C >> 5;  // channels per group: 4, 8, 16
   for (int i = threadIdx.x; i < items; i += 256) {
     const int xp = i / chunks, chunk = i - xp * chunks;
@@ -115,24 +120,29 @@ __global__ __launch_bounds__(256) void spatial_norm_kernel(const bf16_t* __restr
     uint4 o = make_uint4(0, 0, 0, 0);
     if (xx >= 0 && xx < g.W) {
       const int c0 = chunk * 8;
-      float f[8], ga[8], be[8], zy[8], zb[8];
-      unpack8(*(const uint4*)(xrow + (int64_t)xx * g.C + c0), f);
-      unpack8(*(const uint4*)(gamma + c0), ga);
-      unpack8(*(const uint4*)(beta + c0), be);
-      const bf16_t* z = zrow + (int64_t)(xx / g.lat_scale) * (2 * g.C) + c0;
-      unpack8(*(const uint4*)z, zy);
-      unpack8(*(const uint4*)(z + g.C), zb);
-      const int g0 = c0 / gs, g1 = (c0 + 4) / gs;
-      const float m0 = st[g0 * 2], r0 = st[g0 * 2 + 1], m1 = st[g1 * 2], r1 = st[g1 * 2 + 1];
-      float v[8];
+      o = *(const uint4*)(xrow + (int64_t)xx * g.C + c0);
+      if (MODE) {
+        float f[8], ga[8], be[8], zy[8], zb[8];
+        unpack8(o, f);
+        unpack8(*(const uint4*)(gamma + c0), ga);
+        unpack8(*(const uint4*)(beta + c0), be);
+        if (MODE == 2) {
+          const bf16_t* z = zrow + (int64_t)(xx / g.lat_scale) * (2 * g.C) + c0;
+          unpack8(*(const uint4*)z, zy);
+          unpack8(*(const uint4*)(z + g.C), zb);
+        }
+        const int g0 = c0 / gs, g1 = (c0 + 4) / gs;
+        const float m0 = st[g0 * 2], r0 = st[g0 * 2 + 1], m1 = st[g1 * 2], r1 = st[g1 * 2 + 1];
+        float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float n = rbf((f[e] - (e < 4 ? m0 : m1)) * (e < 4 ? r0 : r1) * ga[e] + be[e]);
-        float a = rbf(rbf(n * zy[e]) + zb[e]);
-        if (SILU) a = a / (1.0f + __expf(-a));
-        v[e] = a;
+        for (int e = 0; e < 8; ++e) {
+          float a = rbf((f[e] - (e < 4 ? m0 : m1)) * (e < 4 ? r0 : r1) * ga[e] + be[e]);
+          if (MODE == 2) a = rbf(rbf(a * zy[e]) + zb[e]);
+          if (SILU) a = a / (1.0f + __expf(-a));
+          v[e] = a;
+        }
+        o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
       }
-      o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
     }
     *(uint4*)(orow + (int64_t)i * 8) = o;
   }
@@ -202,6 +212,26 @@ __global__ __launch_bounds__(256) void unpack_video_kernel(const bf16_t* __restr
   }
 }
 
+// ---- a strided convolution writes rows at its INPUT's pitch: copy the valid region to the standard virtual layout ----
+__global__ __launch_bounds__(256) void repitch_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int H, int W,
+                                                      int C, int src_rows, int src_wp) {
+  const int t = blockIdx.y, y = blockIdx.x, chunks = C >> 3;
+  const bf16_t* xrow = x + ((int64_t)t * src_rows + (int64_t)y * src_wp) * C;
+  bf16_t* orow = out + ((int64_t)t * (H + 2) + y) * (W + 2) * C;
+  for (int i = threadIdx.x; i < W * chunks; i += 256) *(uint4*)(orow + (int64_t)i * 8) = *(const uint4*)(xrow + (int64_t)i * 8);
+}
+
+// ---- virtual [T][Hp][Wp][C] -> planes [C][T][H][W] (the encoder's moments) ----
+__global__ __launch_bounds__(256) void unpack_planes_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int T,
+                                                            int H, int W, int C) {
+  const int t = blockIdx.y, y = blockIdx.x;
+  const bf16_t* xrow = x + ((int64_t)t * (H + 2) + y) * (W + 2) * C;
+  for (int i = threadIdx.x; i < W * C; i += 256) {
+    const int c = i / W, xx = i - c * W;
+    out[(((int64_t)c * T + t) * H + y) * W + xx] = xrow[(int64_t)xx * C + c];
+  }
+}
+
 }  // namespace vae
 }  // namespace alg
 
@@ -255,12 +285,63 @@ extern "C" int alg_vae_spatial_norm(const void* x, const float* stats, const voi
   }
   const dim3 grid(g->H + 2, g->frames + 2);
   if (silu)
-    hipLaunchKernelGGL(vae::spatial_norm_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, stats,
-                       (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)zyb, (bf16_t*)out, *g);
+    hipLaunchKernelGGL((vae::spatial_norm_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       stats, (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)zyb, (bf16_t*)out, *g);
   else
-    hipLaunchKernelGGL(vae::spatial_norm_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, stats,
-                       (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)zyb, (bf16_t*)out, *g);
+    hipLaunchKernelGGL((vae::spatial_norm_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       stats, (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)zyb, (bf16_t*)out, *g);
   return check_launch("alg_vae_spatial_norm");
+}
+
+extern "C" int alg_vae_group_norm(const void* x, const float* stats, const void* gamma, const void* beta, void* out,
+                                  const alg_vae_geom* g, int silu, void* stream) {
+  if (int rc = check_geom("alg_vae_group_norm", g)) return rc;
+  if (!x || !stats || !gamma || !beta || !out) {
+    set_error("alg_vae_group_norm: null pointer");
+    return ALG_EINVAL;
+  }
+  const dim3 grid(g->H + 2, g->frames + 2);
+  if (silu)
+    hipLaunchKernelGGL((vae::spatial_norm_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       stats, (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)nullptr, (bf16_t*)out, *g);
+  else
+    hipLaunchKernelGGL((vae::spatial_norm_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       stats, (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)nullptr, (bf16_t*)out, *g);
+  return check_launch("alg_vae_group_norm");
+}
+
+extern "C" int alg_vae_pad(const void* x, void* out, int frames, int H, int W, int C, void* stream) {
+  if (frames <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || !x || !out) {
+    set_error("alg_vae_pad: bad argument");
+    return ALG_EINVAL;
+  }
+  alg_vae_geom g = {};
+  g.frames = frames, g.H = H, g.W = W, g.C = C;
+  hipLaunchKernelGGL((vae::spatial_norm_kernel<0, false>), dim3(H + 2, frames + 2), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const float*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
+                     (const bf16_t*)nullptr, (bf16_t*)out, g);
+  return check_launch("alg_vae_pad");
+}
+
+extern "C" int alg_vae_repitch(const void* x, void* out, int frames, int H, int W, int C, int src_rows, int src_wp,
+                               void* stream) {
+  if (frames <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || src_wp < W || src_rows < H * src_wp || !x || !out) {
+    set_error("alg_vae_repitch: bad argument");
+    return ALG_EINVAL;
+  }
+  hipLaunchKernelGGL(vae::repitch_kernel, dim3(H, frames), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)out, H, W, C, src_rows, src_wp);
+  return check_launch("alg_vae_repitch");
+}
+
+extern "C" int alg_vae_unpack_planes(const void* x, void* out, int frames, int H, int W, int C, void* stream) {
+  if (frames <= 0 || H <= 0 || W <= 0 || C <= 0 || !x || !out) {
+    set_error("alg_vae_unpack_planes: bad argument");
+    return ALG_EINVAL;
+  }
+  hipLaunchKernelGGL(vae::unpack_planes_kernel, dim3(H, frames), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)out, frames, H, W, C);
+  return check_launch("alg_vae_unpack_planes");
 }
 
 extern "C" int alg_vae_upsample(const void* x, void* out, int frames_out, int H, int W, int C, int compress_time,

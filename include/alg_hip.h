@@ -184,12 +184,18 @@ int alg_flash_attn_d128(const void* q, const void* k, const void* vt, void* o, i
  *   w : [Cout][kt*9][Cin] bf16 (tap-major (dt, dy, dx), channels innermost);  bias: [Cout] or NULL
  *   y : virtual output [frames][Hp][Wp][Cout];  res: optional residual in y's layout, y = res + conv (may alias y)
  * Cin a power of two >= 64 (pad thinner inputs with zero channels), Cout % 4 == 0.
- * pair != 0 (Cout <= 128; the GEMM tile is 256 columns wide): one GEMM row produces TWO neighbouring voxels, so a
+ * mode ALG_CONV_PAIR (Cout <= 128; the GEMM tile is 256 columns wide): one GEMM row produces TWO neighbouring voxels, so a
  * 128-channel convolution fills the tile: w is then [2*Cout][kt*3*4][Cin] with rows [0, Cout) = the kernel at dx 0..2
  * (dx 3 zero) and rows [Cout, 2*Cout) = the kernel at dx 1..3 (dx 0 zero), bias is [2*Cout] (the bias twice), Hp*Wp must
- * be even, and x must be readable for 2*Wp + 3 rows past its end.  Same results, 4/3 of the useful MFMA work instead of 2x. */
+ * be even, and x must be readable for 2*Wp + 3 rows past its end.  Same results, 4/3 of the useful MFMA work instead of 2x.
+ * mode ALG_CONV_STRIDE2 (kt = 1; CogVideoXDownsample3D: pad (0,1,0,1) + Conv2d k3 s2 p0): x is the padded input of the
+ * [H][W] activation (H, W even), y has (H/2)*Wp rows per frame -- output (Y, X) at row Y*Wp + X, i.e. at the INPUT's pitch
+ * (alg_vae_repitch moves it to the standard layout of the half-resolution level). */
+#define ALG_CONV_PLAIN 0
+#define ALG_CONV_PAIR 1
+#define ALG_CONV_STRIDE2 2
 int alg_conv_cl_bf16(const void* x, const void* w, const void* bias, const void* res, void* y, int frames, int Hp,
-                     int Wp, int Cin, int Cout, int kt, int pair, void* stream);
+                     int Wp, int Cin, int Cout, int kt, int mode, void* stream);
 
 typedef struct alg_vae_geom {
   int32_t frames, H, W, C;     /* activation extent; C a power of two in [128, 2048] (32 groups) */
@@ -210,6 +216,20 @@ int alg_vae_groupnorm_stats(const void* x, const alg_vae_geom* g, float eps, voi
  * as the eager reference does. */
 int alg_vae_spatial_norm(const void* x, const float* stats, const void* gamma, const void* beta, const void* zyb,
                          void* out, const alg_vae_geom* g, int silu, void* stream);
+
+/* The encoder's plain GroupNorm (+ SiLU), virtual -> padded: same kernel without the conditioning (lat_* ignored). */
+int alg_vae_group_norm(const void* x, const float* stats, const void* gamma, const void* beta, void* out,
+                       const alg_vae_geom* g, int silu, void* stream);
+
+/* virtual -> padded copy (zero borders, causal frames), for convolutions that read an un-normalised activation. */
+int alg_vae_pad(const void* x, void* out, int frames, int H, int W, int C, void* stream);
+
+/* Rows written at another pitch (ALG_CONV_STRIDE2: src_rows rows per frame, src_wp per line) -> the standard virtual
+ * layout [frames][H + 2][W + 2][C]. */
+int alg_vae_repitch(const void* x, void* out, int frames, int H, int W, int C, int src_rows, int src_wp, void* stream);
+
+/* virtual [frames][H+2][W+2][C] -> planes [C][frames][H][W] bf16 (the encoder's moments, `AutoencoderKLCogVideoX.encode`). */
+int alg_vae_unpack_planes(const void* x, void* out, int frames, int H, int W, int C, void* stream);
 
 /* CogVideoXUpsample3D nearest-neighbour part: virtual [T][H+2][W+2][C] -> padded [frames_out][2H+2][2W+2][C] (no time
  * padding, the convolution that follows is 2-D); compress_time doubles every frame but the first (first_single) . */

@@ -17,6 +17,11 @@ Restated as published (module by module, so the product's whole-video formulatio
     kept single; then a per-frame Conv2d 3x3;
   * decoder: conv_in, mid block (2 resnets), 4 up blocks (layers_per_block + 1 resnets each; upsample on all but the last,
     `compress_time` on the first log2(temporal_compression_ratio)), norm_out, silu, conv_out.
+  * encoder (`encode`, used by the reference on single frames only: cog:388-391, cog:645): conv_in, 4 down blocks
+    (layers_per_block resnets with plain GroupNorm(32, eps 1e-6); `CogVideoXDownsample3D` = optional temporal average
+    pooling with the first frame kept, pad (0,1,0,1), per-frame Conv2d k3 s2 p0), mid block, GroupNorm, silu, conv_out
+    to 2 x latent channels; frames go through in batches of `num_sample_frames_batch_size` = 8 with conv caches;
+    `DiagonalGaussianDistribution`: logvar clamped to [-30, 20], sample = mean + exp(0.5 logvar) * noise.
 State-dict names are diffusers' (`decoder.up_blocks.0.resnets.1.norm1.conv_y.conv.weight` ...).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
@@ -79,15 +84,49 @@ def decoder_param_shapes(cfg):
     return out
 
 
-def synthetic_state_dict(cfg, seed=0):
+def encoder_param_shapes(cfg, in_channels=3):
+    boc = list(cfg.block_out_channels)
+    out = {}
+
+    def conv3(name, ci, co):
+        out[name + ".conv.weight"], out[name + ".conv.bias"] = (co, ci, 3, 3, 3), (co,)
+
+    def resnet(name, ci, co):
+        out[name + ".norm1.weight"], out[name + ".norm1.bias"] = (ci,), (ci,)
+        conv3(name + ".conv1", ci, co)
+        out[name + ".norm2.weight"], out[name + ".norm2.bias"] = (co,), (co,)
+        conv3(name + ".conv2", co, co)
+        if ci != co:
+            out[name + ".conv_shortcut.weight"], out[name + ".conv_shortcut.bias"] = (co, ci, 1, 1, 1), (co,)
+
+    prev = boc[0]
+    for i, c in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            resnet("encoder.down_blocks.%d.resnets.%d" % (i, j), prev if j == 0 else c, c)
+        if i != len(boc) - 1:
+            out["encoder.down_blocks.%d.downsamplers.0.conv.weight" % i] = (c, c, 3, 3)
+            out["encoder.down_blocks.%d.downsamplers.0.conv.bias" % i] = (c,)
+        prev = c
+    for j in range(2):
+        resnet("encoder.mid_block.resnets.%d" % j, boc[-1], boc[-1])
+    conv3("encoder.conv_in", in_channels, boc[0])
+    out["encoder.norm_out.weight"], out["encoder.norm_out.bias"] = (boc[-1],), (boc[-1],)
+    conv3("encoder.conv_out", boc[-1], 2 * cfg.latent_channels)
+    return out
+
+
+def synthetic_state_dict(cfg, seed=0, encoder=False):
     """Seeded random decoder weights (bf16-representable, stored as float32) at the published shapes: variance-preserving
     convolutions, norm scales near 1, conv_y near 1 and conv_b near 0 so activations stay O(1) through 40 layers."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
-    for name, shape in decoder_param_shapes(cfg).items():
-        if name.endswith("norm_layer.weight"):
+    shapes = dict(decoder_param_shapes(cfg))
+    if encoder:
+        shapes.update(encoder_param_shapes(cfg))
+    for name, shape in shapes.items():
+        if name.split(".")[-2] in ("norm_layer", "norm1", "norm2", "norm_out") and name.endswith(".weight"):
             t = 1.0 + 0.1 * torch.randn(shape, generator=g)
-        elif name.endswith("norm_layer.bias"):
+        elif name.split(".")[-2] in ("norm_layer", "norm1", "norm2", "norm_out"):
             t = 0.1 * torch.randn(shape, generator=g)
         elif name.endswith(".bias"):
             t = 0.05 * torch.randn(shape, generator=g)
@@ -187,6 +226,70 @@ def decode_latents(latents, sd, cfg):
     z = latents.permute(0, 2, 1, 3, 4)
     z = 1 / cfg.scaling_factor * z
     return decode(z.float(), sd, cfg)
+
+
+def _enc_resnet(x, sd, name, cfg, cache):
+    h = F.group_norm(x, cfg.norm_num_groups, sd[name + ".norm1.weight"], sd[name + ".norm1.bias"], 1e-6)
+    h = _causal_conv(F.silu(h), sd, name + ".conv1", cache)
+    h = F.group_norm(h, cfg.norm_num_groups, sd[name + ".norm2.weight"], sd[name + ".norm2.bias"], 1e-6)
+    h = _causal_conv(F.silu(h), sd, name + ".conv2", cache)
+    if name + ".conv_shortcut.weight" in sd:
+        x = F.conv3d(x, sd[name + ".conv_shortcut.weight"], sd[name + ".conv_shortcut.bias"])
+    return h + x
+
+
+def _downsample(x, sd, name, compress_time):
+    if compress_time:
+        b, c, t, h, w = x.shape
+        x = x.permute(0, 3, 4, 1, 2).reshape(b * h * w, c, t)
+        if t % 2 == 1:
+            first, rest = x[..., 0], x[..., 1:]
+            if rest.shape[-1] > 0:
+                rest = F.avg_pool1d(rest, kernel_size=2, stride=2)
+            x = torch.cat([first[..., None], rest], dim=-1)
+        else:
+            x = F.avg_pool1d(x, kernel_size=2, stride=2)
+        x = x.reshape(b, h, w, c, x.shape[-1]).permute(0, 3, 4, 1, 2)
+    x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
+    b, c, t, h, w = x.shape
+    y = F.conv2d(x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w), sd[name + ".conv.weight"], sd[name + ".conv.bias"],
+                 stride=2)
+    return y.reshape(b, t, y.shape[1], y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
+
+
+def _encoder(x, sd, cfg, cache):
+    boc = list(cfg.block_out_channels)
+    levels = int(math.log2(cfg.temporal_compression_ratio))
+    h = _causal_conv(x, sd, "encoder.conv_in", cache)
+    for i in range(len(boc)):
+        for j in range(cfg.layers_per_block):
+            h = _enc_resnet(h, sd, "encoder.down_blocks.%d.resnets.%d" % (i, j), cfg, cache)
+        if i != len(boc) - 1:
+            h = _downsample(h, sd, "encoder.down_blocks.%d.downsamplers.0" % i, i < levels)
+    for j in range(2):
+        h = _enc_resnet(h, sd, "encoder.mid_block.resnets.%d" % j, cfg, cache)
+    h = F.group_norm(h, cfg.norm_num_groups, sd["encoder.norm_out.weight"], sd["encoder.norm_out.bias"], 1e-6)
+    return _causal_conv(F.silu(h), sd, "encoder.conv_out", cache)
+
+
+def encode_moments(x, sd, cfg, frame_batch_size=8):
+    """AutoencoderKLCogVideoX._encode on float32: x [B, 3, T, H, W] -> moments [B, 2 * latent, T', H/8, W/8]."""
+    T = x.shape[2]
+    num_batches = max(T // frame_batch_size, 1)
+    remaining = T % frame_batch_size
+    cache, enc = {}, []
+    for i in range(num_batches):
+        start = frame_batch_size * i + (0 if i == 0 else remaining)
+        end = frame_batch_size * (i + 1) + remaining
+        enc.append(_encoder(x[:, :, start:end], sd, cfg, cache))
+    return torch.cat(enc, dim=2)
+
+
+def gaussian_sample(moments, noise):
+    """DiagonalGaussianDistribution.sample with the noise given: per-op arithmetic in the moments' dtype."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+    return mean + std * noise
 
 
 def postprocess_uint8(video):

@@ -233,3 +233,73 @@ def test_pipeline_decodes_through_the_hip_vae():
     assert (u8[0].cpu().numpy() == want).all()
     import numpy as np
     assert len(pil[0]) == 9 and (np.asarray(pil[0][3]) == want[3]).all()
+
+
+@pytest.mark.parametrize("Cin,Cout", [(128, 128), (256, 256)])
+def test_stride2_conv_and_repitch(Cin, Cout):
+    """CogVideoXDownsample3D's spatial part: pad (0, 1, 0, 1) + Conv2d k3 s2 p0, as ALG_CONV_STRIDE2 + alg_vae_repitch."""
+    g = torch.Generator().manual_seed(Cin)
+    T, H, W = 2, 8, 12
+    x = torch.randn(1, Cin, T, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).bfloat16().float()
+    b = torch.randn(Cout, generator=g).bfloat16().float()
+    xp = F.pad(x[0].permute(1, 0, 2, 3), (0, 1, 0, 1))
+    want = F.conv2d(xp, w, b, stride=2).permute(1, 0, 2, 3)                       # [Cout, T, H/2, W/2]
+    wp = w.reshape(Cout, Cin, 9).permute(0, 2, 1).reshape(Cout, -1).contiguous().bfloat16().to(_dev())
+    m = H // 2 * (W + 2)
+    wide = torch.full((T * m * Cout,), 3.0, dtype=torch.bfloat16, device=_dev())
+    _lib.conv_cl(_padded(x, 0), wp, b.bfloat16().to(_dev()), None, wide, T, H + 2, W + 2, Cin, Cout, 1, stride2=True)
+    out = torch.full((T * (H // 2 + 2) * (W // 2 + 2) * Cout,), 5.0, dtype=torch.bfloat16, device=_dev())
+    _lib.vae_repitch(wide, out, T, H // 2, W // 2, Cout, m, W + 2)
+    got = _from_virtual(out, T, H // 2, W // 2, Cout)
+    assert (got - want).abs().max().item() <= 2.0 ** -7 * want.abs().max().item()
+
+
+def test_group_norm_pad_and_planes_kernels():
+    g = torch.Generator().manual_seed(3)
+    C, H, W = 128, 6, 10
+    x = (torch.randn(1, C, 1, H, W, generator=g) * 1.5 - 0.3).bfloat16().float()
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).bfloat16()
+    beta = (0.2 * torch.randn(C, generator=g)).bfloat16()
+    geom = _lib.vae_geom(frames=1, H=H, W=W, C=C, first_len=1, seg_len=2, lat_first_single=1, lat_rate=1, lat_scale=1,
+                         lat_h=H, lat_w=W)
+    xv = _virtual(x, fill=float("nan"))
+    ws = torch.empty(_lib.vae_groupnorm_workspace(geom) // 4, device=_dev())
+    stats = torch.empty(64, device=_dev())
+    _lib.vae_groupnorm_stats(xv, geom, 1e-6, ws, stats)
+    out = torch.full((3 * (H + 2) * (W + 2) * C,), 9.0, dtype=torch.bfloat16, device=_dev())
+    _lib.vae_group_norm(xv, stats, gamma.to(_dev()), beta.to(_dev()), out, geom, silu=True)
+    got = out.reshape(3, H + 2, W + 2, C).float().cpu()
+    want = F.silu(F.group_norm(x, 32, gamma.float(), beta.float(), 1e-6).bfloat16().float()).bfloat16().float()
+    err = (got[2, 1:-1, 1:-1].permute(2, 0, 1) - want[0, :, 0]).abs()
+    assert err.max().item() <= 2.0 ** -6 * max(1.0, want.abs().max().item()) and err.mean().item() < 1e-3
+    assert torch.equal(got[0], got[2]) and bool((got[:, 0] == 0).all() and (got[:, :, -1] == 0).all())
+    _lib.vae_pad(xv, out, 1, H, W, C)
+    got = out.reshape(3, H + 2, W + 2, C).float().cpu()
+    assert torch.equal(got[2, 1:-1, 1:-1].permute(2, 0, 1), x[0, :, 0]) and bool((got[:, 0] == 0).all())
+    planes = torch.empty(C, 1, H, W, dtype=torch.bfloat16, device=_dev())
+    _lib.vae_unpack_planes(xv, planes, 1, H, W, C)
+    assert torch.equal(planes.float().cpu(), x[0])
+
+
+@pytest.mark.parametrize("layers", [1, 3])
+def test_encoder_matches_the_oracle(layers):
+    """encode() on single frames (cog:388-391 / cog:645) vs the fp32 restatement; the sample uses the same CPU noise."""
+    kw = dict(layers_per_block=layers)
+    ocfg = vae_oracle.VAEConfig(**kw)
+    sd = vae_oracle.synthetic_state_dict(ocfg, seed=50 + layers, encoder=True)
+    vae = AutoencoderKLCogVideoX(AutoencoderKLCogVideoXConfig(**kw), device=_dev()).load_state_dict(sd)
+    g = torch.Generator().manual_seed(9)
+    img = (torch.rand(2, 3, 1, 32, 48, generator=g) * 2 - 1).bfloat16()
+    want = vae_oracle.encode_moments(img.float(), sd, ocfg)
+    dist = vae.encode(img.to(_dev())).latent_dist
+    got = dist.parameters.float().cpu()
+    assert got.shape == want.shape == (2, 32, 1, 4, 6)
+    rel = ((got - want).norm() / want.norm()).item()
+    assert rel < 3e-2, rel
+    z = dist.sample(torch.Generator().manual_seed(4))
+    noise = torch.randn(2, 16, 1, 4, 6, generator=torch.Generator().manual_seed(4), dtype=torch.bfloat16)
+    assert torch.equal(z.cpu(), vae_oracle.gaussian_sample(dist.parameters.cpu(), noise))   # same eager ops, same noise
+    assert torch.equal(dist.mode(), dist.mean)
+    with pytest.raises(ValueError, match="single frames"):
+        vae.encode(torch.zeros(1, 3, 2, 32, 48, dtype=torch.bfloat16, device=_dev()))

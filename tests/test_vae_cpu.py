@@ -91,3 +91,34 @@ def test_decode_requires_device_tensors():
     vae = AutoencoderKLCogVideoX(device="cpu")
     with pytest.raises(_lib.AlgHipError, match="HIP-only"):
         vae.decode(torch.zeros(1, 16, 3, 2, 2, dtype=torch.bfloat16))
+
+
+def test_encoder_tables_and_oracle_shapes():
+    vae = AutoencoderKLCogVideoX(device="cpu")
+    assert vae.encoder_param_shapes() == vae_oracle.encoder_param_shapes(vae_oracle.VAEConfig())
+    es = vae.encoder_param_shapes()
+    assert es["encoder.conv_in.conv.weight"] == (128, 3, 3, 3, 3) and es["encoder.conv_out.conv.weight"] == (32, 512, 3, 3, 3)
+    assert es["encoder.down_blocks.1.resnets.0.conv_shortcut.weight"] == (256, 128, 1, 1, 1)
+    assert "encoder.down_blocks.3.downsamplers.0.conv.weight" not in es
+    cfg = vae_oracle.VAEConfig(block_out_channels=(32, 32, 64, 64), layers_per_block=1)
+    sd = vae_oracle.synthetic_state_dict(cfg, seed=1, encoder=True)
+    # synthetic conv_y biases stay near 1 (the decoder's norms must not collapse) -- guards the name classifier
+    assert abs(sd["decoder.norm_out.conv_y.conv.bias"].mean().item() - 1.0) < 0.1
+    g = torch.Generator().manual_seed(0)
+    m1 = vae_oracle.encode_moments(torch.randn(1, 3, 1, 32, 48, generator=g), sd, cfg)
+    assert m1.shape == (1, 32, 1, 4, 6)
+    # 9 frames -> 1 + 8/4 = 3 latent frames (first frame kept through both temporal poolings)
+    assert vae_oracle.encode_moments(torch.randn(1, 3, 9, 32, 48, generator=g), sd, cfg).shape == (1, 32, 3, 4, 6)
+    noise = torch.randn(1, 16, 1, 4, 6, generator=g)
+    z = vae_oracle.gaussian_sample(m1, noise)
+    assert torch.allclose(z, m1[:, :16] + torch.exp(0.5 * m1[:, 16:]) * noise)
+
+
+def test_product_vae_without_encoder_weights_refuses_encode():
+    from alg_amd import _lib
+    vae = AutoencoderKLCogVideoX.from_synthetic(AutoencoderKLCogVideoXConfig(layers_per_block=0), device="cpu")
+    with pytest.raises(_lib.AlgHipError, match="without encoder"):
+        vae.encode(torch.zeros(1, 3, 1, 16, 16, dtype=torch.bfloat16))
+    vae = AutoencoderKLCogVideoX.from_synthetic(AutoencoderKLCogVideoXConfig(layers_per_block=0), device="cpu", encoder=True)
+    with pytest.raises(_lib.AlgHipError, match="HIP-only"):
+        vae.encode(torch.zeros(1, 3, 1, 16, 16, dtype=torch.bfloat16))
