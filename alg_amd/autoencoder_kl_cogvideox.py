@@ -212,6 +212,8 @@ class AutoencoderKLCogVideoX:
             raise KeyError("missing decoder weights: %s ..." % missing[:3])
         enc_shapes = self.encoder_param_shapes()
         has_encoder = any(k.startswith("encoder.") for k in sd)
+        if has_encoder and self.config.layers_per_block < 1:
+            raise ValueError("the encoder changes channel width in its resnets: layers_per_block must be >= 1")
         if has_encoder:
             missing = [k for k in enc_shapes if k not in sd]
             if missing:

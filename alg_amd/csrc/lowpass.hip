@@ -6,6 +6,8 @@
 // The antialias tap tables are computed in-kernel in strict (unfused) fp32, operation for operation what
 // ATen's _upsample_bilinear2d_aa does for float/bf16 tensors (support = max(scale, 1), triangle filter,
 // per-output normalisation), so tap sets match ATen's and results agree to fp32 rounding.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace alg {
@@ -275,6 +277,17 @@ static int plane_threads(int H, int W, int64_t planes) {
   return n >= 4096 ? 1024 : (n >= 1024 ? 512 : 256);
 }
 
+// planes beyond the LDS budget: same arithmetic through a global workspace (lowpass_big.hip)
+int down_up_big(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
+                hipStream_t s);
+int gaussian_big(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype,
+                 hipStream_t s);
+
+static bool force_global() {  // debug knob: run LDS-sized planes through the global-memory passes (parity tests)
+  const char* e = getenv("ALG_LOWPASS_FORCE_GLOBAL");
+  return e && e[0] == '1';
+}
+
 template <typename K>
 static int set_lds_limit(K kernel, size_t bytes) {
   if (bytes > 160 * 1024) return ALG_ELIMIT;
@@ -314,6 +327,7 @@ extern "C" int alg_down_up(const void* in, void* out, int64_t planes, int H, int
   if (planes == 0) return ALG_OK;
   const size_t lds = down_up_lds_bytes(H, W, h1, w1);
   hipStream_t s = (hipStream_t)stream;
+  if (lds > 160 * 1024 || force_global()) return down_up_big(in, out, planes, H, W, h1, w1, dtype, round_intermediate ? 1 : 0, s);
   int rc;
   if (dtype == ALG_F32) {
     rc = set_lds_limit(down_up_kernel<float>, lds);
@@ -365,6 +379,7 @@ extern "C" int alg_gaussian_blur(const void* in, void* out, int64_t planes, int 
   if (planes == 0) return ALG_OK;
   const size_t lds = (((size_t)2 * H * W + ksize) * 4 + 15) & ~(size_t)15;
   hipStream_t s = (hipStream_t)stream;
+  if (lds > 160 * 1024 || force_global()) return gaussian_big(in, out, planes, H, W, ksize, sigma, dtype, s);
   int rc;
   if (dtype == ALG_F32) {
     rc = set_lds_limit(gaussian_kernel<float>, lds);

@@ -134,8 +134,9 @@ def test_filter_edge_cases(device):
     assert lp_utils.apply_low_pass_filter(x, "gaussian_blur", 0, 3, 0.5) is x
     with pytest.raises(RuntimeError):
         lp_utils.apply_low_pass_filter(x.permute(0, 2, 1, 3, 4), "down_up", 0.0, 0, 0.5)
-    with pytest.raises(alg_amd.AlgHipError, match="LDS"):  # pixel-sized planes: not an LDS-resident case
-        lp_utils.apply_low_pass_filter(torch.zeros(1, 3, 480, 720, device=device), "down_up", 0.0, 0, 0.25)
+    # pixel-sized planes exceed the LDS-resident kernel and take the global-memory passes (same arithmetic)
+    y = lp_utils.apply_low_pass_filter(torch.ones(1, 3, 480, 720, device=device), "down_up", 0.0, 0, 0.25)
+    assert (y - 1).abs().max() <= 1e-6
     with pytest.raises(alg_amd.AlgHipError):
         lp_utils.apply_low_pass_filter(torch.zeros(1, 3, 8, 8, device=device, dtype=torch.float16), "down_up", 0., 0, .5)
     # strength-modulated factors of a linear schedule all run
@@ -143,3 +144,45 @@ def test_filter_edge_cases(device):
         f_eff = 1.0 - 0.75 * s
         y = lp_utils.apply_low_pass_filter(x.new_ones(1, 1, 1, 60, 90), "down_up", 0.0, 0, f_eff)
         assert (y - 1).abs().max() <= 1e-6
+
+
+@pytest.mark.parametrize("shape,factor", [((1, 3, 480, 720), 0.25), ((2, 3, 256, 256), 0.4), ((1, 3, 352, 608), 0.625)])
+def test_down_up_pixel_sized_planes(device, shape, factor):
+    """The pixel-space ALG branch (cog:628-643) filters the RGB image: planes beyond the LDS budget go through
+    lowpass_big.hip -- same oracle, same tolerances as the LDS-resident kernel, and the two paths agree bit-for-bit
+    on a plane both can take."""
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(shape, generator=g)
+    y = lp_utils.apply_low_pass_filter(x.to(device), "down_up", 0.0, 0, factor).cpu().numpy()
+    ref = lp_oracle.down_up(x.numpy(), factor, np.float32)
+    assert np.abs(y - ref).max() <= 3e-6
+    xb = x.to(torch.bfloat16)
+    yb = lp_utils.apply_low_pass_filter(xb.to(device), "down_up", 0.0, 0, factor).float().cpu().numpy()
+    refb = lp_oracle.down_up(xb.float().numpy(), factor, np.float32, storage="bf16")
+    assert (np.abs(yb - refb) <= 2 * bf16_ulp(refb) + 1e-3).all()
+    assert (np.abs(yb - refb) > 0).mean() < 0.05
+
+
+def test_gaussian_pixel_sized_planes(device):
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(1, 3, 480, 720, generator=g)
+    y = lp_utils.apply_low_pass_filter(x.to(device), "gaussian_blur", 2.0, 9, 1.0).cpu().numpy()
+    ref = lp_oracle.gaussian_blur(x.numpy().astype(np.float64), 9, 2.0)
+    assert np.abs(y - ref).max() <= 1e-5
+    xb = x.to(torch.bfloat16)
+    yb = lp_utils.apply_low_pass_filter(xb.to(device), "gaussian_blur", 2.0, 9, 1.0).float().cpu().numpy()
+    refb = lp_oracle.gaussian_blur(xb.float().numpy().astype(np.float64), 9, 2.0)
+    assert (np.abs(yb - refb) <= bf16_ulp(refb) + 1e-3).all()
+
+
+def test_global_memory_path_is_bit_identical_to_the_lds_path(device, monkeypatch):
+    """ALG_LOWPASS_FORCE_GLOBAL=1 (debug knob) sends LDS-sized planes through lowpass_big.hip: same bits."""
+    g = torch.Generator().manual_seed(31)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(1, 16, 3, 60, 90, generator=g).to(dt).to(device)
+        monkeypatch.delenv("ALG_LOWPASS_FORCE_GLOBAL", raising=False)
+        a = lp_utils.apply_low_pass_filter(x, "down_up", 0.0, 0, 0.25)
+        b = lp_utils.apply_low_pass_filter(x, "gaussian_blur", 3.0, 9, 1.0)
+        monkeypatch.setenv("ALG_LOWPASS_FORCE_GLOBAL", "1")
+        assert torch.equal(lp_utils.apply_low_pass_filter(x, "down_up", 0.0, 0, 0.25), a)
+        assert torch.equal(lp_utils.apply_low_pass_filter(x, "gaussian_blur", 3.0, 9, 1.0), b)

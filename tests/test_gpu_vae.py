@@ -303,3 +303,45 @@ def test_encoder_matches_the_oracle(layers):
     assert torch.equal(dist.mode(), dist.mean)
     with pytest.raises(ValueError, match="single frames"):
         vae.encode(torch.zeros(1, 3, 2, 32, 48, dtype=torch.bfloat16, device=_dev()))
+
+
+def test_pipeline_from_image_with_pixel_space_alg_branch():
+    """End to end on HIP: image tensor -> VAE encode (cog:388-391) -> loop with `lp_filter_in_latent=False` (cog:628-680:
+    the RGB image is filtered and re-encoded every step, drawing fresh posterior noise) -> VAE decode -> uint8 frames."""
+    from alg_amd import CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, lp_utils
+    from alg_amd.transformer_cogvideox import CogVideoXTransformer3DModel, CogVideoXTransformerConfig
+    from oracle import dit_oracle
+    dev = _dev()
+    small = dict(num_attention_heads=8, attention_head_dim=64, in_channels=32, out_channels=16, num_layers=1,
+                 time_embed_dim=64, text_embed_dim=128, max_text_seq_length=10, sample_width=6, sample_height=4,
+                 sample_frames=9, patch_size=2)
+    w = dit_oracle.init_weights(dit_oracle.DiTConfig(**small), seed=4, std=0.05, randomize_affine=True)
+    tr = CogVideoXTransformer3DModel(CogVideoXTransformerConfig(**small), {k: v.bfloat16() for k, v in w.items()}, device=dev)
+    vae = AutoencoderKLCogVideoX.from_synthetic(AutoencoderKLCogVideoXConfig(layers_per_block=1), seed=5, device=dev,
+                                                encoder=True)
+    pipe = CogVideoXImageToVideoPipeline(transformer=tr, scheduler=CogVideoXDDIMScheduler(), vae=vae).to(dev)
+    g = torch.Generator().manual_seed(1)
+    image = (torch.rand(1, 3, 32, 48, generator=g) * 2 - 1).bfloat16()
+    kw = dict(image=image, prompt_embeds=torch.randn(1, 10, 128, generator=g).bfloat16(),
+              negative_prompt_embeds=torch.randn(1, 10, 128, generator=g).bfloat16(), height=32, width=48, num_frames=9,
+              num_inference_steps=3, guidance_scale=6.0, use_low_pass_guidance=True, lp_filter_type="down_up",
+              lp_resize_factor=0.25, lp_strength_schedule_type="interval", schedule_interval_start_time=0.0,
+              schedule_interval_end_time=0.5)
+    run = lambda **over: pipe(**dict(kw, **over), generator=torch.Generator().manual_seed(2)).frames
+    pix = run(lp_filter_in_latent=False, output_type="uint8")
+    assert pix.shape == (1, 9, 32, 48, 3) and pix.dtype == torch.uint8
+    assert torch.equal(pix, run(lp_filter_in_latent=False, output_type="uint8"))          # same seeds, same frames
+    lat_pix = run(lp_filter_in_latent=False, output_type="latent")
+    lat_lat = run(lp_filter_in_latent=True, output_type="latent")
+    assert bool(torch.isfinite(lat_pix.float()).all()) and not torch.equal(lat_pix, lat_lat)
+    # the conditioning frame the loop starts from is the scaled posterior sample of the image (cog:388-396)
+    gen = torch.Generator().manual_seed(2)
+    first = vae.encode(image.to(dev).unsqueeze(2)).latent_dist.sample(gen)
+    _, cond = pipe.prepare_latents(image.to(dev), 1, 16, 9, 32, 48, torch.bfloat16, dev, torch.Generator().manual_seed(2))
+    assert torch.equal(cond[:, :1], (0.7 * first).permute(0, 2, 1, 3, 4)) and bool((cond[:, 1:] == 0).all())
+    # and the per-step pixel-branch conditioning is the scaled sample of the filtered image, zero-padded in time
+    gen = torch.Generator().manual_seed(3)
+    lp = pipe.prepare_lp("down_up", 0.0, 0, 0.25, gen, 9, True, False, cond, image.to(dev))
+    img_lp = lp_utils.apply_low_pass_filter(image.to(dev), "down_up", 0.0, 0, 0.25)
+    want = 0.7 * vae.encode(img_lp.unsqueeze(2)).latent_dist.sample(torch.Generator().manual_seed(3))
+    assert lp.shape == cond.shape and torch.equal(lp[:, :1], want.permute(0, 2, 1, 3, 4)) and bool((lp[:, 1:] == 0).all())

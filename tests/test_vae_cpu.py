@@ -119,6 +119,8 @@ def test_product_vae_without_encoder_weights_refuses_encode():
     vae = AutoencoderKLCogVideoX.from_synthetic(AutoencoderKLCogVideoXConfig(layers_per_block=0), device="cpu")
     with pytest.raises(_lib.AlgHipError, match="without encoder"):
         vae.encode(torch.zeros(1, 3, 1, 16, 16, dtype=torch.bfloat16))
-    vae = AutoencoderKLCogVideoX.from_synthetic(AutoencoderKLCogVideoXConfig(layers_per_block=0), device="cpu", encoder=True)
+    with pytest.raises(ValueError, match="layers_per_block"):
+        AutoencoderKLCogVideoX.from_synthetic(AutoencoderKLCogVideoXConfig(layers_per_block=0), device="cpu", encoder=True)
+    vae = AutoencoderKLCogVideoX.from_synthetic(AutoencoderKLCogVideoXConfig(layers_per_block=1), device="cpu", encoder=True)
     with pytest.raises(_lib.AlgHipError, match="HIP-only"):
         vae.encode(torch.zeros(1, 3, 1, 16, 16, dtype=torch.bfloat16))
