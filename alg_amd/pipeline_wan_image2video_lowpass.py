@@ -64,6 +64,19 @@ def build_wan_condition(latent_condition, num_frames, vae_scale_factor_temporal=
     return torch.concat([mask.to(latent_condition.device, latent_condition.dtype), latent_condition], dim=1)
 
 
+def prompt_clean(text):
+    """wan:97-111: ftfy.fix_text (when the package is present), double html.unescape, whitespace collapse."""
+    import html
+    import re
+    try:
+        import ftfy
+        text = ftfy.fix_text(text)
+    except ImportError:
+        pass
+    text = html.unescape(html.unescape(text)).strip()
+    return re.sub(r"\s+", " ", text).strip()
+
+
 class WanImageToVideoPipeline:
     _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]
 
@@ -137,12 +150,50 @@ class WanImageToVideoPipeline:
                 not isinstance(negative_prompt, str) and not isinstance(negative_prompt, list)):
             raise ValueError(f"`negative_prompt` has to be of type `str` or `list` but is {type(negative_prompt)}")
 
+    def _get_t5_prompt_embeds(self, prompt, num_videos_per_prompt=1, max_sequence_length=512, device=None, dtype=None):
+        """wan:185-226: clean, tokenise to `max_sequence_length` with an attention mask, run the (U)MT5 encoder with that
+        mask, keep each prompt's valid rows and zero the rest."""
+        if self.text_encoder is None or self.tokenizer is None:
+            raise _lib.AlgHipError("no text encoder / tokenizer is attached: pass prompt_embeds / negative_prompt_embeds "
+                                   "(UMT5 embeddings [B, %d, 4096])" % max_sequence_length)
+        dtype = dtype or self.text_encoder.dtype
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        prompt = [prompt_clean(u) for u in prompt]
+        batch_size = len(prompt)
+        text_inputs = self.tokenizer(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
+                                     add_special_tokens=True, return_attention_mask=True, return_tensors="pt")
+        text_input_ids, mask = text_inputs.input_ids, text_inputs.attention_mask
+        seq_lens = mask.gt(0).sum(dim=1).long()
+        prompt_embeds = self.text_encoder(text_input_ids.to(device), mask.to(device)).last_hidden_state
+        prompt_embeds = prompt_embeds.to(dtype=dtype, device=device)
+        prompt_embeds = [u[:v] for u, v in zip(prompt_embeds, seq_lens)]
+        prompt_embeds = torch.stack(
+            [torch.cat([u, u.new_zeros(max_sequence_length - u.size(0), u.size(1))]) for u in prompt_embeds], dim=0)
+        _, seq_len, _ = prompt_embeds.shape
+        prompt_embeds = prompt_embeds.repeat(1, num_videos_per_prompt, 1)
+        return prompt_embeds.view(batch_size * num_videos_per_prompt, seq_len, -1)
+
     def encode_prompt(self, prompt, negative_prompt=None, do_classifier_free_guidance=True, num_videos_per_prompt=1,
-                      prompt_embeds=None, negative_prompt_embeds=None, max_sequence_length=226, device=None):
-        if (prompt_embeds is None or (do_classifier_free_guidance and negative_prompt_embeds is None)):
-            if self.text_encoder is None:
-                raise _lib.AlgHipError("no text encoder is attached: pass prompt_embeds / negative_prompt_embeds")
-            raise NotImplementedError("UMT5 prompt encoding is outside the hot path (SURVEY section 8 row f-1)")
+                      prompt_embeds=None, negative_prompt_embeds=None, max_sequence_length=226, device=None, dtype=None):
+        """wan:237-317."""
+        device = device or self._execution_device
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        batch_size = len(prompt) if prompt is not None else prompt_embeds.shape[0]
+        if prompt_embeds is None:
+            prompt_embeds = self._get_t5_prompt_embeds(prompt, num_videos_per_prompt, max_sequence_length, device, dtype)
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            negative_prompt = negative_prompt or ""
+            negative_prompt = batch_size * [negative_prompt] if isinstance(negative_prompt, str) else negative_prompt
+            if prompt is not None and type(prompt) is not type(negative_prompt):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} !="
+                                f" {type(prompt)}.")
+            elif batch_size != len(negative_prompt):
+                raise ValueError(
+                    f"`negative_prompt`: {negative_prompt} has batch size {len(negative_prompt)}, but `prompt`:"
+                    f" {prompt} has batch size {batch_size}. Please make sure that passed `negative_prompt` matches"
+                    " the batch size of `prompt`.")
+            negative_prompt_embeds = self._get_t5_prompt_embeds(negative_prompt, num_videos_per_prompt,
+                                                                max_sequence_length, device, dtype)
         return prompt_embeds.to(device), (None if negative_prompt_embeds is None else negative_prompt_embeds.to(device))
 
     def prepare_latents(self, image_condition, batch_size, num_channels_latents=16, height=480, width=832,

@@ -103,3 +103,40 @@ def test_padded_tokens_do_not_reach_valid_rows():
     b = model(ids2.to(_dev()), attention_mask=mask.to(_dev())).last_hidden_state
     keep = mask.bool().to(_dev())
     assert torch.equal(a[keep], b[keep])
+
+
+def test_cogvideox_pipeline_encodes_prompts_through_the_hip_t5():
+    """cog:228-268: `tokenizer(prompt, padding="max_length", max_length=226, ...)` then `text_encoder(ids)[0]`; with the
+    HIP encoder attached the prompt path equals passing its embeddings as `prompt_embeds` (the tokenizer here is a stand-in:
+    sentencepiece vocabularies are checkpoint files)."""
+    from alg_amd import CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline
+    from alg_amd.transformer_cogvideox import CogVideoXTransformer3DModel, CogVideoXTransformerConfig
+    from oracle import dit_oracle
+    dev = _dev()
+    small = dict(num_attention_heads=8, attention_head_dim=64, in_channels=16, out_channels=8, num_layers=1,
+                 time_embed_dim=64, text_embed_dim=128, max_text_seq_length=10, sample_width=12, sample_height=8,
+                 sample_frames=9, patch_size=2)
+    w = dit_oracle.init_weights(dit_oracle.DiTConfig(**small), seed=4, std=0.05, randomize_affine=True)
+    tr = CogVideoXTransformer3DModel(CogVideoXTransformerConfig(**small), {k: v.to(BF) for k, v in w.items()}, device=dev)
+    t5 = T5EncoderModel.from_synthetic(T5EncoderConfig(vocab_size=256, d_model=128, d_ff=256, num_layers=2, num_heads=2),
+                                       seed=3, device=dev)
+
+    class Tok:
+        def __call__(self, texts, padding=None, max_length=None, truncation=None, add_special_tokens=None,
+                     return_tensors=None):
+            rows = [[ord(ch) % 255 + 1 for ch in t][:max_length - 1] + [1] for t in texts]       # </s> = 1, pad = 0
+            ids = torch.tensor([r + [0] * (max_length - len(r)) for r in rows])
+            return type("Enc", (), {"input_ids": ids})()
+
+    pipe = CogVideoXImageToVideoPipeline(tokenizer=Tok(), text_encoder=t5, transformer=tr,
+                                         scheduler=CogVideoXDDIMScheduler()).to(dev)
+    g = torch.Generator().manual_seed(1)
+    kw = dict(image=None, image_latents=(torch.randn(1, 1, 8, 8, 12, generator=g) * 0.7).to(BF), height=64, width=96,
+              num_frames=9, num_inference_steps=2, use_low_pass_guidance=False, output_type="latent",
+              max_sequence_length=10)
+    a = pipe(prompt="a red bus", negative_prompt="blurry", generator=torch.Generator().manual_seed(2), **kw).frames
+    tok = Tok()
+    pe = t5(tok(["a red bus"], max_length=10).input_ids.to(dev))[0]
+    ne = t5(tok(["blurry"], max_length=10).input_ids.to(dev))[0]
+    b = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, generator=torch.Generator().manual_seed(2), **kw).frames
+    assert torch.equal(a, b) and bool(torch.isfinite(a.float()).all())

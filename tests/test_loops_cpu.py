@@ -196,3 +196,36 @@ def test_wan_condition_builder():
     c2 = build_wan_condition(lat, 81, has_last_image=True)
     assert bool((c2[:, :4, 0] == 1).all()) and bool((c2[:, :4, 1:20] == 0).all())
     assert bool((c2[:, 3, 20] == 1).all()) and bool((c2[:, :3, 20] == 0).all())   # pixel frame 80 = last slot of group 20
+
+
+def test_wan_prompt_encoding_trims_and_zero_pads():
+    """wan:185-226 with stand-in tokenizer / encoder: rows past each prompt's length are zero, cleaning collapses
+    whitespace and HTML entities, negative prompts default to ''."""
+    from alg_amd.pipeline_wan_image2video_lowpass import prompt_clean
+    assert prompt_clean("  a &amp;amp; b \n\t c ") == "a & b c"
+
+    class Tok:
+        def __call__(self, texts, max_length=None, **_):
+            ids = torch.zeros(len(texts), max_length, dtype=torch.long)
+            mask = torch.zeros(len(texts), max_length, dtype=torch.long)
+            for i, t in enumerate(texts):
+                n = min(len(t) + 1, max_length)
+                ids[i, :n] = torch.arange(1, n + 1)
+                mask[i, :n] = 1
+            return type("Enc", (), {"input_ids": ids, "attention_mask": mask})()
+
+    class Enc:
+        dtype = torch.float32
+
+        def __call__(self, ids, mask):
+            assert mask is not None
+            return type("Out", (), {"last_hidden_state": torch.ones(ids.shape + (4,)) * ids[..., None].float() + 100})()
+
+    pipe = WanImageToVideoPipeline(tokenizer=Tok(), text_encoder=Enc(), transformer=_T(patch_size=(1, 2, 2)),
+                                   scheduler=UniPCMultistepScheduler())
+    pe, ne = pipe.encode_prompt(["abc", "  abcdefg  "], None, True, 1, None, None, 12, torch.device("cpu"))
+    assert pe.shape == ne.shape == (2, 12, 4)
+    assert bool((pe[0, :4] > 100).all()) and bool((pe[0, 4:] == 0).all()) and bool((pe[1, :8] > 100).all())
+    assert bool((ne[:, :1] > 100).all()) and bool((ne[:, 1:] == 0).all())          # '' -> just the end-of-sequence token
+    with pytest.raises(ValueError, match="batch size"):
+        pipe.encode_prompt(["a", "b"], ["x"], True, 1, None, None, 12, torch.device("cpu"))
