@@ -343,24 +343,34 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
     for (int t = 0; t < nk; ++t) {
       const char* As = smem + (t & 1) * STAGE_BYTES;
       const char* Bs = As + TILE_BYTES;
+      // two-voxel convolution rows (conv_kw == 4): the first voxel's weights are zero at dx = 3, the second's at dx = 0,
+      // so those k-tiles feed only one half of the N tile -- the other half's MFMA sections are skipped (uniform branch;
+      // barriers, fragment reads and DMA keep their places, the phase just ends early)
+      bool do_b0 = true, do_b1 = true;
+      if constexpr (CONV) {
+        if (p.conv_kw == 4 && p.N == 256) {  // the voxel halves coincide with the B half-tiles only at Cout = 128
+          const int dx = (t >> (p.conv_cin_log2 - 6)) & 3;
+          do_b0 = dx != 3, do_b1 = dx != 0;
+        }
+      }
       // p0: (A0, B0)
       load_a(As, 0);
-      load_b(Bs, 0, b0f);
+      if (do_b0) load_b(Bs, 0, b0f);
       if (t + 1 < nk) stage_half(t + 1, 2);
       enter_mfma();
-      quad(0, 0, b0f);
+      if (do_b0) quad(0, 0, b0f);
       leave_mfma();
       // p1: (A0, B1)
-      load_b(Bs, 1, b1f);
+      if (do_b1) load_b(Bs, 1, b1f);
       if (t + 2 < nk) stage_half(t + 2, 0);
       enter_mfma();
-      quad(0, 1, b1f);
+      if (do_b1) quad(0, 1, b1f);
       leave_mfma();
       // p2: (A1, B1)
       load_a(As, 1);
       if (t + 2 < nk) stage_half(t + 2, 3);
       enter_mfma();
-      quad(1, 1, b1f);
+      if (do_b1) quad(1, 1, b1f);
       leave_mfma();
       // p3: (A1, B0); the wait that publishes K-tile t+1
       if (t + 2 < nk) {
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       enter_mfma();
-      quad(1, 0, b0f);
+      if (do_b0) quad(1, 0, b0f);
       leave_mfma();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
