@@ -3,7 +3,7 @@
 // kernels, nothing here is worth an MFMA tile.
 //   alg_embed_rows      token embedding gather
 //   alg_t5_layernorm    T5LayerNorm: bf16(bf16(x * rsqrt(mean(x^2) + eps)) * w), out of place
-//   alg_attn_bias_d64   eager attention with an additive relative-position bias and a key mask, head_dim 64, every tensor
+//   alg_attn_bias       eager attention with an additive relative-position bias and a key mask, head_dim 64 / 80, every tensor
 //                       op rounded as the eager bf16 graph does (scores, + bias, fp32 softmax -> bf16 P, P @ V)
 //   alg_mul_bf16        gated-GELU product
 #include "common.h"
@@ -50,8 +50,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   for (int c = lane; c < D; c += 64) y[row * D + c] = f2bf(rbf(bf2f(xr[c]) * rstd) * bf2f(w[c]));
 }
 
-// grid (row blocks, batch * heads); 4 waves, wave w takes query rows row0 + w, + 4, ...
-// LDS: KT [64][Lp] bf16 | V [Lp][64] bf16 | q [4][64] f32 | p [4][Lp] f32
+// grid (row blocks, batch * heads); 4 waves, wave w takes query rows row0 + w, + 4, ...; DH = head_dim (64: T5 / UMT5,
+// 80: CLIP ViT-H)
+// LDS: KT [DH][Lp] bf16 | V [Lp][DH] bf16 | q [4][128] f32 | p [4][Lp] f32
+template <int DH>
 __global__ __launch_bounds__(256) void attn_bias_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                         const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
                                                         const bf16_t* __restrict__ bias_table,
@@ -60,21 +62,22 @@ __global__ __launch_bounds__(256) void attn_bias_kernel(const bf16_t* __restrict
                                                         int rows_per_wg, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* KT = (bf16_t*)smem;
-  bf16_t* V = KT + (size_t)64 * Lp;
-  float* qs = (float*)(V + (size_t)Lp * 64);
-  float* ps = qs + 4 * 64;
+  bf16_t* V = KT + (size_t)DH * Lp;
+  float* qs = (float*)(V + (size_t)Lp * DH);
+  float* ps = qs + 4 * 128;
+  constexpr int CH = DH / 8;  // 16-byte chunks per head row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y / heads, h = blockIdx.y % heads;
-  const bf16_t* kb = k + (int64_t)b * L * qkv_rs + h * 64;
-  const bf16_t* vb = v + (int64_t)b * L * qkv_rs + h * 64;
-  for (int e = tid; e < Lp * 8; e += 256) {
-    const int j = e >> 3, c = (e & 7) * 8;
+  const bf16_t* kb = k + (int64_t)b * L * qkv_rs + h * DH;
+  const bf16_t* vb = v + (int64_t)b * L * qkv_rs + h * DH;
+  for (int e = tid; e < Lp * CH; e += 256) {
+    const int j = e / CH, c = (e - j * CH) * 8;
     uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
     if (j < L) {
       kv = *(const uint4*)(kb + (int64_t)j * qkv_rs + c);
       vv = *(const uint4*)(vb + (int64_t)j * qkv_rs + c);
     }
-    *(uint4*)(V + (size_t)j * 64 + c) = vv;
+    *(uint4*)(V + (size_t)j * DH + c) = vv;
     const uint32_t u[4] = {kv.x, kv.y, kv.z, kv.w};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -87,15 +90,17 @@ __global__ __launch_bounds__(256) void attn_bias_kernel(const bf16_t* __restrict
   const int row0 = blockIdx.x * rows_per_wg;
   const int row1 = min(row0 + rows_per_wg, L);
   const int* mb = mask ? mask + (int64_t)b * L : nullptr;
-  float* qw = qs + wave * 64;
+  float* qw = qs + wave * 128;
   float* pw = ps + (size_t)wave * Lp;
   for (int i = row0 + wave; i < row1; i += 4) {
-    qw[lane] = bf2f(q[((int64_t)b * L + i) * qkv_rs + h * 64 + lane]);
+    const bf16_t* qr = q + ((int64_t)b * L + i) * qkv_rs + h * DH;
+    qw[lane] = bf2f(qr[lane]);
+    if (DH > 64 && lane + 64 < DH) qw[lane + 64] = bf2f(qr[lane + 64]);
     __builtin_amdgcn_wave_barrier();
     float acc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
-    for (int d = 0; d < 64; ++d) {
+    for (int d = 0; d < DH; ++d) {
       const float qd = qw[d];
       const bf16_t* kr = KT + (size_t)d * Lp + lane;
 #pragma unroll
@@ -129,9 +134,16 @@ __global__ __launch_bounds__(256) void attn_bias_kernel(const bf16_t* __restrict
     for (int c = 0; c < 8; ++c)
       if (c < nchunk) pw[c * 64 + lane] = rbf(acc[c] * inv);   // softmax(fp32).type_as(bf16)
     __builtin_amdgcn_wave_barrier();
-    float o = 0.0f;
-    for (int j = 0; j < L; ++j) o = fmaf(pw[j], bf2f(V[(size_t)j * 64 + lane]), o);
-    out[((int64_t)b * L + i) * out_rs + h * 64 + lane] = f2bf(o);
+    float o = 0.0f, o2 = 0.0f;
+    const bool hi = DH > 64 && lane + 64 < DH;
+    for (int j = 0; j < L; ++j) {
+      const float pj = pw[j];
+      o = fmaf(pj, bf2f(V[(size_t)j * DH + lane]), o);
+      if (hi) o2 = fmaf(pj, bf2f(V[(size_t)j * DH + lane + 64]), o2);
+    }
+    bf16_t* orow = out + ((int64_t)b * L + i) * out_rs + h * DH;
+    orow[lane] = f2bf(o);
+    if (hi) orow[lane + 64] = f2bf(o2);
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -182,36 +194,44 @@ extern "C" int alg_t5_layernorm(const void* x, const void* weight, void* y, int6
   return check_launch("alg_t5_layernorm");
 }
 
-extern "C" int alg_attn_bias_d64(const void* q, const void* k, const void* v, void* out, const void* bias_table,
-                                 const int* rel_bucket, const int* key_mask, int batch, int heads, int L,
-                                 int64_t qkv_rstride, int64_t out_rstride, float scale, void* stream) {
-  if (batch < 0 || heads <= 0 || L <= 0 || L > 512 || (qkv_rstride & 7) || (bias_table && !rel_bucket)) {
-    set_error("alg_attn_bias_d64: bad shape batch=%d heads=%d L=%d (L <= 512, strides %% 8 == 0)", batch, heads, L);
+extern "C" int alg_attn_bias(const void* q, const void* k, const void* v, void* out, const void* bias_table,
+                             const int* rel_bucket, const int* key_mask, int batch, int heads, int head_dim, int L,
+                             int64_t qkv_rstride, int64_t out_rstride, float scale, void* stream) {
+  const int Lp = (L + 63) & ~63;
+  const size_t lds = (size_t)2 * head_dim * Lp * 2 + 4 * 128 * 4 + (size_t)4 * Lp * 4;
+  if (batch < 0 || heads <= 0 || L <= 0 || Lp > 512 || (head_dim != 64 && head_dim != 80) || lds > 160 * 1024 ||
+      (qkv_rstride & 7) || (bias_table && !rel_bucket)) {
+    set_error("alg_attn_bias: bad shape batch=%d heads=%d head_dim=%d L=%d (head_dim 64 or 80, L <= 512 / 448, strides %% 8 == 0)",
+              batch, heads, head_dim, L);
     return ALG_EINVAL;
   }
   if (batch == 0) return ALG_OK;
   if (!q || !k || !v || !out) {
-    set_error("alg_attn_bias_d64: null pointer");
+    set_error("alg_attn_bias: null pointer");
     return ALG_EINVAL;
   }
-  const int Lp = (L + 63) & ~63;
-  const size_t lds = (size_t)2 * 64 * Lp * 2 + 4 * 64 * 4 + (size_t)4 * Lp * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)t5::attn_bias_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * 64 * 512 * 2 + 4 * 64 * 4 + 4 * 512 * 4);
-    if (e != hipSuccess) {
-      set_error("alg_attn_bias_d64: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return ALG_ELAUNCH;
+    for (const void* fn : {(const void*)t5::attn_bias_kernel<64>, (const void*)t5::attn_bias_kernel<80>}) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        set_error("alg_attn_bias: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return ALG_ELAUNCH;
+      }
     }
     attr_set = true;
   }
   const int rows_per_wg = 32;
-  hipLaunchKernelGGL(t5::attn_bias_kernel, dim3((L + rows_per_wg - 1) / rows_per_wg, batch * heads), dim3(256), lds,
-                     (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out,
-                     (const bf16_t*)bias_table, rel_bucket, key_mask, heads, L, Lp, qkv_rstride, out_rstride, rows_per_wg,
-                     scale);
-  return check_launch("alg_attn_bias_d64");
+  const dim3 grid((L + rows_per_wg - 1) / rows_per_wg, batch * heads);
+  if (head_dim == 64)
+    hipLaunchKernelGGL(t5::attn_bias_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, (const bf16_t*)bias_table, rel_bucket, key_mask,
+                       heads, L, Lp, qkv_rstride, out_rstride, rows_per_wg, scale);
+  else
+    hipLaunchKernelGGL(t5::attn_bias_kernel<80>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, (const bf16_t*)bias_table, rel_bucket, key_mask,
+                       heads, L, Lp, qkv_rstride, out_rstride, rows_per_wg, scale);
+  return check_launch("alg_attn_bias");
 }
 
 extern "C" int alg_mul_bf16(const void* a, const void* b, void* out, int64_t numel, void* stream) {

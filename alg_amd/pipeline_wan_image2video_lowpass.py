@@ -150,6 +150,16 @@ class WanImageToVideoPipeline:
                 not isinstance(negative_prompt, str) and not isinstance(negative_prompt, list)):
             raise ValueError(f"`negative_prompt` has to be of type `str` or `list` but is {type(negative_prompt)}")
 
+    def encode_image(self, image, device=None):
+        """wan:228-234: CLIP image processor, vision tower, penultimate hidden state."""
+        if self.image_encoder is None or self.image_processor is None:
+            raise _lib.AlgHipError("no image encoder / processor is attached: pass `image_embeds` (CLIP penultimate hidden "
+                                   "state, [B, 257, 1280])")
+        device = device or self._execution_device
+        image = self.image_processor(images=image, return_tensors="pt").to(device)
+        image_embeds = self.image_encoder(**image, output_hidden_states=True)
+        return image_embeds.hidden_states[-2]
+
     def _get_t5_prompt_embeds(self, prompt, num_videos_per_prompt=1, max_sequence_length=512, device=None, dtype=None):
         """wan:185-226: clean, tokenise to `max_sequence_length` with an attention mask, run the (U)MT5 encoder with that
         mask, keep each prompt's valid rows and zero the rest."""
@@ -302,8 +312,8 @@ class WanImageToVideoPipeline:
             image_condition = build_wan_condition(latent_condition.float(), num_frames, self.vae_scale_factor_temporal,
                                                   has_last_image=last_image is not None)
         if image_condition is None:
-            raise _lib.AlgHipError("the Wan VAE / CLIP encoders are not built (SURVEY section 8 row f-1): pass the "
-                                   "pre-encoded `image_condition` [B, 20, F, h, w] and `image_embeds`")
+            raise _lib.AlgHipError("the Wan VAE is not built (SURVEY section 8 row f-1): pass the pre-encoded "
+                                   "`image_condition` [B, 20, F, h, w] or `latent_condition` [B, 16, F, h, w]")
         if not isinstance(self.scheduler, UniPCMultistepScheduler):
             raise TypeError("this sampler drives alg_amd.schedulers.UniPCMultistepScheduler (HIP step)")
 
@@ -321,6 +331,13 @@ class WanImageToVideoPipeline:
         prompt_embeds = prompt_embeds.to(tdtype)
         if negative_prompt_embeds is not None:
             negative_prompt_embeds = negative_prompt_embeds.to(tdtype)
+        if image_embeds is None:                                                      # wan:805-810
+            if last_image is None:
+                image_embeds = self.encode_image(image, device)
+            else:
+                image_embeds = self.encode_image([image, last_image], device)
+                _, l, d = image_embeds.shape
+                image_embeds = image_embeds.reshape(-1, 2 * l, d)
         image_embeds = image_embeds.to(device).repeat(batch_size, 1, 1).to(tdtype)  # wan:811-812
 
         self.scheduler.set_timesteps(num_inference_steps, device=device)

@@ -5,7 +5,7 @@ transformers' `T5EncoderModel` (T5 v1.1 XXL, no attention mask), `pipeline_wan_i
 block instead of a shared one).  Same call signature, `.dtype`, `.config`, transformers state-dict names; tokenisation
 stays outside (sentencepiece vocabularies are checkpoint files).
 
-Launch order per block over the C ABI: `alg_t5_layernorm`, one fused QKV `alg_gemm_bf16`, `alg_attn_bias_d64` (eager
+Launch order per block over the C ABI: `alg_t5_layernorm`, one fused QKV `alg_gemm_bf16`, `alg_attn_bias` (eager
 bf16 graph: un-scaled scores + bucketed relative bias + key mask, fp32 softmax), output projection with the residual in
 the GEMM epilogue, `alg_t5_layernorm`, `wi_0` with the tanh-GELU epilogue, `wi_1`, `alg_mul_bf16`, `wo` + residual.  A
 few hundred tokens once per video: nothing here is performance-critical, it exists so that the prompt path needs no
@@ -163,7 +163,7 @@ class T5EncoderModel:
             bias = W[p + "bias"] if self.per_layer_bias else W["encoder.block.0.bias"]
             _lib.t5_layernorm(x, W[p + "ln0"], n, T, D, c.layer_norm_epsilon)
             _lib.gemm(n, W[p + "qkv"], qkv, T, 3 * inner, D, D, D, 3 * inner)
-            _lib.attn_bias_d64(qkv, att, bias, lut, mask, B, H, L, scale=1.0)
+            _lib.attn_bias(qkv, att, bias, lut, mask, B, H, L, scale=1.0)
             _lib.gemm(att, W[p + "o"], x, T, D, inner, inner, inner, D, R=x, ldr=D)
             _lib.t5_layernorm(x, W[p + "ln1"], n, T, D, c.layer_norm_epsilon)
             _lib.gemm(n, W[p + "wi_0"], g, T, F, D, D, D, F, act=_lib.ACT_GELU_TANH)

@@ -182,15 +182,15 @@ int alg_embed_rows(const int64_t* ids, const void* table, void* out, int64_t n, 
 /* T5LayerNorm: y = bf16( bf16(x * rsqrt(mean(x^2) + eps)) * weight ), variance in fp32, no mean subtraction, no bias. */
 int alg_t5_layernorm(const void* x, const void* weight, void* y, int64_t rows, int D, float eps, void* stream);
 
-/* T5Attention (eager graph, head_dim 64, L <= 512): for batch b, head h
+/* T5Attention / CLIPAttention (eager graph; head_dim 64 with L <= 512, or 80 with L <= 448): for batch b, head h
  *   s = bf16(q k^T) [* scale -> bf16]  + bias_table[rel_bucket[j - i + L - 1]][h] -> bf16;  masked keys (key_mask[b][j]
  *   == 0) get probability 0;  p = bf16(softmax_fp32(s));  out = bf16(p v)
- * q / k / v: element (b, i, h, d) at ptr + (b*L + i)*qkv_rstride + h*64 + d (three pointers into one fused QKV buffer);
+ * q / k / v: element (b, i, h, d) at ptr + (b*L + i)*qkv_rstride + h*head_dim + d (three pointers into one fused QKV buffer);
  * out likewise with out_rstride; bias_table: [buckets][heads] bf16 (relative_attention_bias.weight) or NULL;
  * rel_bucket: int32 [2L - 1], the bucket of relative position (key - query); key_mask: int32 [batch][L] or NULL. */
-int alg_attn_bias_d64(const void* q, const void* k, const void* v, void* out, const void* bias_table,
-                      const int* rel_bucket, const int* key_mask, int batch, int heads, int L, int64_t qkv_rstride,
-                      int64_t out_rstride, float scale, void* stream);
+int alg_attn_bias(const void* q, const void* k, const void* v, void* out, const void* bias_table, const int* rel_bucket,
+                  const int* key_mask, int batch, int heads, int head_dim, int L, int64_t qkv_rstride, int64_t out_rstride,
+                  float scale, void* stream);
 
 /* out = bf16(a * b) (T5DenseGatedActDense: gelu_new(wi_0 x) * wi_1 x). */
 int alg_mul_bf16(const void* a, const void* b, void* out, int64_t numel, void* stream);

@@ -57,7 +57,7 @@ def test_attention_with_bias_vs_eager_graph(B, H, L, masked, bias):
         mask[B - 1, L - masked:] = 0
     mask = mask.to(dev)
     out = torch.empty(B * L, inner, dtype=BF, device=dev)
-    _lib.attn_bias_d64(qkv, out, table, lut if bias else None, mask if masked else None, B, H, L, scale=1.0)
+    _lib.attn_bias(qkv, out, table, lut if bias else None, mask if masked else None, B, H, L, scale=1.0)
     q, k, v = [t.view(B, L, H, 64).transpose(1, 2).float() for t in qkv.split(inner, dim=1)]
     s = (q @ k.transpose(-1, -2)).to(BF)
     if bias:
