@@ -27,7 +27,7 @@ EXPORTS = (
     "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu", "alg_gemm_fp8", "alg_quantize_fp8_rows",
     "alg_conv_cl_bf16", "alg_vae_groupnorm_workspace", "alg_vae_groupnorm_stats", "alg_vae_spatial_norm", "alg_vae_upsample",
     "alg_vae_pack_latent", "alg_vae_unpack_video", "alg_vae_group_norm", "alg_vae_pad", "alg_vae_repitch",
-    "alg_vae_unpack_planes", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16",
+    "alg_vae_unpack_planes", "alg_patchify_t", "alg_unpatchify_t", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16",
 )
 
 
@@ -135,6 +135,8 @@ def load_library():
     lib.alg_patchify.argtypes = [c_void_p, c_int64, POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_void_p]
     lib.alg_unpatchify.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.alg_patchify_t.argtypes = [c_void_p, c_int64, POINTER(c_void_p), c_void_p] + [c_int] * 7 + [c_void_p]
+    lib.alg_unpatchify_t.argtypes = [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]
     lib.alg_timestep_embedding.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -559,16 +561,16 @@ def qk_norm_rope_(qk, wq, bq, wk, bk, cos, sin, batch, S, heads, text_len, eps):
                                 heads, text_len, float(eps), _stream()), "alg_qk_norm_rope")
 
 
-def patchify(latents, lat_bstride, conds, out, n_samples, frames, C, H, W, p):
+def patchify(latents, lat_bstride, conds, out, n_samples, frames, C, H, W, p, p_t=1):
     lib = load_library()
     arr = (c_void_p * n_samples)(*[c.data_ptr() for c in conds])
-    _check(lib.alg_patchify(_ptr(latents), lat_bstride, arr, _ptr(out), n_samples, frames, C, H, W, p, _stream()),
+    _check(lib.alg_patchify_t(_ptr(latents), lat_bstride, arr, _ptr(out), n_samples, frames, C, H, W, p, p_t, _stream()),
            "alg_patchify")
 
 
-def unpatchify(x, out, n_samples, frames, C, H, W, p):
+def unpatchify(x, out, n_samples, frames, C, H, W, p, p_t=1):
     lib = load_library()
-    _check(lib.alg_unpatchify(_ptr(x), _ptr(out), n_samples, frames, C, H, W, p, _stream()), "alg_unpatchify")
+    _check(lib.alg_unpatchify_t(_ptr(x), _ptr(out), n_samples, frames, C, H, W, p, p_t, _stream()), "alg_unpatchify")
 
 
 def timestep_embedding(t, out, n, dim, flip_sin_to_cos=True):

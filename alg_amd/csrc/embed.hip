@@ -10,14 +10,15 @@ struct CondPtrs {
 };
 
 // thread = (n, f, c2, y, gx): reads p consecutive x from latents (c2 < C) or cond[n] (c2 >= C), writes p
-// consecutive k entries of row (f, y / p, gx).
+// consecutive k entries of row (f / pt, y / p, gx).  pt = 1: CogVideoX 1.0 (Conv2d patch embed, k = (c, py, px));
+// pt > 1: CogVideoX 1.5 (Linear over (c, t, py, px), frames folded in groups of pt).
 __global__ __launch_bounds__(256) void patchify_kernel(const bf16_t* __restrict__ lat, int64_t lat_bs,
                                                        const CondPtrs cond, bf16_t* __restrict__ out, int n_samples,
-                                                       int F, int C, int H, int W, int p) {
+                                                       int F, int C, int H, int W, int p, int pt) {
   const int gw = W / p, gh = H / p;
   const int64_t per_sample = (int64_t)F * 2 * C * H * gw;
   const int64_t total = per_sample * n_samples;
-  const int K = 2 * C * p * p;
+  const int K = 2 * C * pt * p * p;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = i;
     const int gx = (int)(r % gw); r /= gw;
@@ -27,17 +28,17 @@ __global__ __launch_bounds__(256) void patchify_kernel(const bf16_t* __restrict_
     const int n = (int)(r / F);
     const bf16_t* src = c2 < C ? lat + (int64_t)n * lat_bs + (((int64_t)f * C + c2) * H + y) * W
                                : cond.p[n] + (((int64_t)f * C + (c2 - C)) * H + y) * W;
-    const int64_t tok = ((int64_t)f * gh + y / p) * gw + gx;
-    bf16_t* dst = out + ((int64_t)n * F * gh * gw + tok) * K + (c2 * p + (y % p)) * p;
+    const int64_t tok = ((int64_t)(f / pt) * gh + y / p) * gw + gx;
+    bf16_t* dst = out + ((int64_t)n * (F / pt) * gh * gw + tok) * K + ((c2 * pt + f % pt) * p + (y % p)) * p;
     for (int px = 0; px < p; ++px) dst[px] = src[gx * p + px];
   }
 }
 
 // thread = output element (n, f, c, y, x)
 __global__ __launch_bounds__(256) void unpatchify_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
-                                                         int n_samples, int F, int C, int H, int W, int p) {
+                                                         int n_samples, int F, int C, int H, int W, int p, int pt) {
   const int gw = W / p, gh = H / p;
-  const int K = C * p * p;
+  const int K = C * pt * p * p;
   const int64_t total = (int64_t)n_samples * F * C * H * W;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = i;
@@ -46,8 +47,8 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const bf16_t* __restric
     const int c = (int)(r % C); r /= C;
     const int f = (int)(r % F);
     const int n = (int)(r / F);
-    const int64_t tok = ((int64_t)f * gh + y / p) * gw + x / p;
-    out[i] = in[((int64_t)n * F * gh * gw + tok) * K + (c * p + (y % p)) * p + (x % p)];
+    const int64_t tok = ((int64_t)(f / pt) * gh + y / p) * gw + x / p;
+    out[i] = in[((int64_t)n * (F / pt) * gh * gw + tok) * K + ((c * pt + f % pt) * p + (y % p)) * p + (x % p)];
   }
 }
 
@@ -71,10 +72,18 @@ __global__ __launch_bounds__(256) void timestep_kernel(const float* __restrict__
 
 using namespace alg;
 
+extern "C" int alg_patchify_t(const void* latents, int64_t lat_bstride, const void* const* cond_ptrs, void* out,
+                              int n_samples, int frames, int C, int H, int W, int p, int p_t, void* stream);
+
 extern "C" int alg_patchify(const void* latents, int64_t lat_bstride, const void* const* cond_ptrs, void* out,
                             int n_samples, int frames, int C, int H, int W, int p, void* stream) {
+  return alg_patchify_t(latents, lat_bstride, cond_ptrs, out, n_samples, frames, C, H, W, p, 1, stream);
+}
+
+extern "C" int alg_patchify_t(const void* latents, int64_t lat_bstride, const void* const* cond_ptrs, void* out,
+                              int n_samples, int frames, int C, int H, int W, int p, int p_t, void* stream) {
   if (!latents || !cond_ptrs || !out || n_samples <= 0 || n_samples > MAX_SAMPLES || frames <= 0 || C <= 0 || H <= 0 ||
-      W <= 0 || p <= 0 || H % p || W % p) {
+      W <= 0 || p <= 0 || H % p || W % p || p_t <= 0 || frames % p_t) {
     set_error("alg_patchify: bad argument (n=%d F=%d C=%d H=%d W=%d p=%d; n <= %d, H,W %% p == 0)", n_samples, frames,
               C, H, W, p, MAX_SAMPLES);
     return ALG_EINVAL;
@@ -90,13 +99,22 @@ extern "C" int alg_patchify(const void* latents, int64_t lat_bstride, const void
   int64_t want = (total + 255) / 256;
   const unsigned grid = (unsigned)(want > 4096 ? 4096 : want);
   hipLaunchKernelGGL(patchify_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)latents,
-                     lat_bstride, cp, (bf16_t*)out, n_samples, frames, C, H, W, p);
+                     lat_bstride, cp, (bf16_t*)out, n_samples, frames, C, H, W, p, p_t);
   return check_launch("alg_patchify");
 }
 
+extern "C" int alg_unpatchify_t(const void* in, void* out, int n_samples, int frames, int C, int H, int W, int p, int p_t,
+                                void* stream);
+
 extern "C" int alg_unpatchify(const void* in, void* out, int n_samples, int frames, int C, int H, int W, int p,
                               void* stream) {
-  if (!in || !out || n_samples <= 0 || frames <= 0 || C <= 0 || H <= 0 || W <= 0 || p <= 0 || H % p || W % p) {
+  return alg_unpatchify_t(in, out, n_samples, frames, C, H, W, p, 1, stream);
+}
+
+extern "C" int alg_unpatchify_t(const void* in, void* out, int n_samples, int frames, int C, int H, int W, int p, int p_t,
+                                void* stream) {
+  if (!in || !out || n_samples <= 0 || frames <= 0 || C <= 0 || H <= 0 || W <= 0 || p <= 0 || H % p || W % p || p_t <= 0 ||
+      frames % p_t) {
     set_error("alg_unpatchify: bad argument (n=%d F=%d C=%d H=%d W=%d p=%d)", n_samples, frames, C, H, W, p);
     return ALG_EINVAL;
   }
@@ -104,7 +122,7 @@ extern "C" int alg_unpatchify(const void* in, void* out, int n_samples, int fram
   int64_t want = (total + 255) / 256;
   const unsigned grid = (unsigned)(want > 4096 ? 4096 : want);
   hipLaunchKernelGGL(unpatchify_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in,
-                     (bf16_t*)out, n_samples, frames, C, H, W, p);
+                     (bf16_t*)out, n_samples, frames, C, H, W, p, p_t);
   return check_launch("alg_unpatchify");
 }
 

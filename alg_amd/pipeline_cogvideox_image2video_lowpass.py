@@ -73,13 +73,20 @@ def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timeste
     return scheduler.timesteps, num_inference_steps
 
 
-def rotary_tables(embed_dim, crops_coords, grid_size, temporal_size, theta=10000.0):
-    """diffusers get_3d_rotary_pos_embed ('linspace' grid, use_real) -> (cos, sin) each [T*H*W, embed_dim] fp32.
-    Head-dim split t/h/w = d/4, 3d/8, 3d/8; each axis' cos/sin repeat-interleaved x2."""
-    (top, left), (bottom, right) = crops_coords
+def rotary_tables(embed_dim, crops_coords, grid_size, temporal_size, theta=10000.0, max_size=None):
+    """diffusers get_3d_rotary_pos_embed (use_real) -> (cos, sin) each [T*H*W, embed_dim] fp32: the 'linspace' grid over
+    `crops_coords` (CogVideoX 1.0) or, with `max_size`, the 'slice' grid (CogVideoX 1.5: integer positions of
+    arange(max), cut to the grid).  Head-dim split t/h/w = d/4, 3d/8, 3d/8; each axis' cos/sin repeat-interleaved x2."""
     gh, gw = grid_size
-    axis_h = torch.linspace(top, bottom * (gh - 1) / gh, gh, dtype=torch.float32)
-    axis_w = torch.linspace(left, right * (gw - 1) / gw, gw, dtype=torch.float32)
+    if max_size is None:
+        (top, left), (bottom, right) = crops_coords
+        axis_h = torch.linspace(top, bottom * (gh - 1) / gh, gh, dtype=torch.float32)
+        axis_w = torch.linspace(left, right * (gw - 1) / gw, gw, dtype=torch.float32)
+    else:
+        if gh > max_size[0] or gw > max_size[1]:
+            raise ValueError("the latent grid exceeds the transformer's sample size (slice rotary embedding)")
+        axis_h = torch.arange(max_size[0], dtype=torch.float32)[:gh]
+        axis_w = torch.arange(max_size[1], dtype=torch.float32)[:gw]
     axis_t = torch.arange(temporal_size, dtype=torch.float32)
 
     def axis_table(dim, pos):
@@ -269,6 +276,9 @@ class CogVideoXImageToVideoPipeline:
         f_lat = (num_frames - 1) // self.vae_scale_factor_temporal + 1
         h, w = height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial
         shape = (batch_size, f_lat, num_channels_latents, h, w)
+        p_t = getattr(self.transformer.config, "patch_size_t", None)
+        if p_t is not None:  # cog:380-382: CogVideoX 1.5 pads the noise to a multiple of patch_size_t
+            shape = shape[:1] + (shape[1] + shape[1] % p_t,) + shape[2:]
         if image_latents is None:
             if self.vae is None:
                 raise _lib.AlgHipError(
@@ -286,11 +296,13 @@ class CogVideoXImageToVideoPipeline:
                 first = 1 / self.vae_scaling_factor_image * first
         else:
             first = image_latents.to(device=device, dtype=dtype)
-        if first.shape[1] == f_lat:
+        if first.shape[1] >= f_lat:
             cond = first.contiguous()
         else:
-            cond = torch.zeros(shape, device=device, dtype=dtype)
+            cond = torch.zeros((batch_size, f_lat, num_channels_latents, h, w), device=device, dtype=dtype)
             cond[:, : first.shape[1]] = first.to(device)
+        if p_t is not None and cond.shape[1] % p_t:  # cog:413-416: repeat the leading frame(s) in front
+            cond = torch.cat([cond[:, : cond.shape[1] % p_t], cond], dim=1).contiguous()
         if latents is None:
             if isinstance(generator, list):
                 parts = [torch.randn((1,) + shape[1:], generator=g, device=g.device, dtype=dtype) for g in generator]
@@ -324,15 +336,18 @@ class CogVideoXImageToVideoPipeline:
         return kw
 
     def _prepare_rotary_positional_embeddings(self, height, width, num_frames, device):
-        """reference cog:542-584 (CogVideoX 1.0 branch)."""
+        """reference cog:542-584: the cropped linspace grid (CogVideoX 1.0) or the slice grid over
+        (num_frames + p_t - 1) // p_t temporal positions (CogVideoX 1.5)."""
         cfg = self.transformer.config
-        p = cfg.patch_size
+        p, p_t = cfg.patch_size, cfg.patch_size_t
         gh = height // (self.vae_scale_factor_spatial * p)
         gw = width // (self.vae_scale_factor_spatial * p)
-        if cfg.patch_size_t is not None:
-            raise NotImplementedError("CogVideoX 1.5 rotary grid ('slice') is not built yet")
-        crops = get_resize_crop_region_for_grid((gh, gw), cfg.sample_width // p, cfg.sample_height // p)
-        cos, sin = rotary_tables(cfg.attention_head_dim, crops, (gh, gw), num_frames)
+        if p_t is None:
+            crops = get_resize_crop_region_for_grid((gh, gw), cfg.sample_width // p, cfg.sample_height // p)
+            cos, sin = rotary_tables(cfg.attention_head_dim, crops, (gh, gw), num_frames)
+        else:
+            cos, sin = rotary_tables(cfg.attention_head_dim, None, (gh, gw), (num_frames + p_t - 1) // p_t,
+                                     max_size=(cfg.sample_height // p, cfg.sample_width // p))
         return cos.to(device), sin.to(device)
 
     # -- ALG conditioning ---------------------------------------------------------------------------------
@@ -342,10 +357,18 @@ class CogVideoXImageToVideoPipeline:
         pixel branch: filter the RGB image, re-encode with the VAE (needs an attached VAE), pad with zero frames."""
         if not use_low_pass_guidance:
             return None
+        p_t = getattr(self.transformer.config, "patch_size_t", None)
+
+        def pad_t(x):  # cog:673-680 / 693-699: CogVideoX 1.5 repeats leading frames up to a multiple of patch_size_t
+            if p_t is not None and x.size(1) % p_t:
+                n = min(p_t - x.size(1) % p_t, x.shape[1])
+                x = torch.cat([x[:, :n], x], dim=1)
+            return x
+
         if lp_filter_in_latent:
             out = lp_utils.apply_low_pass_filter(orig_image_latents, lp_filter_type, lp_blur_sigma,
                                                  lp_blur_kernel_size, lp_resize_factor)
-            return out.to(dtype=orig_image_latents.dtype)
+            return pad_t(out).to(dtype=orig_image_latents.dtype).contiguous()
         if self.vae is None:
             raise _lib.AlgHipError("lp_filter_in_latent=False re-encodes the filtered image every step and needs a VAE")
         img = lp_utils.apply_low_pass_filter(orig_image_tensor, lp_filter_type, lp_blur_sigma, lp_blur_kernel_size,
@@ -363,7 +386,7 @@ class CogVideoXImageToVideoPipeline:
             enc = torch.cat([enc, pad], dim=1)
         else:
             enc = enc[:, :f_lat]
-        return enc.to(dtype=orig_image_latents.dtype).contiguous()
+        return pad_t(enc).to(dtype=orig_image_latents.dtype).contiguous()
 
     def _cached_lp(self, key, make):
         hit = self._lp_cache.get(key)
@@ -463,8 +486,12 @@ class CogVideoXImageToVideoPipeline:
         timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, timesteps)
         self._num_timesteps = len(timesteps)
 
-        if tcfg.patch_size_t is not None:
-            raise NotImplementedError("CogVideoX 1.5 (temporal patching) is not built yet")
+        # cog:961-968: CogVideoX 1.5 pads the latent frames to a multiple of patch_size_t
+        latent_frames = (num_frames - 1) // self.vae_scale_factor_temporal + 1
+        additional_frames = 0
+        if tcfg.patch_size_t is not None and latent_frames % tcfg.patch_size_t != 0:
+            additional_frames = tcfg.patch_size_t - latent_frames % tcfg.patch_size_t
+            num_frames += additional_frames * self.vae_scale_factor_temporal
         image_tensor = None
         if image is not None and (image_latents is None or not lp_filter_in_latent):
             image_tensor = self.preprocess_image(image, height, width).to(device, dtype=dtype)
@@ -477,8 +504,7 @@ class CogVideoXImageToVideoPipeline:
 
         image_rotary_emb = (self._prepare_rotary_positional_embeddings(height, width, latents.size(1), device)
                             if tcfg.use_rotary_positional_embeddings else None)
-        if tcfg.ofs_embed_dim is not None:
-            raise NotImplementedError("ofs embedding (CogVideoX 1.5) is not built yet")
+        ofs_emb = None if tcfg.ofs_embed_dim is None else latents.new_full((1,), fill_value=2.0)  # cog:998
 
         if not isinstance(self.scheduler, CogVideoXDDIMScheduler) or not hasattr(self.transformer, "forward_assembled"):
             raise TypeError("this sampler drives alg_amd's CogVideoXTransformer3DModel and CogVideoXDDIMScheduler "
@@ -542,10 +568,10 @@ class CogVideoXImageToVideoPipeline:
                 rows = [p_ * B + b for p_ in cfg_split.my_passes(n_pass) for b in range(B)]
                 lat_l = latents if B == 1 else torch.cat([latents] * (len(rows) // B), dim=0)
                 local = self.transformer.forward_assembled(lat_l, [conds[r] for r in rows], embeds[rows].contiguous(),
-                                                           ts[:len(rows)], image_rotary_emb)
+                                                           ts[:len(rows)], image_rotary_emb, ofs=ofs_emb)
                 noise_pred = cfg_split.merge(local, n_pass, B)
             else:
-                noise_pred = self.transformer.forward_assembled(lat_in, conds, embeds, ts, image_rotary_emb)
+                noise_pred = self.transformer.forward_assembled(lat_in, conds, embeds, ts, image_rotary_emb, ofs=ofs_emb)
             gs = guidance_scale
             if do_cfg and not use_low_pass_guidance and use_dynamic_cfg:  # cog:1105-1108
                 gs = 1 + guidance_scale * (
@@ -576,6 +602,8 @@ class CogVideoXImageToVideoPipeline:
                 negative_prompt_embeds = outs.pop("negative_prompt_embeds", negative_prompt_embeds)
         self._current_timestep = None
 
+        if output_type != "latent":
+            latents = latents[:, additional_frames:]  # cog:1144: discard the CogVideoX 1.5 padding frames
         if output_type == "latent":
             video = latents
         elif output_type in ("pil", "uint8") and hasattr(self.vae, "decode_latents"):

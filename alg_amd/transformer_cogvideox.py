@@ -83,8 +83,8 @@ class CogVideoXTransformer3DModel:
             raise _lib.AlgHipError("CogVideoXTransformer3DModel runs on the GPU only (HIP kernels, no CPU fallback)")
         if cfg.attention_head_dim != 64:
             raise _lib.AlgHipError("the attention kernel is specialised for head_dim 64")
-        if cfg.patch_size_t is not None or cfg.ofs_embed_dim is not None:
-            raise NotImplementedError("CogVideoX 1.5 (patch_size_t / ofs embedding) is not built yet")
+        if cfg.ofs_embed_dim is not None and cfg.ofs_embed_dim != cfg.time_embed_dim:
+            raise _lib.AlgHipError("ofs_embed_dim must equal time_embed_dim (emb = emb + ofs_emb)")
         D = cfg.inner_dim
         if D % 512:
             raise _lib.AlgHipError("inner_dim must be a multiple of 512 (LayerNorm kernel tiling)")
@@ -92,7 +92,8 @@ class CogVideoXTransformer3DModel:
         dev = self.device
         w = weights
         p = cfg.patch_size
-        self.k_patch = cfg.in_channels * p * p
+        self.p_t = cfg.patch_size_t or 1   # CogVideoX 1.5: Linear patch embed over (c, t, py, px), frames folded in p_t
+        self.k_patch = cfg.in_channels * p * p * self.p_t
         if self.k_patch % 64 or cfg.text_embed_dim % 64 or cfg.time_embed_dim % 64:
             raise _lib.AlgHipError("GEMM K dimensions must be multiples of 64")
         self.w_patch = _bf(w["patch_embed.proj.weight"].reshape(D, self.k_patch), dev)
@@ -104,6 +105,9 @@ class CogVideoXTransformer3DModel:
         self.b_t1 = _bf(w["time_embedding.linear_1.bias"], dev)
         self.w_t2 = _bf(w["time_embedding.linear_2.weight"], dev)
         self.b_t2 = _bf(w["time_embedding.linear_2.bias"], dev)
+        if cfg.ofs_embed_dim is not None:  # CogVideoX 1.5: emb = time_embedding(t) + ofs_embedding(Timesteps(ofs))
+            self.w_o1, self.b_o1 = _bf(w["ofs_embedding.linear_1.weight"], dev), _bf(w["ofs_embedding.linear_1.bias"], dev)
+            self.w_o2, self.b_o2 = _bf(w["ofs_embedding.linear_2.weight"], dev), _bf(w["ofs_embedding.linear_2.bias"], dev)
 
         # AdaLN linears of all layers + norm_out, concatenated into one [TOT, time_embed_dim] weight.  Rows are
         # re-ordered from diffusers' chunk order (shift, scale, gate, enc_shift, enc_scale, enc_gate) to
@@ -232,7 +236,7 @@ class CogVideoXTransformer3DModel:
         return hit
 
     # ------------------------------------------------------------------------------------------------
-    def forward_assembled(self, latents, conds, encoder_hidden_states, timestep, image_rotary_emb=None):
+    def forward_assembled(self, latents, conds, encoder_hidden_states, timestep, image_rotary_emb=None, ofs=None):
         """The loop's form of the forward, with the CFG batch assembly (cog:1060-1070) folded into the patch
         gather: sample n sees channels [latents | conds[n]].
 
@@ -255,8 +259,10 @@ class CogVideoXTransformer3DModel:
         if ehs.shape[0] != N:
             raise ValueError("encoder_hidden_states batch %d != %d samples" % (ehs.shape[0], N))
         T = ehs.shape[1]
-        p = cfg.patch_size
-        P = Fr * (Hh // p) * (Ww // p)
+        p, p_t = cfg.patch_size, self.p_t
+        if Fr % p_t:
+            raise ValueError("latent frames (%d) must be a multiple of patch_size_t=%d (cog:963-968 pads them)" % (Fr, p_t))
+        P = (Fr // p_t) * (Hh // p) * (Ww // p)
         S = T + P
         D, Hn = cfg.inner_dim, cfg.num_attention_heads
         if cfg.use_learned_positional_embeddings:
@@ -280,14 +286,28 @@ class CogVideoXTransformer3DModel:
         _lib.timestep_embedding(ts, ws["tsin"], N, D, cfg.flip_sin_to_cos)
         E = cfg.time_embed_dim
         G(ws["tsin"], self.w_t1, ws["t1"], N, E, D, D, D, E, bias=self.b_t1, act=_lib.ACT_SILU)
-        G(ws["t1"], self.w_t2, ws["semb"], N, E, E, E, E, E, bias=self.b_t2, act=_lib.ACT_SILU)
+        if cfg.ofs_embed_dim is None:
+            G(ws["t1"], self.w_t2, ws["semb"], N, E, E, E, E, E, bias=self.b_t2, act=_lib.ACT_SILU)
+        else:
+            if ofs is None:
+                raise ValueError("this transformer has an ofs embedding: pass `ofs` (cog:998)")
+            O = cfg.ofs_embed_dim
+            emb, osin, o1, oemb = (torch.empty(N, E, device=self.device, dtype=torch.bfloat16) for _ in range(4))
+            G(ws["t1"], self.w_t2, emb, N, E, E, E, E, E, bias=self.b_t2)
+            ofs_v = ofs.to(device=self.device, dtype=torch.float32).reshape(-1)
+            ofs_v = (ofs_v if ofs_v.numel() == N else ofs_v[:1].expand(N)).contiguous()
+            _lib.timestep_embedding(ofs_v, osin, N, O, cfg.flip_sin_to_cos)
+            G(osin, self.w_o1, o1, N, O, O, O, O, O, bias=self.b_o1, act=_lib.ACT_SILU)
+            G(o1, self.w_o2, oemb, N, O, O, O, O, O, bias=self.b_o2)
+            _lib.lincomb([(1.0, emb), (1.0, oemb)], torch.bfloat16, out=emb)
+            _lib.silu(emb, ws["semb"])
         # every AdaLN vector of the forward in one GEMM
         G(ws["semb"], self.w_mod, mod, N, self.mod_cols, E, E, E, self.mod_cols, bias=self.b_mod)
 
         # 2. patch embedding (+ positional embedding as the residual operand), text tokens first
         G(ehs, self.w_text, x, T, D, cfg.text_embed_dim, cfg.text_embed_dim, cfg.text_embed_dim, D,
           bias=self.b_text, R=self.pos_emb, ldr=D, batch=N, strideA=T * cfg.text_embed_dim, strideC=S * D)
-        _lib.patchify(lat, 0 if Bl == 1 else Fr * C * Hh * Ww, conds, ws["patches"], N, Fr, C, Hh, Ww, p)
+        _lib.patchify(lat, 0 if Bl == 1 else Fr * C * Hh * Ww, conds, ws["patches"], N, Fr, C, Hh, Ww, p, p_t)
         G(ws["patches"], self.w_patch, x, P, D, self.k_patch, self.k_patch, self.k_patch, D, bias=self.b_patch,
           R=self.pos_emb, ldr=D, r_off=T * D, batch=N, strideA=P * self.k_patch, strideC=S * D, c_off=T * D)
 
@@ -324,19 +344,19 @@ class CogVideoXTransformer3DModel:
         n_out = self.w_out.shape[0]
         G(att, self.w_out, ws["po"], N * P, n_out, D, D, D, n_out, bias=self.b_out)
         out = torch.empty(N, Fr, cfg.out_channels, Hh, Ww, device=self.device, dtype=torch.bfloat16)
-        _lib.unpatchify(ws["po"], out, N, Fr, cfg.out_channels, Hh, Ww, p)
+        _lib.unpatchify(ws["po"], out, N, Fr, cfg.out_channels, Hh, Ww, p, p_t)
         return out
 
     def __call__(self, hidden_states, encoder_hidden_states, timestep, timestep_cond=None, ofs=None,
                  image_rotary_emb=None, attention_kwargs=None, return_dict=True):
         """diffusers-style entry: hidden_states [N, F, 2C, H, W] (latents and condition already concatenated on
         the channel axis, cog:1068-1070)."""
-        if timestep_cond is not None or ofs is not None:
-            raise NotImplementedError("timestep_cond / ofs are not used by CogVideoX-5B-I2V")
+        if timestep_cond is not None:
+            raise NotImplementedError("timestep_cond is not used by the CogVideoX I2V checkpoints")
         C = hidden_states.shape[2] // 2
         lat = hidden_states[:, :, :C].contiguous()
         conds = [hidden_states[n:n + 1, :, C:].contiguous() for n in range(hidden_states.shape[0])]
-        out = self.forward_assembled(lat, conds, encoder_hidden_states, timestep, image_rotary_emb)
+        out = self.forward_assembled(lat, conds, encoder_hidden_states, timestep, image_rotary_emb, ofs=ofs)
         if not return_dict:
             return (out,)
         return TransformerOutput(sample=out)

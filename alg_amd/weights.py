@@ -11,15 +11,17 @@ import torch
 
 
 def parameter_shapes(cfg):
-    """diffusers state-dict name -> shape for CogVideoXTransformer3DModel (patch_size_t None)."""
+    """diffusers state-dict name -> shape for CogVideoXTransformer3DModel (1.0: Conv2d patch embed; 1.5 (`patch_size_t`):
+    Linear patch embed over (c, t, py, px), p_t-fold proj_out, optional ofs embedding)."""
     D, H = cfg.inner_dim, cfg.attention_head_dim
     p = cfg.patch_size
     lat_f = (cfg.sample_frames - 1) // cfg.temporal_compression_ratio + 1
     n_patch = (cfg.sample_height // p) * (cfg.sample_width // p) * lat_f
     E = cfg.time_embed_dim
     F4 = cfg.ff_inner_mult * D
+    p_t = cfg.patch_size_t
     shapes = {
-        "patch_embed.proj.weight": (D, cfg.in_channels, p, p),
+        "patch_embed.proj.weight": (D, cfg.in_channels, p, p) if p_t is None else (D, cfg.in_channels * p * p * p_t),
         "patch_embed.proj.bias": (D,),
         "patch_embed.text_proj.weight": (D, cfg.text_embed_dim),
         "patch_embed.text_proj.bias": (D,),
@@ -33,9 +35,13 @@ def parameter_shapes(cfg):
         "norm_out.linear.bias": (2 * D,),
         "norm_out.norm.weight": (D,),
         "norm_out.norm.bias": (D,),
-        "proj_out.weight": (p * p * cfg.out_channels, D),
-        "proj_out.bias": (p * p * cfg.out_channels,),
+        "proj_out.weight": (p * p * (p_t or 1) * cfg.out_channels, D),
+        "proj_out.bias": (p * p * (p_t or 1) * cfg.out_channels,),
     }
+    if cfg.ofs_embed_dim is not None:
+        O = cfg.ofs_embed_dim
+        shapes.update({"ofs_embedding.linear_1.weight": (O, O), "ofs_embedding.linear_1.bias": (O,),
+                       "ofs_embedding.linear_2.weight": (O, O), "ofs_embedding.linear_2.bias": (O,)})
     if cfg.use_learned_positional_embeddings:
         shapes["patch_embed.pos_embedding"] = (1, cfg.max_text_seq_length + n_patch, D)
     for i in range(cfg.num_layers):

@@ -357,6 +357,13 @@ int alg_patchify(const void* latents, int64_t lat_bstride, const void* const* co
 /* proj_out rows [n][(f,gy,gx)][c*p*p + py*p + px] -> [n][F][C][H][W] bf16. */
 int alg_unpatchify(const void* in, void* out, int n_samples, int frames, int C, int H, int W, int p, void* stream);
 
+/* CogVideoX 1.5 (`patch_size_t`; CogVideoXPatchEmbed's Linear over (c, t, py, px) and the matching unpatchify): frames
+ * are folded in groups of p_t: out[n][(f / p_t, gy, gx)][((c*p_t + f % p_t)*p + py)*p + px];  p_t = 1 is the above. */
+int alg_patchify_t(const void* latents, int64_t lat_bstride, const void* const* cond_ptrs, void* out, int n_samples,
+                   int frames, int C, int H, int W, int p, int p_t, void* stream);
+int alg_unpatchify_t(const void* in, void* out, int n_samples, int frames, int C, int H, int W, int p, int p_t,
+                     void* stream);
+
 /* Timesteps(dim, flip_sin_to_cos, freq_shift=0): out [n][dim] bf16 sinusoid of t[n] (fp32 timesteps). */
 int alg_timestep_embedding(const float* t, void* out, int n, int dim, int flip_sin_to_cos, void* stream);
 

@@ -66,8 +66,9 @@ def param_shapes(cfg: DiTConfig):
     p = cfg.patch_size
     lat_f = (cfg.sample_frames - 1) // cfg.temporal_compression_ratio + 1
     n_patch = (cfg.sample_height // p) * (cfg.sample_width // p) * lat_f
+    p_t = cfg.patch_size_t
     s = {
-        "patch_embed.proj.weight": (D, cfg.in_channels, p, p),
+        "patch_embed.proj.weight": (D, cfg.in_channels, p, p) if p_t is None else (D, cfg.in_channels * p * p * p_t),
         "patch_embed.proj.bias": (D,),
         "patch_embed.text_proj.weight": (D, cfg.text_embed_dim),
         "patch_embed.text_proj.bias": (D,),
@@ -81,9 +82,13 @@ def param_shapes(cfg: DiTConfig):
         "norm_out.linear.bias": (2 * D,),
         "norm_out.norm.weight": (D,),
         "norm_out.norm.bias": (D,),
-        "proj_out.weight": (p * p * cfg.out_channels, D),
-        "proj_out.bias": (p * p * cfg.out_channels,),
+        "proj_out.weight": (p * p * (p_t or 1) * cfg.out_channels, D),
+        "proj_out.bias": (p * p * (p_t or 1) * cfg.out_channels,),
     }
+    if cfg.ofs_embed_dim is not None:
+        O = cfg.ofs_embed_dim
+        s.update({"ofs_embedding.linear_1.weight": (O, O), "ofs_embedding.linear_1.bias": (O,),
+                  "ofs_embedding.linear_2.weight": (O, O), "ofs_embedding.linear_2.bias": (O,)})
     if cfg.use_learned_positional_embeddings:
         s["patch_embed.pos_embedding"] = (1, cfg.max_text_seq_length + n_patch, D)
     for i in range(cfg.num_layers):
@@ -160,15 +165,24 @@ def _rope_1d(dim, pos, theta=10000.0):
 
 
 def rope_tables(cfg: DiTConfig, height, width, latent_frames, vae_scale_factor_spatial=8):
-    """(cos, sin), each [latent_frames*gh*gw, head_dim] fp32 -- CogVideoX 1.0 branch (cog:558-569)."""
+    """(cos, sin), each [tokens_t*gh*gw, head_dim] fp32: CogVideoX 1.0 (cog:558-569: cropped linspace grid) or, with
+    `patch_size_t`, CogVideoX 1.5 (cog:570-582: `grid_type="slice"`, integer positions, (F + p_t - 1) // p_t time steps)."""
     p = cfg.patch_size
     gh = height // (vae_scale_factor_spatial * p)
     gw = width // (vae_scale_factor_spatial * p)
     base_w = cfg.sample_width // p
     base_h = cfg.sample_height // p
-    start, stop = get_resize_crop_region_for_grid((gh, gw), base_w, base_h)
-    grid_h = torch.linspace(start[0], stop[0] * (gh - 1) / gh, gh, dtype=torch.float32)
-    grid_w = torch.linspace(start[1], stop[1] * (gw - 1) / gw, gw, dtype=torch.float32)
+    if cfg.patch_size_t is None:
+        start, stop = get_resize_crop_region_for_grid((gh, gw), base_w, base_h)
+        grid_h = torch.linspace(start[0], stop[0] * (gh - 1) / gh, gh, dtype=torch.float32)
+        grid_w = torch.linspace(start[1], stop[1] * (gw - 1) / gw, gw, dtype=torch.float32)
+    else:
+        # get_3d_rotary_pos_embed(grid_type="slice", max_size=(base_h, base_w)): tables over arange(max), sliced to the grid
+        latent_frames = (latent_frames + cfg.patch_size_t - 1) // cfg.patch_size_t
+        grid_h = torch.arange(base_h, dtype=torch.float32)[:gh]
+        grid_w = torch.arange(base_w, dtype=torch.float32)[:gw]
+        if grid_h.numel() != gh or grid_w.numel() != gw:
+            raise ValueError("the grid exceeds the configured sample size (slice rotary embedding)")
     grid_t = torch.arange(latent_frames, dtype=torch.float32)
     d = cfg.attention_head_dim
     dim_t, dim_h, dim_w = d // 4, d // 8 * 3, d // 8 * 3
@@ -237,7 +251,7 @@ def sincos_pos_embed_3d(cfg: DiTConfig, gh, gw, lat_f):
 
 
 def dit_forward(cfg: DiTConfig, w, hidden_states, encoder_hidden_states, timestep, image_rotary_emb=None,
-                collect=None):
+                collect=None, ofs=None):
     """hidden_states [B, F, C_in, H, W]; encoder_hidden_states [B, T, text_dim]; timestep [B];
     image_rotary_emb (cos, sin) or None.  Returns [B, F, C_out, H, W] in the compute dtype of ``w``.
     ``collect`` (dict) receives named intermediates for kernel-level tests."""
@@ -251,11 +265,26 @@ def dit_forward(cfg: DiTConfig, w, hidden_states, encoder_hidden_states, timeste
     t_emb = timestep_sinusoid(timestep, D, cfg.flip_sin_to_cos, cfg.freq_shift).to(dt)
     emb = F.linear(t_emb, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"])
     emb = F.linear(F.silu(emb), w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"])
+    if cfg.ofs_embed_dim is not None:
+        # CogVideoX 1.5: ofs_emb = ofs_embedding(ofs_proj(ofs)); emb = emb + ofs_emb
+        o = timestep_sinusoid(ofs.reshape(-1).float().expand(B) if ofs.numel() == 1 else ofs.float(), cfg.ofs_embed_dim,
+                              cfg.flip_sin_to_cos, cfg.freq_shift).to(dt)
+        o = F.linear(o, w["ofs_embedding.linear_1.weight"], w["ofs_embedding.linear_1.bias"])
+        o = F.linear(F.silu(o), w["ofs_embedding.linear_2.weight"], w["ofs_embedding.linear_2.bias"])
+        emb = emb + o
 
-    # 2. patch embedding (CogVideoXPatchEmbed, patch_size_t None): Conv2d k=p s=p per frame; text Linear
+    # 2. patch embedding (CogVideoXPatchEmbed): Conv2d k=p s=p per frame (patch_size_t None) or a Linear over
+    #    (c, p_t, p, p) blocks of p_t frames (CogVideoX 1.5); text Linear
     txt = F.linear(encoder_hidden_states.to(dt), w["patch_embed.text_proj.weight"], w["patch_embed.text_proj.bias"])
-    img = F.conv2d(x_in.reshape(-1, C, Hh, Ww), w["patch_embed.proj.weight"], w["patch_embed.proj.bias"], stride=p)
-    img = img.view(B, Fr, D, -1).transpose(2, 3).flatten(1, 2)  # [B, F*gh*gw, D]
+    p_t = cfg.patch_size_t
+    if p_t is None:
+        img = F.conv2d(x_in.reshape(-1, C, Hh, Ww), w["patch_embed.proj.weight"], w["patch_embed.proj.bias"], stride=p)
+        img = img.view(B, Fr, D, -1).transpose(2, 3).flatten(1, 2)  # [B, F*gh*gw, D]
+    else:
+        img = x_in.permute(0, 1, 3, 4, 2)                                          # [B, F, H, W, C]
+        img = img.reshape(B, Fr // p_t, p_t, Hh // p, p, Ww // p, p, C)
+        img = img.permute(0, 1, 3, 5, 7, 2, 4, 6).flatten(4, 7).flatten(1, 3)     # [B, tokens, C * p_t * p * p]
+        img = F.linear(img, w["patch_embed.proj.weight"], w["patch_embed.proj.bias"])
     x = torch.cat([txt, img], dim=1)
     if cfg.use_learned_positional_embeddings:
         if cfg.sample_width != Ww or cfg.sample_height != Hh:
@@ -322,8 +351,12 @@ def dit_forward(cfg: DiTConfig, w, hidden_states, encoder_hidden_states, timeste
     x = x * (1 + scale)[:, None] + shift[:, None]
     x = F.linear(x, w["proj_out.weight"], w["proj_out.bias"])
     # unpatchify
-    out = x.reshape(B, Fr, Hh // p, Ww // p, -1, p, p)
-    out = out.permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
+    if p_t is None:
+        out = x.reshape(B, Fr, Hh // p, Ww // p, -1, p, p)
+        out = out.permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
+    else:
+        out = x.reshape(B, (Fr + p_t - 1) // p_t, Hh // p, Ww // p, -1, p_t, p, p)
+        out = out.permute(0, 1, 5, 4, 2, 6, 3, 7).flatten(6, 7).flatten(4, 5).flatten(1, 2)
     return out
 
 

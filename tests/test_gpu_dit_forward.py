@@ -217,3 +217,57 @@ def test_alg_sampler_with_dpm_scheduler(device):
     assert out.dtype == BF and torch.isfinite(out.float()).all()
     r = rel(out.float().cpu(), ref.float())
     assert r < 5e-2, r
+
+
+def test_cogvideox_1_5_forward_matches_the_oracle(device):
+    """CogVideoX 1.5 variant of row a-6 (`patch_size_t`, cog:380-382/553-582/998): Linear patch embed over (c, t, py, px),
+    slice rotary grid, ofs embedding added to the timestep embedding, p_t-fold unpatchify."""
+    ocfg, w, model = make_pair(device, overrides=dict(patch_size_t=2, ofs_embed_dim=64,
+                                                      use_learned_positional_embeddings=False), seed=9)
+    g = torch.Generator().manual_seed(3)
+    N, Fr, C, H, W = 2, 4, 8, 8, 12
+    x = torch.randn(N, Fr, 2 * C, H, W, generator=g).to(BF)
+    e = torch.randn(N, 10, 128, generator=g).to(BF)
+    t = torch.tensor([731.0, 731.0])
+    rope = dit_oracle.rope_tables(ocfg, H * 8, W * 8, Fr)
+    assert rope[0].shape == (2 * 4 * 6, 64)
+    ofs = torch.full((1,), 2.0)
+    want = dit_oracle.dit_forward(ocfg, w, x.float(), e.float(), t, rope, ofs=ofs)
+    got = model(x.to(device), e.to(device), t.to(device), ofs=ofs.to(device),
+                image_rotary_emb=(rope[0].to(device), rope[1].to(device)), return_dict=False)[0]
+    assert got.shape == want.shape == (N, Fr, C, H, W)
+    r = rel(got.float().cpu(), want)
+    assert r < 3e-2, r
+    with pytest.raises(ValueError, match="ofs"):
+        model(x.to(device), e.to(device), t.to(device), image_rotary_emb=(rope[0].to(device), rope[1].to(device)))
+    with pytest.raises(ValueError, match="multiple of patch_size_t"):
+        model(x[:, :3].contiguous().to(device), e.to(device), t.to(device), ofs=ofs.to(device))
+
+
+def test_cogvideox_1_5_sampler_pads_frames_and_matches_the_loop_oracle(device):
+    """cog:961-968: 9 frames -> 3 latent frames -> padded to 4 (13 frames); the padding frame is dropped on decode paths
+    (cog:1144) and kept for output_type='latent'; loop vs oracle with the ofs embedding in the stand-in closure."""
+    ocfg, w, model = make_pair(device, overrides=dict(patch_size_t=2, ofs_embed_dim=64,
+                                                      use_learned_positional_embeddings=False), seed=10)
+    pipe = CogVideoXImageToVideoPipeline(transformer=model, scheduler=CogVideoXDDIMScheduler()).to(device)
+    g = torch.Generator().manual_seed(5)
+    C, H, W = 8, 8, 12
+    first = (torch.randn(1, 1, C, H, W, generator=g) * 0.7).to(BF)
+    pe, ne = torch.randn(1, 10, 128, generator=g).to(BF), torch.randn(1, 10, 128, generator=g).to(BF)
+    kw = dict(num_inference_steps=3, guidance_scale=6.0, use_low_pass_guidance=True, lp_filter_type="down_up",
+              lp_resize_factor=0.25, lp_strength_schedule_type="interval", schedule_interval_start_time=0.0,
+              schedule_interval_end_time=0.4)
+    latents = torch.randn(1, 4, C, H, W, generator=g).to(BF)
+    out = pipe(image=None, image_latents=first, latents=latents, prompt_embeds=pe, negative_prompt_embeds=ne,
+               height=H * 8, width=W * 8, num_frames=9, output_type="latent", lp_filter_in_latent=True,
+               generator=torch.Generator().manual_seed(7), **kw).frames
+    assert out.shape == (1, 4, C, H, W)
+    cond = torch.zeros(1, 4, C, H, W)
+    cond[:, :1] = first.float()                      # [image, 0, 0] + one more zero frame: 3 % 2 == 1 -> 4 frames
+    rope = dit_oracle.rope_tables(ocfg, H * 8, W * 8, 4)
+    ofs = torch.full((1,), 2.0)
+    tf = lambda x, e, ts, r: dit_oracle.dit_forward(ocfg, w, x, e, ts, r, ofs=ofs)
+    ref = loop_oracle.alg_denoise_loop(tf, ddim_oracle.DDIMOracle(), latents.float(), cond, pe.float(), ne.float(),
+                                       image_rotary_emb=rope, **kw)
+    r = rel(out.float().cpu(), ref.float())
+    assert r < 5e-2, r

@@ -117,6 +117,23 @@ def test_param_count_and_shapes():
     assert abs(dit_oracle.flops_per_forward(dit_oracle.DiTConfig(), tokens) - 3.322e14) / 3.322e14 < 0.01
 
 
+def test_cogvideox_1_5_shapes_and_rope():
+    """CogVideoX1.5-5B-I2V: patch_size_t 2 (Linear patch embed over c*p_t*p*p = 256 inputs, proj_out 128 wide), ofs embedding,
+    no learned positions, 81 frames @ 768x1360 -> 22 padded latent frames -> 11 x 48 x 85 tokens on the slice rotary grid."""
+    kw = dict(patch_size_t=2, ofs_embed_dim=512, use_learned_positional_embeddings=False, sample_height=96,
+              sample_width=170, sample_frames=81)
+    cfg, ocfg = CogVideoXTransformerConfig(**kw), dit_oracle.DiTConfig(**kw)
+    shapes = W.parameter_shapes(cfg)
+    assert shapes == dit_oracle.param_shapes(ocfg)
+    assert shapes["patch_embed.proj.weight"] == (3072, 256) and shapes["proj_out.weight"] == (128, 3072)
+    assert shapes["ofs_embedding.linear_1.weight"] == (512, 512) and "patch_embed.pos_embedding" not in shapes
+    cos, sin = dit_oracle.rope_tables(ocfg, 768, 1360, 22)
+    assert cos.shape == (11 * 48 * 85, 64)
+    from alg_amd.pipeline_cogvideox_image2video_lowpass import rotary_tables
+    c2, s2 = rotary_tables(64, None, (48, 85), 11, max_size=(48, 85))
+    assert torch.equal(c2, cos) and torch.equal(s2, sin)
+
+
 def test_c_abi_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "alg_hip.h")).read()
     declared = set(re.findall(r"\b(alg_[a-z0-9_]+)\s*\(", header))
