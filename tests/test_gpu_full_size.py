@@ -147,3 +147,53 @@ def test_wan_self_attention_full_size_properties():
     _lib.flash_attn_d128(q, torch.zeros_like(k), vt, o, *args)
     mean = v.float().mean(dim=2)          # the kv permutation inside 16-blocks does not change a mean
     assert (o.float() - mean[:, None, :]).abs().max().item() <= 3e-3
+
+
+def test_vae_decode_full_size_properties(device):
+    """C2's decode (13 x 60 x 90 latents -> 49 x 480 x 720) through size-independent properties of the published batched
+    decoder: later latent batches cannot change earlier frames (causal convolutions, per-batch GroupNorm: frames < 9 depend
+    on latent frames 0-2 only), run-to-run bit identity, and the fused uint8 writer == postprocess of the bf16 frames."""
+    from alg_amd.autoencoder_kl_cogvideox import AutoencoderKLCogVideoX
+    from oracle import vae_oracle
+    vae = AutoencoderKLCogVideoX.from_synthetic(device=device)
+    g = torch.Generator(device=device).manual_seed(2)
+    lat = torch.randn(1, 13, 16, 60, 90, generator=g, device=device).to(BF)
+    a = vae.decode_latents(lat)
+    assert a.shape == (1, 3, 49, 480, 720) and bool(torch.isfinite(a.float()).all())
+    assert torch.equal(vae.decode_latents(lat), a)
+    lat2 = lat.clone()
+    lat2[:, 5:] += 0.5                                   # latent batches: [0-2], [3-4], [5-6], ... -> frames 17.. change
+    b = vae.decode_latents(lat2)
+    assert torch.equal(b[:, :, :17], a[:, :, :17]) and not torch.equal(b[:, :, 17:25], a[:, :, 17:25])
+    u8 = vae.decode_latents(lat, to_uint8=True)
+    sl = slice(0, 49, 12)
+    assert torch.equal(u8[0, sl].cpu(), vae_oracle.postprocess_uint8(a[0][:, sl].cpu()))
+
+
+def test_text_and_image_encoders_full_size_properties(device):
+    """T5 v1.1 XXL at the CogVideoX prompt length (226, no mask), UMT5-width at Wan's 512 with a mask, ViT-H/14 at 257
+    tokens: finite, unit RMS after the final T5LayerNorm (synthetic gains ~ 1), padded tokens never reach valid rows."""
+    from alg_amd import CLIPVisionModel, T5EncoderConfig, T5EncoderModel, UMT5EncoderModel
+    t5 = T5EncoderModel.from_synthetic(T5EncoderConfig(num_layers=2), seed=1, device=device)   # XXL widths, 2 of 24 blocks
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 32128, (1, 226), generator=g).to(device)
+    out = t5(ids)[0]
+    assert out.shape == (1, 226, 4096) and bool(torch.isfinite(out.float()).all())
+    rms = out.float().pow(2).mean(-1).sqrt()
+    assert 0.9 < rms.mean().item() < 1.1
+    um = UMT5EncoderModel.from_synthetic(T5EncoderConfig(num_layers=2, vocab_size=4096), seed=2, device=device)
+    ids = torch.randint(0, 4096, (2, 512), generator=g)
+    mask = torch.ones(2, 512, dtype=torch.long)
+    mask[0, 40:] = 0
+    mask[1, 300:] = 0
+    x = um(ids.to(device), mask.to(device)).last_hidden_state
+    ids2 = ids.clone()
+    ids2[mask == 0] = 5
+    y = um(ids2.to(device), mask.to(device)).last_hidden_state
+    keep = mask.bool().to(device)
+    assert torch.equal(x[keep], y[keep]) and bool(torch.isfinite(x.float()).all())
+    from alg_amd.image_encoder_clip import CLIPVisionEncoderConfig
+    clip = CLIPVisionModel.from_synthetic(CLIPVisionEncoderConfig(num_hidden_layers=3), seed=3, device=device)
+    px = torch.randn(1, 3, 224, 224, generator=g).to(device)
+    hs = clip(pixel_values=px, output_hidden_states=True).hidden_states
+    assert len(hs) == 4 and hs[-2].shape == (1, 257, 1280) and bool(torch.isfinite(hs[-2].float()).all())
