@@ -55,6 +55,11 @@ struct AttnP {
   int batch, heads, S, q_blocks;
   int64_t q_bs, q_rs, vt_bs, vt_rs, o_bs, o_rs;
   float scale_log2;  // scale * log2(e)
+  // split-KV tail (see alg_flash_attn_d64): the last `tail_units` (head, q block) units of every XCD are cut into
+  // `tail_split` KV chunks of `tail_tiles` KV tiles each; chunk results go to a workspace and are merged by a second kernel
+  int unit0, tail_units, tail_split, tail_tiles;
+  float* ws_o;   // [8 * tail_units][tail_split][q rows per block][64] fp32, unnormalised
+  float* ws_ml;  // [8 * tail_units][tail_split][q rows per block][2]: running max (raw score units), row sum
 };
 
 struct Frag {
@@ -171,8 +176,9 @@ __device__ __forceinline__ void pv_tile(const char* Vs, const bf16x8 (&pf)[4], c
 // NW = waves per workgroup (8 or 4).  With 4 waves a workgroup puts ONE wave on each SIMD, so the waves that share a
 // SIMD belong to different workgroups and are not phase-locked by the per-tile barrier (one runs MFMAs while the
 // other runs its softmax); the price is that K/V^T tiles are staged once per 128 instead of 256 queries.
-template <int VARIANT, int NW = 8>
+template <int VARIANT, int NW = 8, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d64_kernel(const AttnP p) {
+  static_assert(!SPLIT || (VARIANT == 1 && NW == 8), "the split-KV tail is built on the default variant");
   constexpr int ROUNDS = NW >= 8 ? 1 : 8 / NW;  // DMA rounds per 8 KiB tile (one round = min(NW, 8) KiB)
   constexpr int DW = NW >= 8 ? 8 : NW;           // waves that issue DMA (a 16-wave workgroup only needs half)
   constexpr int K_SLOTS = VARIANT == 2 ? 3 : 2;
@@ -187,9 +193,17 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
   // ---- workgroup -> (batch*head, q block): XCD x walks heads x, x+8, ... ----
   const int nbh = p.batch * p.heads;
   int bh, qb;
+  int part = 0, chunk = 0;  // SPLIT: workspace slot of this (unit, chunk)
   {
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, idx = bid >> 3;
+    const int xcd = bid & 7;
+    int idx = bid >> 3;
+    if (SPLIT) {  // the tail launch: block j of an XCD = chunk j % split of tail unit j / split
+      chunk = idx % p.tail_split;
+      const int u = idx / p.tail_split;
+      part = xcd * p.tail_units + u;
+      idx = p.unit0 + u;
+    }
     const int slot = idx / p.q_blocks;
     qb = idx - slot * p.q_blocks;
     bh = slot * 8 + xcd;
@@ -356,17 +370,22 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
     // no barrier 8.62 | no exp2 7.95 | no DMA/LDS/exp2 5.30 (MFMA floor at the sustained clock ~3.9)
     constexpr int ABL = VARIANT >= 16 ? VARIANT - 16 : 0;
     constexpr int NOEXP = VARIANT == 10 ? 1 : (VARIANT == 11 || (ABL & 4)) ? 2 : 0;
-    stage_k(0, 0);
-    stage_v(0, 0);
+    // SPLIT: this workgroup owns KV tiles [t0, t1) of its unit only
+    const int t0 = SPLIT ? min(chunk * p.tail_tiles, n_tiles) : 0;
+    const int t1 = SPLIT ? min(t0 + p.tail_tiles, n_tiles) : n_tiles;
+    if (!SPLIT || t0 < t1) {
+      stage_k(t0 & 1, t0 * KVB);
+      stage_v(t0 & 1, t0 * KVB);
+    }
     constexpr bool PEEL = VARIANT == 13;  // the ragged last tile runs in its own copy of the body: hipcc otherwise
                                           // if-converts the tail mask into 32 v_cndmask on EVERY tile
-    const int n_loop = (PEEL && ragged) ? n_tiles - 1 : n_tiles;
-    for (int t = 0; t < n_loop; ++t) {
+    const int n_loop = (PEEL && ragged) ? n_tiles - 1 : t1;
+    for (int t = t0; t < n_loop; ++t) {
       if (!(ABL & 8) || t == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
-      if (t + 1 < n_tiles && !(ABL & 1)) {
+      if (t + 1 < t1 && !(ABL & 1)) {
         stage_k((t + 1) & 1, (t + 1) * KVB);
         stage_v((t + 1) & 1, (t + 1) * KVB);
       }
@@ -423,6 +442,18 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
 
   // ---- finish: combine the half-waves' sums, normalise, store O[q][d] ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (SPLIT) {  // partial result of this KV chunk: unnormalised O, running max, row sum
+    const int64_t row = ((int64_t)part * p.tail_split + chunk) * (NW * 32) + wave * 32 + l31;
+    float* wo = p.ws_o + row * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(float4*)(wo + dt * 32 + 8 * g + 4 * h2) =
+            make_float4(o_acc[dt][4 * g], o_acc[dt][4 * g + 1], o_acc[dt][4 * g + 2], o_acc[dt][4 * g + 3]);
+    if (h2 == 0) *(float2*)(p.ws_ml + row * 2) = make_float2(m_run, l_tot);
+    return;
+  }
   const float inv = 1.0f / l_tot;
   if (q_row < S) {
     bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + h * 64;
@@ -1084,6 +1115,65 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d64_duo_kernel(const At
   }
 }
 
+// Merge of the split-KV tail: O = sum_c 2^((m_c - M) c) O_c / sum_c 2^((m_c - M) c) l_c.  One thread = 4 output values.
+__global__ __launch_bounds__(256) void flash_attn_d64_merge_kernel(const AttnP p) {
+  constexpr int QBR = 256;  // query rows per unit (8 waves x 32)
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)8 * p.tail_units * QBR * 16;
+  if (e >= total) return;
+  const int d4 = (int)(e & 15);
+  const int row = (int)((e >> 4) % QBR);
+  const int part = (int)(e / (16 * QBR));
+  const int xcd = part / p.tail_units, u = part - xcd * p.tail_units;
+  const int idx = p.unit0 + u;
+  const int slot = idx / p.q_blocks, qb = idx - slot * p.q_blocks;
+  const int bh = slot * 8 + xcd;
+  const int q_row = qb * QBR + row;
+  if (bh >= p.batch * p.heads || q_row >= p.S) return;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int64_t base = (int64_t)part * p.tail_split * QBR + row;
+  float M = -INFINITY;
+  for (int c = 0; c < p.tail_split; ++c) M = fmaxf(M, p.ws_ml[(base + (int64_t)c * QBR) * 2]);
+  float L = 0.0f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < p.tail_split; ++c) {
+    const int64_t r = base + (int64_t)c * QBR;
+    const float2 ml = *(const float2*)(p.ws_ml + r * 2);
+    if (ml.y == 0.0f) continue;  // empty chunk
+    const float w = __builtin_amdgcn_exp2f((ml.x - M) * p.scale_log2);
+    const float4 o = *(const float4*)(p.ws_o + r * 64 + d4 * 4);
+    L += w * ml.y;
+    acc.x += w * o.x, acc.y += w * o.y, acc.z += w * o.z, acc.w += w * o.w;
+  }
+  const float inv = 1.0f / L;
+  uint2 v;
+  v.x = pack_bf2(acc.x * inv, acc.y * inv);
+  v.y = pack_bf2(acc.z * inv, acc.w * inv);
+  *(uint2*)(p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + h * 64 + d4 * 4) = v;
+}
+
+// Workgroup-count quantisation (measured, scripts/attn_tail_probe.py): every XCD runs 64 workgroups at a time (32 CUs x
+// 2), a workgroup takes ~0.64 ms at S = 17,776, and a 2-sample C2 launch is 840 units per XCD = 13.125 rounds: the
+// fourteenth round keeps 8 of 64 slots busy and costs 1.5-5 % of the launch depending on the box.  When the last round is at most 1/4 full its units
+// are cut along KV instead: tail_units x split chunk-workgroups fill the slots, then one small merge kernel.
+struct TailPlan {
+  int units, split, tiles;
+};
+static TailPlan plan_tail(int nbh, int q_blocks, int n_tiles) {
+  TailPlan t = {0, 0, 0};
+  const char* e = getenv("ALG_ATTN_SPLIT_TAIL");  // "0" disables (A/B runs and parity tests)
+  if (e && e[0] == '0') return t;
+  if (nbh % 8) return t;  // heads spread unevenly over the XCDs: a different imbalance, not this one
+  const int slots = 64;
+  const int per_xcd = nbh / 8 * q_blocks;
+  const int r = per_xcd % slots;
+  if (per_xcd < slots || r == 0 || r > 16 || n_tiles < 64) return t;  // fuller last rounds gain little
+  t.units = r;
+  t.split = (r * 8) % slots == 0 ? 8 : 16;
+  t.tiles = (n_tiles + t.split - 1) / t.split;
+  return t;
+}
+
 // default = the fastest measured variant; ALG_ATTN_VARIANT (read per call) overrides it for A/B runs and tests
 static int attn_variant() {
   const char* e = getenv("ALG_ATTN_VARIANT");
@@ -1125,8 +1215,33 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
   p.scale_log2 = scale * 1.4426950408889634f;
   const int nbh = batch * heads;
   const int64_t grid = (int64_t)((nbh + 7) / 8) * 8 * p.q_blocks;
-  const dim3 g((unsigned)grid), blk(nw * 64);
+  const dim3 blk(nw * 64);
   hipStream_t s = (hipStream_t)stream;
+  p.unit0 = p.tail_units = p.tail_split = p.tail_tiles = 0;
+  p.ws_o = p.ws_ml = nullptr;
+  if (variant == 1) {
+    const TailPlan tp = plan_tail(nbh, p.q_blocks, (S + KVB - 1) / KVB);
+    if (tp.units) {
+      const int per_xcd = nbh / 8 * p.q_blocks;
+      p.unit0 = per_xcd - tp.units, p.tail_units = tp.units, p.tail_split = tp.split, p.tail_tiles = tp.tiles;
+      const size_t rows = (size_t)8 * tp.units * tp.split * 256;
+      float* ws = nullptr;
+      hipError_t e = hipMallocAsync((void**)&ws, rows * 66 * sizeof(float), s);
+      if (e != hipSuccess) {
+        set_error("alg_flash_attn_d64: split-KV workspace (%zu bytes): %s", rows * 66 * sizeof(float), hipGetErrorString(e));
+        return ALG_ELAUNCH;
+      }
+      p.ws_o = ws, p.ws_ml = ws + rows * 64;
+      hipLaunchKernelGGL(flash_attn_d64_kernel<1>, dim3((unsigned)(8 * p.unit0)), blk, 0, s, p);
+      hipLaunchKernelGGL((flash_attn_d64_kernel<1, 8, true>), dim3((unsigned)(8 * tp.units * tp.split)), blk, 0, s, p);
+      const int64_t merge = (int64_t)8 * tp.units * 256 * 16;
+      hipLaunchKernelGGL(flash_attn_d64_merge_kernel, dim3((unsigned)((merge + 255) / 256)), dim3(256), 0, s, p);
+      const int rc = check_launch("alg_flash_attn_d64");
+      (void)hipFreeAsync(ws, s);
+      return rc;
+    }
+  }
+  const dim3 g((unsigned)grid);
   switch (variant) {
     case 0: hipLaunchKernelGGL(flash_attn_d64_kernel<0>, g, blk, 0, s, p); break;
     case 1: hipLaunchKernelGGL(flash_attn_d64_kernel<1>, g, blk, 0, s, p); break;

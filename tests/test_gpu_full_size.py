@@ -82,10 +82,11 @@ def test_gemm_full_shapes_vs_torch(device):
     assert (vt[:, pos].float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
 
 
-def test_dit_full_width_two_layers_consistency(device):
+def test_dit_full_width_two_layers_consistency(device, monkeypatch):
     """Full C2 token count and width, 2 of the 42 layers: deterministic, finite, and a sample's prediction does not
-    depend on its position in the CFG batch or on the batch size (N = 2 vs N = 3) -- the property the 2-/3-pass loop
-    relies on."""
+    depend on its position in the CFG batch or on the batch size (N = 2 vs N = 3): bit for bit with one attention
+    schedule (ALG_ATTN_SPLIT_TAIL=0), and to bf16 rounding with the default one, whose split-KV tail sums the last
+    few (head, q-block) units of a launch in a launch-shape dependent order."""
     cfg = CogVideoXTransformerConfig(num_layers=2)
     model = CogVideoXTransformer3DModel.from_synthetic(cfg, seed=7, device=device)
     g = torch.Generator().manual_seed(3)
@@ -99,6 +100,12 @@ def test_dit_full_width_two_layers_consistency(device):
     out3 = model.forward_assembled(lat, [c0, c1, c1], torch.cat([ne, ne, pe]), ts3, rope)
     out2 = model.forward_assembled(lat, [c1, c1], torch.cat([ne, pe]), ts2, rope)
     assert out3.shape == (3, 13, 16, 60, 90) and torch.isfinite(out3.float()).all()
+    for a, b in ((out3[1], out2[0]), (out3[2], out2[1])):
+        r = ((a.float() - b.float()).norm() / b.float().norm()).item()
+        assert r < 1e-2, r
+    monkeypatch.setenv("ALG_ATTN_SPLIT_TAIL", "0")
+    out3 = model.forward_assembled(lat, [c0, c1, c1], torch.cat([ne, ne, pe]), ts3, rope)
+    out2 = model.forward_assembled(lat, [c1, c1], torch.cat([ne, pe]), ts2, rope)
     assert torch.equal(out3[1], out2[0]) and torch.equal(out3[2], out2[1])
     assert not torch.equal(out3[0], out3[1])  # the sharp and the low-passed condition give different predictions
     again = model.forward_assembled(lat, [c0, c1, c1], torch.cat([ne, ne, pe]), ts3, rope)
@@ -197,3 +204,36 @@ def test_text_and_image_encoders_full_size_properties(device):
     px = torch.randn(1, 3, 224, 224, generator=g).to(device)
     hs = clip(pixel_values=px, output_hidden_states=True).hidden_states
     assert len(hs) == 4 and hs[-2].shape == (1, 257, 1280) and bool(torch.isfinite(hs[-2].float()).all())
+
+
+def test_attention_split_kv_tail_matches_the_unsplit_kernel(device, monkeypatch):
+    """2-sample C2 launch: 840 (head, q-block) units per XCD = 13.125 rounds of 64 slots, so the last 8 units per XCD are
+    cut into 8 KV chunks + a merge.  Same softmax, different fp32 summation order: rows of the tail units agree with the
+    unsplit kernel to bf16 rounding, all other rows are bit-identical."""
+    g = torch.Generator(device=device).manual_seed(5)
+    N, heads = 2, 48
+    Dh = heads * 64
+    S_pad = (S + 127) // 128 * 128
+    qk = torch.randn(N, S, 2 * Dh, generator=g, device=device).to(BF)
+    vt = torch.randn(N, Dh, S_pad, generator=g, device=device).to(BF)
+    vt[:, :, S:] = 0
+    run = lambda: _lib.flash_attn_d64(qk, qk, vt, torch.empty(N, S, Dh, dtype=BF, device=device), N, heads, S,
+                                      S * 2 * Dh, 2 * Dh, Dh * S_pad, S_pad, S * Dh, Dh, 0.125, k_off=Dh)
+
+    def call():
+        out = torch.empty(N, S, Dh, dtype=BF, device=device)
+        _lib.flash_attn_d64(qk, qk, vt, out, N, heads, S, S * 2 * Dh, 2 * Dh, Dh * S_pad, S_pad, S * Dh, Dh, 0.125, k_off=Dh)
+        return out
+
+    monkeypatch.setenv("ALG_ATTN_SPLIT_TAIL", "0")
+    ref = call()
+    monkeypatch.delenv("ALG_ATTN_SPLIT_TAIL")
+    got = call()
+    assert bool(torch.isfinite(got.float()).all())
+    same = (got == ref).reshape(N, S, heads, 64).all(dim=3)                 # [N, S, heads]
+    # tail units: per XCD the last 8 of 840 units = q blocks 62..69 of the last (batch, head) slot of that XCD
+    assert bool(same[0].all()) and bool(same[1, :, :40].all()) and bool(same[1, :62 * 256].all())
+    tail = (got.float() - ref.float())[1, 62 * 256:, 40:]
+    scale = ref.float()[1, 62 * 256:, 40:].abs().max().item()
+    assert tail.abs().max().item() <= 2.0 ** -7 * scale and not bool(same[1, 62 * 256:, 40:].all())
+    assert torch.equal(call(), got)                                          # deterministic
