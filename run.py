@@ -123,9 +123,15 @@ def main(args):
     video_frames = frames[0]
     logger.info(f"Video generation complete. Received {len(video_frames)} frames.")
     import numpy as np
-    arr = np.stack([np.asarray(f) for f in video_frames])  # [T, H, W, C] uint8
-    np.save(args.output_path, arr)  # the h264 writer (torchvision/PyAV) is outside the hot path and not installed
-    logger.info(f"Saved frames array {arr.shape} (fps {config['video']['fps']}) to: {args.output_path}")
+    from alg_amd import video_io
+    arr = np.stack([np.asarray(f) for f in video_frames])  # [T, H, W, C] uint8 (run.py:121-125)
+    out_path = args.output_path
+    if out_path.lower().endswith(".mp4"):
+        # run.py:127-133 writes h264 through torchvision / PyAV; no such encoder exists here -> Motion-JPEG AVI next to it
+        out_path = out_path[:-4] + ".avi"
+        logger.info("no h264 encoder in this environment: writing Motion-JPEG AVI instead of mp4")
+    video_io.write_video(out_path, arr, fps=config["video"]["fps"])
+    logger.info(f"Saved {arr.shape} frames (fps {config['video']['fps']}) to: {out_path}")
 
 
 if __name__ == "__main__":

@@ -260,3 +260,26 @@ def test_dpm_scheduler_scalars_match_the_oracle():
     g = torch.Generator().manual_seed(1)
     nxt, x0 = o.step(torch.zeros_like(x), None, ts[49], ts[48], x, generator=g)
     assert torch.allclose(nxt, x0)                                    # alpha_prev = 1: the last step returns x0 (no noise)
+
+
+def test_output_writer_round_trips(tmp_path):
+    """run:121-133 stand-in (no h264 encoder here): npy exact, Motion-JPEG AVI decodes back close to the frames, PNG
+    directory exact, mp4 refuses loudly."""
+    from alg_amd import video_io
+    yy, xx = np.mgrid[0:48, 0:64]
+    frames = np.stack([np.stack([(xx * 4 + 8 * t) % 256, (yy * 5) % 256, (xx + yy + t) % 256], -1) for t in range(5)]).astype(np.uint8)
+    p = video_io.write_video(str(tmp_path / "v.npy"), frames)
+    assert np.array_equal(np.load(p), frames)
+    p = video_io.write_video(str(tmp_path / "v.avi"), torch.from_numpy(frames), fps=8)
+    back = video_io.read_mjpeg_avi(p)
+    assert back.shape == frames.shape
+    mse = ((back.astype(np.float32) - frames.astype(np.float32)) ** 2).mean()
+    assert 10 * np.log10(255.0 ** 2 / mse) > 28.0
+    d = video_io.write_video(str(tmp_path / "frames"), frames)
+    from PIL import Image
+    assert sorted(os.listdir(d))[0] == "frame_00000.png" and np.array_equal(np.asarray(Image.open(os.path.join(d, "frame_00003.png"))), frames[3])
+    video_io.write_video(str(tmp_path / "v.gif"), frames)
+    with pytest.raises(RuntimeError, match="h264"):
+        video_io.write_video(str(tmp_path / "v.mp4"), frames)
+    with pytest.raises(ValueError, match="uint8"):
+        video_io.write_video(str(tmp_path / "w.npy"), frames.astype(np.float32))
