@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <atomic>
 #include <stdio.h>
 
 #include "../../include/alg_hip.h"

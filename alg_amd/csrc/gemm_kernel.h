@@ -709,7 +709,7 @@ using namespace alg;
 
 template <int PIPE, int WNW = 4, bool FP8 = false>
 int launch_gemm(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s) {
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};  // idempotent one-time setup; racing first calls both succeed
   if (!attr_set) {
     const void* fns[4] = {(const void*)gemm_bf16_kernel<ALG_ACT_NONE, true, PIPE, WNW, FP8>,
                           (const void*)gemm_bf16_kernel<ALG_ACT_GELU_TANH, false, PIPE, WNW, FP8>,

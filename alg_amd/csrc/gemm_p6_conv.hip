@@ -3,7 +3,7 @@
 
 namespace alg {
 int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s) {
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};  // idempotent one-time setup; racing first calls both succeed
   if (!attr_set) {
     const void* fns[2] = {(const void*)gemm_bf16_kernel<ALG_ACT_NONE, true, 6, 4, false, true>,
                           (const void*)gemm_bf16_kernel<ALG_ACT_NONE, false, 6, 4, false, true>};

@@ -210,7 +210,7 @@ extern "C" int alg_attn_bias(const void* q, const void* k, const void* v, void* 
     set_error("alg_attn_bias: null pointer");
     return ALG_EINVAL;
   }
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};  // idempotent one-time setup; racing first calls both succeed
   if (!attr_set) {
     for (const void* fn : {(const void*)t5::attn_bias_kernel<64>, (const void*)t5::attn_bias_kernel<80>}) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
