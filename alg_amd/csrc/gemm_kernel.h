@@ -106,18 +106,13 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WNW, wn = wave % WNW;
 
-  // ---- workgroup -> (batch, m_tile, n_tile): XCD-contiguous, grouped along M ----
-  int wg;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
   // debug-only ablation bits ride in the upper half of group_m (ALG_GEMM_ABLATE: 1 = no DMA after the prologue,
   // 2 = no LDS fragment reads in the PIPE 3 main loop); results are garbage, timing shows what the loop is bound by
   const int abl = group_m >> 16;
   group_m &= 0xffff;
   const int tiles = m_tiles * n_tiles;
+  // one output tile; the kernel is persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (see the loop at the end)
+  auto do_tile = [&](const int wg) {
   const int b = wg / tiles;
   int t = wg - b * tiles;
   const int grp = t / (group_m * n_tiles);
@@ -547,6 +542,22 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
       park_band(IntC<2>{});
       park_band(IntC<3>{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave reads back only what it wrote itself
+      // The residual may alias C (in-place update), so hipcc keeps every R load behind the previous iteration's store:
+      // sixteen serialised HBM round trips per tile (measured: 21.7 us of per-tile overhead with a residual vs 6.9 us
+      // without, scripts/gemm_k_sweep.py).  A thread reads exactly the elements it later writes, so all sixteen loads
+      // can go out first; the accumulators are parked, their registers are free.
+      uint4 rbuf[RES ? 16 : 1];
+      if (RES) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int blk = it >> 1, mt = blk >> 1, nt = blk & 1;
+          const int rr = (it & 1) * 16 + (lane >> 2), ch = lane & 3;
+          const int row = m0 + (mt >> 1) * 128 + wm * 64 + (mt & 1) * 32 + rr;
+          const int c0 = n0 + nt * 128 + wn * 32 + ch * 8;
+          rbuf[it] = (row < p.M && c0 < p.N) ? *(const uint4*)(R + row * ldr + c0) : make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int blk = it >> 1, mt = blk >> 1, nt = blk & 1;
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
           if (RES) {
             float x[8], r[8], gq[8];
             const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
-            const uint4 rraw = *(const uint4*)(R + row * ldr + c0);
+            const uint4 rraw = rbuf[it];
             const uint32_t ru[4] = {rraw.x, rraw.y, rraw.z, rraw.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -688,12 +699,42 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
   epilogue_band(IntC<1>{});
   epilogue_band(IntC<2>{});
   epilogue_band(IntC<3>{});
+  };  // do_tile
+
+  // ---- logical workgroup -> (batch, m_tile, n_tile): XCD-contiguous, grouped along M ----
+  // Logical index L keeps its XCD (gridDim.x is a multiple of 8 when the launch is persistent), so the per-XCD tile
+  // order -- and with it the L2 reuse -- is the one a full grid would have.
+  const int total_wg = tiles * p.batch;
+  for (int L = blockIdx.x; L < total_wg; L += gridDim.x) {
+    const int xcd = L & 7, q = total_wg >> 3, r = total_wg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    if (L != (int)blockIdx.x) __syncthreads();  // the previous tile's epilogue is done with the LDS ring
+    do_tile(wg);
+  }
 }
 
 inline int gemm_pipe() {
   const char* e = getenv("ALG_GEMM_PIPE");
   const int v = e ? atoi(e) : 6;  // default: 8-wave ping-pong over half-tiles (fastest measured)
   return (v == 0 || v == 6 || v == 7) ? v : 6;
+}
+
+// persistent launch: one workgroup per CU walks the tile list (saves a workgroup launch + teardown per tile: at K = 3072
+// a tile's main loop is only ~80 us).  ALG_GEMM_PERSIST=0 launches one workgroup per tile as before.
+inline unsigned gemm_grid(int64_t nwg) {
+  static std::atomic<int> cus{0};
+  int n = cus.load();
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    n &= ~7;
+    if (n < 8) n = 8;
+    cus.store(n);
+  }
+  const char* e = getenv("ALG_GEMM_PERSIST");
+  if (e && e[0] == '0') return (unsigned)nwg;
+  return (unsigned)(nwg < n ? nwg : n);
 }
 
 inline int gemm_group_m() {
@@ -724,7 +765,7 @@ int launch_gemm(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, h
     }
     attr_set = true;
   }
-  const dim3 grid((unsigned)nwg), block(2 * WNW * 64);
+  const dim3 grid(gemm_grid(nwg)), block(2 * WNW * 64);
   const int gm = gemm_group_m();
   if (a->R) {
     hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, true, PIPE, WNW, FP8>), grid, block, GEMM_LDS, s, *a, m_tiles,
