@@ -64,24 +64,31 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
   }
 }
 
-__global__ __launch_bounds__(64) void gn_final_kernel(const float* __restrict__ partial, float* __restrict__ stats,
-                                                      const alg_vae_geom g, int nsplit, float eps) {
-  const int seg = blockIdx.x, grp = threadIdx.x;
-  if (grp >= 32) return;
+// one block per segment: thread (grp, lane) sums a fixed strided subset of the partials in double, then a fixed-order
+// tree over the 8 lanes of a group -- deterministic, and 8x the memory parallelism of one thread per group
+__global__ __launch_bounds__(256) void gn_final_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                                       const alg_vae_geom g, int nsplit, float eps) {
+  const int seg = blockIdx.x, grp = threadIdx.x >> 3, ln = threadIdx.x & 7;
   const int f0 = seg == 0 ? 0 : g.first_len + (seg - 1) * g.seg_len;
   const int f1 = min(seg == 0 ? g.first_len : f0 + g.seg_len, g.frames);
+  const int n_part = (f1 - f0) * nsplit;
   double s = 0.0, q = 0.0;
-  for (int t = f0; t < f1; ++t)
-    for (int sp = 0; sp < nsplit; ++sp) {
-      const float* p = partial + ((int64_t)(t * nsplit + sp) * 32 + grp) * 2;
-      s += (double)p[0], q += (double)p[1];
-    }
-  const double n = (double)(f1 - f0) * g.H * g.W * (g.C >> 5);
-  const double mean = s / n;
-  double var = q / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  stats[(seg * 32 + grp) * 2] = (float)mean;
-  stats[(seg * 32 + grp) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  for (int i = ln; i < n_part; i += 8) {
+    const float* p = partial + ((int64_t)(f0 * nsplit + i) * 32 + grp) * 2;
+    s += (double)p[0], q += (double)p[1];
+  }
+  __shared__ double red[256][2];
+  red[threadIdx.x][0] = s, red[threadIdx.x][1] = q;
+  __syncthreads();
+  if (ln == 0) {
+    for (int j = 1; j < 8; ++j) s += red[threadIdx.x + j][0], q += red[threadIdx.x + j][1];
+    const double n = (double)(f1 - f0) * g.H * g.W * (g.C >> 5);
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(seg * 32 + grp) * 2] = (float)mean;
+    stats[(seg * 32 + grp) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 // ---- CogVideoXSpatialNorm3D + SiLU: virtual -> padded ----
@@ -114,8 +121,9 @@ __global__ __launch_bounds__(256) void spatial_norm_kernel(const bf16_t* __restr
     zrow = zyb + (((int64_t)(lt + 2) * lhp + ly + 1) * lwp + 1) * (2 * g.C);
   }
   const int gs = g.C >> 5;  // channels per group: 4, 8, 16
+  const int csh = __builtin_ctz((unsigned)chunks);  // C is a power of two: no integer division per item
   for (int i = threadIdx.x; i < items; i += 256) {
-    const int xp = i / chunks, chunk = i - xp * chunks;
+    const int xp = i >> csh, chunk = i & (chunks - 1);
     const int xx = xp - 1;
     uint4 o = make_uint4(0, 0, 0, 0);
     if (xx >= 0 && xx < g.W) {
@@ -271,7 +279,7 @@ extern "C" int alg_vae_groupnorm_stats(const void* x, const alg_vae_geom* g, flo
   const int nseg = g->frames <= g->first_len ? 1 : 1 + (g->frames - g->first_len + g->seg_len - 1) / g->seg_len;
   hipLaunchKernelGGL(vae::gn_partial_kernel, dim3(ns, g->frames), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (float*)workspace, *g, ns);
-  hipLaunchKernelGGL(vae::gn_final_kernel, dim3(nseg), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, stats,
+  hipLaunchKernelGGL(vae::gn_final_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, stats,
                      *g, ns, eps);
   return check_launch("alg_vae_groupnorm_stats");
 }
@@ -311,8 +319,8 @@ extern "C" int alg_vae_group_norm(const void* x, const float* stats, const void*
 }
 
 extern "C" int alg_vae_pad(const void* x, void* out, int frames, int H, int W, int C, void* stream) {
-  if (frames <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || !x || !out) {
-    set_error("alg_vae_pad: bad argument");
+  if (frames <= 0 || H <= 0 || W <= 0 || C < 8 || (C & (C - 1)) || !x || !out) {
+    set_error("alg_vae_pad: bad argument (C must be a power of two >= 8)");
     return ALG_EINVAL;
   }
   alg_vae_geom g = {};
