@@ -271,3 +271,27 @@ def test_cogvideox_1_5_sampler_pads_frames_and_matches_the_loop_oracle(device):
                                        image_rotary_emb=rope, **kw)
     r = rel(out.float().cpu(), ref.float())
     assert r < 5e-2, r
+
+
+def test_sampler_batch_of_two_prompts_equals_two_runs(device):
+    """cog:929-937, 1060-1070: two prompts in one call -> CFG batches of 4 / 6 samples; each video must come out exactly as
+    in its own call (same latents, embeddings and condition): rows of every kernel are independent of the batch."""
+    ocfg, w, model = make_pair(device, seed=12)
+    pipe = CogVideoXImageToVideoPipeline(transformer=model, scheduler=CogVideoXDDIMScheduler()).to(device)
+    g = torch.Generator().manual_seed(21)
+    Fr, C, H, W = 3, 8, 8, 12
+    latents = torch.randn(2, Fr, C, H, W, generator=g).to(BF)
+    first = (torch.randn(2, 1, C, H, W, generator=g) * 0.7).to(BF)
+    pe, ne = torch.randn(2, 10, 128, generator=g).to(BF), torch.randn(2, 10, 128, generator=g).to(BF)
+    kw = dict(num_inference_steps=3, guidance_scale=6.0, use_low_pass_guidance=True, lp_filter_type="down_up",
+              lp_resize_factor=0.25, lp_strength_schedule_type="interval", schedule_interval_start_time=0.0,
+              schedule_interval_end_time=0.4, height=H * 8, width=W * 8, num_frames=9, output_type="latent",
+              lp_filter_in_latent=True, image=None)
+    trace = []
+    both = pipe(image_latents=first, latents=latents, prompt_embeds=pe, negative_prompt_embeds=ne, step_trace=trace,
+                **kw).frames
+    assert both.shape == (2, Fr, C, H, W) and [n for _, _, n in trace] == [6, 4, 4]
+    for b in range(2):
+        one = pipe(image_latents=first[b:b + 1], latents=latents[b:b + 1], prompt_embeds=pe[b:b + 1],
+                   negative_prompt_embeds=ne[b:b + 1], **kw).frames
+        assert torch.equal(one[0], both[b]), b
