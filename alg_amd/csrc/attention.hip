@@ -665,8 +665,12 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void flash_attn_d64_lean_kernel(con
           f32x2v pp;
           pp[0] = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j]);
           pp[1] = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j + 1]);
-          psum2 += pp;
           pk.u[j] = pack_bf2(pp[0], pp[1]);
+          {  // row sum of the rounded pair in one v_dot2c_f32_bf16 (see variant 32)
+            typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+            psum2[0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk.u[j]),
+                                                      __builtin_bit_cast(bf2v, 0x3f803f80u), psum2[0], false);
+          }
         }
         pf[sub * 2 + g] = pk.v;
       }
