@@ -167,8 +167,13 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
           const f32x2p sv = {s[sub][8 * g + 2 * j], s[sub][8 * g + 2 * j + 1]};
           const f32x2p x = __builtin_elementwise_fma(sv, c2, -mc2);
           const f32x2p pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-          ps2 += pv;  // row sum over the unrounded fp32 probabilities
           pk.u[j] = pack_bf2(pv.x, pv.y);
+          {  // row sum of the rounded pair in one v_dot2c_f32_bf16 (16 instead of 32 VALU adds per tile; sums the
+             // probabilities the PV MFMA actually uses -- see attention.hip variant 32)
+            typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+            ps2.x = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk.u[j]),
+                                                   __builtin_bit_cast(bf2v, 0x3f803f80u), ps2.x, false);
+          }
         }
         pf[sub * 2 + g] = pk.v;
       }
