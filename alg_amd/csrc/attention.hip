@@ -28,9 +28,11 @@
 //       v_permlane32_swap max exchange: no exposed LDS round trip left in the loop
 //   15/16  "duo": two 32-query streams per wave sharing every fragment read, one stream's MFMAs interleaved with the
 //       other's softmax by sched_group_barrier (8 / 4 waves per workgroup)
-//   32  (DEFAULT) variant 1 with the row sums taken by v_dot2c_f32_bf16 from the packed P pairs (16 instructions per
-//       tile instead of 32 adds; sums the bf16-rounded probabilities the PV MFMA uses): 925 -> 945 TFLOP/s on the same
-//       box; also the variant the split-KV tail launch is built on
+//   32  variant 1 with the row sums taken by v_dot2c_f32_bf16 from the packed P pairs (16 instructions per tile instead
+//       of 32 adds; sums the bf16-rounded probabilities the PV MFMA uses): 925 -> 945 TFLOP/s on the same box
+//   33  (DEFAULT) 32 + lazy running max (softmax_tile_lazy): no tile max in the common path, the exact max / rescale
+//       path runs only when a row sum leaves [0, 2^40): 919 -> 990 TFLOP/s on the same box; the split-KV tail launch is
+//       built on it
 // Measured on MI355X at the C2 shape (2 x 48 heads x 17,776 tokens, profiles/): 1: 860-915 TFLOP/s,
 // 0: 875, 2: 830, 3: 867, 4: 861, 5: 836, 6: 804, 7: 599, 8: 899, 9: 893, 12: 860, 13: 880, 14: 865, 15: 835, 16: 875.
 // All of them sit at 1225-1330 W with the clock pulled down to 1.9-2.2 GHz (profiles/r1_power_and_issue_rates.txt):
@@ -171,6 +173,52 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&s)[2], float c, floa
   l_run += psum;
 }
 
+// Lazy running max (variant 33).  Softmax is invariant to the subtracted offset, and fp32 / bf16 keep their relative
+// precision at any magnitude, so the offset only has to keep exp2 inside the exponent range: the probabilities are formed
+// against the CURRENT m (no tile max: 23 VALU instructions saved per tile) and the exact path -- tile max, grow m, rescale
+// O and l, recompute -- runs only when a tile's row sum leaves [0, 2^40) (inf on the first tile, where m = -inf; NaN if
+// a masked score meets m = -inf).  m is then always a max actually seen, so nothing that matters can underflow.
+__device__ __forceinline__ void softmax_tile_lazy(const f32x16 (&s)[2], float c, float& m_run, float& l_run,
+                                                  f32x16 (&o_acc)[2], bf16x8 (&pf)[4]) {
+  typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+  auto probs = [&](float mc) -> float {
+    float psum = 0.0f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p0 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j] * c - mc);
+          const float p1 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j + 1] * c - mc);
+          pk.u[j] = pack_bf2(p0, p1);
+          psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk.u[j]), __builtin_bit_cast(bf2v, 0x3f803f80u),
+                                                 psum, false);
+        }
+        pf[sub * 2 + g] = pk.v;
+      }
+    return psum;
+  };
+  float psum = probs(m_run * c);
+  if (__any(!(psum < 1.0995116e12f))) {  // 2^40; also true for inf and NaN
+    float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    m_run = m_new;
+    l_run *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+    psum = probs(m_run * c);
+  }
+  l_run += psum;
+}
+
 // O^T += V^T P^T for one 64-row tile
 template <bool NOLDS = false>
 __device__ __forceinline__ void pv_tile(const char* Vs, const bf16x8 (&pf)[4], const Frag f, f32x16 (&o_acc)[2]) {
@@ -189,7 +237,7 @@ __device__ __forceinline__ void pv_tile(const char* Vs, const bf16x8 (&pf)[4], c
 // other runs its softmax); the price is that K/V^T tiles are staged once per 128 instead of 256 queries.
 template <int VARIANT, int NW = 8, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d64_kernel(const AttnP p) {
-  static_assert(!SPLIT || (VARIANT == 32 && NW == 8), "the split-KV tail is built on the default variant");
+  static_assert(!SPLIT || (VARIANT == 33 && NW == 8), "the split-KV tail is built on the default variant");
   constexpr int ROUNDS = NW >= 8 ? 1 : 8 / NW;  // DMA rounds per 8 KiB tile (one round = min(NW, 8) KiB)
   constexpr int DW = NW >= 8 ? 8 : NW;           // waves that issue DMA (a 16-wave workgroup only needs half)
   constexpr int K_SLOTS = VARIANT == 2 ? 3 : 2;
@@ -379,7 +427,7 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
     // bits 1 no DMA after tile 0, 2 no LDS fragment reads, 4 no exp2, 8 no per-tile wait + barrier.  Round-1 readings
     // at the C2 shape (ms per 2-sample launch): full 8.75 | no DMA 7.62 | no LDS reads 6.76 | neither 6.10 |
     // no barrier 8.62 | no exp2 7.95 | no DMA/LDS/exp2 5.30 (MFMA floor at the sustained clock ~3.9)
-    constexpr int ABL = (VARIANT >= 16 && VARIANT < 32) ? VARIANT - 16 : 0;
+    constexpr int ABL = (VARIANT >= 16 && VARIANT < 32) ? VARIANT - 16 : 0;  // 32, 33: real variants
     constexpr int NOEXP = VARIANT == 10 ? 1 : (VARIANT == 11 || (ABL & 4)) ? 2 : 0;
     // SPLIT: this workgroup owns KV tiles [t0, t1) of its unit only
     const int t0 = SPLIT ? min(chunk * p.tail_tiles, n_tiles) : 0;
@@ -404,7 +452,10 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
       qk_tile<(ABL & 2) != 0>(k_ring + (t & 1) * ATT_TILE, qf, f, s);
       if (!PEEL && ragged && t == n_tiles - 1) mask_tail(s, t * KVB, S, h2);
       bf16x8 pf[4];
-      softmax_tile<(VARIANT >= 1), NOEXP, PEEL, VARIANT == 32>(s, c, m_run, l_run, o_acc, pf);
+      if (VARIANT == 33)
+        softmax_tile_lazy(s, c, m_run, l_run, o_acc, pf);
+      else
+        softmax_tile<(VARIANT >= 1), NOEXP, PEEL, VARIANT == 32>(s, c, m_run, l_run, o_acc, pf);
       pv_tile<(ABL & 2) != 0>(v_ring + (t & 1) * ATT_TILE, pf, f, o_acc);
     }
     if (PEEL && ragged) {
@@ -1192,8 +1243,8 @@ static TailPlan plan_tail(int nbh, int q_blocks, int n_tiles) {
 // default = the fastest measured variant; ALG_ATTN_VARIANT (read per call) overrides it for A/B runs and tests
 static int attn_variant() {
   const char* e = getenv("ALG_ATTN_VARIANT");
-  const int v = e ? atoi(e) : 32;
-  if (v == 32) return v;  // the default: variant 1 with v_dot2c row sums (+2 %: the kernel is VALU-bound at d = 64)
+  const int v = e ? atoi(e) : 33;
+  if (v == 32 || v == 33) return v;  // 33 = the default: dot2 row sums + lazy running max (the kernel is VALU-bound at d = 64)
   return (v < 0 || v > 16 || v == 10 || v == 11) ? 1 : v;
 }
 
@@ -1222,7 +1273,7 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;
   p.batch = batch; p.heads = heads; p.S = S;
   int variant = attn_variant();
-  if (variant >= 8 && variant != 32 && !vt128) variant = 32;
+  if (variant >= 8 && variant < 32 && !vt128) variant = 33;
   const int nw = (variant == 5 || variant == 7 || variant == 16) ? 4 : (variant == 12 ? 16 : 8);
   const int q_per_wave = (variant == 6 || variant == 7 || variant == 15 || variant == 16) ? 64 : 32;
   p.q_blocks = (S + nw * q_per_wave - 1) / (nw * q_per_wave);
@@ -1235,7 +1286,7 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
   hipStream_t s = (hipStream_t)stream;
   p.unit0 = p.tail_units = p.tail_split = p.tail_tiles = 0;
   p.ws_o = p.ws_ml = nullptr;
-  if (variant == 32) {
+  if (variant == 33) {
     const TailPlan tp = plan_tail(nbh, p.q_blocks, (S + KVB - 1) / KVB);
     if (tp.units) {
       const int per_xcd = nbh / 8 * p.q_blocks;
@@ -1248,8 +1299,8 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
         return ALG_ELAUNCH;
       }
       p.ws_o = ws, p.ws_ml = ws + rows * 64;
-      hipLaunchKernelGGL((flash_attn_d64_kernel<32, 8>), dim3((unsigned)(8 * p.unit0)), blk, 0, s, p);
-      hipLaunchKernelGGL((flash_attn_d64_kernel<32, 8, true>), dim3((unsigned)(8 * tp.units * tp.split)), blk, 0, s, p);
+      hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8>), dim3((unsigned)(8 * p.unit0)), blk, 0, s, p);
+      hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8, true>), dim3((unsigned)(8 * tp.units * tp.split)), blk, 0, s, p);
       const int64_t merge = (int64_t)8 * tp.units * 256 * 16;
       hipLaunchKernelGGL(flash_attn_d64_merge_kernel, dim3((unsigned)((merge + 255) / 256)), dim3(256), 0, s, p);
       const int rc = check_launch("alg_flash_attn_d64");
@@ -1270,6 +1321,7 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
     case 13: hipLaunchKernelGGL((flash_attn_d64_kernel<13, 8>), g, blk, 0, s, p); break;
     case 14: hipLaunchKernelGGL((flash_attn_d64_kernel<14, 8>), g, blk, 0, s, p); break;
     case 32: hipLaunchKernelGGL((flash_attn_d64_kernel<32, 8>), g, blk, 0, s, p); break;
+    case 33: hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8>), g, blk, 0, s, p); break;
     case 15: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<8>, g, blk, 0, s, p); break;
     case 16: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<4>, g, blk, 0, s, p); break;
     case 8: hipLaunchKernelGGL(flash_attn_d64_kv128_kernel<false>, g, blk, 0, s, p); break;

@@ -130,7 +130,7 @@ def sdpa_ref(q, k, v, scale):
     return (p @ vv).transpose(1, 2)
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "12", "13", "14", "15", "16", "32"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "12", "13", "14", "15", "16", "32", "33"])
 @pytest.mark.parametrize("Bn,S,H", [(1, 64, 1), (1, 100, 3), (2, 273, 9), (1, 1000, 8), (3, 994, 2), (1, 17, 1)])
 def test_flash_attention_vs_sdpa(device, monkeypatch, Bn, S, H, variant):
     monkeypatch.setenv("ALG_ATTN_VARIANT", variant)  # every kernel variant must pass, not just the default
@@ -142,7 +142,7 @@ def test_flash_attention_vs_sdpa(device, monkeypatch, Bn, S, H, variant):
     assert rel_err(got, ref) < 1e-2
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "12", "13", "14", "15", "16", "32"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "12", "13", "14", "15", "16", "32", "33"])
 def test_flash_attention_forced_rescale_and_asymmetry(device, monkeypatch, variant):
     """A key that dominates late in the sequence forces the online-softmax rescale; V = one-hot rows make any
     kv-order / transpose mistake in the P@V operand layout visible."""
@@ -158,6 +158,26 @@ def test_flash_attention_forced_rescale_and_asymmetry(device, monkeypatch, varia
     ref = sdpa_ref(q, k, v, 0.125)
     assert (got - ref).abs().max() <= 1e-2
     assert ref[0, 5, 0, 257 % 64] > 0.9  # the spike really dominates
+
+
+@pytest.mark.parametrize("variant", ["1", "32", "33"])
+@pytest.mark.parametrize("gain", [0.5, 2.5, 3.4, 4.0, 40.0])
+def test_flash_attention_lazy_max_thresholds(device, monkeypatch, variant, gain):
+    """The default softmax keeps a LAZY running max: probabilities are formed against the current m and the exact
+    max / rescale path only runs when a row sum leaves [0, 2^40).  Spikes that stay below the threshold (scores up to ~220
+    above m: probabilities up to 2^39), cross it, or overflow exp2 outright (gain 40: +inf) must all give the softmax the
+    reference gives -- also on a ragged last tile and with the spike in the first tile (m = -inf start)."""
+    monkeypatch.setenv("ALG_ATTN_VARIANT", variant)
+    g = torch.Generator().manual_seed(7)
+    S = 333
+    q, k = rnd((1, S, 2, 64), g), rnd((1, S, 2, 64), g)
+    k[0, 300, 0] = q[0, 5, 0] * gain       # late spike for query 5, head 0
+    k[0, 3, 1] = q[0, 9, 1] * gain         # spike inside the first tile for query 9, head 1
+    k[0, 330, 1] = q[0, 200, 1] * gain     # spike in the ragged tail tile
+    v = rnd((1, S, 2, 64), g)
+    got = run_attention(device, q, k, v, 0.125).double()
+    ref = sdpa_ref(q, k, v, 0.125)
+    assert torch.isfinite(got).all() and (got - ref).abs().max() <= 1.5e-2
 
 
 # ------------------------------------------------------------------------------------- row kernels
