@@ -137,47 +137,47 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
           if (kv >= Skv) s[sub][e] = -INFINITY;
         }
     }
-    // ---- online softmax ----
-    float mt = fmaxf(s[0][0], s[1][0]);
+    // ---- online softmax with a LAZY running max (see attention.hip softmax_tile_lazy): probabilities are formed against
+    // the current m; the exact tile max / rescale path runs only when a row sum leaves [0, 2^40) (inf on the first tile) ----
+    typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+    bf16x8 pf[4];
+    auto probs = [&](float mc) -> float {
+      float psum = 0.0f;
 #pragma unroll
-    for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
-    {
-      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
-      mt = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    }
-    if (__any(mt > m_run)) {
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float p0 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j] * c - mc);
+            const float p1 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j + 1] * c - mc);
+            pk.u[j] = pack_bf2(p0, p1);
+            psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk.u[j]),
+                                                  __builtin_bit_cast(bf2v, 0x3f803f80u), psum, false);
+          }
+          pf[sub * 2 + g] = pk.v;
+        }
+      return psum;
+    };
+    float psum = probs(m_run * c);
+    if (__any(!(psum < 1.0995116e12f))) {  // 2^40; also inf / NaN
+      float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+      for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
+      {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+        mt = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+      }
       const float m_new = fmaxf(m_run, mt);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
       m_run = m_new;
       l_run *= alpha;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o_acc[dt] *= alpha;
+      psum = probs(m_run * c);
     }
-    const float mc = m_run * c;
-    const f32x2p c2 = {c, c}, mc2 = {mc, mc};
-    f32x2p ps2 = {0.0f, 0.0f};
-    bf16x8 pf[4];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        union { bf16x8 v; uint32_t u[4]; } pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x2p sv = {s[sub][8 * g + 2 * j], s[sub][8 * g + 2 * j + 1]};
-          const f32x2p x = __builtin_elementwise_fma(sv, c2, -mc2);
-          const f32x2p pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-          pk.u[j] = pack_bf2(pv.x, pv.y);
-          {  // row sum of the rounded pair in one v_dot2c_f32_bf16 (16 instead of 32 VALU adds per tile; sums the
-             // probabilities the PV MFMA actually uses -- see attention.hip variant 32)
-            typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
-            ps2.x = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk.u[j]),
-                                                   __builtin_bit_cast(bf2v, 0x3f803f80u), ps2.x, false);
-          }
-        }
-        pf[sub * 2 + g] = pk.v;
-      }
-    l_run += ps2.x + ps2.y;
+    l_run += psum;
     // ---- O^T += V^T P^T: four 32-row d-tiles x 4 kv blocks ----
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
