@@ -33,6 +33,8 @@
 //   33  (DEFAULT) 32 + lazy running max (softmax_tile_lazy): no tile max in the common path, the exact max / rescale
 //       path runs only when a row sum leaves [0, 2^40): 919 -> 990 TFLOP/s on the same box; the split-KV tail launch is
 //       built on it
+//   34  33 with Q pre-scaled by scale*log2(e) in registers and the offset snapped to zero when the first tile's max allows
+//       it: p = exp2(s) with no per-score fma (+2 %; one more bf16 rounding of q, so opt-in)
 // Measured on MI355X at the C2 shape (2 x 48 heads x 17,776 tokens, profiles/): 1: 860-915 TFLOP/s,
 // 0: 875, 2: 830, 3: 867, 4: 861, 5: 836, 6: 804, 7: 599, 8: 899, 9: 893, 12: 860, 13: 880, 14: 865, 15: 835, 16: 875.
 // All of them sit at 1225-1330 W with the clock pulled down to 1.9-2.2 GHz (profiles/r1_power_and_issue_rates.txt):
@@ -219,6 +221,59 @@ __device__ __forceinline__ void softmax_tile_lazy(const f32x16 (&s)[2], float c,
   l_run += psum;
 }
 
+// Variant 34: Q is pre-scaled, so the scores arrive in log2 units and the only per-score VALU work left in the common path
+// is exp2, the bf16 pack and the dot2 row sum: the offset is SNAPPED TO ZERO whenever the first tile's max lies in
+// (-64, 64) (probabilities then span 2^-64 .. 2^64 at most before the lazy rescale threshold trips: harmless for fp32 /
+// bf16), and p = exp2(s) needs no subtraction at all.  Rows whose scores are further out keep a non-zero offset and take
+// the subtracting path; the exact max / rescale path is the lazy one of variant 33.
+__device__ __forceinline__ void softmax_tile_zero(const f32x16 (&s)[2], float& m_run, float& l_run, f32x16 (&o_acc)[2],
+                                                  bf16x8 (&pf)[4]) {
+  typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+  auto probs = [&](auto sub_c, float m) -> float {
+    constexpr bool SUB = decltype(sub_c)::value;
+    float psum = 0.0f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x0 = s[sub][8 * g + 2 * j], x1 = s[sub][8 * g + 2 * j + 1];
+          const float p0 = __builtin_amdgcn_exp2f(SUB ? x0 - m : x0);
+          const float p1 = __builtin_amdgcn_exp2f(SUB ? x1 - m : x1);
+          pk.u[j] = pack_bf2(p0, p1);
+          psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk.u[j]), __builtin_bit_cast(bf2v, 0x3f803f80u),
+                                                 psum, false);
+        }
+        pf[sub * 2 + g] = pk.v;
+      }
+    return psum;
+  };
+  float psum;
+  if (__all(m_run == 0.0f))
+    psum = probs(BoolC<false>{}, 0.0f);
+  else
+    psum = probs(BoolC<true>{}, m_run);
+  if (__any(!(psum < 1.0995116e12f))) {  // 2^40; also inf (first tile: m = -inf) and NaN
+    float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    float m_new = fmaxf(m_run, mt);
+    if (m_run == -INFINITY && fabsf(m_new) < 64.0f) m_new = 0.0f;  // first tile: snap the offset to zero when it is safe
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    l_run *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+    psum = probs(BoolC<true>{}, m_run);
+  }
+  l_run += psum;
+}
+
 // O^T += V^T P^T for one 64-row tile
 template <bool NOLDS = false>
 __device__ __forceinline__ void pv_tile(const char* Vs, const bf16x8 (&pf)[4], const Frag f, f32x16 (&o_acc)[2]) {
@@ -281,6 +336,18 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
     const bf16_t* qp = Q + (int64_t)min(q_row, S - 1) * p.q_rs + h2 * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    if (VARIANT == 34) {  // scores come out of the MFMA in log2 units: q * (scale * log2 e), one more bf16 rounding of q
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        union { bf16x8 v; uint32_t u[4]; } raw, sc;
+        raw.v = qf[ks];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          sc.u[j] = pack_bf2(__uint_as_float(raw.u[j] << 16) * p.scale_log2,
+                             __uint_as_float(raw.u[j] & 0xffff0000u) * p.scale_log2);
+        qf[ks] = sc.v;
+      }
+    }
   }
 
   // ---- DMA sources: ROUNDS 16-B pieces of K and of V^T per thread per tile ----
@@ -452,7 +519,9 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
       qk_tile<(ABL & 2) != 0>(k_ring + (t & 1) * ATT_TILE, qf, f, s);
       if (!PEEL && ragged && t == n_tiles - 1) mask_tail(s, t * KVB, S, h2);
       bf16x8 pf[4];
-      if (VARIANT == 33)
+      if (VARIANT == 34)
+        softmax_tile_zero(s, m_run, l_run, o_acc, pf);
+      else if (VARIANT == 33)
         softmax_tile_lazy(s, c, m_run, l_run, o_acc, pf);
       else
         softmax_tile<(VARIANT >= 1), NOEXP, PEEL, VARIANT == 32>(s, c, m_run, l_run, o_acc, pf);
@@ -1244,7 +1313,7 @@ static TailPlan plan_tail(int nbh, int q_blocks, int n_tiles) {
 static int attn_variant() {
   const char* e = getenv("ALG_ATTN_VARIANT");
   const int v = e ? atoi(e) : 33;
-  if (v == 32 || v == 33) return v;  // 33 = the default: dot2 row sums + lazy running max (the kernel is VALU-bound at d = 64)
+  if (v >= 32 && v <= 34) return v;  // 33 = the default: dot2 row sums + lazy running max (the kernel is VALU-bound at d = 64)
   return (v < 0 || v > 16 || v == 10 || v == 11) ? 1 : v;
 }
 
@@ -1322,6 +1391,7 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
     case 14: hipLaunchKernelGGL((flash_attn_d64_kernel<14, 8>), g, blk, 0, s, p); break;
     case 32: hipLaunchKernelGGL((flash_attn_d64_kernel<32, 8>), g, blk, 0, s, p); break;
     case 33: hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8>), g, blk, 0, s, p); break;
+    case 34: hipLaunchKernelGGL((flash_attn_d64_kernel<34, 8>), g, blk, 0, s, p); break;
     case 15: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<8>, g, blk, 0, s, p); break;
     case 16: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<4>, g, blk, 0, s, p); break;
     case 8: hipLaunchKernelGGL(flash_attn_d64_kv128_kernel<false>, g, blk, 0, s, p); break;
