@@ -915,7 +915,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const AttnP
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       if (ragged && t == n_tiles - 1) mask_tail(s[g], t * KVB, S, h2);
-      softmax_tile<true>(s[g], c, m_run[g], l_run[g], o_acc[g], pf[g]);
+      softmax_tile_lazy(s[g], c, m_run[g], l_run[g], o_acc[g], pf[g]);
     }
     // O^T for both groups from ONE read of each V^T fragment
 #pragma unroll
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(512, 4) void flash_attn_d64_kv128_kernel(const Attn
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         if (ragged && t == n_tiles - 1) mask_tail(s, t * KVB, S, h2);
         bf16x8 pf[4];
-        softmax_tile<true>(s, c, m_run, l_run, o_acc, pf);
+        softmax_tile_lazy(s, c, m_run, l_run, o_acc, pf);
         if (PRIO) __builtin_amdgcn_s_setprio(1);
         pv_tile(base + (2 + j) * ATT_TILE, pf, f, o_acc);
         if (PRIO) __builtin_amdgcn_s_setprio(0);
