@@ -237,3 +237,23 @@ def test_attention_split_kv_tail_matches_the_unsplit_kernel(device, monkeypatch)
     scale = ref.float()[1, 62 * 256:, 40:].abs().max().item()
     assert tail.abs().max().item() <= 2.0 ** -7 * scale and not bool(same[1, 62 * 256:, 40:].all())
     assert torch.equal(call(), got)                                          # deterministic
+
+
+def test_default_attention_agrees_with_the_exact_max_variant_in_a_full_width_forward(device, monkeypatch):
+    """The default attention keeps a lazy running max and sums rounded probabilities (variant 33); variant 1 subtracts the
+    exact running max and sums fp32 probabilities.  Same softmax: a 2-layer forward at the full C2 token count and width
+    must agree to bf16 rounding."""
+    cfg = CogVideoXTransformerConfig(num_layers=2)
+    model = CogVideoXTransformer3DModel.from_synthetic(cfg, seed=11, device=device)
+    g = torch.Generator().manual_seed(4)
+    lat = torch.randn(1, 13, 16, 60, 90, generator=g).to(device, BF)
+    c0 = torch.zeros(1, 13, 16, 60, 90, dtype=BF, device=device)
+    c0[:, 0] = (torch.randn(1, 16, 60, 90, generator=g) * 0.7).to(device, BF)
+    pe, ne = (torch.randn(1, 226, 4096, generator=g).to(device, BF) for _ in range(2))
+    rope = rotary_tables(64, get_resize_crop_region_for_grid((30, 45), 45, 30), (30, 45), 13)
+    ts = torch.full((2,), 500.0)
+    a = model.forward_assembled(lat, [c0, c0], torch.cat([ne, pe]), ts, rope).float()
+    monkeypatch.setenv("ALG_ATTN_VARIANT", "1")
+    b = model.forward_assembled(lat, [c0, c0], torch.cat([ne, pe]), ts, rope).float()
+    rel = ((a - b).norm() / b.norm()).item()
+    assert bool(torch.isfinite(a).all()) and rel < 5e-3, rel
