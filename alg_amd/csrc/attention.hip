@@ -180,6 +180,7 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&s)[2], float c, floa
 // against the CURRENT m (no tile max: 23 VALU instructions saved per tile) and the exact path -- tile max, grow m, rescale
 // O and l, recompute -- runs only when a tile's row sum leaves [0, 2^40) (inf on the first tile, where m = -inf; NaN if
 // a masked score meets m = -inf).  m is then always a max actually seen, so nothing that matters can underflow.
+template <bool DOT2 = true>
 __device__ __forceinline__ void softmax_tile_lazy(const f32x16 (&s)[2], float c, float& m_run, float& l_run,
                                                   f32x16 (&o_acc)[2], bf16x8 (&pf)[4]) {
   typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
@@ -195,8 +196,11 @@ __device__ __forceinline__ void softmax_tile_lazy(const f32x16 (&s)[2], float c,
           const float p0 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j] * c - mc);
           const float p1 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j + 1] * c - mc);
           pk.u[j] = pack_bf2(p0, p1);
-          psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk.u[j]), __builtin_bit_cast(bf2v, 0x3f803f80u),
-                                                 psum, false);
+          if (DOT2)
+            psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk.u[j]), __builtin_bit_cast(bf2v, 0x3f803f80u),
+                                                   psum, false);
+          else
+            psum += p0 + p1;
         }
         pf[sub * 2 + g] = pk.v;
       }
@@ -521,6 +525,8 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
       bf16x8 pf[4];
       if (VARIANT == 34)
         softmax_tile_zero(s, m_run, l_run, o_acc, pf);
+      else if (VARIANT == 36)
+        softmax_tile_lazy<false>(s, c, m_run, l_run, o_acc, pf);
       else if (VARIANT == 33)
         softmax_tile_lazy(s, c, m_run, l_run, o_acc, pf);
       else
@@ -1313,7 +1319,7 @@ static TailPlan plan_tail(int nbh, int q_blocks, int n_tiles) {
 static int attn_variant() {
   const char* e = getenv("ALG_ATTN_VARIANT");
   const int v = e ? atoi(e) : 33;
-  if (v >= 32 && v <= 34) return v;  // 33 = the default: dot2 row sums + lazy running max (the kernel is VALU-bound at d = 64)
+  if (v >= 32 && v <= 36 && v != 35) return v;  // 33 = the default: dot2 row sums + lazy running max (the kernel is VALU-bound at d = 64)
   return (v < 0 || v > 16 || v == 10 || v == 11) ? 1 : v;
 }
 
@@ -1392,6 +1398,7 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
     case 32: hipLaunchKernelGGL((flash_attn_d64_kernel<32, 8>), g, blk, 0, s, p); break;
     case 33: hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8>), g, blk, 0, s, p); break;
     case 34: hipLaunchKernelGGL((flash_attn_d64_kernel<34, 8>), g, blk, 0, s, p); break;
+    case 36: hipLaunchKernelGGL((flash_attn_d64_kernel<36, 8>), g, blk, 0, s, p); break;
     case 15: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<8>, g, blk, 0, s, p); break;
     case 16: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<4>, g, blk, 0, s, p); break;
     case 8: hipLaunchKernelGGL(flash_attn_d64_kv128_kernel<false>, g, blk, 0, s, p); break;

@@ -65,6 +65,26 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
     } else if (OP == 8) {  // v_pk_add_f32
       REP16(asm volatile("v_pk_add_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_add_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3"
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));)
+    } else if (OP == 20) {  // v_exp_legacy_f32
+      REP16(asm volatile("v_exp_legacy_f32 %0, %0\n v_exp_legacy_f32 %1, %1\n v_exp_legacy_f32 %2, %2\n v_exp_legacy_f32 %3, %3"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (OP == 21) {  // v_exp_f16
+      REP16(asm volatile("v_exp_f16 %0, %0\n v_exp_f16 %1, %1\n v_exp_f16 %2, %2\n v_exp_f16 %3, %3"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (OP == 22) {  // v_dot2c_f32_bf16
+      REP16(asm volatile("v_dot2c_f32_bf16 %0, %1, %2\n v_dot2c_f32_bf16 %1, %2, %3\n v_dot2c_f32_bf16 %2, %3, %0\n v_dot2c_f32_bf16 %3, %0, %1"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (OP == 23) {  // v_ldexp_f32
+      REP16(asm volatile("v_ldexp_f32 %0, %0, %1\n v_ldexp_f32 %1, %1, %2\n v_ldexp_f32 %2, %2, %3\n v_ldexp_f32 %3, %3, %0"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (OP == 24) {  // mfma + 7 v_dot2c behind each
+      REP16(asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n"
+                         "v_dot2c_f32_bf16 %4, %5, %6\n v_dot2c_f32_bf16 %5, %6, %7\n v_dot2c_f32_bf16 %6, %7, %4\n v_dot2c_f32_bf16 %7, %4, %5\n"
+                         "v_dot2c_f32_bf16 %4, %5, %6\n v_dot2c_f32_bf16 %5, %6, %7\n v_dot2c_f32_bf16 %6, %7, %4\n"
+                         : "+v"(acc0), "+v"(acc1), "+v"(fa), "+v"(fb), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (OP == 25) {  // v_rcp_f32 (another transcendental, for reference)
+      REP16(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
     } else if (OP == 9) {  // v_cndmask
       REP16(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
@@ -104,6 +124,12 @@ int main() {
   for (int w : {1, 2, 4}) {
     run<0>("v_fma_f32", 64, w);
     run<1>("v_exp_f32", 64, w);
+    run<20>("v_exp_legacy_f32", 64, w);
+    run<21>("v_exp_f16", 64, w);
+    run<25>("v_rcp_f32", 64, w);
+    run<22>("v_dot2c_f32_bf16", 64, w);
+    run<23>("v_ldexp_f32", 64, w);
+    run<24>("mfma + 7 dot2c (per group)", 16, w);
     run<2>("v_pk_fma_f32", 64, w);
     run<8>("v_pk_add_f32", 64, w);
     run<3>("v_max3_f32", 64, w);
