@@ -527,7 +527,7 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
         softmax_tile_zero(s, m_run, l_run, o_acc, pf);
       else if (VARIANT == 36)
         softmax_tile_lazy<false>(s, c, m_run, l_run, o_acc, pf);
-      else if (VARIANT == 33)
+      else if (VARIANT == 33 || ABL != 0)   // the ablation variants (wrong results) time the default softmax
         softmax_tile_lazy(s, c, m_run, l_run, o_acc, pf);
       else
         softmax_tile<(VARIANT >= 1), NOEXP, PEEL, VARIANT == 32>(s, c, m_run, l_run, o_acc, pf);
@@ -1319,7 +1319,8 @@ static TailPlan plan_tail(int nbh, int q_blocks, int n_tiles) {
 static int attn_variant() {
   const char* e = getenv("ALG_ATTN_VARIANT");
   const int v = e ? atoi(e) : 33;
-  if (v >= 32 && v <= 36 && v != 35) return v;  // 33 = the default: dot2 row sums + lazy running max (the kernel is VALU-bound at d = 64)
+  if (v >= 32 && v <= 36 && v != 35) return v;
+  if (v == 17 || v == 18 || v == 19 || v == 24) return v;  // ablations of the default kernel: WRONG RESULTS, timing only  // 33 = the default: dot2 row sums + lazy running max (the kernel is VALU-bound at d = 64)
   return (v < 0 || v > 16 || v == 10 || v == 11) ? 1 : v;
 }
 
@@ -1399,6 +1400,10 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
     case 33: hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8>), g, blk, 0, s, p); break;
     case 34: hipLaunchKernelGGL((flash_attn_d64_kernel<34, 8>), g, blk, 0, s, p); break;
     case 36: hipLaunchKernelGGL((flash_attn_d64_kernel<36, 8>), g, blk, 0, s, p); break;
+    case 17: hipLaunchKernelGGL((flash_attn_d64_kernel<17, 8>), g, blk, 0, s, p); break;  // no DMA after tile 0
+    case 18: hipLaunchKernelGGL((flash_attn_d64_kernel<18, 8>), g, blk, 0, s, p); break;  // no LDS fragment reads
+    case 19: hipLaunchKernelGGL((flash_attn_d64_kernel<19, 8>), g, blk, 0, s, p); break;  // neither
+    case 24: hipLaunchKernelGGL((flash_attn_d64_kernel<24, 8>), g, blk, 0, s, p); break;  // no per-tile wait + barrier
     case 15: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<8>, g, blk, 0, s, p); break;
     case 16: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<4>, g, blk, 0, s, p); break;
     case 8: hipLaunchKernelGGL(flash_attn_d64_kv128_kernel<false>, g, blk, 0, s, p); break;
