@@ -33,6 +33,9 @@
 //   33  (DEFAULT) 32 + lazy running max (softmax_tile_lazy): no tile max in the common path, the exact max / rescale
 //       path runs only when a row sum leaves [0, 2^40): 919 -> 990 TFLOP/s on the same box; the split-KV tail launch is
 //       built on it
+//   39/40  the duo kernels (15/16) with the lazy softmax; the exact-max fix-up sits between the scheduling regions:
+//       828 -> 995 / 1044 TFLOP/s (8 / 4 waves), i.e. on par with 33 (1027 on the same box); the interleave granularity
+//       (6..16 VALU per MFMA) moves it by < 2 %
 //   34  33 with Q pre-scaled by scale*log2(e) in registers and the offset snapped to zero when the first tile's max allows
 //       it: p = exp2(s) with no per-score fma (+2 %; one more bf16 rounding of q, so opt-in)
 // Measured on MI355X at the C2 shape (2 x 48 heads x 17,776 tokens, profiles/): 1: 860-915 TFLOP/s,
@@ -1068,8 +1071,10 @@ __global__ __launch_bounds__(512, 4) void flash_attn_d64_kv128_kernel(const Attn
 // ---------------------------------------------------------------------------------------------------------------
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
-template <int NW>
+template <int NW, bool LAZY_ = false, int SG = 10>
 __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d64_duo_kernel(const AttnP p) {
+  constexpr bool LAZY = LAZY_;  // lazy running max + dot2 row sums (see softmax_tile_lazy): the common path has no branch
+                                // inside a scheduling region; the exact-max fix-up sits between the regions
   constexpr int ROUNDS = 8 / NW;
   __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE];
   char* const k_ring = smem;
@@ -1167,6 +1172,45 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d64_duo_kernel(const At
       }
     l += ps2.x + ps2.y;
   };
+  // LAZY: probabilities against the current m (straight-line: 32 fma, 32 exp, 16 pack, 16 dot2), the row sum is returned
+  auto soft_fast = [&](const f32x16 (&s)[2], float m, bf16x8 (&pf)[4]) -> float {
+    typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+    const float mc = m * c;
+    float psum = 0.0f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p0 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j] * c - mc);
+          const float p1 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j + 1] * c - mc);
+          pk.u[j] = pack_bf2(p0, p1);
+          psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk.u[j]), __builtin_bit_cast(bf2v, 0x3f803f80u),
+                                                 psum, false);
+        }
+        pf[sub * 2 + g] = pk.v;
+      }
+    return psum;
+  };
+  // LAZY fix-up between two scheduling regions: exact tile max, grow m, rescale, recompute (rare)
+  auto soft_fix = [&](const f32x16 (&s)[2], float& psum, float& m, float& l, f32x16 (&o)[2], bf16x8 (&pf)[4]) {
+    if (__any(!(psum < 1.0995116e12f))) {
+      float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+      for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m, mt);
+      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
+      m = m_new;
+      l *= alpha;
+      o[0] *= alpha;
+      o[1] *= alpha;
+      psum = soft_fast(s, m, pf);
+    }
+    l += psum;
+  };
   auto qk = [&](const bf16x8 (&kf)[8], const bf16x8 (&q)[4], f32x16 (&s)[2]) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -1205,30 +1249,39 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d64_duo_kernel(const At
     qk(kf, qf[1], sb);
 #pragma unroll
     for (int i = 0; i < 8; ++i) vf[i] = *(const bf16x8*)(Vs + (i >> 2) * 4096 + (((2 * (i & 3) + h2) ^ sw) * 16));
-    softmax(sa, m_run[0], l_run[0], o_acc[0], pfa);
+    float psa = 0.0f, psb = 0.0f;
+    if (LAZY)
+      psa = soft_fast(sa, m_run[0], pfa);
+    else
+      softmax(sa, m_run[0], l_run[0], o_acc[0], pfa);
     if (!MASK) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        SGB(0x008, 1);   // 1 MFMA
-        SGB(0x402, 14);  // 14 VALU / transcendental
+        SGB(0x008, 1);               // 1 MFMA
+        SGB(0x402, LAZY ? SG : 14);  // VALU / transcendental
       }
-      SGB(0x100, 8);     // the 8 V^T fragment reads
-      SGB(0x402, 40);    // the rest of the softmax
+      SGB(0x100, 8);                 // the 8 V^T fragment reads
+      SGB(0x402, 40);                // the rest of the softmax
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (LAZY) soft_fix(sa, psa, m_run[0], l_run[0], o_acc[0], pfa);
     if (MASK) mask_tail(sb, t * KVB, S, h2);
     // R3: PV of stream A between the softmax instructions of stream B
     pv(vf, pfa, o_acc[0]);
-    softmax(sb, m_run[1], l_run[1], o_acc[1], pfb);
+    if (LAZY)
+      psb = soft_fast(sb, m_run[1], pfb);
+    else
+      softmax(sb, m_run[1], l_run[1], o_acc[1], pfb);
     if (!MASK) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         SGB(0x008, 1);
-        SGB(0x402, 14);
+        SGB(0x402, LAZY ? SG : 14);
       }
       SGB(0x402, 40);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (LAZY) soft_fix(sb, psb, m_run[1], l_run[1], o_acc[1], pfb);
     // R4
     pv(vf, pfb, o_acc[1]);
   };
@@ -1320,7 +1373,8 @@ static int attn_variant() {
   const char* e = getenv("ALG_ATTN_VARIANT");
   const int v = e ? atoi(e) : 33;
   if (v >= 32 && v <= 36 && v != 35) return v;
-  if (v == 17 || v == 18 || v == 19 || v == 24) return v;  // ablations of the default kernel: WRONG RESULTS, timing only  // 33 = the default: dot2 row sums + lazy running max (the kernel is VALU-bound at d = 64)
+  if (v == 17 || v == 18 || v == 19 || v == 24) return v;
+  if (v == 39 || v == 40) return v;  // duo kernels with the lazy softmax (8 / 4 waves)  // ablations of the default kernel: WRONG RESULTS, timing only  // 33 = the default: dot2 row sums + lazy running max (the kernel is VALU-bound at d = 64)
   return (v < 0 || v > 16 || v == 10 || v == 11) ? 1 : v;
 }
 
@@ -1350,8 +1404,8 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
   p.batch = batch; p.heads = heads; p.S = S;
   int variant = attn_variant();
   if (variant >= 8 && variant < 32 && !vt128) variant = 33;
-  const int nw = (variant == 5 || variant == 7 || variant == 16) ? 4 : (variant == 12 ? 16 : 8);
-  const int q_per_wave = (variant == 6 || variant == 7 || variant == 15 || variant == 16) ? 64 : 32;
+  const int nw = (variant == 5 || variant == 7 || variant == 16 || variant == 40) ? 4 : (variant == 12 ? 16 : 8);
+  const int q_per_wave = (variant == 6 || variant == 7 || variant == 15 || variant == 16 || variant == 39 || variant == 40) ? 64 : 32;
   p.q_blocks = (S + nw * q_per_wave - 1) / (nw * q_per_wave);
   p.q_bs = q_bstride; p.q_rs = q_rstride; p.vt_bs = vt_bstride; p.vt_rs = vt_rstride;
   p.o_bs = o_bstride; p.o_rs = o_rstride;
@@ -1405,6 +1459,8 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
     case 19: hipLaunchKernelGGL((flash_attn_d64_kernel<19, 8>), g, blk, 0, s, p); break;  // neither
     case 24: hipLaunchKernelGGL((flash_attn_d64_kernel<24, 8>), g, blk, 0, s, p); break;  // no per-tile wait + barrier
     case 15: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<8>, g, blk, 0, s, p); break;
+    case 39: hipLaunchKernelGGL((flash_attn_d64_duo_kernel<8, true>), g, blk, 0, s, p); break;
+    case 40: hipLaunchKernelGGL((flash_attn_d64_duo_kernel<4, true>), g, blk, 0, s, p); break;
     case 16: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<4>, g, blk, 0, s, p); break;
     case 8: hipLaunchKernelGGL(flash_attn_d64_kv128_kernel<false>, g, blk, 0, s, p); break;
     case 9: hipLaunchKernelGGL(flash_attn_d64_kv128_kernel<true>, g, blk, 0, s, p); break;

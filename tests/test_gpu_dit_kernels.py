@@ -130,7 +130,7 @@ def sdpa_ref(q, k, v, scale):
     return (p @ vv).transpose(1, 2)
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "12", "13", "14", "15", "16", "32", "33", "34"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "12", "13", "14", "15", "16", "32", "33", "34", "36", "39", "40"])
 @pytest.mark.parametrize("Bn,S,H", [(1, 64, 1), (1, 100, 3), (2, 273, 9), (1, 1000, 8), (3, 994, 2), (1, 17, 1)])
 def test_flash_attention_vs_sdpa(device, monkeypatch, Bn, S, H, variant):
     monkeypatch.setenv("ALG_ATTN_VARIANT", variant)  # every kernel variant must pass, not just the default
@@ -142,7 +142,7 @@ def test_flash_attention_vs_sdpa(device, monkeypatch, Bn, S, H, variant):
     assert rel_err(got, ref) < 1e-2
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "12", "13", "14", "15", "16", "32", "33", "34"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "12", "13", "14", "15", "16", "32", "33", "34", "36", "39", "40"])
 def test_flash_attention_forced_rescale_and_asymmetry(device, monkeypatch, variant):
     """A key that dominates late in the sequence forces the online-softmax rescale; V = one-hot rows make any
     kv-order / transpose mistake in the P@V operand layout visible."""
