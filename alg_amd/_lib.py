@@ -27,7 +27,7 @@ EXPORTS = (
     "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu", "alg_gemm_fp8", "alg_quantize_fp8_rows",
     "alg_conv_cl_bf16", "alg_vae_groupnorm_workspace", "alg_vae_groupnorm_stats", "alg_vae_spatial_norm", "alg_vae_upsample",
     "alg_vae_pack_latent", "alg_vae_unpack_video", "alg_vae_group_norm", "alg_vae_pad", "alg_vae_repitch",
-    "alg_vae_unpack_planes", "alg_patchify_t", "alg_unpatchify_t", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16",
+    "alg_vae_unpack_planes", "alg_patchify_t", "alg_unpatchify_t", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
 )
 
 
@@ -115,7 +115,8 @@ def load_library():
     lib.alg_vae_unpack_planes.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]
     lib.alg_embed_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]
     lib.alg_t5_layernorm.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]
-    lib.alg_attn_bias.argtypes = [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_int64, c_int64, c_float, c_void_p]
+    lib.alg_attn_bias.argtypes = [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_int64, c_int64, c_float, c_int, c_void_p]
+    lib.alg_quick_gelu.argtypes = [c_void_p, c_int64, c_void_p]
     lib.alg_mul_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
     lib.alg_vae_upsample.argtypes = [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]
     lib.alg_vae_pack_latent.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]
@@ -373,13 +374,18 @@ def t5_layernorm(x, weight, y, rows, D, eps):
     return y
 
 
-def attn_bias(qkv, out, bias_table, rel_bucket, key_mask, batch, heads, L, scale=1.0, head_dim=64):
+def attn_bias(qkv, out, bias_table, rel_bucket, key_mask, batch, heads, L, scale=1.0, head_dim=64, causal=False):
     """qkv: [batch*L, 3*heads*head_dim] fused projections (q | k | v); out: [batch*L, heads*head_dim]."""
     inner = heads * head_dim
     _check(load_library().alg_attn_bias(_p(qkv), _p(qkv, inner), _p(qkv, 2 * inner), _p(out), _p(bias_table),
                                         _p(rel_bucket), _p(key_mask), batch, heads, head_dim, L, 3 * inner, inner,
-                                        float(scale), _stream()), "alg_attn_bias")
+                                        float(scale), int(causal), _stream()), "alg_attn_bias")
     return out
+
+
+def quick_gelu_(x):
+    _check(load_library().alg_quick_gelu(_p(x), x.numel(), _stream()), "alg_quick_gelu")
+    return x
 
 
 def mul_bf16(a, b, out):

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void attn_bias_kernel(const bf16_t* __restrict
                                                         const bf16_t* __restrict__ bias_table,
                                                         const int* __restrict__ rel_bucket, const int* __restrict__ mask,
                                                         int heads, int L, int Lp, int64_t qkv_rs, int64_t out_rs,
-                                                        int rows_per_wg, float scale) {
+                                                        int rows_per_wg, float scale, int causal) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* KT = (bf16_t*)smem;
   bf16_t* V = KT + (size_t)DH * Lp;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void attn_bias_kernel(const bf16_t* __restrict
     for (int c = 0; c < 8; ++c) {
       const int j = c * 64 + lane;
       float s = -INFINITY;
-      if (c < nchunk && j < L && (!mb || mb[j] != 0)) {
+      if (c < nchunk && j < L && (!mb || mb[j] != 0) && (!causal || j <= i)) {
         s = rbf(acc[c]);                                 // matmul output, bf16
         if (scale != 1.0f) s = rbf(s * scale);
         if (bias_table) s = rbf(s + bf2f(bias_table[(int64_t)rel_bucket[j - i + L - 1] * heads + h]));
@@ -145,6 +145,15 @@ __global__ __launch_bounds__(256) void attn_bias_kernel(const bf16_t* __restrict
     orow[lane] = f2bf(o);
     if (hi) orow[lane + 64] = f2bf(o2);
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// CLIP text tower activation: x * sigmoid(1.702 x), in place, each op rounded to bf16 as the eager graph does
+__global__ __launch_bounds__(256) void quick_gelu_kernel(bf16_t* __restrict__ x, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float v = bf2f(x[e]);
+    const float sg = rbf(1.0f / (1.0f + expf(-rbf(1.702f * v))));
+    x[e] = f2bf(v * sg);
   }
 }
 
@@ -196,7 +205,7 @@ extern "C" int alg_t5_layernorm(const void* x, const void* weight, void* y, int6
 
 extern "C" int alg_attn_bias(const void* q, const void* k, const void* v, void* out, const void* bias_table,
                              const int* rel_bucket, const int* key_mask, int batch, int heads, int head_dim, int L,
-                             int64_t qkv_rstride, int64_t out_rstride, float scale, void* stream) {
+                             int64_t qkv_rstride, int64_t out_rstride, float scale, int causal, void* stream) {
   const int Lp = (L + 63) & ~63;
   const size_t lds = (size_t)2 * head_dim * Lp * 2 + 4 * 128 * 4 + (size_t)4 * Lp * 4;
   if (batch < 0 || heads <= 0 || L <= 0 || Lp > 512 || (head_dim != 64 && head_dim != 80) || lds > 160 * 1024 ||
@@ -226,12 +235,26 @@ extern "C" int alg_attn_bias(const void* q, const void* k, const void* v, void* 
   if (head_dim == 64)
     hipLaunchKernelGGL(t5::attn_bias_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, (const bf16_t*)bias_table, rel_bucket, key_mask,
-                       heads, L, Lp, qkv_rstride, out_rstride, rows_per_wg, scale);
+                       heads, L, Lp, qkv_rstride, out_rstride, rows_per_wg, scale, causal);
   else
     hipLaunchKernelGGL(t5::attn_bias_kernel<80>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, (const bf16_t*)bias_table, rel_bucket, key_mask,
-                       heads, L, Lp, qkv_rstride, out_rstride, rows_per_wg, scale);
+                       heads, L, Lp, qkv_rstride, out_rstride, rows_per_wg, scale, causal);
   return check_launch("alg_attn_bias");
+}
+
+extern "C" int alg_quick_gelu(void* x, int64_t numel, void* stream) {
+  if (numel < 0) {
+    set_error("alg_quick_gelu: bad argument");
+    return ALG_EINVAL;
+  }
+  if (numel == 0) return ALG_OK;
+  if (!x) {
+    set_error("alg_quick_gelu: null pointer");
+    return ALG_EINVAL;
+  }
+  hipLaunchKernelGGL(t5::quick_gelu_kernel, dim3(t5::grid_for(numel)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, numel);
+  return check_launch("alg_quick_gelu");
 }
 
 extern "C" int alg_mul_bf16(const void* a, const void* b, void* out, int64_t numel, void* stream) {

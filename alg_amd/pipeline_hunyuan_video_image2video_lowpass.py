@@ -172,6 +172,16 @@ class HunyuanVideoImageToVideoPipeline:
                 out = torch.cat([out[:, :n_pre], out], dim=1)
         return out.to(dtype=orig_image_latents.dtype)
 
+    def _get_clip_prompt_embeds(self, prompt, num_videos_per_prompt=1, device=None, dtype=None, max_sequence_length=77):
+        """hy:421-452: tokenizer_2 to 77 tokens, CLIP text tower, `pooler_output`."""
+        if self.text_encoder_2 is None or self.tokenizer_2 is None:
+            raise _lib.AlgHipError("no CLIP text encoder / tokenizer is attached: pass pooled_prompt_embeds")
+        device = device or self._execution_device
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        text_inputs = self.tokenizer_2(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
+                                       return_tensors="pt")
+        return self.text_encoder_2(text_inputs.input_ids.to(device), output_hidden_states=False).pooler_output
+
     @torch.no_grad()
     def __call__(
         self,
@@ -224,13 +234,16 @@ class HunyuanVideoImageToVideoPipeline:
         # ---- extensions (not in the reference signature) ----
         image_latents: Optional[torch.Tensor] = None,
         step_trace: Optional[list] = None,
+        clip_prompt: Optional[Union[str, List[str]]] = None,
+        negative_clip_prompt: Optional[Union[str, List[str]]] = None,
     ):
         self.check_inputs(prompt, prompt_2, height, width, prompt_embeds, callback_on_step_end_tensor_inputs,
                           prompt_template, true_cfg_scale, guidance_scale)
         tcfg = self.transformer.config
         image_condition_type = tcfg.image_condition_type
         has_neg_prompt = negative_prompt is not None or (
-            negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None)
+            negative_prompt_embeds is not None
+            and (negative_pooled_prompt_embeds is not None or negative_clip_prompt is not None))
         do_true_cfg = true_cfg_scale > 1 and has_neg_prompt
         self._guidance_scale = guidance_scale
         self._attention_kwargs = attention_kwargs
@@ -244,9 +257,20 @@ class HunyuanVideoImageToVideoPipeline:
         if image_latents is None:
             raise _lib.AlgHipError("the HunyuanVideo VAE is not built (SURVEY section 8 row f-1): pass the pre-encoded, "
                                    "scaled first frame as `image_latents` [B, C, 1, h, w]")
+        # hy:483-490 / hy:1005-1013: the pooled embedding comes from the CLIP text tower when it is attached
+        # (`clip_prompt` / `negative_clip_prompt` are extension kwargs: the reference's check_inputs forbids a prompt next to
+        # prompt_embeds, and the Llava tower that would consume the prompt is not built)
+        clip_text = clip_prompt if clip_prompt is not None else prompt
+        if pooled_prompt_embeds is None and clip_text is not None and self.text_encoder_2 is not None:
+            pooled_prompt_embeds = self._get_clip_prompt_embeds(clip_text, num_videos_per_prompt, device=device)
+        neg_text = negative_clip_prompt if negative_clip_prompt is not None else negative_prompt
+        if (do_true_cfg and negative_pooled_prompt_embeds is None and neg_text is not None
+                and self.text_encoder_2 is not None):
+            negative_pooled_prompt_embeds = self._get_clip_prompt_embeds(neg_text, num_videos_per_prompt, device=device)
         if prompt_embeds is None or pooled_prompt_embeds is None or prompt_attention_mask is None:
-            raise _lib.AlgHipError("the Llava / CLIP prompt encoders are not built (SURVEY section 8 row f-1): pass "
-                                   "prompt_embeds, pooled_prompt_embeds and prompt_attention_mask")
+            raise _lib.AlgHipError("the Llava prompt encoder is not built (SURVEY section 8 row f-3): pass prompt_embeds and "
+                                   "prompt_attention_mask (and pooled_prompt_embeds unless a CLIP text tower is attached as "
+                                   "`text_encoder_2` / `tokenizer_2`)")
         if do_true_cfg and (negative_prompt_embeds is None or negative_pooled_prompt_embeds is None
                             or negative_prompt_attention_mask is None):
             raise _lib.AlgHipError("true CFG needs negative_prompt_embeds, negative_pooled_prompt_embeds and "

@@ -184,13 +184,16 @@ int alg_t5_layernorm(const void* x, const void* weight, void* y, int64_t rows, i
 
 /* T5Attention / CLIPAttention (eager graph; head_dim 64 with L <= 512, or 80 with L <= 448): for batch b, head h
  *   s = bf16(q k^T) [* scale -> bf16]  + bias_table[rel_bucket[j - i + L - 1]][h] -> bf16;  masked keys (key_mask[b][j]
- *   == 0) get probability 0;  p = bf16(softmax_fp32(s));  out = bf16(p v)
+ *   == 0) get probability 0, and with `causal` keys j > i too (CLIPTextModel);  p = bf16(softmax_fp32(s));  out = bf16(p v)
  * q / k / v: element (b, i, h, d) at ptr + (b*L + i)*qkv_rstride + h*head_dim + d (three pointers into one fused QKV buffer);
  * out likewise with out_rstride; bias_table: [buckets][heads] bf16 (relative_attention_bias.weight) or NULL;
  * rel_bucket: int32 [2L - 1], the bucket of relative position (key - query); key_mask: int32 [batch][L] or NULL. */
 int alg_attn_bias(const void* q, const void* k, const void* v, void* out, const void* bias_table, const int* rel_bucket,
                   const int* key_mask, int batch, int heads, int head_dim, int L, int64_t qkv_rstride, int64_t out_rstride,
-                  float scale, void* stream);
+                  float scale, int causal, void* stream);
+
+/* CLIPTextModel's `quick_gelu` (hy:421-452 `text_encoder_2`): x = bf16(x * bf16(sigmoid(bf16(1.702 x)))), in place. */
+int alg_quick_gelu(void* x, int64_t numel, void* stream);
 
 /* out = bf16(a * b) (T5DenseGatedActDense: gelu_new(wi_0 x) * wi_1 x). */
 int alg_mul_bf16(const void* a, const void* b, void* out, int64_t numel, void* stream);

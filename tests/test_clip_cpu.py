@@ -43,3 +43,32 @@ def test_product_class_tables_and_processor():
     assert feat["pixel_values"].shape == (1, 3, 224, 224) and set(feat.keys()) == {"pixel_values"}
     assert feat.to("cpu")["pixel_values"].dtype == torch.float32
     assert abs(float(feat["pixel_values"].mean())) < 0.5
+
+
+def test_clip_text_oracle_matches_transformers_outputs():
+    from oracle import clip_text_oracle as cto
+    vec = np.load(os.path.join(os.path.dirname(GOLD), "clip_text_vectors.npz"))
+    cfg, sd, ids = cto.golden_inputs()
+    assert np.array_equal(vec["input_ids"], ids.numpy())
+    x, pooled = cto.encode(cfg, sd, ids)
+    assert np.abs(x.numpy() - vec["last_hidden_state"]).max() <= 2e-5
+    assert np.abs(pooled.numpy() - vec["pooler_output"]).max() <= 2e-5
+
+
+def test_clip_text_product_tables_and_pooling_rule():
+    from alg_amd import _lib
+    from alg_amd.text_encoder_clip import CLIPTextEncoderConfig, CLIPTextModel
+    from oracle import clip_text_oracle as cto
+    m = CLIPTextModel(device="cpu")
+    assert m.param_shapes() == cto.param_shapes(cto.CLIPTextConfig())
+    n = sum(torch.Size(s).numel() for s in m.param_shapes().values())
+    assert 0.12e9 < n < 0.13e9                      # CLIP-L/14 text tower
+    ids = torch.tensor([[5, 9, 49407, 0, 0], [7, 49407, 3, 3, 3]])
+    assert m.eos_positions(ids).tolist() == [2, 1]              # legacy rule: argmax of the ids
+    m2 = CLIPTextModel(CLIPTextEncoderConfig(**cto.GOLDEN["cfg"]), device="cpu")
+    assert m2.eos_positions(torch.tensor([[97, 5, 98, 0], [97, 98, 98, 0]])).tolist() == [2, 1]   # first eos token
+    cfg, sd, _ = cto.golden_inputs()
+    m2.load_state_dict({"text_model." + k: v for k, v in sd.items()})
+    assert m2.w["encoder.layers.1.qkv"].shape == (384, 128)
+    with pytest.raises(_lib.AlgHipError, match="HIP-only"):
+        m2(torch.zeros(1, 8, dtype=torch.long))
