@@ -140,3 +140,32 @@ def test_cogvideox_pipeline_encodes_prompts_through_the_hip_t5():
     ne = t5(tok(["blurry"], max_length=10).input_ids.to(dev))[0]
     b = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, generator=torch.Generator().manual_seed(2), **kw).frames
     assert torch.equal(a, b) and bool(torch.isfinite(a.float()).all())
+
+
+def test_wan_pipeline_encodes_prompts_through_the_hip_umt5():
+    """wan:185-234 on HIP: tokenizer (stand-in) -> UMT5 with the attention mask -> rows past each prompt's length zeroed;
+    equals running the encoder by hand, and the negative prompt defaults to ''."""
+    from alg_amd import UniPCMultistepScheduler, WanImageToVideoPipeline
+    um = UMT5EncoderModel.from_synthetic(T5EncoderConfig(vocab_size=256, d_model=128, d_ff=256, num_layers=2, num_heads=2),
+                                         seed=4, device=_dev())
+
+    class Tok:
+        def __call__(self, texts, max_length=None, **_):
+            ids = torch.zeros(len(texts), max_length, dtype=torch.long)
+            mask = torch.zeros(len(texts), max_length, dtype=torch.long)
+            for i, t in enumerate(texts):
+                row = [ord(ch) % 250 + 2 for ch in t][:max_length - 1] + [1]
+                ids[i, :len(row)] = torch.tensor(row)
+                mask[i, :len(row)] = 1
+            return type("Enc", (), {"input_ids": ids, "attention_mask": mask})()
+
+    t = type("T", (), {"dtype": BF, "config": type("C", (), {"patch_size": (1, 2, 2)})()})()
+    pipe = WanImageToVideoPipeline(tokenizer=Tok(), text_encoder=um, transformer=t, scheduler=UniPCMultistepScheduler())
+    pe, ne = pipe.encode_prompt(["a  red &amp; blue bus", "fog"], None, True, 1, None, None, 64, _dev())
+    assert pe.shape == ne.shape == (2, 64, 128) and pe.dtype == BF
+    tok = Tok()(["a red & blue bus", "fog"], max_length=64)            # prompt_clean collapsed spaces / entities
+    want = um(tok.input_ids.to(_dev()), tok.attention_mask.to(_dev())).last_hidden_state
+    n0, n1 = int(tok.attention_mask[0].sum()), int(tok.attention_mask[1].sum())
+    assert torch.equal(pe[0, :n0], want[0, :n0]) and torch.equal(pe[1, :n1], want[1, :n1])
+    assert bool((pe[0, n0:] == 0).all()) and bool((pe[1, n1:] == 0).all())
+    assert bool((ne[:, 1:] == 0).all()) and bool((ne[:, 0] != 0).any())
