@@ -27,7 +27,7 @@ EXPORTS = (
     "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu", "alg_gemm_fp8", "alg_quantize_fp8_rows",
     "alg_conv_cl_bf16", "alg_vae_groupnorm_workspace", "alg_vae_groupnorm_stats", "alg_vae_spatial_norm", "alg_vae_upsample",
     "alg_vae_pack_latent", "alg_vae_unpack_video", "alg_vae_group_norm", "alg_vae_pad", "alg_vae_repitch",
-    "alg_vae_unpack_planes", "alg_patchify_t", "alg_unpatchify_t", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
+    "alg_vae_unpack_planes", "alg_patchify_t", "alg_unpatchify_t", "alg_qk_norm_rope_scaled", "alg_flash_attn_d64_ex", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
 )
 
 
@@ -133,6 +133,9 @@ def load_library():
                                            c_int, c_int, c_int64, c_int64, c_int, c_float, c_void_p]
     lib.alg_qk_norm_rope.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_int, c_int, c_int, c_float, c_void_p]
+    lib.alg_qk_norm_rope_scaled.argtypes = [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]
+    lib.alg_flash_attn_d64_ex.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
+                                          c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_void_p]
     lib.alg_patchify.argtypes = [c_void_p, c_int64, POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_void_p]
     lib.alg_unpatchify.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
@@ -540,12 +543,17 @@ def quantize_fp8_rows(x, q, scale, rows, K, x_rstride=None, x_off=0, q_off=0, sc
     return q, scale
 
 
+ATTN_Q_PRESCALED = 1
+
+
 def flash_attn_d64(q, k, vt, o, batch, heads, S, q_bstride, q_rstride, vt_bstride, vt_rstride, o_bstride, o_rstride,
-                   scale, q_off=0, k_off=0):
+                   scale, q_off=0, k_off=0, q_prescaled=False):
+    """q_prescaled: q already carries scale * log2(e) (qk_norm_rope_ with q_scale): alg_flash_attn_d64_ex."""
     lib = load_library()
-    _check(lib.alg_flash_attn_d64(c_void_p(q.data_ptr() + 2 * q_off), c_void_p(k.data_ptr() + 2 * k_off), _ptr(vt),
-                                  _ptr(o), batch, heads, S, q_bstride, q_rstride, vt_bstride, vt_rstride, o_bstride,
-                                  o_rstride, float(scale), _stream()), "alg_flash_attn_d64")
+    _check(lib.alg_flash_attn_d64_ex(c_void_p(q.data_ptr() + 2 * q_off), c_void_p(k.data_ptr() + 2 * k_off), _ptr(vt),
+                                     _ptr(o), batch, heads, S, q_bstride, q_rstride, vt_bstride, vt_rstride, o_bstride,
+                                     o_rstride, float(scale), ATTN_Q_PRESCALED if q_prescaled else 0, _stream()),
+           "alg_flash_attn_d64")
 
 
 def layernorm_modulate(x, y, weight, bias, scale, shift, mod_bstride, batch, rows, D, seg_split, eps,
@@ -561,10 +569,10 @@ def layernorm_modulate(x, y, weight, bias, scale, shift, mod_bstride, batch, row
                                       y_bstride, seg_split, float(eps), _stream()), "alg_layernorm_modulate")
 
 
-def qk_norm_rope_(qk, wq, bq, wk, bk, cos, sin, batch, S, heads, text_len, eps):
+def qk_norm_rope_(qk, wq, bq, wk, bk, cos, sin, batch, S, heads, text_len, eps, q_scale=1.0):
     lib = load_library()
-    _check(lib.alg_qk_norm_rope(_ptr(qk), _ptr(wq), _ptr(bq), _ptr(wk), _ptr(bk), _ptr(cos), _ptr(sin), batch, S,
-                                heads, text_len, float(eps), _stream()), "alg_qk_norm_rope")
+    _check(lib.alg_qk_norm_rope_scaled(_ptr(qk), _ptr(wq), _ptr(bq), _ptr(wk), _ptr(bk), _ptr(cos), _ptr(sin), batch, S,
+                                       heads, text_len, float(eps), float(q_scale), _stream()), "alg_qk_norm_rope")
 
 
 def patchify(latents, lat_bstride, conds, out, n_samples, frames, C, H, W, p, p_t=1):

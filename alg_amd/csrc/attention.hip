@@ -36,6 +36,8 @@
 //   39/40  the duo kernels (15/16) with the lazy softmax; the exact-max fix-up sits between the scheduling regions:
 //       828 -> 995 / 1044 TFLOP/s (8 / 4 waves), i.e. on par with 33 (1027 on the same box); the interleave granularity
 //       (6..16 VALU per MFMA) moves it by < 2 %
+//   41  the kernel behind alg_flash_attn_d64_ex(ALG_ATTN_Q_PRESCALED): variant 34's softmax on a Q that was scaled where it
+//       was produced (alg_qk_norm_rope_scaled: no extra rounding); not selectable by ALG_ATTN_VARIANT
 //   34  33 with Q pre-scaled by scale*log2(e) in registers and the offset snapped to zero when the first tile's max allows
 //       it: p = exp2(s) with no per-score fma (+2 %; one more bf16 rounding of q, so opt-in)
 // Measured on MI355X at the C2 shape (2 x 48 heads x 17,776 tokens, profiles/): 1: 860-915 TFLOP/s,
@@ -299,7 +301,7 @@ __device__ __forceinline__ void pv_tile(const char* Vs, const bf16x8 (&pf)[4], c
 // other runs its softmax); the price is that K/V^T tiles are staged once per 128 instead of 256 queries.
 template <int VARIANT, int NW = 8, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d64_kernel(const AttnP p) {
-  static_assert(!SPLIT || (VARIANT == 33 && NW == 8), "the split-KV tail is built on the default variant");
+  static_assert(!SPLIT || ((VARIANT == 33 || VARIANT == 41) && NW == 8), "the split-KV tail is built on the default variants");
   constexpr int ROUNDS = NW >= 8 ? 1 : 8 / NW;  // DMA rounds per 8 KiB tile (one round = min(NW, 8) KiB)
   constexpr int DW = NW >= 8 ? 8 : NW;           // waves that issue DMA (a 16-wave workgroup only needs half)
   constexpr int K_SLOTS = VARIANT == 2 ? 3 : 2;
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
       qk_tile<(ABL & 2) != 0>(k_ring + (t & 1) * ATT_TILE, qf, f, s);
       if (!PEEL && ragged && t == n_tiles - 1) mask_tail(s, t * KVB, S, h2);
       bf16x8 pf[4];
-      if (VARIANT == 34)
+      if (VARIANT == 34 || VARIANT == 41)   // 41: Q arrives pre-scaled (alg_flash_attn_d64_ex, ALG_ATTN_Q_PRESCALED)
         softmax_tile_zero(s, m_run, l_run, o_acc, pf);
       else if (VARIANT == 36)
         softmax_tile_lazy<false>(s, c, m_run, l_run, o_acc, pf);
@@ -1385,6 +1387,13 @@ using namespace alg;
 extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S,
                                   int64_t q_bstride, int64_t q_rstride, int64_t vt_bstride, int64_t vt_rstride,
                                   int64_t o_bstride, int64_t o_rstride, float scale, void* stream) {
+  return alg_flash_attn_d64_ex(q, k, vt, o, batch, heads, S, q_bstride, q_rstride, vt_bstride, vt_rstride, o_bstride,
+                               o_rstride, scale, 0, stream);
+}
+
+extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S,
+                                     int64_t q_bstride, int64_t q_rstride, int64_t vt_bstride, int64_t vt_rstride,
+                                     int64_t o_bstride, int64_t o_rstride, float scale, int flags, void* stream) {
   if (!q || !k || !vt || !o || batch <= 0 || heads <= 0 || S <= 0) {
     set_error("alg_flash_attn_d64: bad argument (batch=%d heads=%d S=%d)", batch, heads, S);
     return ALG_EINVAL;
@@ -1404,19 +1413,20 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
   p.batch = batch; p.heads = heads; p.S = S;
   int variant = attn_variant();
   if (variant >= 8 && variant < 32 && !vt128) variant = 33;
+  if (flags & ALG_ATTN_Q_PRESCALED) variant = 41;  // the only kernel that takes log2-unit scores
   const int nw = (variant == 5 || variant == 7 || variant == 16 || variant == 40) ? 4 : (variant == 12 ? 16 : 8);
   const int q_per_wave = (variant == 6 || variant == 7 || variant == 15 || variant == 16 || variant == 39 || variant == 40) ? 64 : 32;
   p.q_blocks = (S + nw * q_per_wave - 1) / (nw * q_per_wave);
   p.q_bs = q_bstride; p.q_rs = q_rstride; p.vt_bs = vt_bstride; p.vt_rs = vt_rstride;
   p.o_bs = o_bstride; p.o_rs = o_rstride;
-  p.scale_log2 = scale * 1.4426950408889634f;
+  p.scale_log2 = (flags & ALG_ATTN_Q_PRESCALED) ? 1.0f : scale * 1.4426950408889634f;  // m is in log2 units already
   const int nbh = batch * heads;
   const int64_t grid = (int64_t)((nbh + 7) / 8) * 8 * p.q_blocks;
   const dim3 blk(nw * 64);
   hipStream_t s = (hipStream_t)stream;
   p.unit0 = p.tail_units = p.tail_split = p.tail_tiles = 0;
   p.ws_o = p.ws_ml = nullptr;
-  if (variant == 33) {
+  if (variant == 33 || variant == 41) {
     const TailPlan tp = plan_tail(nbh, p.q_blocks, (S + KVB - 1) / KVB);
     if (tp.units) {
       const int per_xcd = nbh / 8 * p.q_blocks;
@@ -1429,8 +1439,13 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
         return ALG_ELAUNCH;
       }
       p.ws_o = ws, p.ws_ml = ws + rows * 64;
-      hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8>), dim3((unsigned)(8 * p.unit0)), blk, 0, s, p);
-      hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8, true>), dim3((unsigned)(8 * tp.units * tp.split)), blk, 0, s, p);
+      if (variant == 41) {
+        hipLaunchKernelGGL((flash_attn_d64_kernel<41, 8>), dim3((unsigned)(8 * p.unit0)), blk, 0, s, p);
+        hipLaunchKernelGGL((flash_attn_d64_kernel<41, 8, true>), dim3((unsigned)(8 * tp.units * tp.split)), blk, 0, s, p);
+      } else {
+        hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8>), dim3((unsigned)(8 * p.unit0)), blk, 0, s, p);
+        hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8, true>), dim3((unsigned)(8 * tp.units * tp.split)), blk, 0, s, p);
+      }
       const int64_t merge = (int64_t)8 * tp.units * 256 * 16;
       hipLaunchKernelGGL(flash_attn_d64_merge_kernel, dim3((unsigned)((merge + 255) / 256)), dim3(256), 0, s, p);
       const int rc = check_launch("alg_flash_attn_d64");
@@ -1454,6 +1469,7 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
     case 33: hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8>), g, blk, 0, s, p); break;
     case 34: hipLaunchKernelGGL((flash_attn_d64_kernel<34, 8>), g, blk, 0, s, p); break;
     case 36: hipLaunchKernelGGL((flash_attn_d64_kernel<36, 8>), g, blk, 0, s, p); break;
+    case 41: hipLaunchKernelGGL((flash_attn_d64_kernel<41, 8>), g, blk, 0, s, p); break;
     case 17: hipLaunchKernelGGL((flash_attn_d64_kernel<17, 8>), g, blk, 0, s, p); break;  // no DMA after tile 0
     case 18: hipLaunchKernelGGL((flash_attn_d64_kernel<18, 8>), g, blk, 0, s, p); break;  // no LDS fragment reads
     case 19: hipLaunchKernelGGL((flash_attn_d64_kernel<19, 8>), g, blk, 0, s, p); break;  // neither

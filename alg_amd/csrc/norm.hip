@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
                                                            const bf16_t* __restrict__ bk,
                                                            const float* __restrict__ cos_tab,
                                                            const float* __restrict__ sin_tab, int64_t total_vec, int S,
-                                                           int heads, int text_len, float eps) {
+                                                           int heads, int text_len, float eps, float q_scale) {
   const int lane = threadIdx.x & 63;
   const int sub = lane & 7;
   const int64_t vec = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);
@@ -131,9 +131,17 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
   unpack8(*(const uint4*)((is_k ? wk : wq) + sub * 8), wv);
   unpack8(*(const uint4*)((is_k ? bk : bq) + sub * 8), bv);
   float o[8];
+  // q_scale (alg_qk_norm_rope_scaled): the softmax scale * log2(e) folded into Q where it is produced, inside the LAST
+  // rounding of the row (after the rope for video tokens, in the LayerNorm rounding for text tokens): the attention kernel
+  // then needs no per-score multiply.  K is never scaled.
+  const float qs = is_k ? 1.0f : q_scale;
+  const bool roped = s >= text_len && cos_tab;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) o[k] = rbf((v[k] - mean) * rstd * wv[k] + bv[k]);
-  if (s >= text_len && cos_tab) {
+  for (int k = 0; k < 8; ++k) {
+    const float ln = (v[k] - mean) * rstd * wv[k] + bv[k];
+    o[k] = roped ? rbf(ln) : (qs == 1.0f ? rbf(ln) : rbf(ln * qs));
+  }
+  if (roped) {
     const int64_t pos = (int64_t)(s - text_len) * 64 + sub * 8;
     const float4 c0 = *(const float4*)(cos_tab + pos), c1 = *(const float4*)(cos_tab + pos + 4);
     const float4 s0 = *(const float4*)(sin_tab + pos), s1 = *(const float4*)(sin_tab + pos + 4);
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
       r[2 * k + 1] = __fadd_rn(__fmul_rn(o[2 * k + 1], cs[2 * k + 1]), __fmul_rn(o[2 * k], sn[2 * k + 1]));
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = r[k];
+    for (int k = 0; k < 8; ++k) o[k] = qs == 1.0f ? r[k] : r[k] * qs;
   }
   if (live) *(uint4*)ptr = pack8(o);
 }
@@ -203,9 +211,9 @@ extern "C" int alg_layernorm_modulate_seg(const void* x, void* y, const void* we
   return check_launch("alg_layernorm_modulate");
 }
 
-extern "C" int alg_qk_norm_rope(void* qk, const void* wq, const void* bq, const void* wk, const void* bk,
-                                const float* cos_tab, const float* sin_tab, int batch, int S, int heads,
-                                int text_len, float eps, void* stream) {
+extern "C" int alg_qk_norm_rope_scaled(void* qk, const void* wq, const void* bq, const void* wk, const void* bk,
+                                       const float* cos_tab, const float* sin_tab, int batch, int S, int heads,
+                                       int text_len, float eps, float q_scale, void* stream) {
   if (!qk || !wq || !bq || !wk || !bk || batch <= 0 || S <= 0 || heads <= 0 || text_len < 0) {
     set_error("alg_qk_norm_rope: bad argument (batch=%d S=%d heads=%d text_len=%d)", batch, S, heads, text_len);
     return ALG_EINVAL;
@@ -223,6 +231,11 @@ extern "C" int alg_qk_norm_rope(void* qk, const void* wq, const void* bq, const 
   const unsigned grid = (unsigned)((total_vec + 31) / 32);
   hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qk,
                      (const bf16_t*)wq, (const bf16_t*)bq, (const bf16_t*)wk, (const bf16_t*)bk, cos_tab, sin_tab,
-                     total_vec, S, heads, text_len, eps);
+                     total_vec, S, heads, text_len, eps, q_scale);
   return check_launch("alg_qk_norm_rope");
+}
+
+extern "C" int alg_qk_norm_rope(void* qk, const void* wq, const void* bq, const void* wk, const void* bk, const float* cos_tab,
+                                const float* sin_tab, int batch, int S, int heads, int text_len, float eps, void* stream) {
+  return alg_qk_norm_rope_scaled(qk, wq, bq, wk, bk, cos_tab, sin_tab, batch, S, heads, text_len, eps, 1.0f, stream);
 }

@@ -313,6 +313,8 @@ class CogVideoXTransformer3DModel:
 
         # 3. transformer blocks
         scale = 1.0 / math.sqrt(cfg.attention_head_dim)
+        prescale = os.environ.get("ALG_ATTN_PRESCALE", "1") != "0"
+        q_scale = scale * 1.4426950408889634 if prescale else 1.0
         F4 = cfg.ff_inner_mult * D
         for li, L in enumerate(self.layers):
             m1 = li * 12 * D          # norm1: shift @+0, scale @+2D, gate @+4D (each [2][D])
@@ -322,10 +324,11 @@ class CogVideoXTransformer3DModel:
             TM("gemm_qk", G, y, L["wqk"], qk, S, 2 * D, D, D, D, 2 * D, bias=L["bqk"], batch=N, strideA=S * D, strideC=S * 2 * D)
             TM("gemm_vt", G, L["wv"], y, vt, D, S, D, D, D, S_pad, bias=L["bv"], batch=N, strideB=S * D, strideC=D * S_pad,
               flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
+            # the softmax scale * log2(e) rides in Q's last rounding (ALG_ATTN_PRESCALE=0: scaled per score in the attention)
             TM("qk_norm_rope", _lib.qk_norm_rope_, qk, L["norm_q_w"], L["norm_q_b"], L["norm_k_w"], L["norm_k_b"], cos, sin, N, S, Hn, T,
-                               cfg.qk_norm_eps)
+                               cfg.qk_norm_eps, q_scale=q_scale)
             TM("attn", _lib.flash_attn_d64, qk, qk, vt, att, N, Hn, S, S * 2 * D, 2 * D, D * S_pad, S_pad, S * D, D, scale,
-                                k_off=D)
+                                k_off=D, q_prescaled=prescale)
             TM("gemm_out", G, att, L["wo"], x, S, D, D, D, D, D, bias=L["bo"], R=x, ldr=D, gate=mod, gate_off=m1 + 4 * D,
               strideGate=self.mod_cols, seg_split=T, batch=N, strideA=S * D, strideC=S * D, strideR=S * D)
             TM("ln_mod", _lib.layernorm_modulate, x, y, L["norm2_w"], L["norm2_b"], mod, mod, self.mod_cols, N, S, D,

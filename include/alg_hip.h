@@ -159,6 +159,13 @@ int alg_flash_attn_d64(const void* q, const void* k, const void* vt, void* o, in
                        int64_t q_bstride, int64_t q_rstride, int64_t vt_bstride, int64_t vt_rstride,
                        int64_t o_bstride, int64_t o_rstride, float scale, void* stream);
 
+/* flags = ALG_ATTN_Q_PRESCALED: q already carries scale * log2(e) (alg_qk_norm_rope_scaled); `scale` is ignored and the
+ * scores come out of the MFMA in log2 units.  flags = 0 is alg_flash_attn_d64. */
+#define ALG_ATTN_Q_PRESCALED 1
+int alg_flash_attn_d64_ex(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S,
+                          int64_t q_bstride, int64_t q_rstride, int64_t vt_bstride, int64_t vt_rstride,
+                          int64_t o_bstride, int64_t o_rstride, float scale, int flags, void* stream);
+
 /* wan:910-917 (WanTransformer3DModel self- and cross-attention, head_dim 128; diffusers WanAttnProcessor SDPA)
  * Same contract as alg_flash_attn_d64 with head_dim 128 and separate query / key lengths:
  *   q : element (b, s, h, d) at q + b*q_bstride + s*q_rstride + h*128 + d,  s < Sq
@@ -350,6 +357,12 @@ int alg_layernorm_modulate_seg(const void* x, void* y, const void* weight, const
  * convention) on tokens >= text_len. */
 int alg_qk_norm_rope(void* qk, const void* wq, const void* bq, const void* wk, const void* bk, const float* cos_tab,
                      const float* sin_tab, int batch, int S, int heads, int text_len, float eps, void* stream);
+
+/* The same with Q multiplied by q_scale inside its last rounding (K untouched): q_scale = softmax_scale * log2(e) lets
+ * alg_flash_attn_d64_ex(ALG_ATTN_Q_PRESCALED) form its probabilities as exp2(score) with no per-score multiply. */
+int alg_qk_norm_rope_scaled(void* qk, const void* wq, const void* bq, const void* wk, const void* bk, const float* cos_tab,
+                            const float* sin_tab, int batch, int S, int heads, int text_len, float eps, float q_scale,
+                            void* stream);
 
 /* Patch gather for the patch-embed GEMM (cog:1060-1070 batch assembly folded in, no materialised cat):
  * out[n][(f, gy, gx)][c*p*p + py*p + px]; channels [0, C) come from latents (sample stride lat_bstride, 0 =

@@ -226,6 +226,41 @@ def test_qk_norm_rope(device):
     assert (got - ref).abs().max() <= 4e-2 and rel_err(got, ref) < 5e-3
 
 
+def test_qk_norm_rope_scaled_and_prescaled_attention(device):
+    """alg_qk_norm_rope_scaled folds softmax_scale * log2(e) into Q's last rounding (K untouched); the attention entry with
+    ALG_ATTN_Q_PRESCALED then takes the scores as log2 units.  Q(scaled) == c * Q(unscaled) to one bf16 rounding, K bit
+    equal, and the prescaled attention gives the reference softmax on the ORIGINAL q, k (also across the split-KV tail
+    threshold shapes and a ragged sequence)."""
+    g = torch.Generator().manual_seed(8)
+    nb, S, H, T = 2, 50, 3, 10
+    cfg = dit_oracle.DiTConfig(sample_height=8, sample_width=10, sample_frames=5)
+    cos, sin = dit_oracle.rope_tables(cfg, 64, 80, 2)
+    qk = rnd((nb, S, 2, H, 64), g, 1.5)
+    ws = [(1 + 0.1 * torch.randn(64, generator=g)).to(BF) if i % 2 == 0 else rnd((64,), g, 0.1) for i in range(4)]
+    args = [w.to(device) for w in ws] + [cos.to(device), sin.to(device), nb, S, H, T, 1e-6]
+    a, b = qk.to(device).clone(), qk.to(device).clone()
+    c = 0.125 * 1.4426950408889634
+    _lib.qk_norm_rope_(a, *args)
+    _lib.qk_norm_rope_(b, *args, q_scale=c)
+    assert torch.equal(a[:, :, 1], b[:, :, 1])                                     # K untouched
+    qa, qb = a[:, :, 0].float(), b[:, :, 0].float()
+    assert ((qb - qa * c).abs() <= 2.0 ** -7 * (qa * c).abs() + 1e-6).all()      # one bf16 rounding each: <= 2 * 2^-9 apart
+    for Bn, S2, H2 in [(1, 333, 2), (2, 1000, 3)]:
+        q, k, v = rnd((Bn, S2, H2, 64), g), rnd((Bn, S2, H2, 64), g), rnd((Bn, S2, H2, 64), g)
+        ref = sdpa_ref(q, k, v, 0.125)
+        D = H2 * 64
+        S_pad = (S2 + 127) // 128 * 128
+        qs = (q.float() * c).to(BF)                                              # what the scaled norm kernel would hand over
+        qkb = torch.cat([qs.reshape(Bn, S2, D), k.reshape(Bn, S2, D)], dim=-1).contiguous().to(device)
+        vt = torch.zeros(Bn, D, S_pad, dtype=BF)
+        vt[:, :, torch.tensor([swap23(n) for n in range(S2)])] = v.reshape(Bn, S2, D).transpose(1, 2)
+        o = torch.zeros(Bn, S2, D, dtype=BF, device=device)
+        _lib.flash_attn_d64(qkb, qkb, vt.to(device), o, Bn, H2, S2, S2 * 2 * D, 2 * D, D * S_pad, S_pad, S2 * D, D, 0.125,
+                            k_off=D, q_prescaled=True)
+        got = o.cpu().reshape(Bn, S2, H2, 64).double()
+        assert torch.isfinite(got).all() and (got - ref).abs().max() <= 1e-2
+
+
 def test_patchify_unpatchify_timestep(device):
     g = torch.Generator().manual_seed(6)
     n, Fr, C, H, W, p = 3, 2, 4, 6, 10, 2

@@ -257,3 +257,23 @@ def test_default_attention_agrees_with_the_exact_max_variant_in_a_full_width_for
     b = model.forward_assembled(lat, [c0, c0], torch.cat([ne, pe]), ts, rope).float()
     rel = ((a - b).norm() / b.norm()).item()
     assert bool(torch.isfinite(a).all()) and rel < 5e-3, rel
+
+
+def test_prescaled_attention_path_agrees_in_a_full_width_forward(device, monkeypatch):
+    """The transformer folds the softmax scale into Q (alg_qk_norm_rope_scaled + ALG_ATTN_Q_PRESCALED, default);
+    ALG_ATTN_PRESCALE=0 keeps the per-score multiply: same forward to bf16 rounding at the full C2 size (split-KV tail
+    included on both paths)."""
+    cfg = CogVideoXTransformerConfig(num_layers=2)
+    model = CogVideoXTransformer3DModel.from_synthetic(cfg, seed=13, device=device)
+    g = torch.Generator().manual_seed(6)
+    lat = torch.randn(1, 13, 16, 60, 90, generator=g).to(device, BF)
+    c0 = torch.zeros(1, 13, 16, 60, 90, dtype=BF, device=device)
+    c0[:, 0] = (torch.randn(1, 16, 60, 90, generator=g) * 0.7).to(device, BF)
+    pe, ne = (torch.randn(1, 226, 4096, generator=g).to(device, BF) for _ in range(2))
+    rope = rotary_tables(64, get_resize_crop_region_for_grid((30, 45), 45, 30), (30, 45), 13)
+    ts = torch.full((2,), 500.0)
+    a = model.forward_assembled(lat, [c0, c0], torch.cat([ne, pe]), ts, rope).float()
+    monkeypatch.setenv("ALG_ATTN_PRESCALE", "0")
+    b = model.forward_assembled(lat, [c0, c0], torch.cat([ne, pe]), ts, rope).float()
+    rel = ((a - b).norm() / b.norm()).item()
+    assert bool(torch.isfinite(a).all()) and 0 < rel < 5e-3, rel
