@@ -22,7 +22,7 @@ GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS, GEMM_GATE_F32, GEMM_GATE_SEG_STRIDE = 1, 4
 EXPORTS = (
     "alg_version", "alg_last_error", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16",
     "alg_flash_attn_d64", "alg_layernorm_modulate", "alg_qk_norm_rope", "alg_patchify", "alg_unpatchify",
-    "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128", "alg_layernorm_mod_f32", "alg_rmsnorm_rope",
+    "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128", "alg_layernorm_mod_f32", "alg_layernorm_mod_f32_fp8", "alg_rmsnorm_rope",
     "alg_wan_modulation", "alg_patchify3d", "alg_unpatchify3d", "alg_timestep_embedding_f32", "alg_linear_f32",
     "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu", "alg_gemm_fp8", "alg_quantize_fp8_rows",
     "alg_conv_cl_bf16", "alg_vae_groupnorm_workspace", "alg_vae_groupnorm_stats", "alg_vae_spatial_norm", "alg_vae_upsample",
@@ -94,6 +94,7 @@ def load_library():
         c_void_p, c_int, c_void_p]
     lib.alg_flash_attn_d128.argtypes = [c_void_p] * 4 + [c_int] * 4 + [c_int64] * 8 + [c_float, c_void_p]
     lib.alg_layernorm_mod_f32.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]
+    lib.alg_layernorm_mod_f32_fp8.argtypes = [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]
     lib.alg_rmsnorm_rope.argtypes = [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]
     lib.alg_wan_modulation.argtypes = [c_void_p] * 3 + [c_int] * 5 + [c_void_p]
     lib.alg_patchify3d.argtypes = [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]
@@ -301,6 +302,15 @@ def layernorm_mod_f32(x, y, weight, bias, scale, shift, mod_bstride, batch, rows
                                                 _p(shift, shift_off), mod_bstride, batch, rows, D, float(eps), _stream()),
            "alg_layernorm_mod_f32")
     return y
+
+
+def layernorm_mod_f32_fp8(x, q8, q8_scale, weight, bias, scale, shift, mod_bstride, batch, rows, D, eps, scale_off=0,
+                          shift_off=0):
+    """layernorm_mod_f32 followed by quantize_fp8_rows, in one pass (bit-identical bytes and scales)."""
+    _check(load_library().alg_layernorm_mod_f32_fp8(_p(x), _p(q8), _p(q8_scale), _p(weight), _p(bias),
+                                                    _p(scale, scale_off), _p(shift, shift_off), mod_bstride, batch, rows,
+                                                    D, float(eps), _stream()), "alg_layernorm_mod_f32_fp8")
+    return q8
 
 
 def rmsnorm_rope_(x, weight, cos, sin, x_rstride, batch, rows, D, eps, x_off=0):

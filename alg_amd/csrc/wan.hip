@@ -30,12 +30,15 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 }
 
 // y = bf16( LN_fp32(x) [* w + b] [* (1 + scale[b]) + shift[b]] )
+// q8 != nullptr (fp8 mode): the bf16-rounded row is quantised in registers as alg_quantize_fp8_rows would (amax / 448 per
+// row, OCP e4m3) and ONLY the bytes + the row scale are written: the separate quantiser pass over y disappears.
 template <int ITERS>
 __global__ __launch_bounds__(256) void ln_mod_f32_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                          const float* __restrict__ w, const float* __restrict__ bs,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int64_t mod_bs,
-                                                         int64_t total_rows, int rows, float eps) {
+                                                         int64_t total_rows, int rows, float eps,
+                                                         uint8_t* __restrict__ q8, float* __restrict__ q8_scale) {
   constexpr int D = ITERS * 512;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -62,7 +65,8 @@ __global__ __launch_bounds__(256) void ln_mod_f32_kernel(const bf16_t* __restric
   const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
   const float* sc = scale ? scale + (int64_t)bidx * mod_bs : nullptr;
   const float* sh = shift ? shift + (int64_t)bidx * mod_bs : nullptr;
-  bf16_t* yr = y + row * D;
+  bf16_t* yr = y ? y + row * D : nullptr;
+  float amax = 0.0f;
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
     const int c0 = i * 512 + lane * 8;
@@ -89,7 +93,35 @@ __global__ __launch_bounds__(256) void ln_mod_f32_kernel(const bf16_t* __restric
       if (sh) n = n + shv[k];
       o[k] = n;
     }
-    *(uint4*)(yr + c0) = pack8(o);
+    if (q8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[i][k] = rbf(o[k]);  // the value the bf16 tensor would hold
+        amax = fmaxf(amax, fabsf(v[i][k]));
+      }
+    } else {
+      *(uint4*)(yr + c0) = pack8(o);
+    }
+  }
+  if (q8) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
+    const float qs = amax > 0.0f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / qs;
+    if (lane == 0) q8_scale[row] = qs;
+    uint8_t* qr = q8 + row * D;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      float f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = fminf(fmaxf(v[i][k] * inv, -448.0f), 448.0f);
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+      *(uint2*)(qr + i * 512 + lane * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
   }
 }
 
@@ -287,17 +319,17 @@ using namespace alg;
     default: ok = false;                                                  \
   }
 
-extern "C" int alg_layernorm_mod_f32(const void* x, void* y, const float* weight, const float* bias, const float* scale,
-                                     const float* shift, int64_t mod_bstride, int batch, int rows, int D, float eps,
-                                     void* stream) {
+static int layernorm_mod_entry(const char* who, const void* x, void* y, void* q8, float* q8_scale, const float* weight,
+                               const float* bias, const float* scale, const float* shift, int64_t mod_bstride, int batch,
+                               int rows, int D, float eps, void* stream) {
   if (batch < 0 || rows < 0 || D <= 0) {
-    set_error("alg_layernorm_mod_f32: bad shape batch=%d rows=%d D=%d", batch, rows, D);
+    set_error("%s: bad shape batch=%d rows=%d D=%d", who, batch, rows, D);
     return ALG_EINVAL;
   }
   const int64_t total = (int64_t)batch * rows;
   if (total == 0) return ALG_OK;
-  if (!x || !y) {
-    set_error("alg_layernorm_mod_f32: null pointer");
+  if (!x || (!y && !q8) || (q8 && !q8_scale)) {
+    set_error("%s: null pointer", who);
     return ALG_EINVAL;
   }
   const dim3 grid((unsigned)((total + 3) / 4)), blk(256);
@@ -305,12 +337,32 @@ extern "C" int alg_layernorm_mod_f32(const void* x, void* y, const float* weight
   bool ok = D % 512 == 0;
   if (ok) {
     DISPATCH_ITERS(D / 512, hipLaunchKernelGGL(wan::ln_mod_f32_kernel<IT>, grid, blk, 0, s, (const bf16_t*)x, (bf16_t*)y,
-                                               weight, bias, scale, shift, mod_bstride, total, rows, eps));
+                                               weight, bias, scale, shift, mod_bstride, total, rows, eps, (uint8_t*)q8,
+                                               q8_scale));
   }
-  if (!ok)
+  if (!ok) {
+    if (q8) {
+      set_error("%s: the fp8 output needs D %% 512 == 0 and D <= 6144 (D=%d)", who, D);
+      return ALG_EINVAL;
+    }
     hipLaunchKernelGGL(wan::ln_mod_f32_generic_kernel, grid, blk, 0, s, (const bf16_t*)x, (bf16_t*)y, weight, bias, scale,
                        shift, mod_bstride, total, rows, D, eps);
-  return check_launch("alg_layernorm_mod_f32");
+  }
+  return check_launch(who);
+}
+
+extern "C" int alg_layernorm_mod_f32(const void* x, void* y, const float* weight, const float* bias, const float* scale,
+                                     const float* shift, int64_t mod_bstride, int batch, int rows, int D, float eps,
+                                     void* stream) {
+  return layernorm_mod_entry("alg_layernorm_mod_f32", x, y, nullptr, nullptr, weight, bias, scale, shift, mod_bstride, batch,
+                             rows, D, eps, stream);
+}
+
+extern "C" int alg_layernorm_mod_f32_fp8(const void* x, void* q8, float* q8_scale, const float* weight, const float* bias,
+                                         const float* scale, const float* shift, int64_t mod_bstride, int batch, int rows,
+                                         int D, float eps, void* stream) {
+  return layernorm_mod_entry("alg_layernorm_mod_f32_fp8", x, nullptr, q8, q8_scale, weight, bias, scale, shift, mod_bstride,
+                             batch, rows, D, eps, stream);
 }
 
 extern "C" int alg_rmsnorm_rope(void* x, const void* weight, const float* cos_tab, const float* sin_tab,

@@ -379,12 +379,20 @@ class WanTransformer3DModel:
             return T(name, G, ws.q8, Wt[0], C, M_, N_, K_, K_, K_, ldc, a_scale=ws.q8s, b_scale=Wt[1],
                      strideA=(S * K_ if sa else 0), strideAScale=(S if sa else 0), **kw)
 
+        # fp8 blocks: the norms write the e4m3 tokens + row scales straight into the GEMM operand workspace (the bytes
+        # alg_quantize_fp8_rows would make of the bf16 norm output); ws.y is not touched
+        fuse_q = self.fp8 and D % 512 == 0 and os.environ.get("ALG_WAN_FUSE_QUANT", "1") != "0"
+
+        def ln_mod(wgt, bia, sc, sh, bs, **kw):
+            if fuse_q:
+                return T("ln_mod", _lib.layernorm_mod_f32_fp8, ws.x, ws.q8, ws.q8s, wgt, bia, sc, sh, bs, N, S, D, cfg.eps, **kw)
+            return T("ln_mod", _lib.layernorm_mod_f32, ws.x, ws.y, wgt, bia, sc, sh, bs, N, S, D, cfg.eps, **kw)
+
         for li, L in enumerate(self.blocks):
             m0 = li * N * 6 * D  # element offset of this block's [N, 6, D] modulation: shift, scale, gate, c_shift, c_scale, c_gate
             # ---- self-attention ----
-            T("ln_mod", _lib.layernorm_mod_f32, ws.x, ws.y, None, None, ws.mod, ws.mod, mod_bs, N, S, D, cfg.eps,
-              scale_off=m0 + D, shift_off=m0)
-            lin("gemm_qk", ws.y, L.wqk, ws.qk, N * S, 2 * D, D, D, 2 * D, bias=L.bqk)
+            ln_mod(None, None, ws.mod, ws.mod, mod_bs, scale_off=m0 + D, shift_off=m0)
+            lin("gemm_qk", ws.y, L.wqk, ws.qk, N * S, 2 * D, D, D, 2 * D, requant=not fuse_q, bias=L.bqk)
             if self.fp8:   # V^T: the weight is the A operand, the (already quantised) tokens are B
                 T("gemm_vt", G, L.wv[0], ws.q8, ws.vt, D, S, D, D, D, S_pad, bias=L.bv, batch=N, strideB=S * D,
                   strideC=D * S_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS, a_scale=L.wv[1],
@@ -401,11 +409,10 @@ class WanTransformer3DModel:
                 seg_split=1 << 30, flags=_lib.GEMM_GATE_F32)
             # ---- cross-attention: image tokens and text tokens attend separately, outputs are added ----
             if cfg.cross_attn_norm:
-                T("ln_mod", _lib.layernorm_mod_f32, ws.x, ws.y, L.n2w, L.n2b, None, None, 0, N, S, D, cfg.eps)
-                yc = ws.y
+                ln_mod(L.n2w, L.n2b, None, None, 0)
+                lin("gemm_cq", ws.y, L.cq_w, ws.qc, N * S, D, D, D, D, requant=not fuse_q, bias=L.cq_b)
             else:
-                yc = ws.x
-            lin("gemm_cq", yc, L.cq_w, ws.qc, N * S, D, D, D, D, bias=L.cq_b)
+                lin("gemm_cq", ws.x, L.cq_w, ws.qc, N * S, D, D, D, D, bias=L.cq_b)
             T("rms_rope", _lib.rmsnorm_rope_, ws.qc, L.cnq, None, None, D, N, S, D, cfg.eps)
             G(ws.txt, L.ck_w, ws.kt, N * n_txt, D, D, D, D, D, bias=L.ck_b)
             _lib.rmsnorm_rope_(ws.kt, L.cnk, None, None, D, N, n_txt, D, cfg.eps)
@@ -423,9 +430,9 @@ class WanTransformer3DModel:
                 T("add", _lib.lincomb, [(1.0, ws.att), (1.0, ws.o2)], BF, out=ws.att)
             lin("gemm_cout", ws.att, L.co_w, ws.x, N * S, D, D, D, D, bias=L.co_b, R=ws.x, ldr=D)
             # ---- feed-forward ----
-            T("ln_mod", _lib.layernorm_mod_f32, ws.x, ws.y, None, None, ws.mod, ws.mod, mod_bs, N, S, D, cfg.eps,
-              scale_off=m0 + 4 * D, shift_off=m0 + 3 * D)
-            lin("gemm_ff1", ws.y, L.f1_w, ws.h, N * S, Ff, D, D, Ff, bias=L.f1_b, act=_lib.ACT_GELU_TANH)
+            ln_mod(None, None, ws.mod, ws.mod, mod_bs, scale_off=m0 + 4 * D, shift_off=m0 + 3 * D)
+            lin("gemm_ff1", ws.y, L.f1_w, ws.h, N * S, Ff, D, D, Ff, requant=not fuse_q, bias=L.f1_b,
+                act=_lib.ACT_GELU_TANH)
             lin("gemm_ff2", ws.h, L.f2_w, ws.x, S, D, Ff, Ff, D, bias=L.f2_b, R=ws.x, ldr=D, gate=ws.mod,
                 gate_off=m0 + 5 * D, strideGate=mod_bs, batch=N, strideA=S * Ff, strideC=S * D, strideR=S * D,
                 seg_split=1 << 30, flags=_lib.GEMM_GATE_F32)

@@ -306,6 +306,13 @@ int alg_silu(const void* x, void* y, int64_t numel, void* stream);
 int alg_layernorm_mod_f32(const void* x, void* y, const float* weight, const float* bias, const float* scale,
                           const float* shift, int64_t mod_bstride, int batch, int rows, int D, float eps, void* stream);
 
+/* The same norm feeding an fp8 GEMM: instead of the bf16 tensor, writes what alg_quantize_fp8_rows would make of it
+ * (q8: [batch*rows][D] OCP e4m3 bytes, q8_scale: [batch*rows] float32 = amax / 448 of the bf16-rounded row), bit for bit,
+ * without the bf16 round trip through HBM.  D % 512 == 0 only. */
+int alg_layernorm_mod_f32_fp8(const void* x, void* q8, float* q8_scale, const float* weight, const float* bias,
+                              const float* scale, const float* shift, int64_t mod_bstride, int batch, int rows, int D,
+                              float eps, void* stream);
+
 /* WanAttnProcessor norm_q / norm_k (RMSNorm across all heads) + rotary embedding, in place:
  *   x = rope( bf16( bf16(x * rsqrt(mean(x^2) + eps)) * weight ) ),  x: [batch*rows] rows of D bf16 at stride x_rstride;
  * rope multiplies the interleaved pairs (2j, 2j+1) of every 128-wide head by cos/sin[token][j] (fp32 tables [rows][64],

@@ -77,6 +77,38 @@ def test_layernorm_mod_f32(D, affine, mod):
     assert (y != ref).float().mean().item() < 0.01
 
 
+@pytest.mark.parametrize("D,affine,mod", [(512, False, True), (5120, True, False), (1536, False, True), (1024, True, True)])
+def test_layernorm_mod_f32_fp8_is_norm_then_quantiser(D, affine, mod):
+    """The fused fp8 output is bit for bit alg_layernorm_mod_f32 followed by alg_quantize_fp8_rows (bytes and scales)."""
+    B, S = 2, 37
+    x = _rand((B, S, D), 15)
+    x[0, 3] = 0                                              # an all-zero row: scale 1, zero bytes (or the shift alone)
+    g = torch.Generator().manual_seed(16)
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV) if affine else None
+    b = (0.1 * torch.randn(D, generator=g)).to(DEV) if affine else None
+    modv = (torch.randn(B, 6, D, generator=g) * 0.3).to(DEV) if mod else None
+    y = torch.empty_like(x)
+    _lib.layernorm_mod_f32(x, y, w, b, modv, modv, 6 * D, B, S, D, 1e-6, scale_off=D, shift_off=2 * D)
+    q_want = torch.empty(B * S, D, dtype=torch.uint8, device=DEV)
+    s_want = torch.empty(B * S, dtype=torch.float32, device=DEV)
+    _lib.quantize_fp8_rows(y, q_want, s_want, B * S, D)
+    q_got = torch.full_like(q_want, 0x55)
+    s_got = torch.full_like(s_want, -1.0)
+    _lib.layernorm_mod_f32_fp8(x, q_got, s_got, w, b, modv, modv, 6 * D, B, S, D, 1e-6, scale_off=D, shift_off=2 * D)
+    assert torch.equal(s_got, s_want)
+    assert torch.equal(q_got, q_want)
+
+
+def test_layernorm_mod_f32_fp8_rejects_unsupported_width():
+    x = _rand((1, 4, 1280), 17)
+    q = torch.empty(4, 1280, dtype=torch.uint8, device=DEV)
+    s = torch.empty(4, dtype=torch.float32, device=DEV)
+    with pytest.raises(_lib.AlgHipError, match="512"):
+        _lib.layernorm_mod_f32_fp8(x, q, s, None, None, None, None, 0, 1, 4, 1280, 1e-6)
+    with pytest.raises(_lib.AlgHipError, match="null"):
+        _lib.layernorm_mod_f32_fp8(x, q, None, None, None, None, None, 0, 1, 4, 1024, 1e-6)
+
+
 @pytest.mark.parametrize("D,rope", [(512, True), (5120, True), (512, False)])
 def test_rmsnorm_rope(D, rope):
     B, S = 2, 29
