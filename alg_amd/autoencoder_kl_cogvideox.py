@@ -129,6 +129,12 @@ class AutoencoderKLCogVideoX:
         self.load_state_dict(sd)
         return self
 
+    @classmethod
+    def from_pretrained(cls, path, subfolder="vae", torch_dtype=torch.bfloat16, device="cuda", **_):
+        """diffusers-format directory on local disk (`vae/config.json` + safetensors): decoder, and the encoder if present."""
+        from .weights import component_from_pretrained
+        return component_from_pretrained(cls, AutoencoderKLCogVideoXConfig, path, subfolder, device=device)
+
     def encoder_param_shapes(self):
         """diffusers names / shapes of the encoder (plain GroupNorm, stride-2 downsamplers, 2 x latent moments out)."""
         c = self.config

@@ -50,6 +50,20 @@ class CLIPImageProcessor:
     def __init__(self, size=224, image_mean=(0.48145466, 0.4578275, 0.40821073), image_std=(0.26862954, 0.26130258, 0.27577711)):
         self.size, self.image_mean, self.image_std = size, image_mean, image_std
 
+    @classmethod
+    def from_pretrained(cls, path, subfolder="image_processor", **_):
+        """`preprocessor_config.json` of the checkpoint (size as an int or {"shortest_edge": n}, mean, std)."""
+        import json
+        import os
+        root = os.path.join(path, subfolder) if os.path.isdir(os.path.join(path, subfolder)) else path
+        with open(os.path.join(root, "preprocessor_config.json")) as f:
+            raw = json.load(f)
+        size = raw.get("size", 224)
+        if isinstance(size, dict):
+            size = size.get("shortest_edge", size.get("height", 224))
+        return cls(size=int(size), image_mean=tuple(raw.get("image_mean", cls().image_mean)),
+                   image_std=tuple(raw.get("image_std", cls().image_std)))
+
     def __call__(self, images, return_tensors="pt"):
         import numpy as np
         from PIL import Image
@@ -118,6 +132,12 @@ class CLIPVisionModel:
                 t = torch.randn(shape, generator=g) * torch.Size(shape[1:]).numel() ** -0.5
             sd[name] = t.bfloat16()
         return self.load_state_dict(sd)
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder="image_encoder", torch_dtype=torch.bfloat16, device="cuda", **_):
+        """transformers-format directory on local disk; a joint CLIP config's `vision_config` is unwrapped."""
+        from .weights import component_from_pretrained
+        return component_from_pretrained(cls, CLIPVisionEncoderConfig, path, subfolder, device=device, nested="vision_config")
 
     def load_state_dict(self, sd, strict=True):
         sd = {(k[len("vision_model."):] if k.startswith("vision_model.") else k): v for k, v in sd.items()}

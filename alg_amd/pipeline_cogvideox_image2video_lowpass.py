@@ -130,12 +130,28 @@ class CogVideoXImageToVideoPipeline:
     @classmethod
     def from_pretrained(cls, model_path, torch_dtype=torch.bfloat16, cache_dir=None, transformer=None,
                         scheduler=None, vae=None, text_encoder=None, tokenizer=None, device="cuda", **_):
-        """Local-disk loader (no hub download here).  The transformer comes from a diffusers-format directory;
-        VAE / text encoder are "next" components and must be injected by the caller if needed."""
+        """Local-disk loader of a diffusers-format CogVideoX-I2V directory (`run.py:38-52`; no hub download here):
+        `transformer/`, `vae/`, `text_encoder/` (T5), `tokenizer/`, `scheduler/` -- each read if its sub-directory
+        exists and no instance was passed in.  Without a text encoder the call needs `prompt_embeds`, without a VAE
+        `image_latents` and `output_type="latent"`."""
+        import os
+
+        from .autoencoder_kl_cogvideox import AutoencoderKLCogVideoX
+        from .text_encoder_t5 import T5EncoderModel
+        from .weights import load_tokenizer
+
+        has = lambda sub: os.path.isdir(os.path.join(model_path, sub))
         if transformer is None:
             transformer = CogVideoXTransformer3DModel.from_pretrained(model_path, torch_dtype=torch_dtype,
                                                                       device=device)
-        scheduler = scheduler or CogVideoXDDIMScheduler()
+        if vae is None and has("vae"):
+            vae = AutoencoderKLCogVideoX.from_pretrained(model_path, device=device)
+        if text_encoder is None and has("text_encoder"):
+            text_encoder = T5EncoderModel.from_pretrained(model_path, device=device)
+        if tokenizer is None:
+            tokenizer = load_tokenizer(model_path, "tokenizer")
+        if scheduler is None:
+            scheduler = CogVideoXDDIMScheduler.from_pretrained(model_path) if has("scheduler") else CogVideoXDDIMScheduler()
         return cls(tokenizer, text_encoder, vae, transformer, scheduler)
 
     def to(self, device=None, *args, **kwargs):

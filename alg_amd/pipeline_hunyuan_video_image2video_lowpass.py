@@ -70,6 +70,33 @@ class HunyuanVideoImageToVideoPipeline:
         self._interrupt = False
         self._lp_cache = {}
 
+    @classmethod
+    def from_pretrained(cls, model_path, torch_dtype=torch.bfloat16, transformer=None, scheduler=None, vae=None,
+                        text_encoder=None, tokenizer=None, text_encoder_2=None, tokenizer_2=None, image_processor=None,
+                        device="cuda", **_):
+        """Local-disk loader of a diffusers-format HunyuanVideo-I2V directory (`run.py:68-90`): `transformer/`,
+        `text_encoder_2/` (CLIP-L text tower) + `tokenizer_2/`, `scheduler/`.  The Llava prompt encoder and the
+        HunyuanVideo VAE are not built: pass `prompt_embeds` / `prompt_attention_mask` / `image_latents` and use
+        `output_type="latent"`."""
+        import os
+
+        from .schedulers import FlowMatchEulerDiscreteScheduler
+        from .text_encoder_clip import CLIPTextModel
+        from .transformer_hunyuan_video import HunyuanVideoTransformer3DModel
+        from .weights import load_tokenizer
+
+        has = lambda sub: os.path.isdir(os.path.join(model_path, sub))
+        if transformer is None:
+            transformer = HunyuanVideoTransformer3DModel.from_pretrained(model_path, device=device)
+        if text_encoder_2 is None and has("text_encoder_2"):
+            text_encoder_2 = CLIPTextModel.from_pretrained(model_path, device=device)
+        if tokenizer_2 is None:
+            tokenizer_2 = load_tokenizer(model_path, "tokenizer_2")
+        if scheduler is None:
+            scheduler = (FlowMatchEulerDiscreteScheduler.from_pretrained(model_path) if has("scheduler")
+                         else FlowMatchEulerDiscreteScheduler(shift=7.0))
+        return cls(text_encoder, tokenizer, transformer, vae, scheduler, text_encoder_2, tokenizer_2, image_processor)
+
     def to(self, device=None, *args, **kwargs):
         if device is not None:
             self._device = torch.device(device)

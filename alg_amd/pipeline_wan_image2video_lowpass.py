@@ -95,6 +95,37 @@ class WanImageToVideoPipeline:
         self._interrupt = False
         self._lp_cache = {}
 
+    @classmethod
+    def from_pretrained(cls, model_path, torch_dtype=torch.bfloat16, transformer=None, scheduler=None, vae=None,
+                        text_encoder=None, tokenizer=None, image_encoder=None, image_processor=None, device="cuda",
+                        fp8=False, **_):
+        """Local-disk loader of a diffusers-format Wan2.1-I2V directory (`run.py:54-66`): `transformer/`, `text_encoder/`
+        (UMT5), `tokenizer/`, `image_encoder/` (CLIP ViT-H), `image_processor/`, `scheduler/` (UniPC).  The Wan VAE is
+        not built: pass `image_condition` / `latent_condition` and use `output_type="latent"`."""
+        import os
+
+        from .image_encoder_clip import CLIPImageProcessor, CLIPVisionModel
+        from .schedulers import UniPCMultistepScheduler
+        from .text_encoder_t5 import UMT5EncoderModel
+        from .transformer_wan import WanTransformer3DModel
+        from .weights import load_tokenizer
+
+        has = lambda sub: os.path.isdir(os.path.join(model_path, sub))
+        if transformer is None:
+            transformer = WanTransformer3DModel.from_pretrained(model_path, device=device, fp8=fp8)
+        if text_encoder is None and has("text_encoder"):
+            text_encoder = UMT5EncoderModel.from_pretrained(model_path, device=device)
+        if tokenizer is None:
+            tokenizer = load_tokenizer(model_path, "tokenizer")
+        if image_encoder is None and has("image_encoder"):
+            image_encoder = CLIPVisionModel.from_pretrained(model_path, device=device)
+        if image_processor is None:
+            image_processor = (CLIPImageProcessor.from_pretrained(model_path) if has("image_processor")
+                               else CLIPImageProcessor())
+        if scheduler is None:
+            scheduler = UniPCMultistepScheduler.from_pretrained(model_path) if has("scheduler") else UniPCMultistepScheduler()
+        return cls(tokenizer, text_encoder, image_encoder, image_processor, transformer, vae, scheduler)
+
     def to(self, device=None, *args, **kwargs):
         if device is not None:
             self._device = torch.device(device)

@@ -16,7 +16,26 @@ import torch
 from . import _lib
 
 
-class CogVideoXDDIMScheduler:
+class _ConfigLoading:
+    """`from_pretrained` / `from_config` of the diffusers schedulers: construct from `scheduler/scheduler_config.json` (or a
+    dict), keeping only the keys the constructor knows."""
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder="scheduler", **_):
+        from .weights import scheduler_from_pretrained
+        return scheduler_from_pretrained(cls, path, subfolder)
+
+    @classmethod
+    def from_config(cls, config, **overrides):
+        import inspect
+        known = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        d = dict(config) if isinstance(config, dict) else dict(vars(config))
+        kw = {k: v for k, v in d.items() if k in known}
+        kw.update({k: v for k, v in overrides.items() if k in known})
+        return cls(**kw)
+
+
+class CogVideoXDDIMScheduler(_ConfigLoading):
     order = 1
     init_noise_sigma = 1.0
 
@@ -115,7 +134,7 @@ def _step_index_for(timesteps, timestep):
     return hits[1] if len(hits) > 1 else hits[0]
 
 
-class FlowMatchEulerDiscreteScheduler:
+class FlowMatchEulerDiscreteScheduler(_ConfigLoading):
     """Flow-match Euler scheduler as the HunyuanVideo loop drives it (hy:1111-1112 custom ``sigmas`` through
     retrieve_timesteps, hy:1265-1269 ``step``; run.py:82-86 ``from_config(flow_shift=, invert_sigmas=)``).
     Static shift only (the HunyuanVideo-I2V config; dynamic shifting / karras / beta sigmas are not used by it).
@@ -186,7 +205,7 @@ class FlowMatchEulerDiscreteScheduler:
         return SimpleNamespace(prev_sample=out) if return_dict else (out,)
 
 
-class UniPCMultistepScheduler:
+class UniPCMultistepScheduler(_ConfigLoading):
     """UniPC (bh1/bh2, predict_x0, flow sigmas) as the Wan loop drives it (wan:815-816 ``set_timesteps``, wan:927
     ``step``; run.py:63 ``from_config(flow_shift=3.0 | 5.0)``).  solver_order <= 2 (the Wan checkpoints ship 2).
     Scalars follow the published scheduler's fp32 0-dim tensor arithmetic on the host; the per-element updates run

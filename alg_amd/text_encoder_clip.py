@@ -81,6 +81,12 @@ class CLIPTextModel:
             sd[name] = t.bfloat16()
         return self.load_state_dict(sd)
 
+    @classmethod
+    def from_pretrained(cls, path, subfolder="text_encoder_2", torch_dtype=torch.bfloat16, device="cuda", **_):
+        """transformers-format directory on local disk; a joint CLIP config's `text_config` is unwrapped."""
+        from .weights import component_from_pretrained
+        return component_from_pretrained(cls, CLIPTextEncoderConfig, path, subfolder, device=device, nested="text_config")
+
     def load_state_dict(self, sd, strict=True):
         sd = {(k[len("text_model."):] if k.startswith("text_model.") else k): v for k, v in sd.items()}
         shapes = self.param_shapes()

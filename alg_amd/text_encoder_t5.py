@@ -93,6 +93,12 @@ class T5EncoderModel:
             sd[name] = t.bfloat16()
         return self.load_state_dict(sd)
 
+    @classmethod
+    def from_pretrained(cls, path, subfolder="text_encoder", torch_dtype=torch.bfloat16, device="cuda", **_):
+        """transformers-format directory on local disk (`text_encoder/config.json` + safetensors shards)."""
+        from .weights import component_from_pretrained
+        return component_from_pretrained(cls, T5EncoderConfig, path, subfolder, device=device)
+
     def load_state_dict(self, sd, strict=True):
         shapes = self.param_shapes()
         if "shared.weight" not in sd and "encoder.embed_tokens.weight" in sd:

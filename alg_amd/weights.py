@@ -113,3 +113,73 @@ def load_diffusers_transformer(path, subfolder="transformer"):
     if missing:
         raise KeyError("checkpoint is missing %d tensors, e.g. %s" % (len(missing), missing[:3]))
     return cfg, sd
+
+
+# ---- generic local-checkpoint loading (diffusers / transformers directory layout) ----------------------------------------
+def load_component(path, subfolder=None, config_name="config.json"):
+    """(raw config dict, state dict, directory) of one component of a diffusers-format checkpoint on LOCAL disk:
+    `<path>/<subfolder>/config.json` + every `*.safetensors` shard next to it (the layout `from_pretrained` of the
+    reference's pipelines reads: cog / wan / hy `run.py:38-90`).  No hub access, no pickle (`*.bin`) loading."""
+    from safetensors.torch import load_file
+
+    root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
+    cfg_path = os.path.join(root, config_name)
+    if not os.path.exists(cfg_path):
+        raise FileNotFoundError("%s not found: checkpoints must be on local disk (no network access here)" % cfg_path)
+    with open(cfg_path) as f:
+        raw = json.load(f)
+    shards = sorted(glob.glob(os.path.join(root, "*.safetensors")))
+    if not shards:
+        raise FileNotFoundError("no *.safetensors in %s (pickled *.bin checkpoints are not read)" % root)
+    sd = {}
+    for shard in shards:
+        sd.update(load_file(shard))
+    return raw, sd, root
+
+
+def config_from_dict(config_cls, raw, nested=None):
+    """Dataclass config from a checkpoint's config.json: unknown keys are dropped, a nested sub-config (`vision_config` /
+    `text_config` of a joint CLIP config) is unwrapped, JSON lists become tuples where the dataclass default is a tuple."""
+    if nested and isinstance(raw.get(nested), dict):
+        raw = raw[nested]
+    fields = config_cls.__dataclass_fields__
+    kw = {}
+    for k, v in raw.items():
+        if k in fields and v is not None:
+            kw[k] = tuple(v) if isinstance(v, list) and isinstance(fields[k].default, tuple) else v
+    return config_cls(**kw)
+
+
+def component_from_pretrained(cls, config_cls, path, subfolder, device="cuda", nested=None, **ctor):
+    raw, sd, _ = load_component(path, subfolder)
+    obj = cls(config_from_dict(config_cls, raw, nested), device=device, **ctor)
+    obj.load_state_dict(sd)
+    return obj
+
+
+def scheduler_from_pretrained(cls, path, subfolder="scheduler"):
+    """`scheduler/scheduler_config.json` -> cls(**the keys its __init__ knows)."""
+    import inspect
+
+    root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
+    cfg_path = os.path.join(root, "scheduler_config.json")
+    if not os.path.exists(cfg_path):
+        raise FileNotFoundError("%s not found" % cfg_path)
+    with open(cfg_path) as f:
+        raw = json.load(f)
+    known = set(inspect.signature(cls.__init__).parameters) - {"self"}
+    return cls(**{k: v for k, v in raw.items() if k in known})
+
+
+def load_tokenizer(path, subfolder="tokenizer"):
+    """The checkpoint's tokenizer through `transformers` (vocabulary files are checkpoint data; the tokenisation algorithm
+    itself is outside the hot path and not rebuilt).  None when the directory or the package is absent: the pipelines then
+    ask for `prompt_embeds`."""
+    d = os.path.join(path, subfolder)
+    if not os.path.isdir(d):
+        return None
+    try:
+        from transformers import AutoTokenizer
+    except ImportError:
+        return None
+    return AutoTokenizer.from_pretrained(d, local_files_only=True)

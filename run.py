@@ -49,19 +49,19 @@ def main(args):
         flow_shift = 3.0 if config["generation"]["height"] == "480" else 5.0
         if args.synthetic:
             transformer = WanTransformer3DModel.from_synthetic(WanTransformerConfig(), device=device, fp8=args.fp8)
-        else:
-            transformer = WanTransformer3DModel.from_pretrained(model_path, device=device, fp8=args.fp8)
-        pipe = WanImageToVideoPipeline(transformer=transformer, scheduler=UniPCMultistepScheduler(flow_shift=flow_shift))
+            pipe = WanImageToVideoPipeline(transformer=transformer, scheduler=UniPCMultistepScheduler(flow_shift=flow_shift))
+        else:   # run.py:54-66: encoders from the checkpoint directory, UniPC rebuilt with the run's flow_shift
+            pipe = WanImageToVideoPipeline.from_pretrained(model_path, device=device, fp8=args.fp8,
+                                                           scheduler=UniPCMultistepScheduler(flow_shift=flow_shift))
     elif "HunyuanVideo" in model_path:
-        if args.synthetic:
-            transformer = HunyuanVideoTransformer3DModel.from_synthetic(HunyuanVideoTransformerConfig(), device=device)
-        else:
-            transformer = HunyuanVideoTransformer3DModel.from_pretrained(model_path, device=device)
+        transformer = (HunyuanVideoTransformer3DModel.from_synthetic(HunyuanVideoTransformerConfig(), device=device)
+                       if args.synthetic else None)
         # run.py:82-86: from_config(flow_shift=model.flow_shift, invert_sigmas=model.flow_reverse); `flow_shift` is not a
         # parameter of FlowMatchEulerDiscreteScheduler, the checkpoint's own shift (7.0 for HunyuanVideo-I2V) stays in force
         scheduler = FlowMatchEulerDiscreteScheduler(shift=7.0, flow_shift=config["model"].get("flow_shift"),
                                                     invert_sigmas=bool(config["model"].get("flow_reverse", False)))
-        pipe = HunyuanVideoImageToVideoPipeline(transformer=transformer, scheduler=scheduler)
+        pipe = (HunyuanVideoImageToVideoPipeline(transformer=transformer, scheduler=scheduler) if args.synthetic
+                else HunyuanVideoImageToVideoPipeline.from_pretrained(model_path, device=device, scheduler=scheduler))
     else:
         raise ValueError(f"unknown model family in model.path: {model_path}")
     pipe.to(device)

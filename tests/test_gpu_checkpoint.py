@@ -1,0 +1,156 @@
+"""`from_pretrained` of the pipelines and their components over a diffusers-format checkpoint DIRECTORY (what
+`run.py:38-90` of the reference does): tiny synthetic checkpoints are written with safetensors + config.json in the
+published layout, loaded back, and must run bit-identically to the same weights handed over in memory."""
+import dataclasses
+import json
+import os
+
+import pytest
+import torch
+from safetensors.torch import save_file
+
+from alg_amd import CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, CogVideoXTransformer3DModel
+from alg_amd.autoencoder_kl_cogvideox import AutoencoderKLCogVideoX, AutoencoderKLCogVideoXConfig
+from alg_amd.image_encoder_clip import CLIPImageProcessor, CLIPVisionEncoderConfig, CLIPVisionModel
+from alg_amd.pipeline_wan_image2video_lowpass import WanImageToVideoPipeline
+from alg_amd.schedulers import UniPCMultistepScheduler
+from alg_amd.text_encoder_clip import CLIPTextEncoderConfig, CLIPTextModel
+from alg_amd.text_encoder_t5 import T5EncoderConfig, T5EncoderModel, UMT5EncoderModel
+from alg_amd.transformer_cogvideox import CogVideoXTransformerConfig
+from alg_amd.transformer_wan import WanTransformer3DModel, WanTransformerConfig
+from oracle import clip_oracle, clip_text_oracle, dit_oracle, t5_oracle, vae_oracle, wan_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def _save(root, sub, config, sd, shards=1, extra=None):
+    d = os.path.join(root, sub)
+    os.makedirs(d, exist_ok=True)
+    cfg = dict(config, _class_name="Anything", _diffusers_version="0.0", **(extra or {}))
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    keys = sorted(sd)
+    per = (len(keys) + shards - 1) // shards
+    for i in range(shards):
+        save_file({k: sd[k].to(BF).contiguous() for k in keys[i * per:(i + 1) * per]},
+                  os.path.join(d, "diffusion_pytorch_model-%05d-of-%05d.safetensors" % (i + 1, shards)))
+
+
+class _Tok:
+    """Stands in for the checkpoint's tokenizer (vocabulary files are checkpoint data): deterministic ids + mask."""
+
+    def __call__(self, texts, padding=None, max_length=10, truncation=True, add_special_tokens=True, return_tensors="pt",
+                 **_):
+        texts = [texts] if isinstance(texts, str) else list(texts)
+        ids = torch.zeros(len(texts), max_length, dtype=torch.long)
+        mask = torch.zeros(len(texts), max_length, dtype=torch.long)
+        for i, t in enumerate(texts):
+            n = min(max_length, len(t.split()) + 1)
+            ids[i, :n] = torch.tensor([(hash(w) % 89) + 3 for w in t.split()][:n - 1] + [1])
+            mask[i, :n] = 1
+        return type("Enc", (), {"input_ids": ids, "attention_mask": mask})()
+
+
+def test_cogvideox_pipeline_from_a_checkpoint_directory(tmp_path):
+    root = str(tmp_path)
+    small = dict(num_attention_heads=8, attention_head_dim=64, in_channels=32, out_channels=16, num_layers=1,
+                 time_embed_dim=64, text_embed_dim=128, max_text_seq_length=10, sample_width=6, sample_height=4,
+                 sample_frames=9, patch_size=2)
+    w_tr = {k: v.to(BF) for k, v in dit_oracle.init_weights(dit_oracle.DiTConfig(**small), seed=4, std=0.05,
+                                                             randomize_affine=True).items()}
+    vkw = dict(layers_per_block=1)
+    w_vae = vae_oracle.synthetic_state_dict(vae_oracle.VAEConfig(**vkw), seed=6, encoder=True)
+    tkw = dict(vocab_size=96, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2)
+    w_t5 = t5_oracle.synthetic_state_dict(t5_oracle.T5Config(**tkw), seed=7)
+    _save(root, "transformer", dataclasses.asdict(CogVideoXTransformerConfig(**small)), w_tr, shards=2)
+    _save(root, "vae", dict(dataclasses.asdict(AutoencoderKLCogVideoXConfig(**vkw)), sample_height=480), w_vae)
+    _save(root, "text_encoder", dict(tkw, feed_forward_proj="gated-gelu", architectures=["T5EncoderModel"]), w_t5, shards=3)
+    os.makedirs(os.path.join(root, "scheduler"))
+    with open(os.path.join(root, "scheduler", "scheduler_config.json"), "w") as f:
+        json.dump({"_class_name": "CogVideoXDDIMScheduler", "snr_shift_scale": 1.0, "timestep_spacing": "trailing",
+                   "rescale_betas_zero_snr": True, "beta_schedule": "scaled_linear", "prediction_type": "v_prediction"}, f)
+
+    pipe = CogVideoXImageToVideoPipeline.from_pretrained(root, torch_dtype=BF, device=DEV, tokenizer=_Tok()).to(DEV)
+    assert isinstance(pipe.vae, AutoencoderKLCogVideoX) and isinstance(pipe.text_encoder, T5EncoderModel)
+    assert pipe.scheduler.config.snr_shift_scale == 1.0 and pipe.vae.config.layers_per_block == 1
+    direct = CogVideoXImageToVideoPipeline(
+        _Tok(), T5EncoderModel(T5EncoderConfig(**tkw), device=DEV).load_state_dict({k: v.to(BF) for k, v in w_t5.items()}),
+        AutoencoderKLCogVideoX(AutoencoderKLCogVideoXConfig(**vkw), device=DEV).load_state_dict(w_vae),
+        CogVideoXTransformer3DModel(CogVideoXTransformerConfig(**small), w_tr, device=DEV),
+        CogVideoXDDIMScheduler(snr_shift_scale=1.0)).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    image = torch.rand(1, 3, 32, 48, generator=g) * 2 - 1            # the whole reference call: prompt + image in, frames out
+    kw = dict(prompt="a small boat drifts", negative_prompt="blurry", height=32, width=48, num_frames=9,
+              num_inference_steps=2, max_sequence_length=10, use_low_pass_guidance=True, lp_filter_type="down_up",
+              lp_resize_factor=0.5, lp_strength_schedule_type="interval", schedule_interval_start_time=0.0,
+              schedule_interval_end_time=0.6, lp_filter_in_latent=True, output_type="uint8")
+    a = pipe(image=image, generator=torch.Generator().manual_seed(2), **kw).frames
+    b = direct(image=image, generator=torch.Generator().manual_seed(2), **kw).frames
+    assert a.shape == (1, 9, 32, 48, 3) and a.dtype == torch.uint8
+    assert torch.equal(a, b)
+
+
+def test_encoders_from_checkpoint_directories(tmp_path):
+    root = str(tmp_path)
+    ids = torch.randint(3, 90, (2, 12), generator=torch.Generator().manual_seed(0))
+    mask = torch.ones(2, 12, dtype=torch.long)
+    mask[1, 8:] = 0
+    ukw = dict(vocab_size=96, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2)
+    w_u = t5_oracle.synthetic_state_dict(t5_oracle.T5Config(per_layer_bias=True, **ukw), seed=3)
+    _save(root, "text_encoder", dict(ukw, model_type="umt5"), w_u, shards=2)
+    got = UMT5EncoderModel.from_pretrained(root, device=DEV)(ids.to(DEV), mask.to(DEV)).last_hidden_state
+    want = UMT5EncoderModel(T5EncoderConfig(**ukw), device=DEV).load_state_dict({k: v.to(BF) for k, v in w_u.items()})(
+        ids.to(DEV), mask.to(DEV)).last_hidden_state
+    assert torch.equal(got, want)
+
+    vkw = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, image_size=28, patch_size=14)
+    w_v = clip_oracle.synthetic_state_dict(clip_oracle.CLIPVisionConfig(**vkw), seed=4)
+    # the 4.x `vision_model.` prefix and a joint CLIP config with a nested vision_config
+    _save(root, "image_encoder", {"model_type": "clip", "vision_config": vkw, "text_config": {"hidden_size": 8}},
+          {"vision_model." + k: v for k, v in w_v.items()})
+    px = torch.randn(1, 3, 28, 28, generator=torch.Generator().manual_seed(5)).to(DEV, BF)
+    got = CLIPVisionModel.from_pretrained(root, device=DEV)(px, output_hidden_states=True).hidden_states[-2]
+    want = CLIPVisionModel(CLIPVisionEncoderConfig(**vkw), device=DEV).load_state_dict(
+        {k: v.to(BF) for k, v in w_v.items()})(px, output_hidden_states=True).hidden_states[-2]
+    assert torch.equal(got, want)
+
+    ckw = dict(vocab_size=96, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+               max_position_embeddings=12, eos_token_id=2)
+    w_c = clip_text_oracle.synthetic_state_dict(clip_text_oracle.CLIPTextConfig(**ckw), seed=6)
+    _save(root, "text_encoder_2", dict(ckw, hidden_act="quick_gelu", projection_dim=64), w_c)
+    tid = ids.clone()
+    tid[:, -1] = 2
+    got = CLIPTextModel.from_pretrained(root, device=DEV)(tid.to(DEV)).pooler_output
+    want = CLIPTextModel(CLIPTextEncoderConfig(**ckw), device=DEV).load_state_dict({k: v.to(BF) for k, v in w_c.items()})(
+        tid.to(DEV)).pooler_output
+    assert torch.equal(got, want)
+
+
+def test_wan_pipeline_from_a_checkpoint_directory(tmp_path):
+    root = str(tmp_path)
+    kw = dict(num_attention_heads=4, ffn_dim=1024, num_layers=1, text_dim=128, image_dim=128, added_kv_proj_dim=512)
+    w = wan_oracle.init_weights(wan_oracle.WanConfig(**kw), seed=3)
+    _save(root, "transformer", dataclasses.asdict(WanTransformerConfig(**kw)), w, shards=2)
+    ukw = dict(vocab_size=96, d_model=128, d_kv=64, d_ff=256, num_layers=1, num_heads=2)
+    _save(root, "text_encoder", ukw, t5_oracle.synthetic_state_dict(t5_oracle.T5Config(per_layer_bias=True, **ukw), seed=3))
+    vkw = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=28, patch_size=14)
+    _save(root, "image_encoder", vkw, clip_oracle.synthetic_state_dict(clip_oracle.CLIPVisionConfig(**vkw), seed=4))
+    os.makedirs(os.path.join(root, "image_processor"))
+    with open(os.path.join(root, "image_processor", "preprocessor_config.json"), "w") as f:
+        json.dump({"size": {"shortest_edge": 28}}, f)
+    os.makedirs(os.path.join(root, "scheduler"))
+    with open(os.path.join(root, "scheduler", "scheduler_config.json"), "w") as f:
+        json.dump({"_class_name": "UniPCMultistepScheduler", "flow_shift": 3.0, "prediction_type": "flow_prediction",
+                   "use_flow_sigmas": True, "solver_order": 2}, f)
+    pipe = WanImageToVideoPipeline.from_pretrained(root, device=DEV, tokenizer=_Tok()).to(DEV)
+    assert isinstance(pipe.transformer, WanTransformer3DModel) and isinstance(pipe.text_encoder, UMT5EncoderModel)
+    assert isinstance(pipe.image_encoder, CLIPVisionModel) and isinstance(pipe.image_processor, CLIPImageProcessor)
+    assert isinstance(pipe.scheduler, UniPCMultistepScheduler) and pipe.image_processor.size == 28 and pipe.vae is None
+    g = torch.Generator().manual_seed(9)
+    cond = torch.randn(1, 20, 3, 16, 24, generator=g) * 0.5
+    out = pipe(image=torch.rand(3, 40, 56, generator=g), prompt="a kite over the dunes", negative_prompt="static",
+               image_condition=cond.to(DEV), height=128, width=192, num_frames=9, num_inference_steps=2, guidance_scale=5.0,
+               max_sequence_length=10, output_type="latent", generator=torch.Generator().manual_seed(3)).frames
+    assert out.shape == (1, 16, 3, 16, 24) and bool(torch.isfinite(out.float()).all())
