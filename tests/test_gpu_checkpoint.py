@@ -154,3 +154,32 @@ def test_wan_pipeline_from_a_checkpoint_directory(tmp_path):
                image_condition=cond.to(DEV), height=128, width=192, num_frames=9, num_inference_steps=2, guidance_scale=5.0,
                max_sequence_length=10, output_type="latent", generator=torch.Generator().manual_seed(3)).frames
     assert out.shape == (1, 16, 3, 16, 24) and bool(torch.isfinite(out.float()).all())
+
+
+def test_hunyuan_pipeline_from_a_checkpoint_directory(tmp_path):
+    from alg_amd.pipeline_hunyuan_video_image2video_lowpass import HunyuanVideoImageToVideoPipeline
+    from alg_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from alg_amd.transformer_hunyuan_video import HunyuanVideoTransformer3DModel, HunyuanVideoTransformerConfig
+    from oracle import hy_oracle
+    root = str(tmp_path)
+    kw = dict(num_attention_heads=4, num_layers=1, num_single_layers=1, num_refiner_layers=1, text_embed_dim=64,
+              pooled_projection_dim=128)
+    _save(root, "transformer", dataclasses.asdict(HunyuanVideoTransformerConfig(**kw)),
+          hy_oracle.init_weights(hy_oracle.HyConfig(**kw), seed=3), shards=2)
+    ckw = dict(vocab_size=96, hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+               max_position_embeddings=77, eos_token_id=1)
+    _save(root, "text_encoder_2", ckw, clip_text_oracle.synthetic_state_dict(clip_text_oracle.CLIPTextConfig(**ckw), seed=6))
+    os.makedirs(os.path.join(root, "scheduler"))
+    with open(os.path.join(root, "scheduler", "scheduler_config.json"), "w") as f:
+        json.dump({"_class_name": "FlowMatchEulerDiscreteScheduler", "shift": 7.0, "num_train_timesteps": 1000}, f)
+    pipe = HunyuanVideoImageToVideoPipeline.from_pretrained(root, device=DEV, tokenizer_2=_Tok()).to(DEV)
+    assert isinstance(pipe.transformer, HunyuanVideoTransformer3DModel) and isinstance(pipe.text_encoder_2, CLIPTextModel)
+    assert isinstance(pipe.scheduler, FlowMatchEulerDiscreteScheduler) and pipe.text_encoder is None and pipe.vae is None
+    g = torch.Generator().manual_seed(11)
+    mask = torch.ones(1, 6)
+    # the Llava embeddings are inputs (encoder not built); the pooled CLIP embedding comes from the loaded text tower
+    out = pipe(prompt_embeds=torch.randn(1, 6, 64, generator=g).to(BF).to(DEV), prompt_attention_mask=mask.to(DEV),
+               clip_prompt="a paper boat", negative_prompt=None, image_latents=(torch.randn(1, 16, 1, 16, 16, generator=g) * 0.7).to(DEV),
+               height=128, width=128, num_frames=5, num_inference_steps=2, guidance_scale=6.0, true_cfg_scale=1.0,
+               output_type="latent", generator=torch.Generator().manual_seed(3)).frames
+    assert out.shape == (1, 16, 2, 16, 16) and bool(torch.isfinite(out.float()).all())
