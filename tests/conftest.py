@@ -25,3 +25,26 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def make_tokenizer_dir():
+    """Writes a tiny T5-style tokenizer (a sentencepiece unigram model trained on the spot, saved with transformers'
+    `save_pretrained`) into `<root>/<subfolder>`: the on-disk form of a checkpoint's `tokenizer/` directory."""
+    spm = pytest.importorskip("sentencepiece")
+    transformers = pytest.importorskip("transformers")
+
+    def make(root, subfolder="tokenizer"):
+        d = os.path.join(root, subfolder)
+        os.makedirs(d, exist_ok=True)
+        corpus = os.path.join(root, "corpus.txt")
+        lines = ["a red double decker bus driving down a street", "a small boat drifts on the lake", "blurry static low quality",
+                 "the kite flies over the dunes", "a paper boat in the rain", "people walking in a park at sunset"]
+        with open(corpus, "w") as f:
+            f.write("\n".join(lines * 20))
+        spm.SentencePieceTrainer.train(input=corpus, model_prefix=os.path.join(d, "spiece"), vocab_size=64, model_type="unigram",
+                                       pad_id=0, eos_id=1, unk_id=2, bos_id=-1, hard_vocab_limit=False, minloglevel=2)
+        transformers.T5Tokenizer(vocab_file=os.path.join(d, "spiece.model"), extra_ids=0).save_pretrained(d)
+        return d
+
+    return make

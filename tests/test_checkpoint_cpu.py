@@ -99,3 +99,16 @@ def test_image_processor_config_and_absent_tokenizer(tmp_path):
     _write(str(tmp_path), "ip2", {"size": 224}, name="preprocessor_config.json")
     assert CLIPImageProcessor.from_pretrained(str(tmp_path), subfolder="ip2").size == 224
     assert weights.load_tokenizer(str(tmp_path), "tokenizer") is None          # no directory: the pipelines ask for embeddings
+
+
+def test_tokenizer_directory_loads_through_transformers(tmp_path, make_tokenizer_dir):
+    """`tokenizer/` of a checkpoint -> the object the pipelines call (cog:228-268 / wan:185-234 keyword set)."""
+    make_tokenizer_dir(str(tmp_path))
+    tok = weights.load_tokenizer(str(tmp_path), "tokenizer")
+    assert tok is not None
+    enc = tok(["a red bus", "a small boat drifts on the lake in the rain at sunset"], padding="max_length", max_length=10,
+              truncation=True, add_special_tokens=True, return_attention_mask=True, return_tensors="pt")
+    assert enc.input_ids.shape == (2, 10) and enc.attention_mask.shape == (2, 10)
+    assert enc.attention_mask[1].sum() == 10 and 0 < enc.attention_mask[0].sum() < 10      # truncated / padded
+    assert int(enc.input_ids[0][enc.attention_mask[0].sum() - 1]) == 1                   # </s> closes the short prompt
+    assert int(enc.input_ids.max()) < 96

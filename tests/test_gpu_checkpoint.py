@@ -53,8 +53,9 @@ class _Tok:
         return type("Enc", (), {"input_ids": ids, "attention_mask": mask})()
 
 
-def test_cogvideox_pipeline_from_a_checkpoint_directory(tmp_path):
+def test_cogvideox_pipeline_from_a_checkpoint_directory(tmp_path, make_tokenizer_dir):
     root = str(tmp_path)
+    make_tokenizer_dir(root)                                         # tokenizer/: a real sentencepiece T5 tokenizer
     small = dict(num_attention_heads=8, attention_head_dim=64, in_channels=32, out_channels=16, num_layers=1,
                  time_embed_dim=64, text_embed_dim=128, max_text_seq_length=10, sample_width=6, sample_height=4,
                  sample_frames=9, patch_size=2)
@@ -72,11 +73,12 @@ def test_cogvideox_pipeline_from_a_checkpoint_directory(tmp_path):
         json.dump({"_class_name": "CogVideoXDDIMScheduler", "snr_shift_scale": 1.0, "timestep_spacing": "trailing",
                    "rescale_betas_zero_snr": True, "beta_schedule": "scaled_linear", "prediction_type": "v_prediction"}, f)
 
-    pipe = CogVideoXImageToVideoPipeline.from_pretrained(root, torch_dtype=BF, device=DEV, tokenizer=_Tok()).to(DEV)
+    pipe = CogVideoXImageToVideoPipeline.from_pretrained(root, torch_dtype=BF, device=DEV).to(DEV)
     assert isinstance(pipe.vae, AutoencoderKLCogVideoX) and isinstance(pipe.text_encoder, T5EncoderModel)
+    assert type(pipe.tokenizer).__name__.startswith("T5Tokenizer")
     assert pipe.scheduler.config.snr_shift_scale == 1.0 and pipe.vae.config.layers_per_block == 1
     direct = CogVideoXImageToVideoPipeline(
-        _Tok(), T5EncoderModel(T5EncoderConfig(**tkw), device=DEV).load_state_dict({k: v.to(BF) for k, v in w_t5.items()}),
+        pipe.tokenizer, T5EncoderModel(T5EncoderConfig(**tkw), device=DEV).load_state_dict({k: v.to(BF) for k, v in w_t5.items()}),
         AutoencoderKLCogVideoX(AutoencoderKLCogVideoXConfig(**vkw), device=DEV).load_state_dict(w_vae),
         CogVideoXTransformer3DModel(CogVideoXTransformerConfig(**small), w_tr, device=DEV),
         CogVideoXDDIMScheduler(snr_shift_scale=1.0)).to(DEV)
