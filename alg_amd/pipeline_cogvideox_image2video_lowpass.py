@@ -277,7 +277,7 @@ class CogVideoXImageToVideoPipeline:
         import numpy as np
         imgs = image if isinstance(image, list) else [image]
         arr = [np.asarray(im.convert("RGB").resize((width, height), resample=1), dtype=np.float32) / 255.0 for im in imgs]
-        t = torch.from_numpy(np.stack(arr)).permute(0, 3, 1, 2)
+        t = torch.from_numpy(np.stack(arr)).permute(0, 3, 1, 2).contiguous()
         return 2.0 * t - 1.0
 
     def prepare_latents(self, image, batch_size=1, num_channels_latents=16, num_frames=13, height=60, width=90,
@@ -304,7 +304,7 @@ class CogVideoXImageToVideoPipeline:
             enc = []
             for i in range(frames.shape[0]):
                 g = generator[i] if isinstance(generator, list) else generator
-                enc.append(self.vae.encode(frames[i:i + 1]).latent_dist.sample(g))
+                enc.append(self.vae.encode(frames[i:i + 1].contiguous()).latent_dist.sample(g))
             first = torch.cat(enc, dim=0).to(dtype).permute(0, 2, 1, 3, 4)  # [B, 1, C, h, w]
             if not self.vae.config.invert_scale_latents:
                 first = self.vae_scaling_factor_image * first
@@ -389,7 +389,7 @@ class CogVideoXImageToVideoPipeline:
             raise _lib.AlgHipError("lp_filter_in_latent=False re-encodes the filtered image every step and needs a VAE")
         img = lp_utils.apply_low_pass_filter(orig_image_tensor, lp_filter_type, lp_blur_sigma, lp_blur_kernel_size,
                                              lp_resize_factor)
-        enc = self.vae.encode(img.unsqueeze(2)).latent_dist.sample(generator=generator)
+        enc = self.vae.encode(img.unsqueeze(2).contiguous()).latent_dist.sample(generator=generator)
         if not self.vae.config.invert_scale_latents:
             enc = self.vae_scaling_factor_image * enc
         else:

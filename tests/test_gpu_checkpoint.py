@@ -53,8 +53,8 @@ class _Tok:
         return type("Enc", (), {"input_ids": ids, "attention_mask": mask})()
 
 
-def test_cogvideox_pipeline_from_a_checkpoint_directory(tmp_path, make_tokenizer_dir):
-    root = str(tmp_path)
+def _write_cogvideox_checkpoint(root, make_tokenizer_dir):
+    """A tiny CogVideoX-I2V checkpoint directory in the published layout; returns the in-memory weights too."""
     make_tokenizer_dir(root)                                         # tokenizer/: a real sentencepiece T5 tokenizer
     small = dict(num_attention_heads=8, attention_head_dim=64, in_channels=32, out_channels=16, num_layers=1,
                  time_embed_dim=64, text_embed_dim=128, max_text_seq_length=10, sample_width=6, sample_height=4,
@@ -72,6 +72,12 @@ def test_cogvideox_pipeline_from_a_checkpoint_directory(tmp_path, make_tokenizer
     with open(os.path.join(root, "scheduler", "scheduler_config.json"), "w") as f:
         json.dump({"_class_name": "CogVideoXDDIMScheduler", "snr_shift_scale": 1.0, "timestep_spacing": "trailing",
                    "rescale_betas_zero_snr": True, "beta_schedule": "scaled_linear", "prediction_type": "v_prediction"}, f)
+    return small, w_tr, vkw, w_vae, tkw, w_t5
+
+
+def test_cogvideox_pipeline_from_a_checkpoint_directory(tmp_path, make_tokenizer_dir):
+    root = str(tmp_path)
+    small, w_tr, vkw, w_vae, tkw, w_t5 = _write_cogvideox_checkpoint(root, make_tokenizer_dir)
 
     pipe = CogVideoXImageToVideoPipeline.from_pretrained(root, torch_dtype=BF, device=DEV).to(DEV)
     assert isinstance(pipe.vae, AutoencoderKLCogVideoX) and isinstance(pipe.text_encoder, T5EncoderModel)
@@ -185,3 +191,36 @@ def test_hunyuan_pipeline_from_a_checkpoint_directory(tmp_path):
                height=128, width=128, num_frames=5, num_inference_steps=2, guidance_scale=6.0, true_cfg_scale=1.0,
                output_type="latent", generator=torch.Generator().manual_seed(3)).frames
     assert out.shape == (1, 16, 2, 16, 16) and bool(torch.isfinite(out.float()).all())
+
+
+def test_run_py_command_line_over_a_checkpoint_directory(tmp_path, make_tokenizer_dir):
+    """The reference's own invocation (`run.py --config --image_path --prompt --output_path`, run:26-144) with the YAML's
+    model.path pointing at a checkpoint directory on disk: image + prompt in, a video file out."""
+    import argparse
+
+    import numpy as np
+    import yaml
+    from PIL import Image
+
+    import run
+    from alg_amd import video_io
+    root = os.path.join(str(tmp_path), "CogVideoX-tiny-I2V")
+    os.makedirs(root)
+    _write_cogvideox_checkpoint(root, make_tokenizer_dir)
+    img = os.path.join(str(tmp_path), "in.png")
+    Image.fromarray((np.random.default_rng(0).random((40, 60, 3)) * 255).astype("uint8")).save(img)
+    cfg = os.path.join(str(tmp_path), "alg.yaml")
+    with open(cfg, "w") as f:
+        yaml.safe_dump({"model": {"path": root, "dtype": "bfloat16"},
+                        "generation": {"height": 32, "width": 48, "num_frames": 9, "num_inference_steps": 2,
+                                       "guidance_scale": 6.0, "max_sequence_length": 10},
+                        "alg": {"use_low_pass_guidance": True, "lp_filter_type": "down_up", "lp_filter_in_latent": True,
+                                "lp_resize_factor": 0.5, "lp_strength_schedule_type": "interval",
+                                "schedule_interval_start_time": 0.0, "schedule_interval_end_time": 0.6,
+                                "lp_blur_sigma": None},
+                        "video": {"fps": 8}}, f)
+    out = os.path.join(str(tmp_path), "out.mp4")
+    run.main(argparse.Namespace(config=cfg, image_path=img, prompt="a small boat drifts on the lake", output_path=out,
+                                model_cache_dir=None, fp8=False, synthetic=False))
+    frames = video_io.read_mjpeg_avi(out[:-4] + ".avi")      # no h264 encoder here: Motion-JPEG AVI next to the mp4 name
+    assert frames.shape == (9, 32, 48, 3) and frames.dtype == np.uint8 and frames.std() > 0
