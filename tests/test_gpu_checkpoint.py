@@ -224,3 +224,47 @@ def test_run_py_command_line_over_a_checkpoint_directory(tmp_path, make_tokenize
                                 model_cache_dir=None, fp8=False, synthetic=False))
     frames = video_io.read_mjpeg_avi(out[:-4] + ".avi")      # no h264 encoder here: Motion-JPEG AVI next to the mp4 name
     assert frames.shape == (9, 32, 48, 3) and frames.dtype == np.uint8 and frames.std() > 0
+
+
+@pytest.mark.parametrize("case", ["pixel_gaussian", "two_videos_per_prompt", "no_cfg", "plain_cfg_callback", "prompt_list"])
+def test_reference_style_calls_on_the_loaded_pipeline(tmp_path, make_tokenizer_dir, case):
+    """The keyword combinations a user of the reference passes (cog:727-774), on a pipeline loaded from disk with a PIL
+    image: each must run and give finite frames of the documented shape."""
+    import numpy as np
+    from PIL import Image
+    root = str(tmp_path)
+    _write_cogvideox_checkpoint(root, make_tokenizer_dir)
+    pipe = CogVideoXImageToVideoPipeline.from_pretrained(root, torch_dtype=BF, device=DEV).to(DEV)
+    img = Image.fromarray((np.random.default_rng(1).random((50, 70, 3)) * 255).astype("uint8"))
+    kw = dict(image=img, prompt="a small boat drifts", height=32, width=48, num_frames=9, num_inference_steps=3,
+              max_sequence_length=10, guidance_scale=6.0, generator=torch.Generator().manual_seed(5), output_type="pt",
+              use_low_pass_guidance=True, lp_filter_type="down_up", lp_resize_factor=0.5, lp_filter_in_latent=True,
+              lp_strength_schedule_type="interval", schedule_interval_start_time=0.0, schedule_interval_end_time=0.5)
+    n = 1
+    if case == "pixel_gaussian":        # cog:586-703 pixel branch: blur the image, VAE-encode it again every ALG step
+        kw.update(lp_filter_in_latent=False, lp_filter_type="gaussian_blur", lp_blur_sigma=2.0, lp_blur_kernel_size=5,
+                  lp_strength_schedule_type="linear", schedule_linear_start_weight=1.0, schedule_linear_end_weight=0.0,
+                  schedule_linear_end_time=0.7, schedule_blur_kernel_size=False)
+    elif case == "two_videos_per_prompt":
+        kw.update(num_videos_per_prompt=2)          # cog:903 overwrites it with 1: one video comes back, as in the reference
+    elif case == "no_cfg":
+        with pytest.raises(NameError, match="two_pass"):   # cog:1011-1012, 1084: ALG on + guidance_scale <= 1 is unbound there too
+            pipe(**dict(kw, guidance_scale=1.0))
+        kw.update(guidance_scale=1.0, use_low_pass_guidance=False, generator=torch.Generator().manual_seed(5))
+    elif case == "plain_cfg_callback":
+        seen = []
+
+        def cb(p, i, t, d):
+            seen.append((i, int(t), tuple(d["latents"].shape)))
+            return d
+        kw.update(use_low_pass_guidance=False, negative_prompt="blurry", callback_on_step_end=cb,
+                  callback_on_step_end_tensor_inputs=["latents"])
+    elif case == "prompt_list":
+        kw.update(prompt=["a small boat drifts", "the kite flies over the dunes"], negative_prompt=["blurry", "static"],
+                  image=[img, img.transpose(Image.FLIP_LEFT_RIGHT)])
+        n = 2
+    out = pipe(**kw).frames
+    assert out.shape == (n, 9, 3, 32, 48) and bool(torch.isfinite(out.float()).all())
+    assert 0.0 <= float(out.min()) and float(out.max()) <= 1.0
+    if case == "plain_cfg_callback":
+        assert [i for i, _, _ in seen] == [0, 1, 2] and seen[0][2] == (1, 3, 16, 4, 6)
