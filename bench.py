@@ -332,6 +332,16 @@ def main():
     # sustains 1765 TFLOP/s under the 1400 W package cap -- the matrix-pipe ceiling for real data; `peak` stays the guide's
     roofline["extra"]["mfma_sustained_random_operands_tflops"] = 1765.0
     roofline["extra"]["whole_step_mfma_frac"] = flops_total * world / elapsed / 1e12 / MFMA_PEAK_TFLOPS / world
+    # tile-count quantisation of the persistent GEMM (256x256 tiles on `cus` workgroups): rounds the
+    # last partial round costs as a whole one, for the 2-sample launches that make up 96 % of the steps
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count & ~7
+    tiles = lambda m, n, batch: batch * ((m + 255) // 256) * ((n + 255) // 256)
+    tail = {}
+    for name, (m, n, batch) in dict(gemm_qk=(S, 2 * D, 2), gemm_vt=(D, S, 2), gemm_out=(S, D, 2), gemm_ff1=(S, 4 * D, 2),
+                                    gemm_ff2=(S, D, 2)).items():
+        t = tiles(m, n, batch)
+        tail[name] = {"tiles": t, "rounds_of_work": round(t / cus, 3), "rounds_paid": -(-t // cus)}
+    roofline["extra"]["gemm_tile_rounds"] = tail
 
     out = {
         "metric": "frames/sec (whole node) CogVideoX-5B-I2V 49f x 50-step ALG",
