@@ -162,6 +162,17 @@ def test_wan_pipeline_from_a_checkpoint_directory(tmp_path):
                image_condition=cond.to(DEV), height=128, width=192, num_frames=9, num_inference_steps=2, guidance_scale=5.0,
                max_sequence_length=10, output_type="latent", generator=torch.Generator().manual_seed(3)).frames
     assert out.shape == (1, 16, 3, 16, 24) and bool(torch.isfinite(out.float()).all())
+    # the same call with a PIL image (what run.py hands over): the CLIP processor resizes / crops it on the host
+    import numpy as np
+    from PIL import Image
+    pil = Image.fromarray((np.random.default_rng(2).random((40, 56, 3)) * 255).astype("uint8"))
+    out2 = pipe(image=pil, prompt=["a kite over the dunes"], negative_prompt=["static"], image_condition=cond.to(DEV),
+                height=128, width=192, num_frames=9, num_inference_steps=2, guidance_scale=5.0, max_sequence_length=10,
+                output_type="latent", generator=torch.Generator().manual_seed(3), use_low_pass_guidance=True,
+                lp_filter_type="down_up", lp_resize_factor=0.5, lp_filter_in_latent=True,
+                lp_strength_schedule_type="interval", schedule_interval_start_time=0.0,
+                schedule_interval_end_time=0.6).frames
+    assert out2.shape == out.shape and bool(torch.isfinite(out2.float()).all())
 
 
 def test_hunyuan_pipeline_from_a_checkpoint_directory(tmp_path):
