@@ -69,6 +69,47 @@ def broadcast_state_dict(make_state_dict, shapes, device, src=0, dtype=torch.bfl
     return out
 
 
+def broadcast_loaded_state_dict(sd, device, src=0, bucket_bytes=1 << 30):
+    """``sd`` is the state dict on rank ``src`` and None elsewhere (only rank ``src`` read the checkpoint from disk):
+    names / shapes / dtypes travel as one small object broadcast, the tensors in ~1 GiB flat buckets per dtype (xGMI is
+    point-to-point: few, large transfers).  Returns the same dict -- same names, dtypes, bits -- on every rank, tensors on
+    ``device``."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return sd
+    rank = dist.get_rank()
+    meta = [[(k, tuple(v.shape), v.dtype) for k, v in sd.items()]] if rank == src else [None]
+    dist.broadcast_object_list(meta, src=src)
+    meta = meta[0]
+    out = {}
+    by_dtype = {}
+    for k, shape, dt in meta:
+        by_dtype.setdefault(dt, []).append((k, shape))
+    for dt, items in by_dtype.items():
+        esize = torch.empty((), dtype=dt).element_size()
+        # byte buckets: the collective runs on uint8 so every dtype (fp8 and int64 included) takes the same path
+        i = 0
+        while i < len(items):
+            group, nbytes = [], 0
+            while i < len(items) and (not group or nbytes + _numel(items[i][1]) * esize <= bucket_bytes):
+                group.append(items[i])
+                nbytes += -(-_numel(items[i][1]) * esize // 16) * 16      # keep every tensor 16-byte aligned in the bucket
+                i += 1
+            flat = torch.empty(nbytes, device=device, dtype=torch.uint8)
+            if rank == src:
+                off = 0
+                for k, shape in group:
+                    nb = _numel(shape) * esize
+                    flat[off:off + nb].copy_(sd[k].to(device).contiguous().reshape(-1).view(torch.uint8))
+                    off += -(-nb // 16) * 16
+            dist.broadcast(flat, src=src)
+            off = 0
+            for k, shape in group:
+                nb = _numel(shape) * esize
+                out[k] = flat[off:off + nb].view(dt).view(shape)
+                off += -(-nb // 16) * 16
+    return {k: out[k] for k, _, _ in meta}
+
+
 def _numel(shape):
     n = 1
     for s in shape:
@@ -92,7 +133,7 @@ def barrier():
 
 class CFGPairSplit:
     """The cond / uncond CFG branches of ONE video on two GPUs (BASELINE config 5): ranks 2i and
-    2i+1 form a pair, each evaluates its share of the step's DiT sample-forwards, one small all-reduce per step merges
+    2i+1 form a pair, each evaluates its share of the step's DiT sample-forwards, one small all-gather per step merges
     the predictions (the only data-path collective in this build -- the path has a real exchange step here), and both
     ranks then apply the identical CFG combine + scheduler step, so their latents stay bit-identical without a second
     exchange.  Trades throughput-neutral weak scaling for ~2x lower latency per video.
@@ -126,15 +167,29 @@ class CFGPairSplit:
         return list(range(n_pass - 1)) if self.pair_rank == 0 else [n_pass - 1]
 
     def merge(self, local_pred, n_pass, batch):
-        """local_pred [len(my_passes) * batch, ...] -> full [n_pass * batch, ...] on both ranks: each rank fills its
-        rows of a zeroed buffer, the sum over the pair is exact (every row has exactly one non-zero contributor)."""
+        """local_pred [len(my_passes) * batch, ...] -> full [n_pass * batch, ...] on both ranks.  One all-gather over the
+        pair moves exactly the partner's rows (a 3-pass step is split 2 + 1: the single-pass rank pads its send buffer to
+        the pair's common size, the pad row is never read); rows are copied, never summed, so the merged prediction is the
+        partner's bits (signed zeros included)."""
         mine = self.my_passes(n_pass)
-        full = torch.zeros((n_pass * batch,) + tuple(local_pred.shape[1:]), dtype=local_pred.dtype,
-                           device=local_pred.device)
-        for j, p in enumerate(mine):
-            full[p * batch:(p + 1) * batch] = local_pred[j * batch:(j + 1) * batch]
-        self.all_reduce(full)
+        counts = [len(CFGPairSplit(None, r).my_passes(n_pass)) for r in (0, 1)]
+        rows = max(counts) * batch
+        tail = tuple(local_pred.shape[1:])
+        if local_pred.shape[0] != len(mine) * batch:
+            raise ValueError("local prediction has %d rows, expected %d" % (local_pred.shape[0], len(mine) * batch))
+        send = local_pred.contiguous()
+        if send.shape[0] != rows:
+            pad = torch.empty((rows,) + tail, dtype=send.dtype, device=send.device)
+            pad[:send.shape[0]] = send
+            send = pad
+        parts = [torch.empty((rows,) + tail, dtype=send.dtype, device=send.device) for _ in range(2)]
+        self.all_gather(parts, send)
+        full = torch.empty((n_pass * batch,) + tail, dtype=send.dtype, device=send.device)
+        for r in (0, 1):
+            for j, p in enumerate(CFGPairSplit(None, r).my_passes(n_pass)):
+                full[p * batch:(p + 1) * batch] = parts[r][j * batch:(j + 1) * batch]
         return full
 
-    def all_reduce(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+    def all_gather(self, parts, t):
+        """parts[r] <- rank r's `t` for both ranks of the pair (RCCL over the pair's direct xGMI link)."""
+        dist.all_gather(parts, t, group=self.group)

@@ -151,7 +151,17 @@ class CogVideoXImageToVideoPipeline:
         if tokenizer is None:
             tokenizer = load_tokenizer(model_path, "tokenizer")
         if scheduler is None:
-            scheduler = CogVideoXDDIMScheduler.from_pretrained(model_path) if has("scheduler") else CogVideoXDDIMScheduler()
+            scheduler = CogVideoXDDIMScheduler()
+            if has("scheduler"):
+                # scheduler/scheduler_config.json names its class: CogVideoX-5b-I2V ships the DDIM scheduler, CogVideoX1.5-5B-I2V
+                # the DPM one (the loop's second `step` signature, cog:1114-1122)
+                import json
+                with open(os.path.join(model_path, "scheduler", "scheduler_config.json")) as f:
+                    name = json.load(f).get("_class_name", "CogVideoXDDIMScheduler")
+                known = {"CogVideoXDDIMScheduler": CogVideoXDDIMScheduler, "CogVideoXDPMScheduler": CogVideoXDPMScheduler}
+                if name not in known:
+                    raise NotImplementedError("scheduler class %r is not built (CogVideoXDDIMScheduler / CogVideoXDPMScheduler)" % name)
+                scheduler = known[name].from_pretrained(model_path)
         return cls(tokenizer, text_encoder, vae, transformer, scheduler)
 
     def to(self, device=None, *args, **kwargs):
@@ -579,7 +589,7 @@ class CogVideoXImageToVideoPipeline:
             lat_in = latents if B == 1 else torch.cat([latents] * n_pass, dim=0)
             ts = torch.full((n_pass * B,), int(t), dtype=torch.float32)
             if cfg_split is not None and n_pass > 1:
-                # alg_amd.parallel.CFGPairSplit: this rank evaluates its share of the CFG passes, one all-reduce merges
+                # alg_amd.parallel.CFGPairSplit: this rank evaluates its share of the CFG passes, one all-gather merges
                 # the predictions; combine + step below run identically on both ranks of the pair
                 rows = [p_ * B + b for p_ in cfg_split.my_passes(n_pass) for b in range(B)]
                 lat_l = latents if B == 1 else torch.cat([latents] * (len(rows) // B), dim=0)
@@ -614,8 +624,21 @@ class CogVideoXImageToVideoPipeline:
                 new_lat = outs.pop("latents", latents)
                 if new_lat is not latents:
                     latents = new_lat.to(dtype).contiguous().clone()
-                prompt_embeds = outs.pop("prompt_embeds", prompt_embeds)
-                negative_prompt_embeds = outs.pop("negative_prompt_embeds", negative_prompt_embeds)
+                new_pe = outs.pop("prompt_embeds", prompt_embeds)
+                new_ne = outs.pop("negative_prompt_embeds", negative_prompt_embeds)
+                if new_pe is not prompt_embeds or new_ne is not negative_prompt_embeds:
+                    # cog:1126-1134: the callback may replace the embeddings the next forward uses.  The reference hands it
+                    # the already concatenated batch; here the two halves are exposed under the same names and the
+                    # pre-concatenated CFG batches are rebuilt from what the callback returned.
+                    prompt_embeds, negative_prompt_embeds = new_pe.to(device, dtype), (
+                        None if new_ne is None else new_ne.to(device, dtype))
+                    if do_cfg and use_low_pass_guidance:
+                        prompt_embeds_init = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+                        prompt_embeds_3 = torch.cat([negative_prompt_embeds, negative_prompt_embeds, prompt_embeds], dim=0)
+                    elif do_cfg:
+                        prompt_embeds_init = prompt_embeds_3 = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+                    else:
+                        prompt_embeds_init = prompt_embeds_3 = prompt_embeds
         self._current_timestep = None
 
         if output_type != "latent":

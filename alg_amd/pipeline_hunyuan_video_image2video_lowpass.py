@@ -304,6 +304,8 @@ class HunyuanVideoImageToVideoPipeline:
                                    "negative_prompt_attention_mask (no prompt encoder is attached)")
         if not isinstance(self.scheduler, FlowMatchEulerDiscreteScheduler):
             raise TypeError("this sampler drives alg_amd.schedulers.FlowMatchEulerDiscreteScheduler (HIP step)")
+        if output_type != "latent" and getattr(self, "vae", None) is None:   # before the 50-step loop, not after it
+            raise _lib.AlgHipError("no HunyuanVideo VAE is attached to this pipeline: use output_type='latent'")
         batch_size = prompt_embeds.shape[0]
 
         if image_condition_type == "latent_concat":

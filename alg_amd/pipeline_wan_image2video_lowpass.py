@@ -347,6 +347,8 @@ class WanImageToVideoPipeline:
                                    "`image_condition` [B, 20, F, h, w] or `latent_condition` [B, 16, F, h, w]")
         if not isinstance(self.scheduler, UniPCMultistepScheduler):
             raise TypeError("this sampler drives alg_amd.schedulers.UniPCMultistepScheduler (HIP step)")
+        if output_type != "latent" and self.vae is None:   # before the 40-50 step loop, not after it
+            raise _lib.AlgHipError("no Wan VAE is attached to this pipeline: use output_type='latent'")
 
         if prompt is not None and isinstance(prompt, str):
             batch_size = 1
@@ -419,7 +421,7 @@ class WanImageToVideoPipeline:
             ehs = torch.cat(embeds, dim=0)
             ehs_img = image_embeds.repeat(n, 1, 1) if image_embeds.shape[0] != n else image_embeds
             if cfg_split is not None:
-                # alg_amd.parallel.CFGPairSplit: this rank's share of the CFG passes, one all-reduce merges the predictions
+                # alg_amd.parallel.CFGPairSplit: this rank's share of the CFG passes, one all-gather merges the predictions
                 B_ = latents.shape[0]
                 rows = [p_ * B_ + b for p_ in cfg_split.my_passes(len(groups)) for b in range(B_)]
                 local = self.transformer(hidden_states=latent_model_input[rows].contiguous(), timestep=timestep[:len(rows)],

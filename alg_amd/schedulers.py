@@ -36,8 +36,13 @@ class _ConfigLoading:
 
 
 class CogVideoXDDIMScheduler(_ConfigLoading):
+    """Constructor defaults are the values `THUDM/CogVideoX-5b-I2V/scheduler/scheduler_config.json` ships (snr_shift_scale
+    1.0, trailing spacing, v_prediction, zero terminal SNR) so that `CogVideoXDDIMScheduler()` IS the C2 scheduler; the
+    published class defaults (`_published_defaults`) fill the keys a checkpoint's config file leaves out."""
     order = 1
     init_noise_sigma = 1.0
+    _published_defaults = dict(snr_shift_scale=3.0, timestep_spacing="leading", prediction_type="epsilon",
+                               rescale_betas_zero_snr=False, set_alpha_to_one=True, steps_offset=0)
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                  clip_sample=False, set_alpha_to_one=True, steps_offset=0, prediction_type="v_prediction",

@@ -215,6 +215,7 @@ class HunyuanVideoTransformer3DModel:
         self.w = w
         self._ws = {}
         self._rope_cache = {}
+        self.profile = None  # set to a dict to collect (start, stop) HIP event pairs of the joint attention launches
 
     @classmethod
     def from_synthetic(cls, config=None, seed=1234, device="cuda"):
@@ -223,7 +224,6 @@ class HunyuanVideoTransformer3DModel:
 
     @classmethod
     def from_pretrained(cls, path, subfolder="transformer", torch_dtype=BF, device="cuda", **_):
-        from safetensors.torch import load_file
         root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
         cfg_path = os.path.join(root, "config.json")
         if not os.path.exists(cfg_path):
@@ -234,9 +234,8 @@ class HunyuanVideoTransformer3DModel:
         fields = HunyuanVideoTransformerConfig.__dataclass_fields__
         cfg = HunyuanVideoTransformerConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in raw.items()
                                                if k in fields})
-        sd = {}
-        for shard in sorted(glob.glob(os.path.join(root, "*.safetensors"))):
-            sd.update(load_file(shard))
+        from .weights import read_shards
+        sd = read_shards(root)
         return cls(cfg, sd, device=device)
 
     def to(self, *a, **k):
@@ -391,10 +390,17 @@ class HunyuanVideoTransformer3DModel:
         split = first if tr else 0
 
         def attention():
+            prof = self.profile
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             for b in range(N):
                 _lib.flash_attn_d128(ws.qk, ws.qk, ws.vt, ws.am, 1, heads, J, S + valid[b], J * 2 * D, 2 * D, J * 2 * D, 2 * D,
                                      D * ws.J_pad, ws.J_pad, J * (D + M), D + M, scale, q_off=b * J * 2 * D,
                                      k_off=b * J * 2 * D + D, vt_off=b * D * ws.J_pad, o_off=b * J * (D + M))
+            if prof is not None:
+                e1.record()
+                prof.setdefault("attn_self", []).append((e0, e1))
 
         def ada(lin_, rows_in, out, n_out, two):
             """AdaLN linear on silu(emb): `two` -> both embeddings of every sample ([N][2][n_out]), else temb only."""

@@ -226,7 +226,6 @@ class WanTransformer3DModel:
     @classmethod
     def from_pretrained(cls, path, subfolder="transformer", torch_dtype=BF, device="cuda", fp8=False, **_):
         """Load a diffusers-format checkpoint directory (config.json + *.safetensors) from local disk."""
-        from safetensors.torch import load_file
         root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
         cfg_path = os.path.join(root, "config.json")
         if not os.path.exists(cfg_path):
@@ -236,9 +235,8 @@ class WanTransformer3DModel:
             raw = json.load(f)
         fields = WanTransformerConfig.__dataclass_fields__
         cfg = WanTransformerConfig(**{k: (tuple(v) if k == "patch_size" else v) for k, v in raw.items() if k in fields})
-        sd = {}
-        for shard in sorted(glob.glob(os.path.join(root, "*.safetensors"))):
-            sd.update(load_file(shard))
+        from .weights import read_shards
+        sd = read_shards(root)
         return cls(cfg, sd, device=device, fp8=fp8)
 
     def to(self, *args, **kwargs):

@@ -90,10 +90,36 @@ def synthetic_state_dict(cfg, seed=1234, std=0.02, device="cuda", randomize_affi
     return sd
 
 
-def load_diffusers_transformer(path, subfolder="transformer"):
-    """Read config.json + safetensors shards of a diffusers CogVideoXTransformer3DModel from local disk."""
+def read_shards(root, device=None):
+    """Every `*.safetensors` shard of one component directory -> one state dict.  In a multi-rank run (torch.distributed
+    initialised, world > 1) only rank 0 touches the disk: the tensors reach the other ranks through ONE bucketed RCCL
+    broadcast over xGMI (`parallel.broadcast_loaded_state_dict`) -- eight ranks do not read the same 11-33 GB eight times.
+    `ALG_BROADCAST_WEIGHTS=0` restores per-rank disk reads."""
+    import torch.distributed as dist
     from safetensors.torch import load_file
 
+    shards = sorted(glob.glob(os.path.join(root, "*.safetensors")))
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and \
+        os.environ.get("ALG_BROADCAST_WEIGHTS", "1") != "0"
+    if not multi:
+        sd = {}
+        for shard in shards:
+            sd.update(load_file(shard))
+        return sd
+    from . import parallel
+    sd = None
+    if dist.get_rank() == 0:
+        sd = {}
+        for shard in shards:
+            sd.update(load_file(shard))
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and
+                                                                      dist.get_backend() == "nccl") else torch.device("cpu")
+    return parallel.broadcast_loaded_state_dict(sd, device)
+
+
+def load_diffusers_transformer(path, subfolder="transformer"):
+    """Read config.json + safetensors shards of a diffusers CogVideoXTransformer3DModel from local disk."""
     from .transformer_cogvideox import CogVideoXTransformerConfig
 
     root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
@@ -106,9 +132,7 @@ def load_diffusers_transformer(path, subfolder="transformer"):
         raw = json.load(f)
     fields = CogVideoXTransformerConfig.__dataclass_fields__
     cfg = CogVideoXTransformerConfig(**{k: v for k, v in raw.items() if k in fields})
-    sd = {}
-    for shard in sorted(glob.glob(os.path.join(root, "*.safetensors"))):
-        sd.update(load_file(shard))
+    sd = read_shards(root)
     missing = [k for k in parameter_shapes(cfg) if k not in sd]
     if missing:
         raise KeyError("checkpoint is missing %d tensors, e.g. %s" % (len(missing), missing[:3]))
@@ -120,8 +144,6 @@ def load_component(path, subfolder=None, config_name="config.json"):
     """(raw config dict, state dict, directory) of one component of a diffusers-format checkpoint on LOCAL disk:
     `<path>/<subfolder>/config.json` + every `*.safetensors` shard next to it (the layout `from_pretrained` of the
     reference's pipelines reads: cog / wan / hy `run.py:38-90`).  No hub access, no pickle (`*.bin`) loading."""
-    from safetensors.torch import load_file
-
     root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
     cfg_path = os.path.join(root, config_name)
     if not os.path.exists(cfg_path):
@@ -131,9 +153,7 @@ def load_component(path, subfolder=None, config_name="config.json"):
     shards = sorted(glob.glob(os.path.join(root, "*.safetensors")))
     if not shards:
         raise FileNotFoundError("no *.safetensors in %s (pickled *.bin checkpoints are not read)" % root)
-    sd = {}
-    for shard in shards:
-        sd.update(load_file(shard))
+    sd = read_shards(root)
     return raw, sd, root
 
 
@@ -168,7 +188,12 @@ def scheduler_from_pretrained(cls, path, subfolder="scheduler"):
     with open(cfg_path) as f:
         raw = json.load(f)
     known = set(inspect.signature(cls.__init__).parameters) - {"self"}
-    return cls(**{k: v for k, v in raw.items() if k in known})
+    # a key the file leaves out takes the PUBLISHED class default (diffusers), which for the CogVideoX schedulers differs
+    # from this build's constructor defaults (= the values CogVideoX-5b-I2V ships): a partial config must resolve as it
+    # would under diffusers, and then fail loudly if it lands on a variant that is not built
+    kw = dict(getattr(cls, "_published_defaults", {}))
+    kw.update({k: v for k, v in raw.items() if k in known})
+    return cls(**kw)
 
 
 def load_tokenizer(path, subfolder="tokenizer"):

@@ -231,9 +231,10 @@ def test_run_py_command_line_over_a_checkpoint_directory(tmp_path, make_tokenize
                                 "lp_blur_sigma": None},
                         "video": {"fps": 8}}, f)
     out = os.path.join(str(tmp_path), "out.mp4")
-    run.main(argparse.Namespace(config=cfg, image_path=img, prompt="a small boat drifts on the lake", output_path=out,
-                                model_cache_dir=None, fp8=False, synthetic=False))
-    frames = video_io.read_mjpeg_avi(out[:-4] + ".avi")      # no h264 encoder here: Motion-JPEG AVI next to the mp4 name
+    run.main(run.make_parser().parse_args(["--config", cfg, "--image_path", img, "--prompt", "a small boat drifts on the lake",
+                                           "--output_path", out, "--generator_device", "cpu"]))
+    frames, info = video_io.read_mp4(out)                    # run:127-133: an h264 track in an mp4 container
+    assert info["codec"] == "avc1" and info["fps"] == 8.0
     assert frames.shape == (9, 32, 48, 3) and frames.dtype == np.uint8 and frames.std() > 0
 
 

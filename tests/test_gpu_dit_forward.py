@@ -130,7 +130,7 @@ def test_sampler_schedules_and_filter_cache(device):
 
 class _ThreadPair:
     """Stands in for alg_amd.parallel.CFGPairSplit on ONE GPU: the two 'ranks' are threads with their own model
-    instance (own workspace); merge() is the all-reduce, done through a shared dict and a barrier."""
+    instance (own workspace); merge()'s all-gather goes through a shared dict and a barrier."""
 
     def __init__(self):
         import threading
@@ -142,10 +142,11 @@ class _ThreadPair:
         outer = self
 
         class _Rank(CFGPairSplit):
-            def all_reduce(self, t):
+            def all_gather(self, parts, t):
                 outer.box[self.pair_rank] = t.clone()
                 outer.barrier.wait()
-                t.copy_(outer.box[0] + outer.box[1])
+                for r in (0, 1):
+                    parts[r].copy_(outer.box[r])
                 outer.barrier.wait()
         return _Rank(group=None, pair_rank=pair_rank)
 

@@ -263,8 +263,8 @@ def test_dpm_scheduler_scalars_match_the_oracle():
 
 
 def test_output_writer_round_trips(tmp_path):
-    """run:121-133 stand-in (no h264 encoder here): npy exact, Motion-JPEG AVI decodes back close to the frames, PNG
-    directory exact, mp4 refuses loudly."""
+    """run:121-133: npy exact, Motion-JPEG AVI decodes back close to the frames, PNG directory exact, mp4 = an H.264 (all
+    I_PCM) track whose YUV 4:2:0 samples are exactly the BT.601 conversion of the frames (Motion-JPEG-in-mp4 as an option)."""
     from alg_amd import video_io
     yy, xx = np.mgrid[0:48, 0:64]
     frames = np.stack([np.stack([(xx * 4 + 8 * t) % 256, (yy * 5) % 256, (xx + yy + t) % 256], -1) for t in range(5)]).astype(np.uint8)
@@ -279,7 +279,31 @@ def test_output_writer_round_trips(tmp_path):
     from PIL import Image
     assert sorted(os.listdir(d))[0] == "frame_00000.png" and np.array_equal(np.asarray(Image.open(os.path.join(d, "frame_00003.png"))), frames[3])
     video_io.write_video(str(tmp_path / "v.gif"), frames)
-    with pytest.raises(RuntimeError, match="h264"):
-        video_io.write_video(str(tmp_path / "v.mp4"), frames)
+    # mp4 / h264: container + bitstream walked by an independent parser; the stored samples are the exact 4:2:0 conversion
+    smooth = np.stack([np.stack([(xx * 3 + 5 * t) % 256, 255 - yy * 4, (xx + 2 * yy) % 256], -1) for t in range(3)]).astype(np.uint8)
+    p = video_io.write_video(str(tmp_path / "v.mp4"), smooth, fps=16)
+    back, info = video_io.read_mp4(p)
+    assert (info["codec"], info["fps"], info["frames"], info["profile"], info["cropped"]) == ("avc1", 16.0, 3, 66, (64, 48))
+    for a_, b_ in zip(info["yuv"], video_io.rgb_to_yuv420(smooth)):
+        assert np.array_equal(a_, b_)
+    assert back.shape == smooth.shape
+    mse = ((back.astype(np.float32) - smooth.astype(np.float32)) ** 2).mean()
+    assert 10 * np.log10(255.0 ** 2 / mse) > 30.0            # what 4:2:0 subsampling costs on this pattern
+    data = open(p, "rb").read()
+    assert data[4:8] == b"ftyp" and b"avcC" in data and b"moov" in data
+    mdat = data[data.index(b"mdat") + 4:data.index(b"moov") - 4]
+    assert b"\x00\x00\x00" not in mdat[4:] and b"\x00\x00\x01" not in mdat[4:] and b"\x00\x00\x02" not in mdat[4:]
+    # a size that is not a whole number of macroblocks: padded by edge replication, cropped again by the SPS
+    odd = smooth[:, :36, :50]
+    back, info = video_io.read_mp4(video_io.write_video(str(tmp_path / "odd.mp4"), odd, fps=8))
+    assert info["cropped"] == (50, 36) and back.shape == odd.shape
+    assert all(np.array_equal(a_, b_) for a_, b_ in zip(info["yuv"], video_io.rgb_to_yuv420(odd)))
+    # black / white frames produce runs of equal bytes: emulation prevention must keep start codes out of the payload
+    flat = np.zeros((2, 32, 32, 3), np.uint8)
+    flat[1] = 255
+    back, info = video_io.read_mp4(video_io.write_video(str(tmp_path / "flat.mp4"), flat))
+    assert np.abs(back.astype(int) - flat.astype(int)).max() <= 1
+    back, info = video_io.read_mp4(video_io.write_mp4(str(tmp_path / "j.mp4"), smooth, fps=8, codec="mjpeg"))
+    assert info["codec"] == "mp4v" and back.shape == smooth.shape
     with pytest.raises(ValueError, match="uint8"):
         video_io.write_video(str(tmp_path / "w.npy"), frames.astype(np.float32))

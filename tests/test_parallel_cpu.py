@@ -133,3 +133,110 @@ def test_yaml_schema_matches_wan_call_signature():
                 cfg = yaml.safe_load(f)
             for key in {**cfg.get("generation", {}), **cfg.get("alg", {})}:
                 assert key in params, (name, key)
+
+
+# ---- the product launcher: run.py --jobs ... --gpus N (video v -> rank v mod world, one weight broadcast) -------
+class _ToyPipe:
+    """A CPU stand-in with the pipelines' call protocol: its output is a deterministic function of the (broadcast)
+    weights, the job's generator stream and the job's synthetic inputs -- everything the launcher is responsible for."""
+    vae = None
+
+    def __init__(self, w):
+        self.w = w
+
+    def to(self, device):
+        return self
+
+    def __call__(self, generator=None, prompt_embeds=None, image_latents=None, num_inference_steps=2, **kw):
+        from types import SimpleNamespace
+        x = torch.randn(4, 8, generator=generator)
+        for _ in range(num_inference_steps):
+            x = torch.tanh(x @ self.w["a"].float()) + self.w["b"].float()
+        x = x + prompt_embeds.float().mean() + image_latents.float().std()
+        return SimpleNamespace(frames=x)
+
+
+def _toy_build(config, args, device):
+    sd = None
+    if not dist.is_initialized() or dist.get_rank() == 0:   # only rank 0 "reads the checkpoint"
+        g = torch.Generator().manual_seed(99)
+        sd = {"a": torch.randn(8, 8, generator=g).to(torch.bfloat16), "b": torch.randn(8, generator=g)}
+    return _ToyPipe(parallel.broadcast_loaded_state_dict(sd, torch.device("cpu")))
+
+
+def _run_worker(rank, world, port, argv):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import run
+    run.build_pipeline = _toy_build
+    run.main(run.make_parser().parse_args(argv))
+
+
+def test_run_py_data_parallel_jobs_match_single_process_runs(tmp_path):
+    """`run.py --jobs` on 2 ranks (gloo): weights exist on rank 0 only and arrive by broadcast, video v runs on rank v mod 2
+    with its own seed, and every output equals the same job run alone in one process, bit for bit."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import run
+    cfg = tmp_path / "c.yaml"
+    cfg.write_text(yaml.safe_dump({"model": {"path": "CogVideoX-toy", "dtype": "bfloat16",
+                                             "synthetic_config": {"text_embed_dim": 16, "max_text_seq_length": 4,
+                                                                  "sample_height": 4, "sample_width": 4, "in_channels": 8}},
+                                   "generation": {"num_inference_steps": 3}, "alg": {}, "video": {"fps": 8}}))
+    jobs = [{"output_path": str(tmp_path / ("dp_%d.pt" % v))} for v in range(5)]
+    jobs[3]["seed"] = 7
+    jf = tmp_path / "jobs.yaml"
+    jf.write_text(yaml.safe_dump(jobs))
+    argv = ["--config", str(cfg), "--synthetic", "--jobs", str(jf), "--generator_device", "cpu"]
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_run_worker, args=(r, 2, port, argv)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    # the same jobs, one at a time, in this process (world size 1, no process group)
+    args = run.make_parser().parse_args(argv)
+    config = yaml.safe_load(cfg.read_text())
+    pipe = _toy_build(config, args, torch.device("cpu"))
+    loaded = run.load_jobs(args)
+    assert [j["seed"] for j in loaded] == [42, 43, 44, 7, 46]
+    outs = []
+    for v, job in enumerate(loaded):
+        solo = dict(job, output_path=str(tmp_path / ("solo_%d.pt" % v)))
+        run.run_job(pipe, config, args, solo)
+        a, b = torch.load(solo["output_path"]), torch.load(job["output_path"])
+        assert torch.equal(a, b), v
+        outs.append(a)
+    assert not torch.equal(outs[0], outs[1])     # different seeds -> different videos
+
+
+def _cfg_signed_zero_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_distributed(backend="gloo")
+    split = parallel.CFGPairSplit.from_world()
+    full = torch.tensor([[-0.0, 1.0], [0.0, -2.0], [-0.0, -0.0]]).to(torch.bfloat16)
+    mine = split.my_passes(3)
+    merged = split.merge(torch.stack([full[p] for p in mine]), 3, 1)
+    out.put((rank, torch.equal(merged.view(torch.int16), full.view(torch.int16))))
+    dist.destroy_process_group()
+
+
+def test_cfg_pair_merge_moves_bits_not_sums():
+    """The pair exchange is an all-gather of rows: signed zeros survive (an all-reduce of a zero-padded buffer gives
+    -0 + 0 = +0), and the single-pass rank's pad row is never read."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cfg_signed_zero_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
