@@ -74,7 +74,8 @@ class CogVideoXDDIMScheduler(_ConfigLoading):
 
     @classmethod
     def from_config(cls, config, **overrides):
-        d = dict(vars(config)) if not isinstance(config, dict) else dict(config)
+        d = dict(getattr(cls, "_published_defaults", {}))     # keys a partial config leaves out: the published class defaults
+        d.update(dict(vars(config)) if not isinstance(config, dict) else dict(config))
         d.update(overrides)
         return cls(**d)
 

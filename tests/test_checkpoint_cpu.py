@@ -69,10 +69,11 @@ def test_config_from_dict_filters_unwraps_and_tuples():
 @pytest.mark.parametrize("cls,cfg,check", [
     (CogVideoXDDIMScheduler, {"_class_name": "CogVideoXDDIMScheduler", "beta_end": 0.012, "beta_schedule": "scaled_linear",
                               "snr_shift_scale": 1.0, "timestep_spacing": "trailing", "rescale_betas_zero_snr": True,
-                              "set_alpha_to_one": True, "clip_sample": False},
+                              "set_alpha_to_one": True, "clip_sample": False, "prediction_type": "v_prediction"},
      lambda s: s.config.snr_shift_scale == 1.0 and s.config.timestep_spacing == "trailing"),
-    (CogVideoXDPMScheduler, {"snr_shift_scale": 3.0, "_diffusers_version": "0.30.0.dev0"},
-     lambda s: s.config.snr_shift_scale == 3.0),
+    (CogVideoXDPMScheduler, {"snr_shift_scale": 3.0, "_diffusers_version": "0.30.0.dev0", "prediction_type": "v_prediction"},
+     lambda s: s.config.snr_shift_scale == 3.0 and s.config.timestep_spacing == "leading"
+     and s.config.rescale_betas_zero_snr is False),      # keys the file leaves out: the published class defaults
     (UniPCMultistepScheduler, {"flow_shift": 3.0, "solver_order": 2, "prediction_type": "flow_prediction",
                                "use_flow_sigmas": True, "some_future_key": 1}, lambda s: s.flow_shift == 3.0 if hasattr(s, "flow_shift") else True),
     (FlowMatchEulerDiscreteScheduler, {"shift": 7.0, "num_train_timesteps": 1000, "base_image_seq_len": 256},
@@ -88,6 +89,17 @@ def test_schedulers_load_their_config_and_ignore_unknown_keys(tmp_path, cls, cfg
     assert torch.equal(torch.as_tensor(s.timesteps), torch.as_tensor(s2.timesteps))
     with pytest.raises(FileNotFoundError):
         cls.from_pretrained(str(tmp_path / "nowhere"))
+
+
+def test_partial_cogvideox_scheduler_config_resolves_like_the_published_class(tmp_path):
+    """A scheduler_config.json without `prediction_type` means epsilon prediction under diffusers (the class default), which
+    is not built: loading it must fail loudly instead of silently sampling with the CogVideoX-5b-I2V values."""
+    _write(str(tmp_path), "scheduler", {"_class_name": "CogVideoXDDIMScheduler", "snr_shift_scale": 1.0},
+           name="scheduler_config.json")
+    with pytest.raises(NotImplementedError, match="v_prediction"):
+        CogVideoXDDIMScheduler.from_pretrained(str(tmp_path))
+    s = CogVideoXDDIMScheduler()                          # the constructor itself is the 5b-I2V scheduler (C2)
+    assert (s.config.snr_shift_scale, s.config.timestep_spacing, s.config.rescale_betas_zero_snr) == (1.0, "trailing", True)
 
 
 def test_image_processor_config_and_absent_tokenizer(tmp_path):
