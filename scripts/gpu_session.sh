@@ -10,7 +10,8 @@ WHAT=${@:-tests smoke quick bench prof}
 for w in $WHAT; do
   case $w in
     tests)
-      timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider 2>&1 | tail -300 > $O/pytest_gpu.log
+      rm -f $O/parity_floor.jsonl
+      ALG_PARITY_REPORT=1 timeout 2400 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider ${PYTEST_ARGS:-} 2>&1 | tail -400 > $O/pytest_gpu.log
       echo "pytest exit ${PIPESTATUS[0]}" >> $O/pytest_gpu.log
       tail -25 $O/pytest_gpu.log ;;
     smoke)
@@ -18,8 +19,11 @@ for w in $WHAT; do
     quick)
       timeout 900 python bench.py --layers 4 --steps 6 --warmup 1 --no-cpu-baseline > $O/bench_quick.json 2> $O/bench_quick.err
       echo "quick exit $?"; tail -c 3000 $O/bench_quick.json; tail -5 $O/bench_quick.err ;;
+    driverbench)
+      timeout 1800 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err
+      echo "driverbench exit $?"; tail -c 5000 $O/bench_driver.json; tail -5 $O/bench_driver.err ;;
     bench)
-      timeout 1800 python bench.py > $O/bench_full.json 2> $O/bench_full.err
+      timeout 1800 python bench.py --cross-check > $O/bench_full.json 2> $O/bench_full.err
       echo "bench exit $?"; tail -c 4000 $O/bench_full.json; tail -5 $O/bench_full.err ;;
     kbench)
       for v in ${ATTN_VARIANTS:-1 13}; do

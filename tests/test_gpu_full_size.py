@@ -39,7 +39,10 @@ def test_attention_full_sequence_rows(device):
         p = torch.softmax(q @ k.t() * 0.125, dim=-1)
         ref = p @ v[0, :, hh * 64:(hh + 1) * 64].float()
         got = o[0, rows, hh * 64:(hh + 1) * 64].float()
-        assert (got - ref).abs().max().item() <= 2e-3  # outputs are O(0.01): mean of 17,776 N(0,1) values
+        # outputs are O(0.01) (a mean of 17,776 N(0,1) values), so the bound is RELATIVE to each row: bf16 rounding of P
+        # and of the output contribute ~2^-9 each; 1e-2 of the row norm leaves a 2.5x margin and no more
+        err = (got - ref).norm(dim=-1) / ref.norm(dim=-1)
+        assert err.max().item() <= 1e-2, err
     # softmax rows are convex combinations: V == const  =>  O == const exactly up to bf16 rounding of P
     vt.fill_(0)
     vt[:, :, :S] = 1.5

@@ -1,0 +1,109 @@
+"""BASELINE configs C3 / C4 / C5 at their OWN token counts and model widths (VERDICT r1 "weak" 5), through size-independent
+properties on 1-2 blocks of the real width -- the CPU oracle would need hours at these sizes:
+
+    C3  Wan2.1-I2V-14B bf16, 81 frames @ 832x480   -> 21 x 30 x 52  =  32,760 tokens x 5120
+    C4  HunyuanVideo-I2V bf16, 129 frames @ 1280x720 -> 33 x 45 x 80 = 118,800 latent tokens (+ 256 prompt tokens) x 3072
+    C5  Wan2.1-I2V-14B fp8, 81 frames @ 1280x720    -> 21 x 45 x 80  =  75,600 tokens x 5120
+
+finite, run-to-run bit-identical, a sample's prediction independent of its position in the CFG batch and of the batch size
+(3-pass vs 2-pass ALG step), padded prompt tokens never reaching the latents, fp8 within the stated bound of bf16."""
+import pytest
+import torch
+
+from alg_amd import (HunyuanVideoTransformer3DModel, HunyuanVideoTransformerConfig, WanTransformer3DModel, WanTransformerConfig,
+                     lp_utils)
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+
+def wan_inputs(F, H, W, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    lat = torch.randn(1, 16, F, H, W, generator=g, device=DEV)
+    cond = torch.randn(1, 20, F, H, W, generator=g, device=DEV) * 0.7
+    cond[:, :4] = 0.0
+    cond[:, :4, 0] = 1.0
+    txt = torch.randn(2, 512, 4096, generator=g, device=DEV).to(BF)         # [negative, positive]
+    img = torch.randn(1, 257, 1280, generator=g, device=DEV).to(BF)
+    return lat, cond, txt, img
+
+
+def wan_step_batches(lat, cond, lp, txt, img):
+    """The two batch shapes of a Wan ALG step (wan:882-894): 3-pass [cond | lp | lp] x [neg, neg, pos], 2-pass
+    [lp | lp] x [neg, pos] (the same two last samples)."""
+    cat = lambda c: torch.cat([lat, c], dim=1).to(BF)
+    x3 = torch.cat([cat(cond), cat(lp), cat(lp)])
+    x2 = torch.cat([cat(lp), cat(lp)])
+    return (x3, torch.stack([txt[0], txt[0], txt[1]]), img.repeat(3, 1, 1)), (x2, txt, img.repeat(2, 1, 1))
+
+
+@pytest.mark.parametrize("name,F,H,W,fp8", [("c3", 21, 60, 104, False), ("c5", 21, 90, 160, True)])
+def test_wan_14b_width_full_token_count(name, F, H, W, fp8):
+    cfg = WanTransformerConfig(num_layers=2)                       # 2 of the 40 blocks, everything else as shipped
+    assert cfg.dim == 5120 and cfg.ffn_dim == 13824
+    tokens = F * (H // 2) * (W // 2)
+    assert tokens == {"c3": 32760, "c5": 75600}[name]
+    model = WanTransformer3DModel.from_synthetic(cfg, seed=21, device=DEV, fp8=fp8)
+    lat, cond, txt, img = wan_inputs(F, H, W, seed=5)
+    lp = lp_utils.apply_low_pass_filter(cond, "down_up", 0.0, 0, 0.4)          # the condition filtered as in the ALG step
+    assert lp.shape == cond.shape and not torch.equal(lp, cond)
+    (x3, t3, i3), (x2, t2, i2) = wan_step_batches(lat, cond, lp, txt, img)
+    ts = torch.full((3,), 900.0, device=DEV)
+    run = lambda m, x, t, i: m(hidden_states=x, timestep=ts[:x.shape[0]], encoder_hidden_states=t,
+                               encoder_hidden_states_image=i, return_dict=False)[0]
+    out3 = run(model, x3, t3, i3)
+    assert out3.shape == (3, 16, F, H, W) and out3.dtype == BF and bool(torch.isfinite(out3.float()).all())
+    assert torch.equal(run(model, x3, t3, i3), out3)                              # deterministic
+    out2 = run(model, x2, t2, i2)
+    # batch-position / batch-size invariance: samples 1, 2 of the 3-pass batch are samples 0, 1 of the 2-pass batch
+    for a, b in ((out3[1], out2[0]), (out3[2], out2[1])):
+        assert rel(a, b) < 1e-2, rel(a, b)
+    assert not torch.equal(out3[0], out3[1])                                      # sharp vs low-passed condition differ
+    assert 0.05 < out3.float().std().item() < 50.0                                # a live signal, not saturated / collapsed
+    if fp8:
+        # C5's stated bound: e4m3 block linears within 8 % of the bf16 path on the same weights (tests/test_gpu_fp8.py)
+        ref = run(WanTransformer3DModel.from_synthetic(cfg, seed=21, device=DEV, fp8=False), x2, t2, i2)
+        r = rel(out2, ref)
+        assert 0 < r < 8e-2, r
+
+
+def test_hunyuan_13b_width_c4_token_count():
+    cfg = HunyuanVideoTransformerConfig(num_layers=1, num_single_layers=1)      # 1 dual + 1 single block of 20 + 40
+    assert cfg.dim == 3072
+    F, H, W, L = 33, 90, 160, 256
+    assert F * (H // 2) * (W // 2) == 118800
+    model = HunyuanVideoTransformer3DModel.from_synthetic(cfg, seed=23, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(1, 16, F, H, W, generator=g, device=DEV).to(BF)
+    txt = torch.randn(1, L, cfg.text_embed_dim, generator=g, device=DEV).to(BF)
+    mask = torch.zeros(1, L, device=DEV)
+    mask[:, :48] = 1
+    pooled = torch.randn(1, cfg.pooled_projection_dim, generator=g, device=DEV).to(BF)
+    t = torch.full((1,), 996.0, device=DEV)
+    guid = torch.full((1,), 6000.0, device=DEV) if cfg.guidance_embeds else None
+    run = lambda x_, txt_, mask_, pooled_, t_, g_: model(
+        hidden_states=x_, timestep=t_, encoder_hidden_states=txt_, encoder_attention_mask=mask_.to(BF),
+        pooled_projections=pooled_, guidance=g_, return_dict=False)[0]
+    out = run(x, txt, mask, pooled, t, guid)
+    assert out.shape == (1, 16, F, H, W) and out.dtype == BF and bool(torch.isfinite(out.float()).all())
+    assert torch.equal(run(x, txt, mask, pooled, t, guid), out)                   # deterministic
+    assert 0.05 < out.float().std().item() < 50.0
+    # padded prompt tokens are outside the contract: garbage there must not reach the latents (bit for bit)
+    txt2 = txt.clone()
+    txt2[:, 48:] = 37.0
+    assert torch.equal(run(x, txt2, mask, pooled, t, guid), out)
+    # batch invariance: the same sample as row 1 of a batch of two (row 0: another prompt length, another first frame)
+    x2 = torch.cat([x.flip(3), x])
+    mask2 = torch.cat([torch.ones(1, L, device=DEV), mask])
+    rep = lambda v: None if v is None else v.repeat(2)
+    out2 = run(x2, txt.repeat(2, 1, 1), mask2, pooled.repeat(2, 1), t.repeat(2), rep(guid))
+    assert rel(out2[1], out[0]) < 1e-2, rel(out2[1], out[0])
+    # the ALG single-pass branch (hy:1196-1235) only changes frame 0 of the input: the prediction must respond to it
+    x3 = x.clone()
+    x3[:, :, :1] = lp_utils.apply_low_pass_filter(x[:, :, :1].float().contiguous(), "down_up", 0.0, 0, 0.625).to(BF)
+    assert not torch.equal(run(x3, txt, mask, pooled, t, guid), out)

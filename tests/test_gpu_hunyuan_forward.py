@@ -11,6 +11,7 @@ from alg_amd.transformer_hunyuan_video import (HunyuanVideoTransformer3DModel, H
                                                parameter_shapes)
 from oracle import hy_oracle, loop_oracle
 from oracle.sched_oracle import FlowMatchEulerOracle
+from _parity import check_floor
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -86,15 +87,15 @@ def test_hunyuan_forward_small(mode):
                 encoder_attention_mask=mask.to(DEV).to(BF), pooled_projections=pooled.to(DEV),
                 guidance=None if guid is None else guid.to(DEV), return_dict=False)[0]
     assert out.shape == ref.shape and out.dtype == BF
-    r = rel(out.cpu(), ref)
-    assert r < 3e-2, r
+    eager = hy_oracle.hy_forward(ocfg, sd, x, t, txt, mask, pooled, guid, dtype=BF)
+    check_floor("hunyuan_forward_small_" + mode, out, ref, eager)
     # padded prompt tokens are outside the contract: garbage there must not reach the latents
     txt2 = txt.clone()
     txt2[0, 13:] = 50.0
     out2 = model(x.to(DEV), t.to(DEV), txt2.to(DEV), mask.to(DEV).to(BF), pooled.to(DEV),
                  None if guid is None else guid.to(DEV), return_dict=False)[0]
     assert torch.equal(out2[1], out[1])
-    assert rel(out2[0].cpu(), ref[0]) < 3e-2
+    check_floor("hunyuan_forward_padded_garbage_" + mode, out2[0], ref[0], eager[0])
 
 
 def test_hunyuan_forward_latent_tokens_not_a_multiple_of_16():
@@ -107,7 +108,7 @@ def test_hunyuan_forward_latent_tokens_not_a_multiple_of_16():
     t = torch.tensor([500.0, 500.0])
     ref = hy_oracle.hy_forward(ocfg, {k: v.float() for k, v in sd.items()}, x.float(), t, txt.float(), mask, pooled.float())
     out = model(x.to(DEV), t.to(DEV), txt.to(DEV), mask.to(DEV).to(BF), pooled.to(DEV), return_dict=False)[0]
-    assert rel(out.cpu(), ref) < 3e-2
+    check_floor("hunyuan_forward_180_tokens", out, ref, hy_oracle.hy_forward(ocfg, sd, x, t, txt, mask, pooled, dtype=BF))
 
 
 def test_hunyuan_alg_sampler_with_hip_dit():
@@ -143,5 +144,8 @@ def test_hunyuan_alg_sampler_with_hip_dit():
     passes = [n for _, n, _ in trace_p]
     assert passes == [n for _, n, _ in trace_o] and passes[0] == 3 and passes[-1] == 2
     assert torch.equal(out.frames[:, :, :1].cpu(), img)
-    r = rel(out.frames[:, :, 1:].cpu(), want[:, :, 1:])
-    assert r < 4e-2, r
+    eager = loop_oracle.hunyuan_denoise_loop(
+        lambda x, ts, e, m, p_, g_: hy_oracle.hy_forward(ocfg, sd, x.to(BF), ts.float(), e, m.float(), p_, None, dtype=BF),
+        FlowMatchEulerOracle(shift=7.0), lat, img, pos, neg, 4, true_cfg_scale=6.0, guidance_scale=1.0,
+        use_low_pass_guidance=True, guidance_embeds=False, **alg)
+    check_floor("hunyuan_sampler_4steps", out.frames[:, :, 1:], want[:, :, 1:], eager[:, :, 1:])

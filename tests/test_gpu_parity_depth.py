@@ -1,0 +1,165 @@
+"""Depth and step accumulation (VERDICT r1 "weak" 2): the HIP path against the CPU oracles at the DEPTH of the real models
+(42 CogVideoX blocks) and over WHOLE schedules (the 50-step C2 interval schedule under guidance 6, Wan's 40-step linear
+gaussian decay, HunyuanVideo's 50-step single-pass branch), at widths the CPU oracle finishes in seconds; plus BASELINE
+config 1 at its own shapes (CogVideoX-5B width, 994 tokens, 2 steps).  Every bound is the bf16-eager floor of the same
+oracle (tests/_parity.py), not a bare constant."""
+import pytest
+import torch
+
+from alg_amd import (CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, CogVideoXTransformer3DModel, FlowMatchEulerDiscreteScheduler,
+                     HunyuanVideoImageToVideoPipeline, HunyuanVideoTransformer3DModel, HunyuanVideoTransformerConfig,
+                     UniPCMultistepScheduler, WanImageToVideoPipeline, WanTransformer3DModel, WanTransformerConfig)
+from alg_amd.transformer_cogvideox import CogVideoXTransformerConfig
+from oracle import ddim_oracle, dit_oracle, hy_oracle, loop_oracle, wan_oracle
+from oracle.sched_oracle import FlowMatchEulerOracle, UniPCOracle
+from _parity import check_floor
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+DEV = "cuda:0"
+
+NARROW = dict(num_attention_heads=8, attention_head_dim=64, in_channels=16, out_channels=8, time_embed_dim=64,
+              text_embed_dim=128, max_text_seq_length=10, patch_size=2)
+
+
+def cog_pair(kw, seed, std=0.05):
+    ocfg = dit_oracle.DiTConfig(**kw)
+    w32 = dit_oracle.init_weights(ocfg, seed=seed, std=std, randomize_affine=True)
+    wbf = {k: v.to(BF) for k, v in w32.items()}
+    model = CogVideoXTransformer3DModel(CogVideoXTransformerConfig(**kw), wbf, device=DEV)
+    return ocfg, {k: v.float() for k, v in wbf.items()}, wbf, model
+
+
+def test_cogvideox_forward_42_layers():
+    """The real depth (42 blocks) at 8 heads x 64 and 874 tokens: error must not compound faster than the reference's own
+    bf16 execution does."""
+    kw = dict(NARROW, num_layers=42, sample_width=24, sample_height=16, sample_frames=33)
+    ocfg, w32, wbf, model = cog_pair(kw, seed=3)
+    g = torch.Generator().manual_seed(1)
+    N, Fr, C, H, W = 2, 9, 8, 16, 24
+    hs = torch.randn(N, Fr, 2 * C, H, W, generator=g).to(BF)
+    ehs = torch.randn(N, 10, 128, generator=g).to(BF)
+    ts = torch.tensor([999, 999])
+    rope = dit_oracle.rope_tables(ocfg, H * 8, W * 8, Fr)
+    ref = dit_oracle.dit_forward(ocfg, w32, hs.float(), ehs.float(), ts, rope)
+    eager = dit_oracle.dit_forward(ocfg, wbf, hs, ehs, ts, rope)
+    out = model(hs.to(DEV), ehs.to(DEV), ts, image_rotary_emb=rope, return_dict=False)[0]
+    check_floor("cog_forward_42layers_874tokens", out, ref, eager)
+
+
+def _cog_sampler_case(name, kw, Fr, C, H, W, T, td, steps, seed, std=0.05):
+    ocfg, w32, wbf, model = cog_pair(kw, seed=seed, std=std)
+    pipe = CogVideoXImageToVideoPipeline(transformer=model, scheduler=CogVideoXDDIMScheduler()).to(DEV)
+    g = torch.Generator().manual_seed(42)
+    latents = torch.randn(1, Fr, C, H, W, generator=g).to(BF)
+    first = (torch.randn(1, 1, C, H, W, generator=g) * 0.7).to(BF)
+    pe, ne = torch.randn(1, T, td, generator=g).to(BF), torch.randn(1, T, td, generator=g).to(BF)
+    alg = dict(num_inference_steps=steps, guidance_scale=6.0, use_low_pass_guidance=True, lp_filter_type="down_up",
+               lp_resize_factor=0.25, lp_strength_schedule_type="interval", schedule_interval_start_time=0.0,
+               schedule_interval_end_time=0.04)            # configs/cogvideox_alg.yaml (C2) / BASELINE config 1
+    trace = []
+    out = pipe(image=None, image_latents=first, latents=latents, prompt_embeds=pe, negative_prompt_embeds=ne,
+               height=H * 8, width=W * 8, num_frames=(Fr - 1) * 4 + 1, output_type="latent", lp_filter_in_latent=True,
+               step_trace=trace, **alg).frames
+    cond = torch.zeros(1, Fr, C, H, W)
+    cond[:, :1] = first.float()
+    rope = dit_oracle.rope_tables(ocfg, H * 8, W * 8, Fr)
+    otrace = []
+    ref = loop_oracle.alg_denoise_loop(lambda x, e, ts, r: dit_oracle.dit_forward(ocfg, w32, x, e, ts, r),
+                                       ddim_oracle.DDIMOracle(), latents.float(), cond, pe.float(), ne.float(),
+                                       image_rotary_emb=rope, trace=otrace, **alg)
+    eager = loop_oracle.alg_denoise_loop(lambda x, e, ts, r: dit_oracle.dit_forward(ocfg, wbf, x, e, ts, r),
+                                         ddim_oracle.DDIMOracle(), latents, cond.to(BF), pe, ne, image_rotary_emb=rope, **alg)
+    assert [(s, tp, n) for s, tp, n in trace] == [(s, tp, n) for s, tp, n in otrace]     # schedule + branch flags bit-exact
+    check_floor(name, out, ref, eager)
+    return trace
+
+
+def test_cogvideox_sampler_50_steps_c2_schedule():
+    """The whole C2 schedule: 50 DDIM steps, interval [0, 0.04] (steps 0-1 three-pass, 48 two-pass = 102 forwards),
+    guidance 6.0, bf16 latents re-rounded every step -- on a 2-block DiT."""
+    kw = dict(NARROW, num_layers=2, sample_width=12, sample_height=8, sample_frames=9)
+    trace = _cog_sampler_case("cog_sampler_50steps_c2_schedule", kw, 3, 8, 8, 12, 10, 128, 50, seed=5)
+    assert sum(n for _, _, n in trace) == 102 and [n for _, _, n in trace[:3]] == [3, 3, 2]
+
+
+def test_baseline_config_1_at_its_own_shapes():
+    """BASELINE config 1 / BASELINE.md CPU row 2 on the product path: CogVideoX-5B WIDTH (48 heads x 64 = 3072, T5 width
+    4096, 226 prompt tokens, time embedding 512), 9 frames @ 256x256 -> [1, 3, 16, 32, 32] latents -> 994 tokens, 2 steps
+    (one 3-pass, one 2-pass = 5 forwards), ALG down_up in latent; 2 of the 42 blocks (the CPU oracle's budget)."""
+    kw = dict(num_attention_heads=48, attention_head_dim=64, in_channels=32, out_channels=16, num_layers=2,
+              time_embed_dim=512, text_embed_dim=4096, max_text_seq_length=226, sample_width=32, sample_height=32,
+              sample_frames=9, patch_size=2)
+    trace = _cog_sampler_case("cog_sampler_c1_shapes_5b_width", kw, 3, 16, 32, 32, 226, 4096, 2, seed=6, std=0.02)
+    assert [n for _, _, n in trace] == [3, 2]
+
+
+def test_wan_sampler_40_steps_linear_gaussian():
+    """C3's ALG settings over the whole schedule: 40 UniPC steps, gaussian_blur (sigma 15, k 9) with linear decay to zero
+    at 0.5 -> 20 distinct filters, 20 three-pass + 20 two-pass steps -- on a 1-block Wan DiT."""
+    kw = dict(num_attention_heads=4, ffn_dim=1024, num_layers=1, text_dim=64, image_dim=64, added_kv_proj_dim=512)
+    cfg, ocfg = WanTransformerConfig(**kw), wan_oracle.WanConfig(**kw)
+    sd = wan_oracle.init_weights(ocfg, seed=7)
+    model = WanTransformer3DModel(cfg, sd, device=DEV)
+    g = torch.Generator().manual_seed(8)
+    lat, cond = torch.randn(1, 16, 3, 16, 24, generator=g), torch.randn(1, 20, 3, 16, 24, generator=g)
+    pe, ne = torch.randn(1, 512, 64, generator=g).to(BF), torch.randn(1, 512, 64, generator=g).to(BF)
+    ie = torch.randn(1, 257, 64, generator=g).to(BF)
+    alg = dict(lp_filter_type="gaussian_blur", lp_blur_sigma=15.0, lp_blur_kernel_size=9, lp_strength_schedule_type="linear",
+               schedule_linear_start_weight=1.0, schedule_linear_end_weight=0.0, schedule_linear_end_time=0.5)
+    trace_o, trace_p = [], []
+    want = loop_oracle.wan_denoise_loop(
+        lambda x, ts, e, ei: wan_oracle.wan_forward(ocfg, sd, x.float(), ts.float(), e.float(), ei.float()).to(BF),
+        UniPCOracle(flow_shift=5.0), lat, cond, pe, ne, ie, 40, guidance_scale=5.0, use_low_pass_guidance=True,
+        trace=trace_o, **alg)
+    eager = loop_oracle.wan_denoise_loop(
+        lambda x, ts, e, ei: wan_oracle.wan_forward(ocfg, sd, x.to(BF), ts.float(), e, ei, dtype=BF),
+        UniPCOracle(flow_shift=5.0), lat, cond, pe, ne, ie, 40, guidance_scale=5.0, use_low_pass_guidance=True, **alg)
+    pipe = WanImageToVideoPipeline(transformer=model, scheduler=UniPCMultistepScheduler(flow_shift=5.0)).to(DEV)
+    out = pipe(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), image_embeds=ie.to(DEV),
+               image_condition=cond.to(DEV), latents=lat.to(DEV), height=128, width=192, num_frames=9,
+               num_inference_steps=40, guidance_scale=5.0, output_type="latent", use_low_pass_guidance=True,
+               lp_filter_in_latent=True, step_trace=trace_p, **alg)
+    passes = [n for _, n, _ in trace_p]
+    assert passes == [n for _, n, _ in trace_o] == [3] * 20 + [2] * 20
+    assert [s for s, _, _ in trace_p] == [s for s, _, _ in trace_o]                    # 40 strengths, bit-exact
+    assert len(pipe._lp_cache) == 21                                                   # 20 distinct sigmas + the identity
+    check_floor("wan_sampler_40steps_linear_gaussian", out.frames, want, eager)
+
+
+def test_hunyuan_sampler_50_steps_single_pass():
+    """C4's branch over the whole schedule (configs/hunyuan_video_alg.yaml: true_cfg_scale 1.0 -> hy:1196-1235, ONE forward
+    per step on the low-passed first frame, embedded guidance 6.0, interval [0, 0.04], 50 flow-match Euler steps with
+    first-frame token replace) -- on a 1 + 1 block HunyuanVideo DiT."""
+    kw = dict(num_attention_heads=4, num_layers=1, num_single_layers=1, num_refiner_layers=1, text_embed_dim=64,
+              pooled_projection_dim=64, image_condition_type="token_replace", guidance_embeds=True)
+    cfg, ocfg = HunyuanVideoTransformerConfig(**kw), hy_oracle.HyConfig(**kw)
+    sd = hy_oracle.init_weights(ocfg, seed=9)
+    sd32 = {k: v.float() for k, v in sd.items()}
+    model = HunyuanVideoTransformer3DModel(cfg, sd, device=DEV)
+    g = torch.Generator().manual_seed(10)
+    lat, img = torch.randn(1, 16, 3, 16, 16, generator=g), torch.randn(1, 16, 1, 16, 16, generator=g)
+    pos = (torch.randn(1, 20, 64, generator=g).to(BF), torch.randn(1, 64, generator=g).to(BF),
+           torch.cat([torch.ones(1, 17), torch.zeros(1, 3)], dim=1).to(BF))
+    alg = dict(lp_filter_type="down_up", lp_resize_factor=0.625, lp_strength_schedule_type="interval",
+               schedule_interval_start_time=0.0, schedule_interval_end_time=0.04)
+    trace_o, trace_p = [], []
+    want = loop_oracle.hunyuan_denoise_loop(
+        lambda x, ts, e, m, p_, gd: hy_oracle.hy_forward(ocfg, sd32, x.float(), ts.float(), e.float(), m.float(), p_.float(),
+                                                         None if gd is None else gd.float()).to(BF),
+        FlowMatchEulerOracle(shift=7.0), lat, img, pos, None, 50, true_cfg_scale=1.0, guidance_scale=6.0,
+        use_low_pass_guidance=True, guidance_embeds=True, trace=trace_o, **alg)
+    eager = loop_oracle.hunyuan_denoise_loop(
+        lambda x, ts, e, m, p_, gd: hy_oracle.hy_forward(ocfg, sd, x.to(BF), ts.float(), e, m.float(), p_,
+                                                         None if gd is None else gd.float(), dtype=BF),
+        FlowMatchEulerOracle(shift=7.0), lat, img, pos, None, 50, true_cfg_scale=1.0, guidance_scale=6.0,
+        use_low_pass_guidance=True, guidance_embeds=True, **alg)
+    pipe = HunyuanVideoImageToVideoPipeline(transformer=model, scheduler=FlowMatchEulerDiscreteScheduler(shift=7.0)).to(DEV)
+    d = lambda t_: t_.to(DEV)
+    out = pipe(prompt_embeds=d(pos[0]), pooled_prompt_embeds=d(pos[1]), prompt_attention_mask=d(pos[2]),
+               negative_prompt=None, image_latents=d(img), latents=d(lat), height=128, width=128, num_frames=9,
+               num_inference_steps=50, true_cfg_scale=1.0, guidance_scale=6.0, output_type="latent",
+               use_low_pass_guidance=True, lp_filter_in_latent=True, step_trace=trace_p, **alg)
+    assert [n for _, n, _ in trace_p] == [n for _, n, _ in trace_o] == [1] * 50
+    assert torch.equal(out.frames[:, :, :1].cpu(), img)
+    check_floor("hunyuan_sampler_50steps_single_pass", out.frames[:, :, 1:], want[:, :, 1:], eager[:, :, 1:])

@@ -8,6 +8,7 @@ from alg_amd.schedulers import UniPCMultistepScheduler
 from alg_amd.transformer_wan import WanTransformer3DModel, WanTransformerConfig, parameter_shapes
 from oracle import loop_oracle, wan_oracle
 from oracle.sched_oracle import UniPCOracle
+from _parity import check_floor
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -44,11 +45,9 @@ def test_wan_forward_small(N, image):
     out = model(hidden_states=x.to(DEV), timestep=t.to(DEV), encoder_hidden_states=txt.to(DEV),
                 encoder_hidden_states_image=None if img is None else img.to(DEV), return_dict=False)[0]
     assert out.shape == ref.shape and out.dtype == BF
-    r = rel(out.cpu(), ref)
-    assert r < 3e-2, r       # bf16 activations through 2 blocks vs the fp32 mathematical reference
-    # the bf16-rounding restatement of the published module sits at the same distance from fp32 as we do
+    # anchored bound: the bf16-eager restatement of the published module (the reference's execution mode) vs fp32
     ref_bf = wan_oracle.wan_forward(ocfg, sd, x, t, txt, img, dtype=BF)
-    assert rel(out.cpu(), ref_bf) < 3e-2
+    check_floor("wan_forward_small_N%d_%s" % (N, "img" if image else "noimg"), out, ref, ref_bf)
     # deterministic and batch-consistent: sample 0 alone gives the same bits as sample 0 inside the batch
     out1 = model(hidden_states=x[:1].to(DEV), timestep=t[:1].to(DEV), encoder_hidden_states=txt[:1].to(DEV),
                  encoder_hidden_states_image=None if img is None else img[:1].to(DEV), return_dict=False)[0]
@@ -63,7 +62,7 @@ def test_wan_forward_ragged_tokens_and_scalar_timestep():
     t = torch.tensor(37.0)
     ref = wan_oracle.wan_forward(ocfg, sd, x.float(), t.expand(2), txt.float(), img.float())
     out = model(x.to(DEV), t, txt.to(DEV), img.to(DEV), return_dict=False)[0]
-    assert rel(out.cpu(), ref) < 3e-2
+    check_floor("wan_forward_ragged", out, ref, wan_oracle.wan_forward(ocfg, sd, x, t.expand(2), txt, img, dtype=BF))
 
 
 def test_wan_alg_sampler_with_hip_dit():
@@ -92,8 +91,10 @@ def test_wan_alg_sampler_with_hip_dit():
                lp_filter_in_latent=True, step_trace=trace_p, **alg)
     passes = [n for _, n, _ in trace_p]
     assert passes == [n for _, n, _ in trace_o] and passes[0] == 3 and passes[-1] == 2   # both loop branches run
-    r = rel(out.frames.cpu(), want)
-    assert r < 4e-2, r
+    eager = loop_oracle.wan_denoise_loop(
+        lambda x, ts, e, ei: wan_oracle.wan_forward(ocfg, sd, x.to(BF), ts.float(), e, ei, dtype=BF),
+        UniPCOracle(flow_shift=3.0), lat, cond, pe, ne, ie, 4, guidance_scale=5.0, use_low_pass_guidance=True, **alg)
+    check_floor("wan_sampler_4steps", out.frames, want, eager)
 
 
 def test_wan_forward_fp8_weights():
