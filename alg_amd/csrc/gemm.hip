@@ -60,8 +60,29 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
     return ALG_EINVAL;
   }
   if ((int64_t)a->M * a->ldc >= (1ll << 31) || (a->R && (int64_t)a->M * a->ldr >= (1ll << 31))) {
-    set_error("alg_gemm_bf16: M*ldc must stay below 2^31 (32-bit epilogue offsets)");
-    return ALG_ELIMIT;
+    // The epilogue addresses C / R with 32-bit element offsets inside one batch item.  Taller operands (two or three CFG
+    // samples of a 75,600- or 118,800-token sequence flattened into M) are cut along M into tile-aligned slabs, one launch
+    // each on the same stream: rows are independent, every per-row operand just moves with the slab.
+    const int64_t ld = (a->R && a->ldr > a->ldc) ? a->ldr : a->ldc;
+    const int64_t rows = ((1ll << 31) - 1) / ld / BM * BM;
+    if (a->conv_wp || rows <= 0) {
+      set_error("alg_gemm_bf16: M*ldc must stay below 2^31 (32-bit epilogue offsets)");
+      return ALG_ELIMIT;
+    }
+    const int64_t esz = fp8 ? 1 : 2;
+    for (int64_t m0 = 0; m0 < a->M; m0 += rows) {
+      alg_gemm_args c = *a;
+      c.M = (int32_t)((a->M - m0) < rows ? (a->M - m0) : rows);
+      c.A = (const char*)a->A + m0 * a->lda * esz;
+      c.C = (char*)a->C + m0 * a->ldc * 2;
+      if (a->R) c.R = (const char*)a->R + m0 * a->ldr * 2;
+      if (a->bias && (a->flags & ALG_GEMM_BIAS_PER_ROW)) c.bias = (const char*)a->bias + m0 * 2;
+      if (a->a_scale) c.a_scale = a->a_scale + m0;
+      c.seg_split = a->seg_split > m0 ? (int32_t)(a->seg_split - m0) : 0;   // rows >= seg_split take gate[1]
+      const int rc = gemm_entry(&c, stream, fp8);
+      if (rc != ALG_OK) return rc;
+    }
+    return ALG_OK;
   }
   // 8-byte epilogue accesses need 8-byte aligned quads whenever N is a multiple of 4
   if ((a->N & 3) == 0) {

@@ -219,7 +219,9 @@ def cpu_baseline(with_c1=True, c1_budget=45.0):
     del w, hs, ehs
     if with_c1:
         try:
-            out["c1_call"] = cpu_c1_call(threads, c1_budget)
+            # 994 tokens: 256 threads are 6x SLOWER than 8 here (measured on the GPU box: 43.9 s vs 6.8 s for the 2-layer
+            # probe) -- the small GEMMs drown in synchronisation; 32 threads is the advisor's / VERDICT's setting
+            out["c1_call"] = cpu_c1_call(min(threads, 32), c1_budget)
         except Exception as e:  # the C1 leg must never take the bench line down
             out["c1_call"] = {"error": repr(e)}
     out["filters"] = cpu_filter_baseline()
