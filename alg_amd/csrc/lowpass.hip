@@ -283,6 +283,16 @@ int down_up_big(const void* in, void* out, int64_t planes, int H, int W, int h1,
 int gaussian_big(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype,
                  hipStream_t s);
 
+// bandwidth-shaped kernels for 16-byte-granular planes (lowpass_v2.hip); return 1 = shape not covered
+int down_up_v2(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
+               hipStream_t s);
+int gaussian_v2(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype, hipStream_t s);
+
+static bool force_v1() {  // debug knob: the one-plane-per-workgroup kernels of this file (bit-identity tests)
+  const char* e = getenv("ALG_LOWPASS_V1");
+  return e && e[0] == '1';
+}
+
 static bool force_global() {  // debug knob: run LDS-sized planes through the global-memory passes (parity tests)
   const char* e = getenv("ALG_LOWPASS_FORCE_GLOBAL");
   return e && e[0] == '1';
@@ -329,6 +339,10 @@ extern "C" int alg_down_up(const void* in, void* out, int64_t planes, int H, int
   hipStream_t s = (hipStream_t)stream;
   if (lds > 160 * 1024 || force_global()) return down_up_big(in, out, planes, H, W, h1, w1, dtype, round_intermediate ? 1 : 0, s);
   int rc;
+  if (!force_v1()) {
+    rc = down_up_v2(in, out, planes, H, W, h1, w1, dtype, (dtype == ALG_BF16 && round_intermediate) ? 1 : 0, s);
+    if (rc <= 0) return rc;
+  }
   if (dtype == ALG_F32) {
     rc = set_lds_limit(down_up_kernel<float>, lds);
     if (rc == ALG_OK)
@@ -381,6 +395,10 @@ extern "C" int alg_gaussian_blur(const void* in, void* out, int64_t planes, int 
   hipStream_t s = (hipStream_t)stream;
   if (lds > 160 * 1024 || force_global()) return gaussian_big(in, out, planes, H, W, ksize, sigma, dtype, s);
   int rc;
+  if (!force_v1()) {
+    rc = gaussian_v2(in, out, planes, H, W, ksize, sigma, dtype, s);
+    if (rc <= 0) return rc;
+  }
   if (dtype == ALG_F32) {
     rc = set_lds_limit(gaussian_kernel<float>, lds);
     if (rc == ALG_OK)

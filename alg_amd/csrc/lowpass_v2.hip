@@ -1,0 +1,609 @@
+// ALG low-pass filters, bandwidth-shaped variant.  Same arithmetic, operation for operation, as the
+// one-plane-per-workgroup kernels of lowpass.hip (bit-identical results: tests/test_gpu_lowpass.py); what changes is how the
+// chip is fed when many planes are in flight (8 videos x 208 planes, Wan's 420-plane conditions):
+//
+//   * a PERSISTENT grid (CUs x workgroups that fit by LDS): a workgroup walks planes blockIdx, blockIdx + grid, ...;
+//   * the antialias tap tables are built ONCE per shape on the host (strict fp32, the very expressions of build_taps) and
+//     kept in a small device blob: a workgroup copies it to LDS once, not four tables per plane with ~13 divisions each;
+//   * the NEXT plane is already in flight (16-byte loads into registers) while the current one runs its passes, so the
+//     ~2 us HBM latency of a plane is hidden behind LDS work instead of heading every plane;
+//   * the last pass runs with a wave-uniform output row: its three tap weights and row offsets are scalar loads from the
+//     global blob (SGPRs) instead of five LDS reads per output;
+//   * results are staged in LDS as the output dtype and leave in 16-byte stores (the per-element 2-byte stores of the
+//     column pass were 8x the store instructions).
+//
+// Planes whose byte size is not a multiple of 16 (or misaligned bases) take the original kernels.
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include <math.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace alg {
+namespace v2 {
+
+constexpr int REG_TAPS = 12;
+
+__host__ __device__ inline int aa_taps(int in_size, int out_size) {
+  float scale = (float)in_size / (float)out_size;
+  float support = scale >= 1.0f ? scale : 1.0f;
+  return (int)ceilf(support) * 2 + 1;
+}
+
+// ---- tap tables: blob layout per table = xmin[n_out] | xsize[n_out] | w[n_out][taps] (ints / floats, 4 bytes each) --------
+struct Tab {
+  int off;   // word offset of the table inside the blob
+  int n_out, taps;
+  __host__ __device__ int words() const { return n_out * (2 + taps); }
+};
+
+struct Tabs {
+  Tab dw, dh, uw, uh;
+  int words;
+};
+
+static Tabs layout(int H, int W, int h1, int w1) {
+  Tabs t;
+  int o = 0;
+  auto mk = [&](int n_out, int in_size) {
+    Tab x;
+    x.off = o, x.n_out = n_out, x.taps = aa_taps(in_size, n_out);
+    o += x.words();
+    return x;
+  };
+  t.dw = mk(w1, W), t.dh = mk(h1, H), t.uw = mk(W, w1), t.uh = mk(H, h1);
+  t.words = (o + 3) & ~3;
+  return t;
+}
+
+// Host restatement of lowpass.hip build_taps: every operation is a single IEEE fp32 operation in the same order (this file
+// is compiled with -ffp-contract=off for host and device; x86-64 float arithmetic is SSE, no excess precision), so the
+// table is the one the device builds, bit for bit (checked against the in-kernel tables through the bit-identity test).
+static void host_build(uint32_t* blob, const Tab& t, int in_size) {
+  const int out_size = t.n_out;
+  int* xmin = (int*)blob + t.off;
+  int* xsize = xmin + out_size;
+  float* wt = (float*)(xsize + out_size);
+  volatile float scale = (float)in_size / (float)out_size;
+  const float support = scale >= 1.0f ? scale : 1.0f;
+  volatile float invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
+  for (int i = 0; i < out_size; ++i) {
+    volatile float center = scale * ((float)i + 0.5f);
+    volatile float a = center - support;
+    int lo = (int)(a + 0.5f);
+    lo = lo > 0 ? lo : 0;
+    volatile float b = center + support;
+    int hi = (int)(b + 0.5f);
+    hi = hi < in_size ? hi : in_size;
+    int n = hi - lo;
+    n = n < 0 ? 0 : (n > t.taps ? t.taps : n);
+    float* w = wt + (size_t)i * t.taps;
+    volatile float tot = 0.0f;
+    for (int j = 0; j < n; ++j) {
+      volatile float d = (float)(j + lo) - center;
+      volatile float e = d + 0.5f;
+      float x = fabsf(e * invscale);
+      float wj = x < 1.0f ? 1.0f - x : 0.0f;
+      w[j] = wj;
+      tot = tot + wj;
+    }
+    for (int j = 0; j < n; ++j) w[j] = tot != 0.0f ? w[j] / tot : w[j];
+    for (int j = n; j < t.taps; ++j) w[j] = 0.0f;
+    xmin[i] = lo;
+    xsize[i] = n;
+  }
+}
+
+static std::mutex g_mu;
+static std::map<std::tuple<int, int, int, int, int>, uint32_t*> g_blobs;   // (device, H, W, h1, w1) -> device blob
+
+// Device blob of the four tables for this shape (created on first use: one blocking 2-6 KB copy per shape and device, so
+// the blob is complete for every stream before the first launch that reads it).
+static const uint32_t* tables_for(int H, int W, int h1, int w1, const Tabs& t) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto key = std::make_tuple(dev, H, W, h1, w1);
+  auto it = g_blobs.find(key);
+  if (it != g_blobs.end()) return it->second;
+  std::vector<uint32_t> host((size_t)t.words, 0u);
+  host_build(host.data(), t.dw, W);
+  host_build(host.data(), t.dh, H);
+  host_build(host.data(), t.uw, w1);
+  host_build(host.data(), t.uh, h1);
+  uint32_t* d = nullptr;
+  if (hipMalloc((void**)&d, (size_t)t.words * 4) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, host.data(), (size_t)t.words * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(d);
+    return nullptr;
+  }
+  g_blobs[key] = d;
+  return d;
+}
+
+struct TapView {   // a table inside a word array (LDS copy or the global blob)
+  const int* xmin;
+  const int* xsize;
+  const float* w;
+  int taps;
+};
+
+__device__ __forceinline__ TapView view(const uint32_t* base, const Tab& t) {
+  TapView v;
+  v.xmin = (const int*)base + t.off;
+  v.xsize = v.xmin + t.n_out;
+  v.w = (const float*)(v.xsize + t.n_out);
+  v.taps = t.taps;
+  return v;
+}
+
+// dst[r][o] = sum_j w[o][j] * src[r][xmin[o] + j]: a thread owns one output column (weights in registers) and walks rows
+__device__ __forceinline__ void pass_rows(const float* src, int src_ld, float* dst, int dst_ld, int rows, int n_out,
+                                          const TapView t, int tid, int nthreads) {
+  const bool fits = n_out <= nthreads;
+  const int rstep = fits ? nthreads / n_out : 1;
+  const int r0 = fits ? tid / n_out : 0;
+  for (int o = fits ? tid - r0 * n_out : tid; o < n_out; o += nthreads) {
+    if (r0 >= rstep) break;
+    const int n = t.xsize[o];
+    const float* wp = t.w + (size_t)o * t.taps;
+    const float* s0 = src + t.xmin[o];
+    if (t.taps <= REG_TAPS) {
+      float w[REG_TAPS];
+#pragma unroll
+      for (int j = 0; j < REG_TAPS; ++j) w[j] = j < t.taps ? wp[j] : 0.0f;
+      for (int r = r0; r < rows; r += rstep) {
+        const float* s = s0 + (size_t)r * src_ld;
+        float acc = n > 0 ? s[0] * w[0] : 0.0f;
+#pragma unroll
+        for (int j = 1; j < REG_TAPS; ++j)
+          if (j < n) acc = fmaf(s[j], w[j], acc);
+        dst[(size_t)r * dst_ld + o] = acc;
+      }
+    } else {
+      for (int r = r0; r < rows; r += rstep) {
+        const float* s = s0 + (size_t)r * src_ld;
+        float acc = n > 0 ? s[0] * wp[0] : 0.0f;
+        for (int j = 1; j < n; ++j) acc = fmaf(s[j], wp[j], acc);
+        dst[(size_t)r * dst_ld + o] = acc;
+      }
+    }
+  }
+}
+
+// out(o, c) = sum_j w[o][j] * src[xmin[o] + j][c] for the small middle pass (tables in LDS)
+template <typename Store>
+__device__ __forceinline__ void pass_cols(const float* src, int src_ld, int cols, int n_out, const TapView t, int tid,
+                                          int nthreads, Store store) {
+  const bool fits = cols <= nthreads;
+  const int ostep = fits ? nthreads / cols : 1;
+  const int o0 = fits ? tid / cols : 0;
+  for (int c = fits ? tid - o0 * cols : tid; c < cols; c += nthreads) {
+    if (o0 >= ostep) break;
+    for (int o = o0; o < n_out; o += ostep) {
+      const int n = t.xsize[o];
+      const float* s = src + (size_t)t.xmin[o] * src_ld + c;
+      const float* w = t.w + (size_t)o * t.taps;
+      float acc = n > 0 ? s[0] * w[0] : 0.0f;
+      for (int j = 1; j < n; ++j) acc = fmaf(s[(size_t)j * src_ld], w[j], acc);
+      store(o, c, acc);
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void put(T* p, int i, float v);
+template <>
+__device__ __forceinline__ void put<float>(float* p, int i, float v) { p[i] = v; }
+template <>
+__device__ __forceinline__ void put<bf16_t>(bf16_t* p, int i, float v) { p[i] = f2bf(v); }
+
+// The wide last pass: the output row y is wave-uniform (a wave owns a 64-column strip of the plane and walks rows), so the
+// row's taps come from the GLOBAL blob through scalar loads; lanes read contiguous LDS columns.
+template <typename T>
+__device__ __forceinline__ void pass_cols_uniform(const float* src, int src_ld, int cols, int n_out, const uint32_t* gblob,
+                                                  const Tab tab, T* dst, int dst_ld, int tid, int nthreads) {
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = nthreads >> 6;
+  const int strips = (cols + 63) >> 6;                 // 64-column strips per row
+  const int groups = nwaves / strips > 0 ? nwaves / strips : 1;
+  const int* gxmin = (const int*)gblob + tab.off;
+  const int* gxsize = gxmin + tab.n_out;
+  const float* gw = (const float*)(gxsize + tab.n_out);
+  if (nwaves >= strips) {
+    const int strip = wave % strips, grp = wave / strips;
+    if (grp >= groups) return;
+    const int c = strip * 64 + lane;
+    const bool live = c < cols;
+    for (int o = grp; o < n_out; o += groups) {
+      const int n = gxsize[o], lo = gxmin[o];
+      const float* w = gw + (size_t)o * tab.taps;
+      const float* s = src + (size_t)lo * src_ld + (live ? c : 0);
+      float acc = n > 0 ? s[0] * w[0] : 0.0f;
+      for (int j = 1; j < n; ++j) acc = fmaf(s[(size_t)j * src_ld], w[j], acc);
+      if (live) put<T>(dst, o * dst_ld + c, acc);
+    }
+  } else {   // more strips than waves (very wide planes): a wave takes several strips
+    for (int strip = wave; strip < strips; strip += nwaves) {
+      const int c = strip * 64 + lane;
+      const bool live = c < cols;
+      for (int o = 0; o < n_out; ++o) {
+        const int n = gxsize[o], lo = gxmin[o];
+        const float* w = gw + (size_t)o * tab.taps;
+        const float* s = src + (size_t)lo * src_ld + (live ? c : 0);
+        float acc = n > 0 ? s[0] * w[0] : 0.0f;
+        for (int j = 1; j < n; ++j) acc = fmaf(s[(size_t)j * src_ld], w[j], acc);
+        if (live) put<T>(dst, o * dst_ld + c, acc);
+      }
+    }
+  }
+}
+
+// 16 bytes of T in a register -> fp32 in LDS
+template <typename T>
+__device__ __forceinline__ void unpack_to_lds(const uint4 v, float* lds) {
+  if constexpr (sizeof(T) == 4) {
+    *(float4*)lds = *(const float4*)&v;
+  } else {
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+    float4 a, b;
+    a.x = __uint_as_float(u[0] << 16), a.y = __uint_as_float(u[0] & 0xffff0000u);
+    a.z = __uint_as_float(u[1] << 16), a.w = __uint_as_float(u[1] & 0xffff0000u);
+    b.x = __uint_as_float(u[2] << 16), b.y = __uint_as_float(u[2] & 0xffff0000u);
+    b.z = __uint_as_float(u[3] << 16), b.w = __uint_as_float(u[3] & 0xffff0000u);
+    *(float4*)lds = a;
+    *(float4*)(lds + 4) = b;
+  }
+}
+
+struct DUArgs {
+  int H, W, h1, w1, round_mid, a_floats;   // a_floats: size of the X / T3 / staging region in floats
+  int64_t planes;
+  Tabs tabs;
+};
+
+template <typename T, int PRE>
+__global__ __launch_bounds__(1024) void down_up_v2_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                         const uint32_t* __restrict__ gblob, const DUArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int H = a.H, W = a.W, h1 = a.h1, w1 = a.w1;
+  constexpr int V = 16 / sizeof(T);
+  const int n = H * W, nv = n / V;
+  // LDS: A = X [H*W] fp32, later T3 [h1*W] fp32 | staged output [H*W] of T;  T1 [H*w1];  T2 [h1*w1];  table blob
+  float* X = (float*)smem;
+  float* T1 = X + a.a_floats;
+  float* T2 = T1 + (size_t)H * w1;
+  uint32_t* lt = (uint32_t*)(T2 + (((size_t)h1 * w1 + 3) & ~(size_t)3));
+  for (int i = tid; i < a.tabs.words; i += nt) lt[i] = gblob[i];
+  const TapView dw = view(lt, a.tabs.dw), dh = view(lt, a.tabs.dh), uw = view(lt, a.tabs.uw);
+  float* T3 = X;
+  T* O = (T*)(X + (((size_t)h1 * W + 3) & ~(size_t)3));
+
+  uint4 pre[PRE];
+  int64_t plane = blockIdx.x;
+  if (plane < a.planes) {
+    const uint4* g = (const uint4*)(in + plane * n);
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int idx = tid + k * nt;
+      if (idx < nv) pre[k] = g[idx];
+    }
+  }
+  for (; plane < a.planes; plane += gridDim.x) {
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int idx = tid + k * nt;
+      if (idx < nv) unpack_to_lds<T>(pre[k], X + (size_t)idx * V);
+    }
+    __syncthreads();
+    const int64_t next = plane + gridDim.x;
+    if (next < a.planes) {   // in flight during the four passes below
+      const uint4* g = (const uint4*)(in + next * n);
+#pragma unroll
+      for (int k = 0; k < PRE; ++k) {
+        const int idx = tid + k * nt;
+        if (idx < nv) pre[k] = g[idx];
+      }
+    }
+    // first interpolate call (lp:53): W pass then H pass
+    pass_rows(X, W, T1, w1, H, w1, dw, tid, nt);
+    __syncthreads();
+    pass_cols(T1, w1, w1, h1, dh, tid, nt, [&](int o, int c, float v) { T2[o * w1 + c] = a.round_mid ? rbf(v) : v; });
+    __syncthreads();
+    // second interpolate call (lp:54): W pass into the dead X region, H pass into the staging buffer behind it
+    pass_rows(T2, w1, T3, W, h1, W, uw, tid, nt);
+    __syncthreads();
+    pass_cols_uniform<T>(T3, W, W, H, gblob, a.tabs.uh, O, W, tid, nt);
+    __syncthreads();
+    uint4* go = (uint4*)(out + plane * n);
+    const uint4* lo = (const uint4*)O;
+    for (int i = tid; i < nv; i += nt) go[i] = lo[i];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// gaussian blur: reflect-indexed separable passes, taps in registers, same skeleton
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * (n - 1) - i : i;
+}
+
+struct GArgs {
+  int H, W, ksize;
+  float sigma;
+  int64_t planes;
+};
+
+template <typename T, int PRE, int KMAX>   // KMAX: taps held in registers (ksize <= KMAX), 0 = read them from LDS
+__global__ __launch_bounds__(1024) void gaussian_v2_kernel(const T* __restrict__ in, T* __restrict__ out, const GArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int H = a.H, W = a.W, ksize = a.ksize, pad = ksize / 2;
+  constexpr int V = 16 / sizeof(T);
+  const int n = H * W, nv = n / V;
+  float* X = (float*)smem;                   // [H*W] fp32, later the staged output
+  float* Tm = X + (((size_t)n + 3) & ~(size_t)3);
+  float* g = Tm + (((size_t)n + 3) & ~(size_t)3);
+  T* O = (T*)X;
+  // g = exp(-0.5 (x/sigma)^2), x = -(k-1)/2 + j, normalised by the sequential sum (lowpass.hip gaussian_kernel)
+  if (tid < ksize) {
+    float x = (float)tid - 0.5f * (float)(ksize - 1);
+    float q = __fdiv_rn(x, a.sigma);
+    g[tid] = expf(__fmul_rn(-0.5f, __fmul_rn(q, q)));
+  }
+  __syncthreads();
+  float tot = 0.0f;
+  for (int j = 0; j < ksize; ++j) tot = __fadd_rn(tot, g[j]);
+  __syncthreads();
+  if (tid < ksize) g[tid] = __fdiv_rn(g[tid], tot);
+  __syncthreads();
+  float gr[KMAX > 0 ? KMAX : 1];
+  if constexpr (KMAX > 0) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) gr[j] = j < ksize ? g[j] : 0.0f;
+  }
+
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nt >> 6;
+  const int strips = (W + 63) >> 6;
+  // waves >= strips: wave -> (strip, row group); fewer waves than strips: a wave walks strips, all rows
+  const bool wide = nwaves < strips;
+  const int strip0 = wide ? wave : wave % strips, sstep = wide ? nwaves : strips;
+  const int ystep = wide ? 1 : nwaves / strips;
+  const int y0 = wide ? 0 : (wave / strips < ystep ? wave / strips : H);   // leftover waves of a partial group idle
+
+  uint4 pre[PRE];
+  int64_t plane = blockIdx.x;
+  if (plane < a.planes) {
+    const uint4* gp = (const uint4*)(in + plane * n);
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int idx = tid + k * nt;
+      if (idx < nv) pre[k] = gp[idx];
+    }
+  }
+  for (; plane < a.planes; plane += gridDim.x) {
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int idx = tid + k * nt;
+      if (idx < nv) unpack_to_lds<T>(pre[k], X + (size_t)idx * V);
+    }
+    __syncthreads();
+    const int64_t next = plane + gridDim.x;
+    if (next < a.planes) {
+      const uint4* gp = (const uint4*)(in + next * n);
+#pragma unroll
+      for (int k = 0; k < PRE; ++k) {
+        const int idx = tid + k * nt;
+        if (idx < nv) pre[k] = gp[idx];
+      }
+    }
+    // both passes: a wave owns a 64-column strip and walks rows (wave-uniform y: the border test is a scalar branch)
+    for (int strip = strip0; strip < strips; strip += sstep)
+    for (int y = y0; y < H; y += ystep) {
+      const int x = strip * 64 + lane;
+      if (x < W) {
+        const float* row = X + (size_t)y * W;
+        float acc = 0.0f;
+        if (x >= pad && x + pad < W) {
+          if constexpr (KMAX > 0) {
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j)
+              if (j < ksize) acc = fmaf(gr[j], row[x - pad + j], acc);
+          } else {
+            for (int j = 0; j < ksize; ++j) acc = fmaf(g[j], row[x - pad + j], acc);
+          }
+        } else {
+          for (int j = 0; j < ksize; ++j) acc = fmaf(g[j], row[reflect(x - pad + j, W)], acc);
+        }
+        Tm[(size_t)y * W + x] = acc;
+      }
+    }
+    __syncthreads();
+    for (int strip = strip0; strip < strips; strip += sstep)
+    for (int y = y0; y < H; y += ystep) {
+      const int x = strip * 64 + lane;
+      if (x < W) {
+        float acc = 0.0f;
+        if (y >= pad && y + pad < H) {
+          const float* col = Tm + (size_t)(y - pad) * W + x;
+          if constexpr (KMAX > 0) {
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i)
+              if (i < ksize) acc = fmaf(gr[i], col[(size_t)i * W], acc);
+          } else {
+            for (int i = 0; i < ksize; ++i) acc = fmaf(g[i], col[(size_t)i * W], acc);
+          }
+        } else {
+          for (int i = 0; i < ksize; ++i) acc = fmaf(g[i], Tm[(size_t)reflect(y - pad + i, H) * W + x], acc);
+        }
+        put<T>(O, y * W + x, acc);     // X is dead after the W pass
+      }
+    }
+    __syncthreads();
+    uint4* go = (uint4*)(out + plane * n);
+    const uint4* lo = (const uint4*)O;
+    for (int i = tid; i < nv; i += nt) go[i] = lo[i];
+    __syncthreads();
+  }
+}
+
+static int num_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", bytes, hipGetErrorString(e));
+      return ALG_ELAUNCH;
+    }
+  }
+  return ALG_OK;
+}
+
+// threads and prefetch registers for a plane of `bytes`: PRE * threads * 16 >= bytes, PRE <= 8.  Few planes (at most two
+// per CU): a plane's latency is what counts -> as many threads per plane as v1 used; many planes: 256-thread workgroups,
+// several per CU, so that one workgroup's barriers and load latency hide behind the others' passes.
+static bool geometry(size_t bytes, int n, int64_t planes, int* threads, int* pre) {
+  int first = 256;
+  if (planes <= 512) first = n >= 4096 ? 1024 : (n >= 1024 ? 512 : 256);
+  for (int t : {256, 512, 1024}) {
+    if (t < first) continue;
+    const size_t p = (bytes + (size_t)t * 16 - 1) / ((size_t)t * 16);
+    if (p <= 8) {
+      *threads = t, *pre = (int)p;
+      return true;
+    }
+  }
+  return false;
+}
+
+static unsigned grid_for(int64_t planes, size_t lds, int threads) {
+  int per_cu = (int)((160 * 1024) / lds);
+  const int by_waves = 2048 / threads;
+  if (per_cu > by_waves) per_cu = by_waves;
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  const int64_t g = (int64_t)num_cus() * per_cu;
+  return (unsigned)(planes < g ? planes : g);
+}
+
+template <typename T, int PRE>
+static int launch_du(const T* in, T* out, const uint32_t* blob, const DUArgs& a, size_t lds, int threads, hipStream_t s) {
+  int rc = set_lds(down_up_v2_kernel<T, PRE>, lds);
+  if (rc != ALG_OK) return rc;
+  hipLaunchKernelGGL((down_up_v2_kernel<T, PRE>), dim3(grid_for(a.planes, lds, threads)), dim3(threads), lds, s, in, out,
+                     blob, a);
+  return check_launch("alg_down_up");
+}
+
+template <typename T>
+static int dispatch_du(const void* in, void* out, const uint32_t* blob, const DUArgs& a, size_t lds, int threads, int pre,
+                       hipStream_t s) {
+  const T* i = (const T*)in;
+  T* o = (T*)out;
+  switch (pre) {
+    case 1: return launch_du<T, 1>(i, o, blob, a, lds, threads, s);
+    case 2: return launch_du<T, 2>(i, o, blob, a, lds, threads, s);
+    case 3: return launch_du<T, 3>(i, o, blob, a, lds, threads, s);
+    case 4: return launch_du<T, 4>(i, o, blob, a, lds, threads, s);
+    case 5: return launch_du<T, 5>(i, o, blob, a, lds, threads, s);
+    case 6: return launch_du<T, 6>(i, o, blob, a, lds, threads, s);
+    case 7: return launch_du<T, 7>(i, o, blob, a, lds, threads, s);
+    default: return launch_du<T, 8>(i, o, blob, a, lds, threads, s);
+  }
+}
+
+template <typename T, int PRE>
+static int launch_g(const T* in, T* out, const GArgs& a, size_t lds, int threads, hipStream_t s) {
+  int rc;
+  const unsigned grid = grid_for(a.planes, lds, threads);
+  if (a.ksize <= 16) {
+    rc = set_lds(gaussian_v2_kernel<T, PRE, 16>, lds);
+    if (rc != ALG_OK) return rc;
+    hipLaunchKernelGGL((gaussian_v2_kernel<T, PRE, 16>), dim3(grid), dim3(threads), lds, s, in, out, a);
+  } else {
+    rc = set_lds(gaussian_v2_kernel<T, PRE, 0>, lds);
+    if (rc != ALG_OK) return rc;
+    hipLaunchKernelGGL((gaussian_v2_kernel<T, PRE, 0>), dim3(grid), dim3(threads), lds, s, in, out, a);
+  }
+  return check_launch("alg_gaussian_blur");
+}
+
+template <typename T>
+static int dispatch_g(const void* in, void* out, const GArgs& a, size_t lds, int threads, int pre, hipStream_t s) {
+  const T* i = (const T*)in;
+  T* o = (T*)out;
+  switch (pre) {
+    case 1: return launch_g<T, 1>(i, o, a, lds, threads, s);
+    case 2: return launch_g<T, 2>(i, o, a, lds, threads, s);
+    case 3: return launch_g<T, 3>(i, o, a, lds, threads, s);
+    case 4: return launch_g<T, 4>(i, o, a, lds, threads, s);
+    case 5: return launch_g<T, 5>(i, o, a, lds, threads, s);
+    case 6: return launch_g<T, 6>(i, o, a, lds, threads, s);
+    case 7: return launch_g<T, 7>(i, o, a, lds, threads, s);
+    default: return launch_g<T, 8>(i, o, a, lds, threads, s);
+  }
+}
+
+}  // namespace v2
+
+// Returns ALG_OK when the launch was made, 1 when this shape is not covered (the caller falls back to lowpass.hip's kernels).
+int down_up_v2(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
+               hipStream_t s) {
+  using namespace v2;
+  const size_t esz = dtype == ALG_F32 ? 4 : 2;
+  const size_t bytes = (size_t)H * W * esz;
+  if ((bytes & 15) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return 1;
+  int threads, pre;
+  if (!geometry(bytes, H * W, planes, &threads, &pre)) return 1;
+  DUArgs a;
+  a.H = H, a.W = W, a.h1 = h1, a.w1 = w1, a.round_mid = round_mid, a.planes = planes;
+  a.tabs = layout(H, W, h1, w1);
+  const size_t stage = ((size_t)h1 * W + 3) / 4 * 4 + (bytes + 3) / 4;          // T3 + staged output, in floats
+  const size_t a_fl = (std::max((size_t)H * W, stage) + 3) / 4 * 4;
+  a.a_floats = (int)a_fl;
+  const size_t lds = (a_fl + (size_t)H * w1 + (((size_t)h1 * w1 + 3) & ~(size_t)3) + a.tabs.words) * 4;
+  if (lds > 160 * 1024 || a.tabs.dw.taps > 64) return 1;
+  if (((size_t)H * w1) & 3) return 1;                                              // keeps T2 / the blob 16-byte aligned
+  const uint32_t* blob = tables_for(H, W, h1, w1, a.tabs);
+  if (!blob) return 1;
+  return dtype == ALG_F32 ? dispatch_du<float>(in, out, blob, a, lds, threads, pre, s)
+                          : dispatch_du<bf16_t>(in, out, blob, a, lds, threads, pre, s);
+}
+
+int gaussian_v2(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype, hipStream_t s) {
+  using namespace v2;
+  const size_t esz = dtype == ALG_F32 ? 4 : 2;
+  const size_t bytes = (size_t)H * W * esz;
+  if ((bytes & 15) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return 1;
+  int threads, pre;
+  if (!geometry(bytes, H * W, planes, &threads, &pre)) return 1;
+  GArgs a;
+  a.H = H, a.W = W, a.ksize = ksize, a.sigma = sigma, a.planes = planes;
+  const size_t n4 = ((size_t)H * W + 3) & ~(size_t)3;
+  const size_t lds = ((2 * n4 + ksize) * 4 + 15) & ~(size_t)15;
+  if (lds > 160 * 1024) return 1;
+  return dtype == ALG_F32 ? dispatch_g<float>(in, out, a, lds, threads, pre, s)
+                          : dispatch_g<bf16_t>(in, out, a, lds, threads, pre, s);
+}
+
+}  // namespace alg

@@ -186,3 +186,35 @@ def test_global_memory_path_is_bit_identical_to_the_lds_path(device, monkeypatch
         monkeypatch.setenv("ALG_LOWPASS_FORCE_GLOBAL", "1")
         assert torch.equal(lp_utils.apply_low_pass_filter(x, "down_up", 0.0, 0, 0.25), a)
         assert torch.equal(lp_utils.apply_low_pass_filter(x, "gaussian_blur", 3.0, 9, 1.0), b)
+
+
+@pytest.mark.parametrize("shape,dtype,kind,arg", [
+    ((1, 13, 16, 60, 90), torch.bfloat16, "down_up", 0.25),       # C2 condition (one video: one plane per workgroup)
+    ((8, 13, 16, 60, 90), torch.bfloat16, "down_up", 0.25),       # 8 videos: persistent grid, several planes per workgroup
+    ((8, 13, 16, 60, 90), torch.float32, "down_up", 0.25),
+    ((1, 20, 21, 60, 104), torch.float32, "down_up", 0.4),        # Wan 480p condition
+    ((3, 20, 21, 90, 160), torch.float32, "down_up", 0.4),        # C5 (57.6 KB planes: 512-thread workgroups, 8 prefetch regs)
+    ((2, 16, 1, 90, 160), torch.float32, "down_up", 0.625),       # C4 first frame
+    ((1, 16, 3, 32, 32), torch.float32, "down_up", 0.25),         # C1
+    ((2, 16, 1, 44, 76), torch.bfloat16, "down_up", 0.8125),      # a schedule-modulated factor on a bucketed size
+    ((1, 20, 21, 60, 104), torch.float32, "gaussian_blur", (9, 15.0)),
+    ((8, 20, 21, 60, 104), torch.float32, "gaussian_blur", (9, 7.5)),
+    ((8, 13, 16, 60, 90), torch.bfloat16, "gaussian_blur", (13, 3.0)),
+    ((2, 20, 21, 90, 160), torch.float32, "gaussian_blur", (19, 15.0)),   # k > 16: taps read from LDS
+])
+def test_bandwidth_shaped_kernels_are_bit_identical_to_the_plane_per_workgroup_kernels(device, monkeypatch, shape, dtype,
+                                                                                       kind, arg):
+    """lowpass_v2.hip (persistent grid, host-built tap tables, register prefetch of the next plane, staged 16-byte stores)
+    must reproduce lowpass.hip's kernels bit for bit: same fp32 tap tables, same fma order."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(*shape, generator=g).to(dtype).to(device)
+    call = (lambda: lp_utils.apply_low_pass_filter(x, "down_up", 0.0, 0, arg)) if kind == "down_up" else \
+        (lambda: lp_utils.apply_low_pass_filter(x, "gaussian_blur", arg[1], arg[0], 1.0))
+    new = call()
+    monkeypatch.setenv("ALG_LOWPASS_V1", "1")
+    old = call()
+    monkeypatch.delenv("ALG_LOWPASS_V1")
+    assert new.dtype == dtype and new.shape == x.shape
+    assert torch.equal(new, old)
+    assert torch.equal(call(), new)                      # deterministic, table cache warm
+    assert not torch.equal(new, x)
