@@ -29,6 +29,11 @@
 
 #include "common.h"
 
+// fp8 GEMM on the block-scaled MFMA (1) or on the two-instruction v_mfma_f32_32x32x16_fp8_fp8 form (0, round 1)
+#ifndef ALG_FP8_MX
+#define ALG_FP8_MX 1
+#endif
+
 namespace alg {
 
 // cache-policy bits of the LDS-DMA loads (aux operand: 1 = sc0, 2 = sc1, 4 = nt), per operand, for A/B builds.  Measured on
@@ -308,11 +313,34 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
     };
     auto quad = [&](int mh, int nt, const bf16x8 (&bf)[4]) {
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (FP8 && ALG_FP8_MX) {
+        // CDNA4's fp8 rate lives on the block-scaled instruction only (v_mfma_f32_32x32x16_fp8_fp8 runs at the bf16
+        // rate): v_mfma_scale_f32_32x32x64_f8f6f4 with both formats e4m3 and every E8M0 block scale = 2^0 (0x7f) is a
+        // plain K = 64 fp8 contraction at twice the rate.  A lane's operand is 32 bytes = two of the 16-byte fragments it
+        // already holds; A and B lanes pair the same fragments, so the k order is again a valid contraction order.  The
+        // per-row fp32 scales stay in the epilogue (exactly the arithmetic of the two-instruction form: products of e4m3
+        // values are exact in fp32 and the accumulation is fp32 either way; only the summation order inside K differs).
+        typedef int i8v __attribute__((ext_vector_type(8)));
+        typedef int i4v __attribute__((ext_vector_type(4)));
+        auto cat = [](const bf16x8 lo, const bf16x8 hi) -> i8v {
+          const i4v l = __builtin_bit_cast(i4v, lo), h = __builtin_bit_cast(i4v, hi);
+          return i8v{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+        };
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+        for (int kp = 0; kp < 2; ++kp) {
+          const i8v bq = cat(bf[2 * kp], bf[2 * kp + 1]);
 #pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2)
-          acc[mh * 2 + m2][nt] = fma_frag(bf[ks], af[m2][ks], acc[mh * 2 + m2][nt]);
+          for (int m2 = 0; m2 < 2; ++m2)
+            acc[mh * 2 + m2][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                bq, cat(af[m2][2 * kp], af[m2][2 * kp + 1]), acc[mh * 2 + m2][nt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2)
+            acc[mh * 2 + m2][nt] = fma_frag(bf[ks], af[m2][ks], acc[mh * 2 + m2][nt]);
+      }
       __builtin_amdgcn_s_setprio(0);
     };
     auto enter_mfma = [&]() {

@@ -142,7 +142,45 @@ __device__ __forceinline__ TapView view(const uint32_t* base, const Tab& t) {
   return v;
 }
 
-// dst[r][o] = sum_j w[o][j] * src[r][xmin[o] + j]: a thread owns one output column (weights in registers) and walks rows
+// dst[r][o] = sum_j w[o][j] * src[r][xmin[o] + j]: a thread owns one output column (weights in registers) and walks rows.
+// The taps of a row are fetched as ONE batch of unconditional LDS reads (reads past the row's last tap stay inside the LDS
+// allocation and are discarded by a select: the fma chain is exactly acc = s0 w0, then fma over taps 1 .. n-1), two rows at
+// a time, so a thread has ~2 * taps reads in flight instead of a read -> fma -> read chain.
+template <int NTAP>
+__device__ __forceinline__ float row_dot(const float (&v)[NTAP], const float (&w)[NTAP], int n) {
+  float acc = n > 0 ? v[0] * w[0] : 0.0f;
+#pragma unroll
+  for (int j = 1; j < NTAP; ++j) acc = j < n ? fmaf(v[j], w[j], acc) : acc;
+  return acc;
+}
+
+template <int NTAP>   // taps <= NTAP: weights and one batch of taps per row in registers
+__device__ __forceinline__ void pass_rows_reg(const float* s0, int src_ld, float* dst, int dst_ld, int rows, int o, int n,
+                                              const float* wp, int taps, int r0, int rstep) {
+  float w[NTAP];
+#pragma unroll
+  for (int j = 0; j < NTAP; ++j) w[j] = j < taps ? wp[j] : 0.0f;
+  int r = r0;
+  if constexpr (NTAP <= 4) {   // short rows: two in flight (the 12-tap form already has 12 reads outstanding per row)
+    for (; r + rstep < rows; r += 2 * rstep) {
+      const float* sa = s0 + (size_t)r * src_ld;
+      const float* sb = sa + (size_t)rstep * src_ld;
+      float va[NTAP], vb[NTAP];
+#pragma unroll
+      for (int j = 0; j < NTAP; ++j) va[j] = sa[j], vb[j] = sb[j];
+      dst[(size_t)r * dst_ld + o] = row_dot<NTAP>(va, w, n);
+      dst[(size_t)(r + rstep) * dst_ld + o] = row_dot<NTAP>(vb, w, n);
+    }
+  }
+  for (; r < rows; r += rstep) {
+    const float* sa = s0 + (size_t)r * src_ld;
+    float va[NTAP];
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) va[j] = sa[j];
+    dst[(size_t)r * dst_ld + o] = row_dot<NTAP>(va, w, n);
+  }
+}
+
 __device__ __forceinline__ void pass_rows(const float* src, int src_ld, float* dst, int dst_ld, int rows, int n_out,
                                           const TapView t, int tid, int nthreads) {
   const bool fits = n_out <= nthreads;
@@ -153,18 +191,10 @@ __device__ __forceinline__ void pass_rows(const float* src, int src_ld, float* d
     const int n = t.xsize[o];
     const float* wp = t.w + (size_t)o * t.taps;
     const float* s0 = src + t.xmin[o];
-    if (t.taps <= REG_TAPS) {
-      float w[REG_TAPS];
-#pragma unroll
-      for (int j = 0; j < REG_TAPS; ++j) w[j] = j < t.taps ? wp[j] : 0.0f;
-      for (int r = r0; r < rows; r += rstep) {
-        const float* s = s0 + (size_t)r * src_ld;
-        float acc = n > 0 ? s[0] * w[0] : 0.0f;
-#pragma unroll
-        for (int j = 1; j < REG_TAPS; ++j)
-          if (j < n) acc = fmaf(s[j], w[j], acc);
-        dst[(size_t)r * dst_ld + o] = acc;
-      }
+    if (t.taps <= 4) {
+      pass_rows_reg<4>(s0, src_ld, dst, dst_ld, rows, o, n, wp, t.taps, r0, rstep);
+    } else if (t.taps <= REG_TAPS) {
+      pass_rows_reg<REG_TAPS>(s0, src_ld, dst, dst_ld, rows, o, n, wp, t.taps, r0, rstep);
     } else {
       for (int r = r0; r < rows; r += rstep) {
         const float* s = s0 + (size_t)r * src_ld;
@@ -203,46 +233,79 @@ __device__ __forceinline__ void put<float>(float* p, int i, float v) { p[i] = v;
 template <>
 __device__ __forceinline__ void put<bf16_t>(bf16_t* p, int i, float v) { p[i] = f2bf(v); }
 
-// The wide last pass: the output row y is wave-uniform (a wave owns a 64-column strip of the plane and walks rows), so the
-// row's taps come from the GLOBAL blob through scalar loads; lanes read contiguous LDS columns.
-template <typename T>
-__device__ __forceinline__ void pass_cols_uniform(const float* src, int src_ld, int cols, int n_out, const uint32_t* gblob,
-                                                  const Tab tab, T* dst, int dst_ld, int tid, int nthreads) {
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwaves = nthreads >> 6;
-  const int strips = (cols + 63) >> 6;                 // 64-column strips per row
-  const int groups = nwaves / strips > 0 ? nwaves / strips : 1;
+// The wide last pass: the output row y is wave-uniform (a wave owns a 64-column strip of the plane and walks rows).  The
+// rows' tap parameters (first input row, tap count, <= 3 weights: an upsampling pass has 3 taps) are loaded ONCE per
+// workgroup, row r in lane r & 63 of a register set, and reach the scalar unit through v_readlane -- no memory latency per
+// row; four rows are in flight per wave (12 LDS reads, then the fma chains).
+struct RowParams {   // rows [64 k, 64 k + 64) of the table live in lane (row & 63) of set k (k < 2: up to 128 output rows)
+  int lo[2], n[2];
+  float w[2][3];
+};
+
+__device__ __forceinline__ RowParams load_row_params(const uint32_t* gblob, const Tab tab, int lane) {
+  RowParams rp;
   const int* gxmin = (const int*)gblob + tab.off;
   const int* gxsize = gxmin + tab.n_out;
   const float* gw = (const float*)(gxsize + tab.n_out);
-  if (nwaves >= strips) {
-    const int strip = wave % strips, grp = wave / strips;
-    if (grp >= groups) return;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int row = min(lane + 64 * k, tab.n_out - 1);
+    rp.lo[k] = gxmin[row], rp.n[k] = gxsize[row];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) rp.w[k][j] = j < tab.taps ? gw[(size_t)row * tab.taps + j] : 0.0f;
+  }
+  return rp;
+}
+
+template <typename T>
+__device__ __forceinline__ void pass_cols_fast(const float* src, int src_ld, int cols, int n_out, const RowParams& rp,
+                                               T* dst, int dst_ld, int tid, int nthreads) {
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = nthreads >> 6;
+  const int strips = (cols + 63) >> 6;
+  const bool wide = nwaves < strips;                    // more strips than waves: a wave walks strips, all rows
+  const int groups = wide ? 1 : nwaves / strips;
+  const int grp = wide ? 0 : wave / strips;
+  if (grp >= groups) return;
+  auto rl = [](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
+  auto rlf = [](float v, int l) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); };
+  for (int strip = wide ? wave : wave % strips; strip < strips; strip += wide ? nwaves : strips) {
     const int c = strip * 64 + lane;
     const bool live = c < cols;
-    for (int o = grp; o < n_out; o += groups) {
-      const int n = gxsize[o], lo = gxmin[o];
-      const float* w = gw + (size_t)o * tab.taps;
-      const float* s = src + (size_t)lo * src_ld + (live ? c : 0);
-      float acc = n > 0 ? s[0] * w[0] : 0.0f;
-      for (int j = 1; j < n; ++j) acc = fmaf(s[(size_t)j * src_ld], w[j], acc);
-      if (live) put<T>(dst, o * dst_ld + c, acc);
-    }
-  } else {   // more strips than waves (very wide planes): a wave takes several strips
-    for (int strip = wave; strip < strips; strip += nwaves) {
-      const int c = strip * 64 + lane;
-      const bool live = c < cols;
-      for (int o = 0; o < n_out; ++o) {
-        const int n = gxsize[o], lo = gxmin[o];
-        const float* w = gw + (size_t)o * tab.taps;
-        const float* s = src + (size_t)lo * src_ld + (live ? c : 0);
-        float acc = n > 0 ? s[0] * w[0] : 0.0f;
-        for (int j = 1; j < n; ++j) acc = fmaf(s[(size_t)j * src_ld], w[j], acc);
-        if (live) put<T>(dst, o * dst_ld + c, acc);
+    const float* sc = src + (live ? c : 0);
+    for (int o0 = grp; o0 < n_out; o0 += 4 * groups) {
+      float v[4][3], w[4][3];
+      int nn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int o = min(o0 + u * groups, n_out - 1), l = o & 63;
+        const bool hi = o >= 64;
+        const int lo = hi ? rl(rp.lo[1], l) : rl(rp.lo[0], l);
+        nn[u] = hi ? rl(rp.n[1], l) : rl(rp.n[0], l);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          w[u][j] = hi ? rlf(rp.w[1][j], l) : rlf(rp.w[0][j], l);
+          v[u][j] = sc[(size_t)(lo + j) * src_ld];      // rows past the last tap are inside the LDS allocation
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int o = o0 + u * groups;
+        float acc = nn[u] > 0 ? v[u][0] * w[u][0] : 0.0f;
+        acc = nn[u] > 1 ? fmaf(v[u][1], w[u][1], acc) : acc;
+        acc = nn[u] > 2 ? fmaf(v[u][2], w[u][2], acc) : acc;
+        if (live && o < n_out) put<T>(dst, o * dst_ld + c, acc);
       }
     }
   }
+}
+
+// generic form (more than 3 taps or more than 128 output rows): taps read from the LDS copy of the table
+template <typename T>
+__device__ __forceinline__ void pass_cols_uniform(const float* src, int src_ld, int cols, int n_out, const TapView t,
+                                                  T* dst, int dst_ld, int tid, int nthreads) {
+  pass_cols(src, src_ld, cols, n_out, t, tid, nthreads, [&](int o, int c, float v) { put<T>(dst, o * dst_ld + c, v); });
 }
 
 // 16 bytes of T in a register -> fp32 in LDS
@@ -268,11 +331,12 @@ struct DUArgs {
   Tabs tabs;
 };
 
-template <typename T, int PRE>
-__global__ __launch_bounds__(1024) void down_up_v2_kernel(const T* __restrict__ in, T* __restrict__ out,
-                                                         const uint32_t* __restrict__ gblob, const DUArgs a) {
+template <typename T, int PRE, int NT, int WPS>   // NT threads, WPS = waves per SIMD the register budget must allow
+__global__ __launch_bounds__(NT, WPS) void down_up_v2_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                             const uint32_t* __restrict__ gblob, const DUArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x;
+  constexpr int nt = NT;
   const int H = a.H, W = a.W, h1 = a.h1, w1 = a.w1;
   constexpr int V = 16 / sizeof(T);
   const int n = H * W, nv = n / V;
@@ -282,7 +346,9 @@ __global__ __launch_bounds__(1024) void down_up_v2_kernel(const T* __restrict__ 
   float* T2 = T1 + (size_t)H * w1;
   uint32_t* lt = (uint32_t*)(T2 + (((size_t)h1 * w1 + 3) & ~(size_t)3));
   for (int i = tid; i < a.tabs.words; i += nt) lt[i] = gblob[i];
-  const TapView dw = view(lt, a.tabs.dw), dh = view(lt, a.tabs.dh), uw = view(lt, a.tabs.uw);
+  const TapView dw = view(lt, a.tabs.dw), dh = view(lt, a.tabs.dh), uw = view(lt, a.tabs.uw), uh = view(lt, a.tabs.uh);
+  const bool fast4 = a.tabs.uh.taps <= 3 && H <= 128;
+  const RowParams rp = load_row_params(gblob, a.tabs.uh, tid & 63);
   float* T3 = X;
   T* O = (T*)(X + (((size_t)h1 * W + 3) & ~(size_t)3));
 
@@ -320,7 +386,10 @@ __global__ __launch_bounds__(1024) void down_up_v2_kernel(const T* __restrict__ 
     // second interpolate call (lp:54): W pass into the dead X region, H pass into the staging buffer behind it
     pass_rows(T2, w1, T3, W, h1, W, uw, tid, nt);
     __syncthreads();
-    pass_cols_uniform<T>(T3, W, W, H, gblob, a.tabs.uh, O, W, tid, nt);
+    if (fast4)
+      pass_cols_fast<T>(T3, W, W, H, rp, O, W, tid, nt);
+    else
+      pass_cols_uniform<T>(T3, W, W, H, uh, O, W, tid, nt);
     __syncthreads();
     uint4* go = (uint4*)(out + plane * n);
     const uint4* lo = (const uint4*)O;
@@ -343,10 +412,11 @@ struct GArgs {
   int64_t planes;
 };
 
-template <typename T, int PRE, int KMAX>   // KMAX: taps held in registers (ksize <= KMAX), 0 = read them from LDS
-__global__ __launch_bounds__(1024) void gaussian_v2_kernel(const T* __restrict__ in, T* __restrict__ out, const GArgs a) {
+template <typename T, int PRE, int NT, int WPS>
+__global__ __launch_bounds__(NT, WPS) void gaussian_v2_kernel(const T* __restrict__ in, T* __restrict__ out, const GArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x;
+  constexpr int nt = NT;
   const int H = a.H, W = a.W, ksize = a.ksize, pad = ksize / 2;
   constexpr int V = 16 / sizeof(T);
   const int n = H * W, nv = n / V;
@@ -355,24 +425,27 @@ __global__ __launch_bounds__(1024) void gaussian_v2_kernel(const T* __restrict__
   float* g = Tm + (((size_t)n + 3) & ~(size_t)3);
   T* O = (T*)X;
   // g = exp(-0.5 (x/sigma)^2), x = -(k-1)/2 + j, normalised by the sequential sum (lowpass.hip gaussian_kernel)
-  if (tid < ksize) {
-    float x = (float)tid - 0.5f * (float)(ksize - 1);
+  for (int j = tid; j < ksize; j += nt) {
+    float x = (float)j - 0.5f * (float)(ksize - 1);
     float q = __fdiv_rn(x, a.sigma);
-    g[tid] = expf(__fmul_rn(-0.5f, __fmul_rn(q, q)));
+    g[j] = expf(__fmul_rn(-0.5f, __fmul_rn(q, q)));
   }
   __syncthreads();
   float tot = 0.0f;
   for (int j = 0; j < ksize; ++j) tot = __fadd_rn(tot, g[j]);
   __syncthreads();
-  if (tid < ksize) g[tid] = __fdiv_rn(g[tid], tot);
+  for (int j = tid; j < ksize; j += nt) g[j] = __fdiv_rn(g[j], tot);
   __syncthreads();
-  float gr[KMAX > 0 ? KMAX : 1];
-  if constexpr (KMAX > 0) {
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) gr[j] = j < ksize ? g[j] : 0.0f;
-  }
-
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nt >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int nwaves = nt >> 6;
+  // tap j sits in lane j of `gl` (and taps 64.. in `gh`): a tap reaches the scalar unit by v_readlane, no memory access
+  const float gl = lane < ksize ? g[lane] : 0.0f, gh = lane + 64 < ksize ? g[lane + 64] : 0.0f;
+  const bool big_k = ksize > 128;
+  auto tap = [&](int j) -> float {
+    if (big_k) return g[j];
+    const float v = j < 64 ? gl : gh;
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), j & 63));
+  };
   const int strips = (W + 63) >> 6;
   // waves >= strips: wave -> (strip, row group); fewer waves than strips: a wave walks strips, all rows
   const bool wide = nwaves < strips;
@@ -406,46 +479,54 @@ __global__ __launch_bounds__(1024) void gaussian_v2_kernel(const T* __restrict__
         if (idx < nv) pre[k] = gp[idx];
       }
     }
-    // both passes: a wave owns a 64-column strip and walks rows (wave-uniform y: the border test is a scalar branch)
-    for (int strip = strip0; strip < strips; strip += sstep)
-    for (int y = y0; y < H; y += ystep) {
+    // Both passes: a wave owns a 64-column strip and walks rows FOUR at a time; per tap one (reflected) column / row index
+    // serves the four rows, so four independent fma chains are in flight (acc = 0, then fma over ascending taps: the
+    // reference order).
+    for (int strip = strip0; strip < strips; strip += sstep) {
       const int x = strip * 64 + lane;
-      if (x < W) {
-        const float* row = X + (size_t)y * W;
-        float acc = 0.0f;
-        if (x >= pad && x + pad < W) {
-          if constexpr (KMAX > 0) {
-#pragma unroll
-            for (int j = 0; j < KMAX; ++j)
-              if (j < ksize) acc = fmaf(gr[j], row[x - pad + j], acc);
-          } else {
-            for (int j = 0; j < ksize; ++j) acc = fmaf(g[j], row[x - pad + j], acc);
-          }
-        } else {
-          for (int j = 0; j < ksize; ++j) acc = fmaf(g[j], row[reflect(x - pad + j, W)], acc);
+      const bool live = x < W;
+      const bool inner = x >= pad && x + pad < W;
+      for (int yb = y0; yb < H; yb += 4 * ystep) {
+        const float* r0 = X + (size_t)min(yb, H - 1) * W;
+        const float* r1 = X + (size_t)min(yb + ystep, H - 1) * W;
+        const float* r2 = X + (size_t)min(yb + 2 * ystep, H - 1) * W;
+        const float* r3 = X + (size_t)min(yb + 3 * ystep, H - 1) * W;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (int j = 0; j < ksize; ++j) {
+          const int xi = live ? (inner ? x - pad + j : reflect(x - pad + j, W)) : 0;
+          const float gj = tap(j);
+          a0 = fmaf(gj, r0[xi], a0), a1 = fmaf(gj, r1[xi], a1), a2 = fmaf(gj, r2[xi], a2), a3 = fmaf(gj, r3[xi], a3);
         }
-        Tm[(size_t)y * W + x] = acc;
+        if (live) {
+          Tm[(size_t)yb * W + x] = a0;
+          if (yb + ystep < H) Tm[(size_t)(yb + ystep) * W + x] = a1;
+          if (yb + 2 * ystep < H) Tm[(size_t)(yb + 2 * ystep) * W + x] = a2;
+          if (yb + 3 * ystep < H) Tm[(size_t)(yb + 3 * ystep) * W + x] = a3;
+        }
       }
     }
     __syncthreads();
-    for (int strip = strip0; strip < strips; strip += sstep)
-    for (int y = y0; y < H; y += ystep) {
+    for (int strip = strip0; strip < strips; strip += sstep) {
       const int x = strip * 64 + lane;
-      if (x < W) {
-        float acc = 0.0f;
-        if (y >= pad && y + pad < H) {
-          const float* col = Tm + (size_t)(y - pad) * W + x;
-          if constexpr (KMAX > 0) {
-#pragma unroll
-            for (int i = 0; i < KMAX; ++i)
-              if (i < ksize) acc = fmaf(gr[i], col[(size_t)i * W], acc);
-          } else {
-            for (int i = 0; i < ksize; ++i) acc = fmaf(g[i], col[(size_t)i * W], acc);
-          }
-        } else {
-          for (int i = 0; i < ksize; ++i) acc = fmaf(g[i], Tm[(size_t)reflect(y - pad + i, H) * W + x], acc);
+      const bool live = x < W;
+      const float* col = Tm + (live ? x : 0);
+      for (int yb = y0; yb < H; yb += 4 * ystep) {
+        const int ya = min(yb, H - 1), yc = min(yb + ystep, H - 1), yd = min(yb + 2 * ystep, H - 1),
+                  ye = min(yb + 3 * ystep, H - 1);
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (int i = 0; i < ksize; ++i) {
+          const float gi = tap(i);
+          a0 = fmaf(gi, col[(size_t)reflect(ya - pad + i, H) * W], a0);
+          a1 = fmaf(gi, col[(size_t)reflect(yc - pad + i, H) * W], a1);
+          a2 = fmaf(gi, col[(size_t)reflect(yd - pad + i, H) * W], a2);
+          a3 = fmaf(gi, col[(size_t)reflect(ye - pad + i, H) * W], a3);
         }
-        put<T>(O, y * W + x, acc);     // X is dead after the W pass
+        if (live) {   // X is dead after the W pass: the staged output goes there
+          put<T>(O, yb * W + x, a0);
+          if (yb + ystep < H) put<T>(O, (yb + ystep) * W + x, a1);
+          if (yb + 2 * ystep < H) put<T>(O, (yb + 2 * ystep) * W + x, a2);
+          if (yb + 3 * ystep < H) put<T>(O, (yb + 3 * ystep) * W + x, a3);
+        }
       }
     }
     __syncthreads();
@@ -467,6 +548,41 @@ static int num_cus() {
   return cus;
 }
 
+// Geometry.  Few planes (at most two per CU): a plane's latency is what counts -> as many threads per plane as the
+// plane-per-workgroup kernels used.  Many planes: the kernel is latency-bound per workgroup (six barrier-separated phases
+// per plane), so throughput comes from WAVES PER CU: the thread count is the smallest of 256 / 512 / 1024 that reaches the
+// most resident waves given the LDS the shape needs (all variants are compiled for 8 waves per SIMD: <= 64 VGPRs).
+struct Geo {
+  int threads, pre;
+  unsigned grid;
+};
+
+static bool geometry(size_t bytes, int n, int64_t planes, size_t lds, int wps_small, int wps_1024, Geo* g) {
+  const int cus = num_cus();
+  int best_t = 0, best_waves = -1, best_wgs = 1;
+  for (int t : {256, 512, 1024}) {
+    const size_t p = (bytes + (size_t)t * 16 - 1) / ((size_t)t * 16);
+    if (p > 4) continue;
+    int wgs = (int)((160 * 1024) / lds);
+    wgs = std::min(std::min(wgs, (t == 1024 ? wps_1024 : wps_small) * 256 / t), 8);   // LDS, registers, hardware slots
+    if (wgs < 1) continue;
+    if (planes <= 2 * (int64_t)cus) {   // latency regime
+      const int want = n >= 4096 ? 1024 : (n >= 1024 ? 512 : 256);
+      if (t < want && t < 1024) continue;
+      best_t = t, best_wgs = wgs;
+      break;
+    }
+    const int waves = wgs * t / 64;
+    if (waves > best_waves) best_waves = waves, best_t = t, best_wgs = wgs;
+  }
+  if (!best_t) return false;
+  g->threads = best_t;
+  g->pre = (int)((bytes + (size_t)best_t * 16 - 1) / ((size_t)best_t * 16));
+  const int64_t slots = (int64_t)cus * best_wgs;
+  g->grid = (unsigned)(planes < slots ? planes : slots);
+  return true;
+}
+
 template <typename K>
 static int set_lds(K kernel, size_t bytes) {
   if (bytes > 48 * 1024) {
@@ -479,89 +595,50 @@ static int set_lds(K kernel, size_t bytes) {
   return ALG_OK;
 }
 
-// threads and prefetch registers for a plane of `bytes`: PRE * threads * 16 >= bytes, PRE <= 8.  Few planes (at most two
-// per CU): a plane's latency is what counts -> as many threads per plane as v1 used; many planes: 256-thread workgroups,
-// several per CU, so that one workgroup's barriers and load latency hide behind the others' passes.
-static bool geometry(size_t bytes, int n, int64_t planes, int* threads, int* pre) {
-  int first = 256;
-  if (planes <= 512) first = n >= 4096 ? 1024 : (n >= 1024 ? 512 : 256);
-  for (int t : {256, 512, 1024}) {
-    if (t < first) continue;
-    const size_t p = (bytes + (size_t)t * 16 - 1) / ((size_t)t * 16);
-    if (p <= 8) {
-      *threads = t, *pre = (int)p;
-      return true;
-    }
-  }
-  return false;
-}
-
-static unsigned grid_for(int64_t planes, size_t lds, int threads) {
-  int per_cu = (int)((160 * 1024) / lds);
-  const int by_waves = 2048 / threads;
-  if (per_cu > by_waves) per_cu = by_waves;
-  if (per_cu > 8) per_cu = 8;
-  if (per_cu < 1) per_cu = 1;
-  const int64_t g = (int64_t)num_cus() * per_cu;
-  return (unsigned)(planes < g ? planes : g);
-}
-
-template <typename T, int PRE>
-static int launch_du(const T* in, T* out, const uint32_t* blob, const DUArgs& a, size_t lds, int threads, hipStream_t s) {
-  int rc = set_lds(down_up_v2_kernel<T, PRE>, lds);
+template <typename T, int PRE, int NT>
+static int launch_du(const T* in, T* out, const uint32_t* blob, const DUArgs& a, size_t lds, unsigned grid, hipStream_t s) {
+  constexpr int WPS = NT == 1024 ? 4 : 6;   // 76-92 VGPRs: six waves per SIMD for the 256 / 512-thread forms
+  int rc = set_lds(down_up_v2_kernel<T, PRE, NT, WPS>, lds);
   if (rc != ALG_OK) return rc;
-  hipLaunchKernelGGL((down_up_v2_kernel<T, PRE>), dim3(grid_for(a.planes, lds, threads)), dim3(threads), lds, s, in, out,
-                     blob, a);
+  hipLaunchKernelGGL((down_up_v2_kernel<T, PRE, NT, WPS>), dim3(grid), dim3(NT), lds, s, in, out, blob, a);
   return check_launch("alg_down_up");
 }
 
-template <typename T>
-static int dispatch_du(const void* in, void* out, const uint32_t* blob, const DUArgs& a, size_t lds, int threads, int pre,
-                       hipStream_t s) {
-  const T* i = (const T*)in;
-  T* o = (T*)out;
-  switch (pre) {
-    case 1: return launch_du<T, 1>(i, o, blob, a, lds, threads, s);
-    case 2: return launch_du<T, 2>(i, o, blob, a, lds, threads, s);
-    case 3: return launch_du<T, 3>(i, o, blob, a, lds, threads, s);
-    case 4: return launch_du<T, 4>(i, o, blob, a, lds, threads, s);
-    case 5: return launch_du<T, 5>(i, o, blob, a, lds, threads, s);
-    case 6: return launch_du<T, 6>(i, o, blob, a, lds, threads, s);
-    case 7: return launch_du<T, 7>(i, o, blob, a, lds, threads, s);
-    default: return launch_du<T, 8>(i, o, blob, a, lds, threads, s);
-  }
-}
-
-template <typename T, int PRE>
-static int launch_g(const T* in, T* out, const GArgs& a, size_t lds, int threads, hipStream_t s) {
-  int rc;
-  const unsigned grid = grid_for(a.planes, lds, threads);
-  if (a.ksize <= 16) {
-    rc = set_lds(gaussian_v2_kernel<T, PRE, 16>, lds);
-    if (rc != ALG_OK) return rc;
-    hipLaunchKernelGGL((gaussian_v2_kernel<T, PRE, 16>), dim3(grid), dim3(threads), lds, s, in, out, a);
-  } else {
-    rc = set_lds(gaussian_v2_kernel<T, PRE, 0>, lds);
-    if (rc != ALG_OK) return rc;
-    hipLaunchKernelGGL((gaussian_v2_kernel<T, PRE, 0>), dim3(grid), dim3(threads), lds, s, in, out, a);
-  }
+template <typename T, int PRE, int NT>
+static int launch_g(const T* in, T* out, const GArgs& a, size_t lds, unsigned grid, hipStream_t s) {
+  constexpr int WPS = 8;                    // <= 47 VGPRs
+  int rc = set_lds(gaussian_v2_kernel<T, PRE, NT, WPS>, lds);
+  if (rc != ALG_OK) return rc;
+  hipLaunchKernelGGL((gaussian_v2_kernel<T, PRE, NT, WPS>), dim3(grid), dim3(NT), lds, s, in, out, a);
   return check_launch("alg_gaussian_blur");
 }
 
-template <typename T>
-static int dispatch_g(const void* in, void* out, const GArgs& a, size_t lds, int threads, int pre, hipStream_t s) {
-  const T* i = (const T*)in;
-  T* o = (T*)out;
-  switch (pre) {
-    case 1: return launch_g<T, 1>(i, o, a, lds, threads, s);
-    case 2: return launch_g<T, 2>(i, o, a, lds, threads, s);
-    case 3: return launch_g<T, 3>(i, o, a, lds, threads, s);
-    case 4: return launch_g<T, 4>(i, o, a, lds, threads, s);
-    case 5: return launch_g<T, 5>(i, o, a, lds, threads, s);
-    case 6: return launch_g<T, 6>(i, o, a, lds, threads, s);
-    case 7: return launch_g<T, 7>(i, o, a, lds, threads, s);
-    default: return launch_g<T, 8>(i, o, a, lds, threads, s);
+// (threads, prefetch registers) -> instantiation
+#define ALG_V2_DISPATCH(FN, T, ...)                                                      \
+  switch (geo.threads * 8 + geo.pre) {                                                   \
+    case 256 * 8 + 1: return FN<T, 1, 256>(__VA_ARGS__);                                 \
+    case 256 * 8 + 2: return FN<T, 2, 256>(__VA_ARGS__);                                 \
+    case 256 * 8 + 3: return FN<T, 3, 256>(__VA_ARGS__);                                 \
+    case 256 * 8 + 4: return FN<T, 4, 256>(__VA_ARGS__);                                 \
+    case 512 * 8 + 1: return FN<T, 1, 512>(__VA_ARGS__);                                 \
+    case 512 * 8 + 2: return FN<T, 2, 512>(__VA_ARGS__);                                 \
+    case 512 * 8 + 3: return FN<T, 3, 512>(__VA_ARGS__);                                 \
+    case 512 * 8 + 4: return FN<T, 4, 512>(__VA_ARGS__);                                 \
+    case 1024 * 8 + 1: return FN<T, 1, 1024>(__VA_ARGS__);                               \
+    case 1024 * 8 + 2: return FN<T, 2, 1024>(__VA_ARGS__);                               \
+    case 1024 * 8 + 3: return FN<T, 3, 1024>(__VA_ARGS__);                               \
+    default: return FN<T, 4, 1024>(__VA_ARGS__);                                         \
   }
+
+template <typename T>
+static int dispatch_du(const void* in, void* out, const uint32_t* blob, const DUArgs& a, size_t lds, const Geo& geo,
+                       hipStream_t s) {
+  ALG_V2_DISPATCH(launch_du, T, (const T*)in, (T*)out, blob, a, lds, geo.grid, s)
+}
+
+template <typename T>
+static int dispatch_g(const void* in, void* out, const GArgs& a, size_t lds, const Geo& geo, hipStream_t s) {
+  ALG_V2_DISPATCH(launch_g, T, (const T*)in, (T*)out, a, lds, geo.grid, s)
 }
 
 }  // namespace v2
@@ -573,21 +650,22 @@ int down_up_v2(const void* in, void* out, int64_t planes, int H, int W, int h1, 
   const size_t esz = dtype == ALG_F32 ? 4 : 2;
   const size_t bytes = (size_t)H * W * esz;
   if ((bytes & 15) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return 1;
-  int threads, pre;
-  if (!geometry(bytes, H * W, planes, &threads, &pre)) return 1;
   DUArgs a;
   a.H = H, a.W = W, a.h1 = h1, a.w1 = w1, a.round_mid = round_mid, a.planes = planes;
   a.tabs = layout(H, W, h1, w1);
   const size_t stage = ((size_t)h1 * W + 3) / 4 * 4 + (bytes + 3) / 4;          // T3 + staged output, in floats
   const size_t a_fl = (std::max((size_t)H * W, stage) + 3) / 4 * 4;
   a.a_floats = (int)a_fl;
-  const size_t lds = (a_fl + (size_t)H * w1 + (((size_t)h1 * w1 + 3) & ~(size_t)3) + a.tabs.words) * 4;
+  // + 16 floats of slack: the batched tap reads run up to 11 floats past a row's last tap
+  const size_t lds = (a_fl + (size_t)H * w1 + (((size_t)h1 * w1 + 3) & ~(size_t)3) + a.tabs.words + 16) * 4;
   if (lds > 160 * 1024 || a.tabs.dw.taps > 64) return 1;
   if (((size_t)H * w1) & 3) return 1;                                              // keeps T2 / the blob 16-byte aligned
+  Geo geo;
+  if (!geometry(bytes, H * W, planes, lds, 6, 4, &geo)) return 1;
   const uint32_t* blob = tables_for(H, W, h1, w1, a.tabs);
   if (!blob) return 1;
-  return dtype == ALG_F32 ? dispatch_du<float>(in, out, blob, a, lds, threads, pre, s)
-                          : dispatch_du<bf16_t>(in, out, blob, a, lds, threads, pre, s);
+  return dtype == ALG_F32 ? dispatch_du<float>(in, out, blob, a, lds, geo, s)
+                          : dispatch_du<bf16_t>(in, out, blob, a, lds, geo, s);
 }
 
 int gaussian_v2(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype, hipStream_t s) {
@@ -595,15 +673,14 @@ int gaussian_v2(const void* in, void* out, int64_t planes, int H, int W, int ksi
   const size_t esz = dtype == ALG_F32 ? 4 : 2;
   const size_t bytes = (size_t)H * W * esz;
   if ((bytes & 15) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return 1;
-  int threads, pre;
-  if (!geometry(bytes, H * W, planes, &threads, &pre)) return 1;
   GArgs a;
   a.H = H, a.W = W, a.ksize = ksize, a.sigma = sigma, a.planes = planes;
   const size_t n4 = ((size_t)H * W + 3) & ~(size_t)3;
   const size_t lds = ((2 * n4 + ksize) * 4 + 15) & ~(size_t)15;
   if (lds > 160 * 1024) return 1;
-  return dtype == ALG_F32 ? dispatch_g<float>(in, out, a, lds, threads, pre, s)
-                          : dispatch_g<bf16_t>(in, out, a, lds, threads, pre, s);
+  Geo geo;
+  if (!geometry(bytes, H * W, planes, lds, 8, 8, &geo)) return 1;
+  return dtype == ALG_F32 ? dispatch_g<float>(in, out, a, lds, geo, s) : dispatch_g<bf16_t>(in, out, a, lds, geo, s);
 }
 
 }  // namespace alg
