@@ -27,7 +27,7 @@ EXPORTS = (
     "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu", "alg_gemm_fp8", "alg_quantize_fp8_rows",
     "alg_conv_cl_bf16", "alg_vae_groupnorm_workspace", "alg_vae_groupnorm_stats", "alg_vae_spatial_norm", "alg_vae_upsample",
     "alg_vae_pack_latent", "alg_vae_unpack_video", "alg_vae_group_norm", "alg_vae_pad", "alg_vae_repitch",
-    "alg_vae_unpack_planes", "alg_patchify_t", "alg_unpatchify_t", "alg_qk_norm_rope_scaled", "alg_flash_attn_d64_ex", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
+    "alg_vae_unpack_planes", "alg_rms_norm_rows", "alg_softmax_hilo", "alg_patchify_t", "alg_unpatchify_t", "alg_qk_norm_rope_scaled", "alg_flash_attn_d64_ex", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
 )
 
 
@@ -104,6 +104,8 @@ def load_library():
     lib.alg_headnorm_rope.argtypes = [c_void_p] * 4 + [c_int64, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]
     lib.alg_masked_mean.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.alg_silu.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
+    lib.alg_rms_norm_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]
+    lib.alg_softmax_hilo.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, ctypes.c_float, c_void_p]
     lib.alg_gemm_fp8.argtypes = [POINTER(GemmArgs), c_void_p]
     lib.alg_conv_cl_bf16.argtypes = [c_void_p] * 5 + [c_int] * 7 + [c_void_p]
     lib.alg_vae_groupnorm_workspace.argtypes = [POINTER(VaeGeom)]
@@ -362,6 +364,18 @@ def masked_mean(x, valid, out, batch, L, D):
 def silu(x, y):
     _check(load_library().alg_silu(_p(x), _p(y), x.numel(), _stream()), "alg_silu")
     return y
+
+
+def rms_norm_rows(x, gamma, y, rows, C, Cp, silu=True):
+    """WanRMS_norm (+ SiLU) over rows of Cp (padded) channels, statistics over the first C."""
+    _check(load_library().alg_rms_norm_rows(_p(x), _p(gamma), _p(y), rows, C, Cp, int(silu), _stream()), "alg_rms_norm_rows")
+    return y
+
+
+def softmax_hilo(neg_hi, lo, p, rows, cols, ld, scale):
+    _check(load_library().alg_softmax_hilo(_p(neg_hi), _p(lo), _p(p), rows, cols, ld, float(scale), _stream()),
+           "alg_softmax_hilo")
+    return p
 
 
 CONV_PLAIN, CONV_PAIR, CONV_STRIDE2 = 0, 1, 2

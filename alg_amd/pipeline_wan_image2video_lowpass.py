@@ -14,11 +14,14 @@ Per step (wan:843-927) this sampler launches, all through the C ABI of ``libalg_
     * ``alg_cfg_combine``: ``u0 + g (text - u)`` in the prediction dtype (wan:919-924);
     * ``UniPCMultistepScheduler.step`` (alg_amd.schedulers): ``alg_lincomb`` + ``alg_unipc_update`` launches.
 
-Once-per-video components outside the hot path (UMT5 text encoder, CLIP image encoder, Wan VAE) are injected
-duck-typed objects; without them pass ``prompt_embeds`` / ``negative_prompt_embeds`` / ``image_embeds`` (reference
-kwargs), the pre-encoded ``image_condition`` (extension kwarg: the ``[B, 20, F, h, w]`` tensor wan:372-468 builds) or
-just the normalised VAE latents of the condition video as ``latent_condition`` ``[B, 16, F, h, w]`` (the mask channels are
-then built here, wan:439-456), and ``output_type="latent"``.
+Once-per-video components outside the hot path (UMT5 text encoder, CLIP image encoder, Wan VAE: alg_amd's HIP
+implementations or any duck-typed object with the diffusers call protocol) are injected; without them pass
+``prompt_embeds`` / ``negative_prompt_embeds`` / ``image_embeds`` (reference kwargs), the pre-encoded ``image_condition``
+(extension kwarg: the ``[B, 20, F, h, w]`` tensor wan:372-468 builds) or just the normalised VAE latents of the condition
+video as ``latent_condition`` ``[B, 16, F, h, w]`` (the mask channels are then built here, wan:439-456), and
+``output_type="latent"``.  With a VAE attached the pipeline goes image in -> frames out (wan:426-430 encode, :959 decode) and
+the pixel-space ALG branch (``lp_filter_in_latent=False``, wan:493-540: filter the RGB image, re-encode the 81-frame
+condition video EVERY step with a freshly sampled posterior) is available.
 """
 from __future__ import annotations
 
@@ -100,8 +103,7 @@ class WanImageToVideoPipeline:
                         text_encoder=None, tokenizer=None, image_encoder=None, image_processor=None, device="cuda",
                         fp8=False, **_):
         """Local-disk loader of a diffusers-format Wan2.1-I2V directory (`run.py:54-66`): `transformer/`, `text_encoder/`
-        (UMT5), `tokenizer/`, `image_encoder/` (CLIP ViT-H), `image_processor/`, `scheduler/` (UniPC).  The Wan VAE is
-        not built: pass `image_condition` / `latent_condition` and use `output_type="latent"`."""
+        (UMT5), `tokenizer/`, `image_encoder/` (CLIP ViT-H), `image_processor/`, `scheduler/` (UniPC), `vae/` (AutoencoderKLWan)."""
         import os
 
         from .image_encoder_clip import CLIPImageProcessor, CLIPVisionModel
@@ -124,6 +126,9 @@ class WanImageToVideoPipeline:
                                else CLIPImageProcessor())
         if scheduler is None:
             scheduler = UniPCMultistepScheduler.from_pretrained(model_path) if has("scheduler") else UniPCMultistepScheduler()
+        if vae is None and has("vae"):
+            from .autoencoder_kl_wan import AutoencoderKLWan
+            vae = AutoencoderKLWan.from_pretrained(model_path, device=device)
         return cls(tokenizer, text_encoder, image_encoder, image_processor, transformer, vae, scheduler)
 
     def to(self, device=None, *args, **kwargs):
@@ -237,6 +242,61 @@ class WanImageToVideoPipeline:
                                                                 max_sequence_length, device, dtype)
         return prompt_embeds.to(device), (None if negative_prompt_embeds is None else negative_prompt_embeds.to(device))
 
+    def preprocess_image(self, image, height, width):
+        """Minimal VideoProcessor.preprocess (wan:820): tensors are taken as [B, 3, H, W] in [-1, 1]; PIL images are resized
+        (Lanczos) and scaled to [-1, 1]; fp32 like the reference."""
+        if isinstance(image, torch.Tensor):
+            t = image if image.ndim == 4 else image.unsqueeze(0)
+            return t.to(torch.float32)
+        import numpy as np
+        imgs = image if isinstance(image, list) else [image]
+        arr = [np.asarray(im.convert("RGB").resize((width, height), resample=1), dtype=np.float32) / 255.0 for im in imgs]
+        t = torch.from_numpy(np.stack(arr)).permute(0, 3, 1, 2).contiguous()
+        return 2.0 * t - 1.0
+
+    def _latent_stats(self, device, dtype):
+        cfg = self.vae.config
+        mean = torch.tensor(cfg.latents_mean).view(1, cfg.z_dim, 1, 1, 1).to(device, dtype)
+        inv_std = 1.0 / torch.tensor(cfg.latents_std).view(1, cfg.z_dim, 1, 1, 1).to(device, dtype)
+        return mean, inv_std
+
+    def encode_condition(self, image, batch_size, height, width, num_frames, dtype, device, last_image=None,
+                         sample_generator=None):
+        """wan:402-456 (and wan:505-540 with `sample_generator`): the condition video [image, zeros ...] through the VAE,
+        its posterior mode (or, in the pixel-space ALG branch, a sample) normalised by the latent statistics, the frame
+        mask folded into 4 channels in front."""
+        if self.vae is None:
+            raise _lib.AlgHipError("no Wan VAE is attached to this pipeline: pass the pre-encoded `image_condition` "
+                                   "[B, 20, F, h, w] or `latent_condition` [B, 16, F, h, w]")
+        image = image.unsqueeze(2)
+        if last_image is None:
+            video = torch.cat([image, image.new_zeros(image.shape[0], image.shape[1], num_frames - 1, height, width)], dim=2)
+        else:
+            video = torch.cat([image, image.new_zeros(image.shape[0], image.shape[1], num_frames - 2, height, width),
+                               last_image.unsqueeze(2)], dim=2)
+        video = video.to(device=device, dtype=self.vae.dtype)
+        dist = self.vae.encode(video).latent_dist
+        if sample_generator is None:
+            lat = dist.mode().repeat(batch_size // image.shape[0], 1, 1, 1, 1) if image.shape[0] != batch_size else dist.mode()
+        else:
+            lat = dist.sample(generator=sample_generator)
+        mean, inv_std = self._latent_stats(lat.device, dtype)
+        lat = (lat.to(dtype) - mean) * inv_std
+        return build_wan_condition(lat, num_frames, self.vae_scale_factor_temporal, has_last_image=last_image is not None)
+
+    def postprocess_video(self, video, output_type="np"):
+        """VideoProcessor.postprocess_video (wan:960): [B, C, F, H, W] in [-1, 1] -> 'pt' | 'np' | 'pil'."""
+        v = (video * 0.5 + 0.5).clamp(0, 1)
+        if output_type == "pt":
+            return v.permute(0, 2, 1, 3, 4)
+        arr = v.permute(0, 2, 3, 4, 1).cpu().float().numpy()
+        if output_type == "np":
+            return arr
+        if output_type == "pil":
+            from PIL import Image
+            return [[Image.fromarray((f * 255).round().astype("uint8")) for f in vid] for vid in arr]
+        raise ValueError(f"{output_type} is not supported. Make sure to choose one of ['np', 'pt', 'pil']")
+
     def prepare_latents(self, image_condition, batch_size, num_channels_latents=16, height=480, width=832,
                         num_frames=81, dtype=None, device=None, generator=None, latents=None):
         """wan:372-468 with the VAE-encoded condition supplied: noise latents + shape checks."""
@@ -269,8 +329,16 @@ class WanImageToVideoPipeline:
         if not use_low_pass_guidance:
             return None
         if not lp_filter_in_latent:
-            raise _lib.AlgHipError("lp_filter_in_latent=False re-encodes the filtered image every step and needs the "
-                                   "Wan VAE (SURVEY section 8 row f-1, not built)")
+            # wan:493-540: filter the RGB image, re-encode the zero-padded condition video, SAMPLE the posterior
+            if self.vae is None or orig_image_tensor is None or not torch.is_tensor(orig_image_tensor):
+                raise _lib.AlgHipError("lp_filter_in_latent=False re-encodes the filtered image every step: it needs an "
+                                       "attached Wan VAE and the `image`")
+            image_lp = lp_utils.apply_low_pass_filter(orig_image_tensor, lp_filter_type, lp_blur_sigma, lp_blur_kernel_size,
+                                                      lp_resize_factor)
+            b, _, height, width = orig_image_tensor.shape
+            out = self.encode_condition(image_lp, b, height, width, num_frames, image_lp.dtype, image_lp.device,
+                                        sample_generator=generator)
+            return out.to(dtype=orig_image_latents.dtype)
         out = lp_utils.apply_low_pass_filter(orig_image_latents, lp_filter_type, lp_blur_sigma, lp_blur_kernel_size,
                                              lp_resize_factor)
         patch = getattr(getattr(self.transformer, "config", None), "patch_size", None)
@@ -342,9 +410,17 @@ class WanImageToVideoPipeline:
         if image_condition is None and latent_condition is not None:
             image_condition = build_wan_condition(latent_condition.float(), num_frames, self.vae_scale_factor_temporal,
                                                   has_last_image=last_image is not None)
+        image_tensor = None
+        if image is not None and self.vae is not None and (image_condition is None or not lp_filter_in_latent):
+            image_tensor = self.preprocess_image(image, height, width).to(device)                    # wan:820
         if image_condition is None:
-            raise _lib.AlgHipError("the Wan VAE is not built (SURVEY section 8 row f-1): pass the pre-encoded "
-                                   "`image_condition` [B, 20, F, h, w] or `latent_condition` [B, 16, F, h, w]")
+            if image_tensor is None:
+                raise _lib.AlgHipError("no Wan VAE is attached to this pipeline: pass the pre-encoded `image_condition` "
+                                       "[B, 20, F, h, w] or `latent_condition` [B, 16, F, h, w]")
+            n_vid = (len(prompt) if isinstance(prompt, list) else 1) if prompt is not None else prompt_embeds.shape[0]
+            last_t = None if last_image is None else self.preprocess_image(last_image, height, width).to(device)
+            image_condition = self.encode_condition(image_tensor, n_vid * num_videos_per_prompt, height, width, num_frames,
+                                                    torch.float32, device, last_image=last_t)
         if not isinstance(self.scheduler, UniPCMultistepScheduler):
             raise TypeError("this sampler drives alg_amd.schedulers.UniPCMultistepScheduler (HIP step)")
         if output_type != "latent" and self.vae is None:   # before the 40-50 step loop, not after it
@@ -402,8 +478,9 @@ class WanImageToVideoPipeline:
                 lp_cond = self._lp_cache.get(key) if lp_filter_in_latent else None
                 if lp_cond is None:  # the reference filters every step, also when the result goes unused (wan:866)
                     lp_cond = self.prepare_lp(lp_filter_type, sigma_i, ksize_i, factor_i, generator, num_frames,
-                                              use_low_pass_guidance, lp_filter_in_latent, condition, image)
-                    self._lp_cache[key] = lp_cond
+                                              use_low_pass_guidance, lp_filter_in_latent, condition, image_tensor)
+                    if lp_filter_in_latent:     # the pixel branch draws from the generator every step: never cached
+                        self._lp_cache[key] = lp_cond
                 if strength == 0.0:  # wan:879 equivalent to vanilla
                     groups, embeds = [condition, condition], [negative_prompt_embeds, prompt_embeds]
                 else:
@@ -452,9 +529,15 @@ class WanImageToVideoPipeline:
                 negative_prompt_embeds = outs.pop("negative_prompt_embeds", negative_prompt_embeds)
         self._current_timestep = None
 
-        if output_type != "latent":
-            raise _lib.AlgHipError("no Wan VAE is attached to this pipeline: use output_type='latent'")
+        if output_type != "latent":   # wan:945-960
+            lat = latents.to(self.vae.dtype)
+            mean, inv_std = self._latent_stats(lat.device, lat.dtype)
+            lat = lat / inv_std + mean
+            video = self.vae.decode(lat.contiguous(), return_dict=False)[0]
+            video = self.postprocess_video(video, output_type=output_type)
+        else:
+            video = latents
         self.maybe_free_model_hooks()
         if not return_dict:
-            return (latents,)
-        return WanPipelineOutput(frames=latents)
+            return (video,)
+        return WanPipelineOutput(frames=video)

@@ -390,6 +390,17 @@ int alg_unpatchify_t(const void* in, void* out, int n_samples, int frames, int C
 /* Timesteps(dim, flip_sin_to_cos, freq_shift=0): out [n][dim] bf16 sinusoid of t[n] (fp32 timesteps). */
 int alg_timestep_embedding(const float* t, void* out, int n, int dim, int flip_sin_to_cos, void* stream);
 
+/* ---- Wan 2.1 VAE (diffusers AutoencoderKLWan; reference pipeline_wan_image2video_lowpass.py:426-430 encode, :959 decode) ----
+ * Its convolutions are alg_conv_cl_bf16 / alg_gemm_bf16 launches; these two are the kernels specific to it. */
+
+/* WanRMS_norm (+ the SiLU that follows it in every residual block): y[r][c] = act(x[r][c] * sqrt(C) / max(||x[r][:C]||_2,
+ * 1e-12) * gamma[c]) for c < C and 0 for the padding channels C <= c < Cp.  x, y: [rows][Cp] bf16, gamma: [Cp] bf16. */
+int alg_rms_norm_rows(const void* x, const void* gamma, void* y, int64_t rows, int C, int Cp, int silu, void* stream);
+
+/* Row softmax of the VAE mid-block attention over scores split in two bf16 matrices (hi = -neg_hi, lo): p[r][j] =
+ * softmax_j((lo - neg_hi) * scale), zero in the padding columns cols <= j < ld.  All three [rows][ld] bf16. */
+int alg_softmax_hilo(const void* neg_hi, const void* lo, void* p, int64_t rows, int cols, int64_t ld, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
