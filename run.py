@@ -27,7 +27,7 @@ import sys
 import torch
 import yaml
 
-from alg_amd import (AutoencoderKLCogVideoX, CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, CogVideoXTransformer3DModel,
+from alg_amd import (AutoencoderKLCogVideoX, AutoencoderKLWan, CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, CogVideoXTransformer3DModel,
                      CogVideoXTransformerConfig, FlowMatchEulerDiscreteScheduler, HunyuanVideoImageToVideoPipeline,
                      HunyuanVideoTransformer3DModel, HunyuanVideoTransformerConfig, UniPCMultistepScheduler,
                      WanImageToVideoPipeline, WanTransformer3DModel, WanTransformerConfig, parallel)
@@ -78,7 +78,10 @@ def build_pipeline(config, args, device):
         flow_shift = 3.0 if config["generation"]["height"] == "480" else 5.0
         if args.synthetic:
             transformer = _synthetic_transformer(model_path, config, device, fp8=args.fp8)
-            pipe = WanImageToVideoPipeline(transformer=transformer, scheduler=UniPCMultistepScheduler(flow_shift=flow_shift))
+            full = not config["model"].get("synthetic_config")
+            vae = AutoencoderKLWan.from_synthetic(device=device) if full else None      # decode after the loop: wan:959 on HIP
+            pipe = WanImageToVideoPipeline(transformer=transformer, vae=vae,
+                                           scheduler=UniPCMultistepScheduler(flow_shift=flow_shift))
         else:   # run.py:54-66: encoders from the checkpoint directory, UniPC rebuilt from its config with the run's flow_shift
             pipe = WanImageToVideoPipeline.from_pretrained(model_path, device=device, fp8=args.fp8)
             pipe.scheduler = UniPCMultistepScheduler.from_config(pipe.scheduler.config, flow_shift=flow_shift)
@@ -162,7 +165,10 @@ def run_job(pipe, config, args, job):
 
     if args.synthetic:
         pipe_kwargs.update(synthetic_inputs(config, model_path, model_dtype, seed))
-        pipe_kwargs["output_type"] = "latent" if getattr(pipe, "vae", None) is None else "pil"
+        if getattr(pipe, "vae", None) is None:
+            pipe_kwargs["output_type"] = "latent"
+        elif "CogVideoX" in model_path:
+            pipe_kwargs["output_type"] = "pil"
     else:
         from PIL import Image
         input_image = Image.open(job["image_path"]).convert("RGB")
@@ -185,7 +191,9 @@ def run_job(pipe, config, args, job):
     logger.info(f"Video generation complete. Received {len(video_frames)} frames.")
     import numpy as np
     from alg_amd import video_io
-    arr = np.stack([np.asarray(f) for f in video_frames])  # [T, H, W, C] uint8 (run.py:121-125)
+    arr = np.stack([np.asarray(f) for f in video_frames])  # [T, H, W, C] (run.py:121-125)
+    if arr.dtype != np.uint8:   # output_type "np" (the Wan / HunyuanVideo default): floats in [0, 1] -> (x * 255).clamp.to(uint8)
+        arr = np.clip(arr.astype(np.float32) * 255.0, 0, 255).astype(np.uint8)
     video_io.write_video(out_path, arr, fps=config["video"]["fps"])   # .mp4 -> ISO-BMFF container (run.py:127-133)
     logger.info(f"Saved {arr.shape} frames (fps {config['video']['fps']}) to: {out_path}")
     return out_path

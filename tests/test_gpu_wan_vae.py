@@ -116,12 +116,26 @@ def test_wan_pipeline_image_in_frames_out_and_pixel_space_alg():
     model = WanTransformer3DModel(WanTransformerConfig(**kw), wan_oracle.init_weights(wan_oracle.WanConfig(**kw), seed=7), device=DEV)
     vcfg = AutoencoderKLWanConfig(base_dim=24, z_dim=16)
     vae = AutoencoderKLWan.from_synthetic(vcfg, seed=3, device=DEV)
-    pipe = WanImageToVideoPipeline(transformer=model, vae=vae, scheduler=UniPCMultistepScheduler(flow_shift=3.0)).to(DEV)
     g = torch.Generator().manual_seed(9)
     img = torch.randn(1, 3, 64, 96, generator=g).clamp(-1, 1)
+    clip_tokens = torch.randn(1, 257, 64, generator=g).to(BF).to(DEV)
+
+    class Proc:                                   # duck-typed CLIP processor / vision tower (wan:228-234 call protocol):
+        def __call__(self, images, return_tensors):   # the reference forbids `image` next to `image_embeds`
+            class Batch(dict):
+                def to(self, device):
+                    return self
+            return Batch(pixel_values=images)
+
+    class Enc:
+        def __call__(self, pixel_values, output_hidden_states):
+            from types import SimpleNamespace
+            return SimpleNamespace(hidden_states=[None, clip_tokens, None])
+
+    pipe = WanImageToVideoPipeline(transformer=model, vae=vae, image_encoder=Enc(), image_processor=Proc(),
+                                   scheduler=UniPCMultistepScheduler(flow_shift=3.0)).to(DEV)
     emb = dict(prompt_embeds=torch.randn(1, 512, 64, generator=g).to(BF).to(DEV),
-               negative_prompt_embeds=torch.randn(1, 512, 64, generator=g).to(BF).to(DEV),
-               image_embeds=torch.randn(1, 257, 64, generator=g).to(BF).to(DEV))
+               negative_prompt_embeds=torch.randn(1, 512, 64, generator=g).to(BF).to(DEV))
     alg = dict(use_low_pass_guidance=True, lp_filter_type="down_up", lp_resize_factor=0.5, lp_strength_schedule_type="interval",
                schedule_interval_start_time=0.0, schedule_interval_end_time=0.5)
     trace = []
@@ -147,5 +161,6 @@ def test_wan_pipeline_image_in_frames_out_and_pixel_space_alg():
     assert pix.shape == lat.shape == (1, 16, 3, 8, 12) and bool(torch.isfinite(pix).all())
     assert rel(pix, lat) > 1e-4
     with pytest.raises(_lib.AlgHipError, match="VAE"):
-        WanImageToVideoPipeline(transformer=model, scheduler=UniPCMultistepScheduler()).to(DEV)(
+        WanImageToVideoPipeline(transformer=model, image_encoder=Enc(), image_processor=Proc(),
+                                scheduler=UniPCMultistepScheduler()).to(DEV)(
             image=img, height=64, width=96, num_frames=9, num_inference_steps=1, **emb)
