@@ -72,6 +72,7 @@ struct AttnP {
   int unit0, tail_units, tail_split, tail_tiles;
   float* ws_o;   // [8 * tail_units][tail_split][q rows per block][64] fp32, unnormalised
   float* ws_ml;  // [8 * tail_units][tail_split][q rows per block][2]: running max (raw score units), row sum
+  int prio;      // 1: the younger half of an 8-wave workgroup (waves 4-7) runs at s_setprio 1 (ALG_ATTN_PRIO, A/B knob)
 };
 
 struct Frag {
@@ -408,6 +409,9 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
   const float c = p.scale_log2;
   const int n_tiles = (S + KVB - 1) / KVB;
   const bool ragged = (S & (KVB - 1)) != 0;
+  // static priority for the second-dispatched half (guide T5, static form): it loses VALU arbitration to the older half on
+  // every segment otherwise; one s_setprio, no per-cluster flips (the condition is provably wave-uniform: readfirstlane)
+  if (NW == 8 && p.prio && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   if (VARIANT == 14) {
     // Explicitly staged fragments.  hipcc's scheduler, squeezed to 128 VGPRs, sinks every ds_read_b128 next to the
@@ -1420,6 +1424,10 @@ extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* v
   p.q_bs = q_bstride; p.q_rs = q_rstride; p.vt_bs = vt_bstride; p.vt_rs = vt_rstride;
   p.o_bs = o_bstride; p.o_rs = o_rstride;
   p.scale_log2 = (flags & ALG_ATTN_Q_PRESCALED) ? 1.0f : scale * 1.4426950408889634f;  // m is in log2 units already
+  {
+    const char* e = getenv("ALG_ATTN_PRIO");
+    p.prio = (e && e[0] == '1') ? 1 : 0;
+  }
   const int nbh = batch * heads;
   const int64_t grid = (int64_t)((nbh + 7) / 8) * 8 * p.q_blocks;
   const dim3 blk(nw * 64);
