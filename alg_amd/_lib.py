@@ -27,7 +27,7 @@ EXPORTS = (
     "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu", "alg_gemm_fp8", "alg_quantize_fp8_rows",
     "alg_conv_cl_bf16", "alg_vae_groupnorm_workspace", "alg_vae_groupnorm_stats", "alg_vae_spatial_norm", "alg_vae_upsample",
     "alg_vae_pack_latent", "alg_vae_unpack_video", "alg_vae_group_norm", "alg_vae_pad", "alg_vae_repitch",
-    "alg_vae_unpack_planes", "alg_rms_norm_rows", "alg_softmax_hilo", "alg_patchify_t", "alg_unpatchify_t", "alg_qk_norm_rope_scaled", "alg_flash_attn_d64_ex", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
+    "alg_vae_unpack_planes", "alg_rms_norm_rows", "alg_softmax_hilo", "alg_flash_attn_d128_ex", "alg_rope_half", "alg_patchify_t", "alg_unpatchify_t", "alg_qk_norm_rope_scaled", "alg_flash_attn_d64_ex", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
 )
 
 
@@ -93,6 +93,8 @@ def load_library():
     lib.alg_concat_cast.argtypes = [POINTER(c_void_p), c_int, POINTER(c_void_p), c_int, c_int] + [c_int64] * 7 + [
         c_void_p, c_int, c_void_p]
     lib.alg_flash_attn_d128.argtypes = [c_void_p] * 4 + [c_int] * 4 + [c_int64] * 8 + [c_float, c_void_p]
+    lib.alg_flash_attn_d128_ex.argtypes = [c_void_p] * 4 + [c_int] * 4 + [c_int64] * 8 + [c_float, c_int, c_int, c_void_p]
+    lib.alg_rope_half.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]
     lib.alg_layernorm_mod_f32.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]
     lib.alg_layernorm_mod_f32_fp8.argtypes = [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]
     lib.alg_rmsnorm_rope.argtypes = [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]
@@ -279,13 +281,26 @@ def concat_cast(src0, src1, O, A0, A1, R, s0_ostride, s1_ostride, a1_off, out_dt
     return out
 
 
+def rope_half_(x, cos, sin, pos, rows, heads, x_rstride, x_off=0):
+    """Llama rotary embedding (rotate_half form) in place on [rows][heads][128] bf16."""
+    _check(load_library().alg_rope_half(_p(x, x_off), _p(cos), _p(sin), _p(pos), rows, heads, x_rstride, _stream()),
+           "alg_rope_half")
+    return x
+
+
 def flash_attn_d128(q, k, vt, o, batch, heads, Sq, Skv, q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs, scale,
-                    q_off=0, k_off=0, vt_off=0, o_off=0):
-    """softmax(q k^T * scale) v for head_dim 128; strides / offsets in elements (see include/alg_hip.h)."""
+                    q_off=0, k_off=0, vt_off=0, o_off=0, kv_group=1, causal=False):
+    """softmax(q k^T * scale) v for head_dim 128; strides / offsets in elements (see include/alg_hip.h); kv_group > 1:
+    grouped-query attention; causal: query i sees keys 0..i."""
     lib = load_library()
     for t in (q, k, vt, o):
         _dev(t, "attention operand")
     at = lambda t, off: c_void_p(t.data_ptr() + 2 * off)
+    if kv_group != 1 or causal:
+        _check(lib.alg_flash_attn_d128_ex(at(q, q_off), at(k, k_off), at(vt, vt_off), at(o, o_off), batch, heads, Sq, Skv, q_bs,
+                                          q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs, float(scale), int(kv_group),
+                                          int(bool(causal)), _stream()), "alg_flash_attn_d128_ex")
+        return o
     _check(lib.alg_flash_attn_d128(at(q, q_off), at(k, k_off), at(vt, vt_off), at(o, o_off), batch, heads, Sq, Skv, q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs, float(scale),
                                    _stream()), "alg_flash_attn_d128")
     return o

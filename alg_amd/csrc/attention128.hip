@@ -37,11 +37,15 @@ struct P {
   int batch, heads, Sq, Skv, q_blocks;
   int64_t q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs;
   float scale_log2;
+  int kv_group;   // query heads per key / value head (grouped-query attention: Llama-3 32 / 8 = 4); 1 = ordinary heads
 };
 
 template <bool B>
 struct BoolC { static constexpr bool value = B; };
 
+// CAUSAL: query row i sees keys 0 .. i (the decoder-only language model inside HunyuanVideo's prompt encoder, hy:282-420);
+// KV tiles entirely above the workgroup's last query are skipped, tiles that reach past a wave's first query are masked.
+template <bool CAUSAL>
 __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (K_TILE + V_TILE)];
   char* const k_ring = smem;
@@ -64,8 +68,9 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
   const int b = bh / p.heads, h = bh - b * p.heads;
   const int Sq = p.Sq, Skv = p.Skv;
   const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 128;
-  const bf16_t* K = p.k + (int64_t)b * p.k_bs + h * 128;
-  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 128 * p.vt_rs;
+  const int hk = h / p.kv_group;
+  const bf16_t* K = p.k + (int64_t)b * p.k_bs + hk * 128;
+  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)hk * 128 * p.vt_rs;
 
   // Q^T fragments (B operand): lane (q = l31, h2) holds Q[q][16 ks + 8 h2 .. +8], ks = 0..7
   const int q_row = qb * (NW * 32) + wave * 32 + l31;
@@ -105,8 +110,9 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
     for (int e = 0; e < 16; ++e) o_acc[i][e] = 0.0f;
   float m_run = -INFINITY, l_run = 0.0f;
   const float c = p.scale_log2;
-  const int n_tiles = (Skv + KVB - 1) / KVB;
+  int n_tiles = (Skv + KVB - 1) / KVB;
   const bool ragged = (Skv & (KVB - 1)) != 0;
+  if (CAUSAL) n_tiles = min(n_tiles, (min(qb * (NW * 32) + NW * 32, Sq) + KVB - 1) / KVB);   // keys <= the block's last query
 
   stage(0, 0);
   auto tile = [&](int t, auto masked) {
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int kv = t * KVB + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2;
-          if (kv >= Skv) s[sub][e] = -INFINITY;
+          if (kv >= Skv || (CAUSAL && kv > q_row)) s[sub][e] = -INFINITY;
         }
     }
     // ---- online softmax with a LAZY running max (see attention.hip softmax_tile_lazy): probabilities are formed against
@@ -187,9 +193,19 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
         o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kk], o_acc[dt], 0, 0, 0);
       }
   };
-  const int n_loop = ragged ? n_tiles - 1 : n_tiles;
-  for (int t = 0; t < n_loop; ++t) tile(t, BoolC<false>{});
-  if (ragged) tile(n_tiles - 1, BoolC<true>{});
+  if (CAUSAL) {
+    const int first_masked = (qb * (NW * 32) + wave * 32) / KVB;     // first tile that reaches past this wave's first query
+    for (int t = 0; t < n_tiles; ++t) {                               // (wave-uniform; the barrier inside is hit by all)
+      if (t < first_masked && !(ragged && t == (Skv + KVB - 1) / KVB - 1))
+        tile(t, BoolC<false>{});
+      else
+        tile(t, BoolC<true>{});
+    }
+  } else {
+    const int n_loop = ragged ? n_tiles - 1 : n_tiles;
+    for (int t = 0; t < n_loop; ++t) tile(t, BoolC<false>{});
+    if (ragged) tile(n_tiles - 1, BoolC<true>{});
+  }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
@@ -213,10 +229,18 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
 
 using namespace alg;
 
-extern "C" int alg_flash_attn_d128(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq,
-                                   int Skv, int64_t q_bstride, int64_t q_rstride, int64_t k_bstride, int64_t k_rstride,
-                                   int64_t vt_bstride, int64_t vt_rstride, int64_t o_bstride, int64_t o_rstride,
-                                   float scale, void* stream) {
+static int flash_attn_d128_entry(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq,
+                                 int Skv, int64_t q_bstride, int64_t q_rstride, int64_t k_bstride, int64_t k_rstride,
+                                 int64_t vt_bstride, int64_t vt_rstride, int64_t o_bstride, int64_t o_rstride,
+                                 float scale, int kv_group, int causal, void* stream) {
+  if (kv_group <= 0 || heads % kv_group) {
+    set_error("alg_flash_attn_d128_ex: heads=%d must be a multiple of kv_group=%d", heads, kv_group);
+    return ALG_EINVAL;
+  }
+  if (causal && Sq != Skv) {
+    set_error("alg_flash_attn_d128_ex: causal attention needs Sq == Skv (got %d, %d)", Sq, Skv);
+    return ALG_EINVAL;
+  }
   if (!q || !k || !vt || !o || batch <= 0 || heads <= 0 || Sq <= 0 || Skv <= 0) {
     set_error("alg_flash_attn_d128: bad argument (batch=%d heads=%d Sq=%d Skv=%d)", batch, heads, Sq, Skv);
     return ALG_EINVAL;
@@ -239,12 +263,32 @@ extern "C" int alg_flash_attn_d128(const void* q, const void* k, const void* vt,
   p.q_bs = q_bstride; p.q_rs = q_rstride; p.k_bs = k_bstride; p.k_rs = k_rstride;
   p.vt_bs = vt_bstride; p.vt_rs = vt_rstride; p.o_bs = o_bstride; p.o_rs = o_rstride;
   p.scale_log2 = scale * 1.4426950408889634f;
+  p.kv_group = kv_group;
   const int nbh = batch * heads;
   const int64_t grid = (int64_t)((nbh + 7) / 8) * 8 * p.q_blocks;
   if (grid > 0x7fffffff) {
     set_error("alg_flash_attn_d128: grid too large");
     return ALG_ELIMIT;
   }
-  hipLaunchKernelGGL(a128::flash_attn_d128_kernel, dim3((unsigned)grid), dim3(a128::NW * 64), 0, (hipStream_t)stream, p);
+  if (causal)
+    hipLaunchKernelGGL(a128::flash_attn_d128_kernel<true>, dim3((unsigned)grid), dim3(a128::NW * 64), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(a128::flash_attn_d128_kernel<false>, dim3((unsigned)grid), dim3(a128::NW * 64), 0, (hipStream_t)stream, p);
   return check_launch("alg_flash_attn_d128");
+}
+
+extern "C" int alg_flash_attn_d128(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq,
+                                   int Skv, int64_t q_bstride, int64_t q_rstride, int64_t k_bstride, int64_t k_rstride,
+                                   int64_t vt_bstride, int64_t vt_rstride, int64_t o_bstride, int64_t o_rstride,
+                                   float scale, void* stream) {
+  return flash_attn_d128_entry(q, k, vt, o, batch, heads, Sq, Skv, q_bstride, q_rstride, k_bstride, k_rstride, vt_bstride,
+                               vt_rstride, o_bstride, o_rstride, scale, 1, 0, stream);
+}
+
+extern "C" int alg_flash_attn_d128_ex(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq,
+                                      int Skv, int64_t q_bstride, int64_t q_rstride, int64_t k_bstride, int64_t k_rstride,
+                                      int64_t vt_bstride, int64_t vt_rstride, int64_t o_bstride, int64_t o_rstride,
+                                      float scale, int kv_group, int causal, void* stream) {
+  return flash_attn_d128_entry(q, k, vt, o, batch, heads, Sq, Skv, q_bstride, q_rstride, k_bstride, k_rstride, vt_bstride,
+                               vt_rstride, o_bstride, o_rstride, scale, kv_group, causal, stream);
 }

@@ -178,6 +178,20 @@ int alg_flash_attn_d128(const void* q, const void* k, const void* vt, void* o, i
                         int64_t q_bstride, int64_t q_rstride, int64_t k_bstride, int64_t k_rstride, int64_t vt_bstride,
                         int64_t vt_rstride, int64_t o_bstride, int64_t o_rstride, float scale, void* stream);
 
+/* The same kernel with grouped-query attention (kv_group query heads share one K / V head; k and vt then hold heads / kv_group
+ * heads) and an optional causal mask (query i sees keys 0..i; needs Sq == Skv): the Llama-3 tower of HunyuanVideo's prompt
+ * encoder (reference pipeline_hunyuan_video_image2video_lowpass.py:282-420, transformers LlavaForConditionalGeneration). */
+int alg_flash_attn_d128_ex(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq, int Skv,
+                           int64_t q_bstride, int64_t q_rstride, int64_t k_bstride, int64_t k_rstride, int64_t vt_bstride,
+                           int64_t vt_rstride, int64_t o_bstride, int64_t o_rstride, float scale, int kv_group, int causal,
+                           void* stream);
+
+/* Llama rotary embedding ("rotate_half" form) in place on x [rows][heads][128] bf16 (row stride x_rstride elements):
+ * x' = x * cos[pos[r]] + rotate_half(x) * sin[pos[r]], every product and the sum rounded to bf16 like the eager graph;
+ * cos / sin: fp32 tables [positions][128]; pos: int32 [rows]. */
+int alg_rope_half(void* x, const float* cos_tab, const float* sin_tab, const int* pos, int64_t rows, int heads,
+                  int64_t x_rstride, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Text encoders of the conditioning front-end (transformers T5EncoderModel, cog:228-268 `_get_t5_prompt_embeds`;
  * UMT5EncoderModel, wan:185-234 `_get_t5_prompt_embeds`): the small kernels around alg_gemm_bf16
