@@ -7,6 +7,7 @@ HunyuanVideo samplers with their DiT forwards and UniPC / flow-match Euler sched
 from . import lp_utils  # noqa: F401
 from .image_encoder_clip import CLIPImageProcessor, CLIPVisionEncoderConfig, CLIPVisionModel  # noqa: F401
 from .text_encoder_clip import CLIPTextEncoderConfig, CLIPTextModel  # noqa: F401
+from .text_encoder_llava import LlavaConfig, LlavaForConditionalGeneration  # noqa: F401
 from .text_encoder_t5 import T5EncoderConfig, T5EncoderModel, UMT5EncoderModel  # noqa: F401
 from .autoencoder_kl_cogvideox import AutoencoderKLCogVideoX, AutoencoderKLCogVideoXConfig  # noqa: F401
 from .autoencoder_kl_wan import AutoencoderKLWan, AutoencoderKLWanConfig  # noqa: F401

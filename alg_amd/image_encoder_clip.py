@@ -92,11 +92,16 @@ class CLIPVisionModel:
         if dtype != torch.bfloat16:
             raise ValueError("the HIP encoder computes in bfloat16")
         dh = c.hidden_size // c.num_attention_heads
-        if dh not in (64, 80) or c.hidden_size % 64 or c.intermediate_size % 64 or c.hidden_act != "gelu" or \
-                c.image_size % c.patch_size:
-            raise ValueError("unsupported CLIP vision configuration (head_dim 64 / 80, exact GELU, widths multiples of 64)")
+        if dh not in (64, 80) or c.hidden_size % 64 or c.intermediate_size % 64 or c.hidden_act not in ("gelu", "quick_gelu") \
+                or c.image_size % c.patch_size:
+            raise ValueError("unsupported CLIP vision configuration (head_dim 64 / 80, GELU or quick-GELU, widths multiples of 64)")
         self.head_dim = dh
         self.tokens = (c.image_size // c.patch_size) ** 2 + 1
+        # up to 448 tokens the eager-graph attention kernel (K resident in LDS) is used; longer sequences (ViT-L/14 at 336 px:
+        # 577 tokens, the tower inside HunyuanVideo's Llava prompt encoder) go through the flash attention of the DiT
+        self.flash = self.tokens > 448
+        if self.flash and dh != 64:
+            raise ValueError("CLIP towers with more than 448 tokens need head_dim 64 (flash attention path)")
         self.kpad = -(-3 * c.patch_size * c.patch_size // 64) * 64
         self.device, self.dtype = torch.device(device), dtype
         self.w = {}
@@ -160,8 +165,13 @@ class CLIPVisionModel:
              "pre_ln": (f32(sd["pre_layrnorm.weight"]), f32(sd["pre_layrnorm.bias"]))}
         for i in range(c.num_hidden_layers):
             p, a = "encoder.layers.%d." % i, "encoder.layers.%d.self_attn." % i
-            W[p + "qkv"] = put(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0))
-            W[p + "qkv_b"] = put(torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"], sd[a + "v_proj.bias"]], 0))
+            if self.flash:
+                W[p + "qk"] = put(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"]], 0))
+                W[p + "qk_b"] = put(torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"]], 0))
+                W[p + "v"], W[p + "v_b"] = put(sd[a + "v_proj.weight"]), put(sd[a + "v_proj.bias"])
+            else:
+                W[p + "qkv"] = put(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0))
+                W[p + "qkv_b"] = put(torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"], sd[a + "v_proj.bias"]], 0))
             W[p + "o"], W[p + "o_b"] = put(sd[a + "out_proj.weight"]), put(sd[a + "out_proj.bias"])
             for n in ("layer_norm1", "layer_norm2"):
                 W[p + n] = (f32(sd[p + n + ".weight"]), f32(sd[p + n + ".bias"]))
@@ -194,21 +204,33 @@ class CLIPVisionModel:
         hs = torch.empty(n_states, T, D, device=dev, dtype=bf)
         _lib.layernorm_mod_f32(tok, hs[0], W["pre_ln"][0], W["pre_ln"][1], None, None, 0, 1, T, D, c.layer_norm_eps)
         n = torch.empty(T, D, device=dev, dtype=bf)
-        qkv = torch.empty(T, 3 * D, device=dev, dtype=bf)
         att = torch.empty(T, D, device=dev, dtype=bf)
+        if self.flash:
+            L_pad = (L + 127) // 128 * 128
+            qk = torch.empty(T, 2 * D, device=dev, dtype=bf)
+            vt = torch.zeros(B, D, L_pad, device=dev, dtype=bf)     # V^T written by a GEMM with swapped operands
+        else:
+            qkv = torch.empty(T, 3 * D, device=dev, dtype=bf)
+        act_ = _lib.gelu_erf_ if c.hidden_act == "gelu" else _lib.quick_gelu_
         mid = torch.empty(T, M, device=dev, dtype=bf)
         for i in range(c.num_hidden_layers):
             p = "encoder.layers.%d." % i
             x, y = hs[i], hs[i + 1]
             _lib.layernorm_mod_f32(x, n, W[p + "layer_norm1"][0], W[p + "layer_norm1"][1], None, None, 0, 1, T, D,
                                    c.layer_norm_eps)
-            _lib.gemm(n, W[p + "qkv"], qkv, T, 3 * D, D, D, D, 3 * D, bias=W[p + "qkv_b"])
-            _lib.attn_bias(qkv, att, None, None, None, B, H, L, scale=dh ** -0.5, head_dim=dh)
+            if self.flash:
+                _lib.gemm(n, W[p + "qk"], qk, T, 2 * D, D, D, D, 2 * D, bias=W[p + "qk_b"])
+                _lib.gemm(W[p + "v"], n, vt, D, L, D, D, D, L_pad, bias=W[p + "v_b"], batch=B, strideB=L * D, strideC=D * L_pad,
+                          flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
+                _lib.flash_attn_d64(qk, qk, vt, att, B, H, L, L * 2 * D, 2 * D, D * L_pad, L_pad, L * D, D, dh ** -0.5, k_off=D)
+            else:
+                _lib.gemm(n, W[p + "qkv"], qkv, T, 3 * D, D, D, D, 3 * D, bias=W[p + "qkv_b"])
+                _lib.attn_bias(qkv, att, None, None, None, B, H, L, scale=dh ** -0.5, head_dim=dh)
             _lib.gemm(att, W[p + "o"], y, T, D, D, D, D, D, bias=W[p + "o_b"], R=x, ldr=D)
             _lib.layernorm_mod_f32(y, n, W[p + "layer_norm2"][0], W[p + "layer_norm2"][1], None, None, 0, 1, T, D,
                                    c.layer_norm_eps)
             _lib.gemm(n, W[p + "fc1"], mid, T, M, D, D, D, M, bias=W[p + "fc1_b"])
-            _lib.gelu_erf_(mid)
+            act_(mid)
             _lib.gemm(mid, W[p + "fc2"], y, T, D, M, M, M, D, bias=W[p + "fc2_b"], R=y, ldr=D)
         states = [hs[i].view(B, L, D) for i in range(n_states)]
         out = CLIPVisionOutput(last_hidden_state=states[-1], hidden_states=states if output_hidden_states else None)

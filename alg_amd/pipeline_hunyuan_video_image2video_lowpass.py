@@ -13,10 +13,12 @@ Per step everything elementwise runs through ``libalg_hip.so``: the HIP low-pass
 (``prepare_lp``, once per distinct strength), ``alg_concat_cast`` for the first-frame token replace + CFG batch + cast
 (hy:1146-1160, 1230), ``alg_cfg_combine`` with ``true_cfg_scale`` (hy:1254-1261), ``alg_lincomb`` for the flow-match
 Euler step and ``alg_concat_cast`` again to re-prepend the clean first frame (hy:1265-1270).  The transformer is an
-injected object with the diffusers HunyuanVideo signature (the DiT itself is SURVEY section 8 row a-6h, "next"); text /
-image encoders and the VAE are outside the hot path: pass ``prompt_embeds`` / ``pooled_prompt_embeds`` /
-``prompt_attention_mask`` (+ negatives), the pre-encoded first frame as ``image_latents`` (extension kwarg) and
-``output_type="latent"``.
+injected object with the diffusers HunyuanVideo signature (alg_amd's HIP DiT).  The prompt encoders are outside the hot
+path and attached like diffusers registers them: the Llava-Llama-3 encoder (``text_encoder`` + ``tokenizer`` +
+``image_processor``, hy:282-420: templated prompt next to the input image) and the CLIP-L text tower
+(``text_encoder_2``); without them pass ``prompt_embeds`` / ``pooled_prompt_embeds`` / ``prompt_attention_mask``
+(+ negatives).  The HunyuanVideo VAE is not built: pass the pre-encoded first frame as ``image_latents`` (extension kwarg)
+and use ``output_type="latent"``.
 """
 from __future__ import annotations
 
@@ -30,8 +32,46 @@ from . import _lib, lp_utils
 from .pipeline_cogvideox_image2video_lowpass import retrieve_timesteps
 from .schedulers import FlowMatchEulerDiscreteScheduler
 
-DEFAULT_PROMPT_TEMPLATE = {"template": "", "crop_start": 103, "image_emb_start": 5, "image_emb_end": 581,
-                           "image_emb_len": 576, "double_return_token_id": 271}
+DEFAULT_PROMPT_TEMPLATE = {   # hy:84-100
+    "template": (
+        "<|start_header_id|>system<|end_header_id|>\n\n<image>\nDescribe the video by detailing the following aspects according to the reference image: "
+        "1. The main content and theme of the video."
+        "2. The color, shape, size, texture, quantity, text, and spatial relationships of the objects."
+        "3. Actions, events, behaviors temporal relationships, physical movement changes of the objects."
+        "4. background environment, light, style and atmosphere."
+        "5. camera angles, movements, and transitions used in the video:<|eot_id|>\n\n"
+        "<|start_header_id|>user<|end_header_id|>\n\n{}<|eot_id|>"
+        "<|start_header_id|>assistant<|end_header_id|>\n\n"
+    ),
+    "crop_start": 103,
+    "image_emb_start": 5,
+    "image_emb_end": 581,
+    "image_emb_len": 576,
+    "double_return_token_id": 271,
+}
+
+
+def _expand_input_ids_with_image_tokens(text_input_ids, prompt_attention_mask, max_sequence_length, image_token_index,
+                                        image_emb_len, image_emb_start, image_emb_end, pad_token_id):
+    """hy:107-146: make room for the image embeddings -- every `<image>` placeholder becomes `image_emb_len` image tokens at
+    [image_emb_start, image_emb_end), the text slides right; attention mask and position ids follow."""
+    special_image_token_mask = text_input_ids == image_token_index
+    num_special_image_tokens = torch.sum(special_image_token_mask, dim=-1)
+    batch_indices, non_image_indices = torch.where(text_input_ids != image_token_index)
+    max_expanded_length = max_sequence_length + (num_special_image_tokens.max() * (image_emb_len - 1))
+    new_token_positions = torch.cumsum((special_image_token_mask * (image_emb_len - 1) + 1), -1) - 1
+    text_to_overwrite = new_token_positions[batch_indices, non_image_indices]
+    expanded_input_ids = torch.full((text_input_ids.shape[0], int(max_expanded_length)), pad_token_id,
+                                    dtype=text_input_ids.dtype, device=text_input_ids.device)
+    expanded_input_ids[batch_indices, text_to_overwrite] = text_input_ids[batch_indices, non_image_indices]
+    expanded_input_ids[batch_indices, image_emb_start:image_emb_end] = image_token_index
+    expanded_attention_mask = torch.zeros((text_input_ids.shape[0], int(max_expanded_length)),
+                                          dtype=prompt_attention_mask.dtype, device=prompt_attention_mask.device)
+    attn_batch_indices, attention_indices = torch.where(expanded_input_ids != pad_token_id)
+    expanded_attention_mask[attn_batch_indices, attention_indices] = 1.0
+    expanded_attention_mask = expanded_attention_mask.to(prompt_attention_mask.dtype)
+    position_ids = (expanded_attention_mask.cumsum(-1) - 1).masked_fill_((expanded_attention_mask == 0), 1)
+    return {"input_ids": expanded_input_ids, "attention_mask": expanded_attention_mask, "position_ids": position_ids}
 
 
 @dataclass
@@ -75,9 +115,8 @@ class HunyuanVideoImageToVideoPipeline:
                         text_encoder=None, tokenizer=None, text_encoder_2=None, tokenizer_2=None, image_processor=None,
                         device="cuda", **_):
         """Local-disk loader of a diffusers-format HunyuanVideo-I2V directory (`run.py:68-90`): `transformer/`,
-        `text_encoder_2/` (CLIP-L text tower) + `tokenizer_2/`, `scheduler/`.  The Llava prompt encoder and the
-        HunyuanVideo VAE are not built: pass `prompt_embeds` / `prompt_attention_mask` / `image_latents` and use
-        `output_type="latent"`."""
+        `text_encoder/` (Llava-Llama-3) + `tokenizer/` + `image_processor/`, `text_encoder_2/` (CLIP-L text tower) +
+        `tokenizer_2/`, `scheduler/`.  The HunyuanVideo VAE is not built: pass `image_latents` and use `output_type="latent"`."""
         import os
 
         from .schedulers import FlowMatchEulerDiscreteScheduler
@@ -88,6 +127,14 @@ class HunyuanVideoImageToVideoPipeline:
         has = lambda sub: os.path.isdir(os.path.join(model_path, sub))
         if transformer is None:
             transformer = HunyuanVideoTransformer3DModel.from_pretrained(model_path, device=device)
+        if text_encoder is None and has("text_encoder"):
+            from .text_encoder_llava import LlavaForConditionalGeneration
+            text_encoder = LlavaForConditionalGeneration.from_pretrained(model_path, device=device)
+        if tokenizer is None:
+            tokenizer = load_tokenizer(model_path, "tokenizer")
+        if image_processor is None and has("image_processor"):
+            from .image_encoder_clip import CLIPImageProcessor
+            image_processor = CLIPImageProcessor.from_pretrained(model_path)
         if text_encoder_2 is None and has("text_encoder_2"):
             text_encoder_2 = CLIPTextModel.from_pretrained(model_path, device=device)
         if tokenizer_2 is None:
@@ -199,6 +246,96 @@ class HunyuanVideoImageToVideoPipeline:
                 out = torch.cat([out[:, :n_pre], out], dim=1)
         return out.to(dtype=orig_image_latents.dtype)
 
+    def _get_llama_prompt_embeds(self, image, prompt, prompt_template, num_videos_per_prompt=1, device=None, dtype=None,
+                                 max_sequence_length=256, num_hidden_layers_to_skip=2, image_embed_interleave=2):
+        """hy:282-420, line for line: fill the template, tokenise to crop_start + max_sequence_length, expand the `<image>`
+        placeholder to 576 image tokens, run the Llava encoder with the image's pixel values, take hidden state -(skip + 1),
+        cut the template / assistant header out and put every `image_embed_interleave`-th image token in front."""
+        if self.text_encoder is None or self.tokenizer is None or self.image_processor is None:
+            raise _lib.AlgHipError("no Llava prompt encoder / tokenizer / image processor is attached: pass prompt_embeds and "
+                                   "prompt_attention_mask")
+        device = device or self._execution_device
+        dtype = dtype or self.text_encoder.dtype
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        prompt = [prompt_template["template"].format(p) for p in prompt]
+        crop_start = prompt_template.get("crop_start", None)
+        image_emb_len = prompt_template.get("image_emb_len", 576)
+        image_emb_start = prompt_template.get("image_emb_start", 5)
+        image_emb_end = prompt_template.get("image_emb_end", 581)
+        double_return_token_id = prompt_template.get("double_return_token_id", 271)
+        if crop_start is None:
+            prompt_template_input = self.tokenizer(prompt_template["template"], padding="max_length", return_tensors="pt",
+                                                   return_length=False, return_overflowing_tokens=False,
+                                                   return_attention_mask=False)
+            crop_start = prompt_template_input["input_ids"].shape[-1]
+            crop_start -= 5   # <|start_header_id|>, <|end_header_id|>, assistant, <|eot_id|>, and the placeholder {}
+        max_sequence_length += crop_start
+        text_inputs = self.tokenizer(prompt, max_length=max_sequence_length, padding="max_length", truncation=True,
+                                     return_tensors="pt", return_length=False, return_overflowing_tokens=False,
+                                     return_attention_mask=True)
+        text_input_ids = text_inputs.input_ids.to(device=device)
+        prompt_attention_mask = text_inputs.attention_mask.to(device=device)
+        image_embeds = self.image_processor(image, return_tensors="pt")
+        image_embeds = (image_embeds["pixel_values"] if isinstance(image_embeds, dict) else image_embeds.pixel_values).to(device)
+        image_token_index = self.text_encoder.config.image_token_index
+        pad_token_id = self.text_encoder.config.pad_token_id
+        expanded_inputs = _expand_input_ids_with_image_tokens(text_input_ids, prompt_attention_mask, max_sequence_length,
+                                                              image_token_index, image_emb_len, image_emb_start,
+                                                              image_emb_end, pad_token_id)
+        prompt_embeds = self.text_encoder(**expanded_inputs, pixel_values=image_embeds,
+                                          output_hidden_states=True).hidden_states[-(num_hidden_layers_to_skip + 1)]
+        prompt_embeds = prompt_embeds.to(dtype=dtype)
+        if crop_start is not None and crop_start > 0:
+            text_crop_start = crop_start - 1 + image_emb_len
+            batch_indices, last_double_return_token_indices = torch.where(text_input_ids == double_return_token_id)
+            if last_double_return_token_indices.shape[0] == 3:   # in case the prompt is too long
+                last_double_return_token_indices = torch.cat(
+                    (last_double_return_token_indices, torch.tensor([text_input_ids.shape[-1]], device=device)))
+                batch_indices = torch.cat((batch_indices, torch.tensor([0], device=device)))
+            last_double_return_token_indices = last_double_return_token_indices.reshape(text_input_ids.shape[0], -1)[:, -1]
+            batch_indices = batch_indices.reshape(text_input_ids.shape[0], -1)[:, -1]
+            assistant_crop_start = last_double_return_token_indices - 1 + image_emb_len - 4
+            assistant_crop_end = last_double_return_token_indices - 1 + image_emb_len
+            attention_mask_assistant_crop_start = last_double_return_token_indices - 4
+            attention_mask_assistant_crop_end = last_double_return_token_indices
+            prompt_embed_list, prompt_attention_mask_list, image_embed_list, image_attention_mask_list = [], [], [], []
+            for i in range(text_input_ids.shape[0]):
+                prompt_embed_list.append(torch.cat([prompt_embeds[i, text_crop_start:assistant_crop_start[i].item()],
+                                                    prompt_embeds[i, assistant_crop_end[i].item():]]))
+                prompt_attention_mask_list.append(torch.cat([
+                    prompt_attention_mask[i, crop_start:attention_mask_assistant_crop_start[i].item()],
+                    prompt_attention_mask[i, attention_mask_assistant_crop_end[i].item():]]))
+                image_embed_list.append(prompt_embeds[i, image_emb_start:image_emb_end])
+                image_attention_mask_list.append(
+                    torch.ones(image_embed_list[-1].shape[0]).to(prompt_embeds.device).to(prompt_attention_mask.dtype))
+            prompt_embed_list = torch.stack(prompt_embed_list)
+            prompt_attention_mask_list = torch.stack(prompt_attention_mask_list)
+            image_embed_list = torch.stack(image_embed_list)
+            image_attention_mask_list = torch.stack(image_attention_mask_list)
+            if 0 < image_embed_interleave < 6:
+                image_embed_list = image_embed_list[:, ::image_embed_interleave, :]
+                image_attention_mask_list = image_attention_mask_list[:, ::image_embed_interleave]
+            assert (prompt_embed_list.shape[0] == prompt_attention_mask_list.shape[0]
+                    and image_embed_list.shape[0] == image_attention_mask_list.shape[0])
+            prompt_embeds = torch.cat([image_embed_list, prompt_embed_list], dim=1)
+            prompt_attention_mask = torch.cat([image_attention_mask_list, prompt_attention_mask_list], dim=1)
+        return prompt_embeds, prompt_attention_mask
+
+    def encode_prompt(self, image, prompt, prompt_2=None, prompt_template=DEFAULT_PROMPT_TEMPLATE, num_videos_per_prompt=1,
+                      prompt_embeds=None, pooled_prompt_embeds=None, prompt_attention_mask=None, device=None, dtype=None,
+                      max_sequence_length=256, image_embed_interleave=2):
+        """hy:453-492."""
+        if prompt_embeds is None:
+            prompt_embeds, prompt_attention_mask = self._get_llama_prompt_embeds(
+                image, prompt, prompt_template, num_videos_per_prompt, device=device, dtype=dtype,
+                max_sequence_length=max_sequence_length, image_embed_interleave=image_embed_interleave)
+        if pooled_prompt_embeds is None:
+            if prompt_2 is None:
+                prompt_2 = prompt
+            pooled_prompt_embeds = self._get_clip_prompt_embeds(prompt, num_videos_per_prompt, device=device, dtype=dtype,
+                                                                max_sequence_length=77)
+        return prompt_embeds, pooled_prompt_embeds, prompt_attention_mask
+
     def _get_clip_prompt_embeds(self, prompt, num_videos_per_prompt=1, device=None, dtype=None, max_sequence_length=77):
         """hy:421-452: tokenizer_2 to 77 tokens, CLIP text tower, `pooler_output`."""
         if self.text_encoder_2 is None or self.tokenizer_2 is None:
@@ -294,10 +431,26 @@ class HunyuanVideoImageToVideoPipeline:
         if (do_true_cfg and negative_pooled_prompt_embeds is None and neg_text is not None
                 and self.text_encoder_2 is not None):
             negative_pooled_prompt_embeds = self._get_clip_prompt_embeds(neg_text, num_videos_per_prompt, device=device)
+        if image_embed_interleave is None:   # hy:1021-1027
+            image_embed_interleave = 2 if image_condition_type == "latent_concat" else 4 if image_condition_type == "token_replace" else 1
+        if prompt_embeds is None and prompt is not None and self.text_encoder is not None:
+            # hy:1073-1089: the Llava prompt encoder sees the input image next to the templated prompt
+            prompt_embeds, pooled_prompt_embeds, prompt_attention_mask = self.encode_prompt(
+                image=image, prompt=prompt, prompt_2=prompt_2, prompt_template=prompt_template,
+                num_videos_per_prompt=num_videos_per_prompt, pooled_prompt_embeds=pooled_prompt_embeds, device=device,
+                max_sequence_length=max_sequence_length, image_embed_interleave=image_embed_interleave)
+        if (do_true_cfg and negative_prompt_embeds is None and negative_prompt is not None and self.text_encoder is not None
+                and image is not None):
+            from PIL import Image   # hy:1091-1108: the negative prompt is encoded next to a black image
+            negative_prompt_embeds, negative_pooled_prompt_embeds, negative_prompt_attention_mask = self.encode_prompt(
+                image=Image.new("RGB", (width, height), 0), prompt=negative_prompt, prompt_2=negative_prompt_2,
+                prompt_template=prompt_template, num_videos_per_prompt=num_videos_per_prompt,
+                pooled_prompt_embeds=negative_pooled_prompt_embeds, device=device, max_sequence_length=max_sequence_length,
+                image_embed_interleave=image_embed_interleave)
         if prompt_embeds is None or pooled_prompt_embeds is None or prompt_attention_mask is None:
-            raise _lib.AlgHipError("the Llava prompt encoder is not built (SURVEY section 8 row f-3): pass prompt_embeds and "
-                                   "prompt_attention_mask (and pooled_prompt_embeds unless a CLIP text tower is attached as "
-                                   "`text_encoder_2` / `tokenizer_2`)")
+            raise _lib.AlgHipError("no Llava prompt encoder is attached (`text_encoder` / `tokenizer` / `image_processor`): pass "
+                                   "prompt_embeds and prompt_attention_mask (and pooled_prompt_embeds unless a CLIP text tower "
+                                   "is attached as `text_encoder_2` / `tokenizer_2`)")
         if do_true_cfg and (negative_prompt_embeds is None or negative_pooled_prompt_embeds is None
                             or negative_prompt_attention_mask is None):
             raise _lib.AlgHipError("true CFG needs negative_prompt_embeds, negative_pooled_prompt_embeds and "
