@@ -11,6 +11,7 @@ from .text_encoder_llava import LlavaConfig, LlavaForConditionalGeneration  # no
 from .text_encoder_t5 import T5EncoderConfig, T5EncoderModel, UMT5EncoderModel  # noqa: F401
 from .autoencoder_kl_cogvideox import AutoencoderKLCogVideoX, AutoencoderKLCogVideoXConfig  # noqa: F401
 from .autoencoder_kl_wan import AutoencoderKLWan, AutoencoderKLWanConfig  # noqa: F401
+from .autoencoder_kl_hunyuan_video import AutoencoderKLHunyuanVideo, AutoencoderKLHunyuanVideoConfig  # noqa: F401
 from ._lib import AlgHipError, build_library, load_library  # noqa: F401
 from .pipeline_cogvideox_image2video_lowpass import CogVideoXImageToVideoPipeline, CogVideoXPipelineOutput  # noqa: F401
 from .pipeline_hunyuan_video_image2video_lowpass import HunyuanVideoImageToVideoPipeline  # noqa: F401

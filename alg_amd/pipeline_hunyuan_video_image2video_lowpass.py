@@ -17,8 +17,9 @@ injected object with the diffusers HunyuanVideo signature (alg_amd's HIP DiT).  
 path and attached like diffusers registers them: the Llava-Llama-3 encoder (``text_encoder`` + ``tokenizer`` +
 ``image_processor``, hy:282-420: templated prompt next to the input image) and the CLIP-L text tower
 (``text_encoder_2``); without them pass ``prompt_embeds`` / ``pooled_prompt_embeds`` / ``prompt_attention_mask``
-(+ negatives).  The HunyuanVideo VAE is not built: pass the pre-encoded first frame as ``image_latents`` (extension kwarg)
-and use ``output_type="latent"``.
+(+ negatives).  With the HunyuanVideo VAE attached (``vae``: alg_amd's HIP `AutoencoderKLHunyuanVideo`) the conditioning image
+is encoded by ``prepare_latents`` (hy:550-599) and the final latents are decoded to frames (hy:1290-1295); without it pass the
+pre-encoded, scaled first frame as ``image_latents`` (extension kwarg) and use ``output_type="latent"``.
 """
 from __future__ import annotations
 
@@ -116,7 +117,7 @@ class HunyuanVideoImageToVideoPipeline:
                         device="cuda", **_):
         """Local-disk loader of a diffusers-format HunyuanVideo-I2V directory (`run.py:68-90`): `transformer/`,
         `text_encoder/` (Llava-Llama-3) + `tokenizer/` + `image_processor/`, `text_encoder_2/` (CLIP-L text tower) +
-        `tokenizer_2/`, `scheduler/`.  The HunyuanVideo VAE is not built: pass `image_latents` and use `output_type="latent"`."""
+        `tokenizer_2/`, `vae/`, `scheduler/`."""
         import os
 
         from .schedulers import FlowMatchEulerDiscreteScheduler
@@ -139,6 +140,9 @@ class HunyuanVideoImageToVideoPipeline:
             text_encoder_2 = CLIPTextModel.from_pretrained(model_path, device=device)
         if tokenizer_2 is None:
             tokenizer_2 = load_tokenizer(model_path, "tokenizer_2")
+        if vae is None and has("vae"):
+            from .autoencoder_kl_hunyuan_video import AutoencoderKLHunyuanVideo
+            vae = AutoencoderKLHunyuanVideo.from_pretrained(model_path, device=device)
         if scheduler is None:
             scheduler = (FlowMatchEulerDiscreteScheduler.from_pretrained(model_path) if has("scheduler")
                          else FlowMatchEulerDiscreteScheduler(shift=7.0))
@@ -195,10 +199,43 @@ class HunyuanVideoImageToVideoPipeline:
                 raise ValueError(
                     f"`prompt_template` has to contain a key `template` but only found {prompt_template.keys()}")
 
+    def preprocess_image(self, image, height, width):
+        """Minimal VideoProcessor.preprocess (hy:1046): tensors are taken as [B, 3, H, W] in [-1, 1]; PIL images are resized
+        (Lanczos) and scaled to [-1, 1]."""
+        if isinstance(image, torch.Tensor):
+            return (image if image.ndim == 4 else image.unsqueeze(0)).to(torch.float32)
+        imgs = image if isinstance(image, list) else [image]
+        arr = [np.asarray(im.convert("RGB").resize((width, height), resample=1), dtype=np.float32) / 255.0 for im in imgs]
+        return 2.0 * torch.from_numpy(np.stack(arr)).permute(0, 3, 1, 2).contiguous() - 1.0
+
+    def postprocess_video(self, video, output_type="np"):
+        """VideoProcessor.postprocess_video (hy:1295): [B, C, F, H, W] in [-1, 1] -> 'pt' | 'np' | 'pil'."""
+        v = (video * 0.5 + 0.5).clamp(0, 1)
+        if output_type == "pt":
+            return v.permute(0, 2, 1, 3, 4)
+        arr = v.permute(0, 2, 3, 4, 1).cpu().float().numpy()
+        if output_type == "np":
+            return arr
+        if output_type == "pil":
+            from PIL import Image
+            return [[Image.fromarray((f * 255).round().astype("uint8")) for f in vid] for vid in arr]
+        raise ValueError(f"{output_type} is not supported. Make sure to choose one of ['np', 'pt', 'pil']")
+
+    def encode_image(self, image, dtype, device):
+        """hy:575-584: every image alone through the VAE as a one-frame video, posterior MODE ("argmax": the generator is
+        not consumed), times the scaling factor -> [B, C, 1, h, w]."""
+        if self.vae is None:
+            raise _lib.AlgHipError("no HunyuanVideo VAE is attached to this pipeline: pass the pre-encoded, scaled first "
+                                   "frame as `image_latents` [B, C, 1, h, w]")
+        image = image.to(device=device, dtype=self.vae.dtype).unsqueeze(2)
+        lat = [self.vae.encode(img.unsqueeze(0)).latent_dist.mode() for img in image]
+        return torch.cat(lat, dim=0).to(dtype) * self.vae_scaling_factor
+
     def prepare_latents(self, image_latents, batch_size, num_channels_latents=32, height=720, width=1280,
                         num_frames=129, dtype=None, device=None, generator=None, latents=None,
                         image_condition_type="latent_concat", i2v_stable=False):
-        """hy:550-599 with the VAE-encoded (and scaled) first frame supplied as ``image_latents`` [B, C, 1, h, w]."""
+        """hy:550-599; ``image_latents`` is the VAE-encoded, scaled first frame [B, C, 1, h, w] (`encode_image`, or the
+        extension kwarg of `__call__`)."""
         if isinstance(generator, list) and len(generator) != batch_size:
             raise ValueError(
                 f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
@@ -234,8 +271,12 @@ class HunyuanVideoImageToVideoPipeline:
         if not use_low_pass_guidance:
             return None
         if not lp_filter_in_latent:
-            raise _lib.AlgHipError("lp_filter_in_latent=False re-encodes the filtered image every step and needs the "
-                                   "HunyuanVideo VAE (SURVEY section 8 row f-1, not built)")
+            # hy:741-748 reads `self.vae.config.latents_mean` / `.latents_std` / `.z_dim` (the Wan VAE's config entries, the
+            # branch was carried over from the Wan pipeline): AutoencoderKLHunyuanVideo has none of them, so the reference
+            # stops here with an AttributeError as well
+            raise AttributeError("lp_filter_in_latent=False is not runnable for HunyuanVideo: the branch (hy:741-748) "
+                                 "normalises with vae.config.latents_mean / latents_std / z_dim, which "
+                                 "AutoencoderKLHunyuanVideo's config does not have -- use lp_filter_in_latent=True")
         out = lp_utils.apply_low_pass_filter(orig_image_latents, lp_filter_type, lp_blur_sigma, lp_blur_kernel_size,
                                              lp_resize_factor)
         patch = getattr(getattr(self.transformer, "config", None), "patch_size", None)
@@ -418,9 +459,15 @@ class HunyuanVideoImageToVideoPipeline:
         if device.type != "cuda":
             raise _lib.AlgHipError("the ALG sampler's hot path is HIP-only: move the pipeline to a GPU "
                                    "(`pipe.to('cuda')`); there is no CPU fallback")
+        if output_type not in ("latent", "pt", "np", "pil"):                # before the 50-step loop, not after it
+            raise ValueError(f"{output_type} is not supported. Make sure to choose one of ['latent', 'np', 'pt', 'pil']")
+        if output_type != "latent" and getattr(self, "vae", None) is None:
+            raise _lib.AlgHipError("no HunyuanVideo VAE is attached to this pipeline: use output_type='latent'")
         if image_latents is None:
-            raise _lib.AlgHipError("the HunyuanVideo VAE is not built (SURVEY section 8 row f-1): pass the pre-encoded, "
-                                   "scaled first frame as `image_latents` [B, C, 1, h, w]")
+            if image is None:
+                raise ValueError("`image` (or the pre-encoded `image_latents`) is required")
+            # hy:1045-1046, 575-584
+            image_latents = self.encode_image(self.preprocess_image(image, height, width), torch.float32, device)
         # hy:483-490 / hy:1005-1013: the pooled embedding comes from the CLIP text tower when it is attached
         # (`clip_prompt` / `negative_clip_prompt` are extension kwargs: the reference's check_inputs forbids a prompt next to
         # prompt_embeds, and the Llava tower that would consume the prompt is not built)
@@ -457,8 +504,6 @@ class HunyuanVideoImageToVideoPipeline:
                                    "negative_prompt_attention_mask (no prompt encoder is attached)")
         if not isinstance(self.scheduler, FlowMatchEulerDiscreteScheduler):
             raise TypeError("this sampler drives alg_amd.schedulers.FlowMatchEulerDiscreteScheduler (HIP step)")
-        if output_type != "latent" and getattr(self, "vae", None) is None:   # before the 50-step loop, not after it
-            raise _lib.AlgHipError("no HunyuanVideo VAE is attached to this pipeline: use output_type='latent'")
         batch_size = prompt_embeds.shape[0]
 
         if image_condition_type == "latent_concat":
@@ -564,9 +609,13 @@ class HunyuanVideoImageToVideoPipeline:
                 prompt_embeds = outs.pop("prompt_embeds", prompt_embeds)
         self._current_timestep = None
 
-        if output_type != "latent":
-            raise _lib.AlgHipError("no HunyuanVideo VAE is attached to this pipeline: use output_type='latent'")
-        video = latents[:, :, 1:, :, :] if image_condition_type == "latent_concat" else latents
+        if output_type != "latent":   # hy:1290-1295
+            video = self.vae.decode(latents.to(self.vae.dtype) / self.vae_scaling_factor, return_dict=False)[0]
+            if image_condition_type == "latent_concat":
+                video = video[:, :, 4:, :, :]
+            video = self.postprocess_video(video, output_type=output_type)
+        else:
+            video = latents[:, :, 1:, :, :] if image_condition_type == "latent_concat" else latents
         self.maybe_free_model_hooks()
         if not return_dict:
             return (video,)

@@ -27,7 +27,7 @@ import sys
 import torch
 import yaml
 
-from alg_amd import (AutoencoderKLCogVideoX, AutoencoderKLWan, CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, CogVideoXTransformer3DModel,
+from alg_amd import (AutoencoderKLCogVideoX, AutoencoderKLHunyuanVideo, AutoencoderKLWan, CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, CogVideoXTransformer3DModel,
                      CogVideoXTransformerConfig, FlowMatchEulerDiscreteScheduler, HunyuanVideoImageToVideoPipeline,
                      HunyuanVideoTransformer3DModel, HunyuanVideoTransformerConfig, UniPCMultistepScheduler,
                      WanImageToVideoPipeline, WanTransformer3DModel, WanTransformerConfig, parallel)
@@ -92,7 +92,9 @@ def build_pipeline(config, args, device):
         over = dict(flow_shift=config["model"].get("flow_shift"), invert_sigmas=bool(config["model"].get("flow_reverse", False)))
         if args.synthetic:
             transformer = _synthetic_transformer(model_path, config, device)
-            pipe = HunyuanVideoImageToVideoPipeline(transformer=transformer,
+            full = not config["model"].get("synthetic_config")
+            vae = AutoencoderKLHunyuanVideo.from_synthetic(device=device) if full else None   # decode: hy:1291-1292 on HIP
+            pipe = HunyuanVideoImageToVideoPipeline(transformer=transformer, vae=vae,
                                                     scheduler=FlowMatchEulerDiscreteScheduler(shift=7.0, **over))
         else:
             pipe = HunyuanVideoImageToVideoPipeline.from_pretrained(model_path, device=device)
