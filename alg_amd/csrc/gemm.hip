@@ -1,5 +1,5 @@
 // C ABI entry of the bf16 GEMM: argument validation and schedule dispatch.  The kernel template lives in gemm_kernel.h; one
-// translation unit per schedule (gemm_p0.hip, gemm_p6.hip, gemm_p7.hip) instantiates it.
+// translation unit per schedule (gemm_p0.hip, gemm_p6.hip, gemm_p7.hip, gemm_p8.hip) instantiates it.
 #include <stdlib.h>
 
 #include "common.h"
@@ -9,12 +9,13 @@ constexpr int BM = 256, BN = 256;
 int launch_gemm_p0(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p7(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
+int launch_gemm_p8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 static int gemm_pipe() {
   const char* e = getenv("ALG_GEMM_PIPE");
   const int v = e ? atoi(e) : 6;  // default: 8-wave ping-pong over half-tiles (fastest measured)
-  return (v == 0 || v == 6 || v == 7) ? v : 6;
+  return (v == 0 || v == 6 || v == 7 || v == 8) ? v : 6;
 }
 }  // namespace alg
 
@@ -121,6 +122,7 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
   switch (gemm_pipe()) {
     case 0: return launch_gemm_p0(a, m_tiles, n_tiles, nwg, s);   // 2-stage ring, 8 waves
     case 7: return launch_gemm_p7(a, m_tiles, n_tiles, nwg, s);   // 4 waves, every memory op behind an MFMA
+    case 8: return launch_gemm_p8(a, m_tiles, n_tiles, nwg, s);   // 4 waves, 4-stage BK = 32 ring, never drains
     default: return launch_gemm_p6(a, m_tiles, n_tiles, nwg, s);  // 8-wave ping-pong over half-tiles
   }
 }

@@ -13,7 +13,14 @@
 //                issue; counted vmcnt(6), the DMA queue never drains;
 //        PIPE 0: 8 waves x 128x64, 2 stages of BK = 64, drain + barrier per K-tile;
 //        PIPE 7: 4 waves x 128x128 (one wave per SIMD, 1/3 fewer fragment reads per MFMA), every memory instruction in
-//                the issue shadow of an MFMA.
+//                the issue shadow of an MFMA; 2 stages of BK = 64, the DMA queue drains once per K-tile;
+//        PIPE 8: 4 waves x 128x128 on a 4-stage ring of BK = 32 half-tiles ([row][64 B], own swizzle): per stage ONE
+//                counted wait + ONE barrier, then 32 MFMAs with the next stage's 16 fragment reads and the DMA of the
+//                stage three ahead spread evenly behind them -- the queue never drains (vmcnt(8)), a third fewer
+//                fragment reads than the 8-wave layouts, 2 barriers per K = 64 instead of 8; staged epilogue.  Measured
+//                (profiles/r2_gemm_pipe8_ablation.txt): 870-950 TFLOP/s against 930-1140 for PIPE 6 -- a BK = 32 stage
+//                is fetched as 64-byte row segments, i.e. every 128-byte line travels L2 -> L1 twice; with whole-line
+//                requests (timing experiment) it ties PIPE 6, without any DMA it runs 1075-1405.  Opt-in, kept for A/B.
 //     Measured and removed from the build (they cost 5 minutes of compile time; DESIGN.md section 4b keeps the numbers):
 //     4-stage BK = 32 rings (plain / fragment pipeline across the barrier / asm ds_reads + counted lgkmcnt) and two
 //     simpler 4-wave schedules.
@@ -91,8 +98,9 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
   constexpr int EPS = 16 / (int)sizeof(elem_t);  // elements per 16-byte slot
   constexpr int GEMM_THREADS = 2 * WNW * 64;  // 512 (8 waves, 128x64 each) or 256 (4 waves, 128x128 each)
   constexpr int NT = BN / WNW / 32;           // 32-column MFMA tiles per wave: 2 or 4
-  static_assert(PIPE == 0 || PIPE == 6 || PIPE == 7, "schedules built: 0 (2-stage ring), 6 (ping-pong), 7 (4-wave interleaved)");
-  static_assert((PIPE == 7) == (WNW == 2), "PIPE 7 is the 4-wave layout, the others run 8 waves");
+  static_assert(PIPE == 0 || PIPE == 6 || PIPE == 7 || PIPE == 8,
+                "schedules built: 0 (2-stage ring), 6 (ping-pong), 7 (4-wave interleaved), 8 (4-wave BK = 32 ring)");
+  static_assert((PIPE == 7 || PIPE == 8) == (WNW == 2), "PIPE 7 / 8 are the 4-wave layouts, the others run 8 waves");
   constexpr bool BK64 = true;
   constexpr bool PP = PIPE == 6;  // ping-pong: a wave owns 2 x 64 rows (one piece per A half-tile) x 2 x 32 columns
   constexpr int BK = FP8 ? 128 : 64;
@@ -501,6 +509,114 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
     }
   }
 
+  if constexpr (PIPE == 8) {
+    // 4 waves x 128x128, one wave per SIMD, a 4-stage ring of BK = 32 half-tiles.  Stage s of the ring is
+    // [A: 256 rows x 64 B | B: 256 rows x 64 B] = 32 KiB; logical 16-byte slot q of row r sits at q ^ ((r >> 2) & 3) (16
+    // consecutive rows x one slot cover all 64 banks; lanes l and l + 32 read slots q and q ^ 1 of one row).
+    // Step j (one BK = 32 stage, 32 MFMAs from the fragments in F[j & 1]):
+    //     s_waitcnt vmcnt(16) lgkmcnt(0)  my part of stage j+1 has landed (stages j+2, j+3 stay in flight), F[j & 1] is complete
+    //     s_barrier                       => stage j+1 is whole, and every wave is done READING stage j (its fragments
+    //                                        were fetched during step j-1), so that slot is free
+    //     16 fragment reads of stage j+1 -> F[(j + 1) & 1], 8 DMA of stage j+4 -> the slot of stage j, 32 MFMAs:
+    //     16 x {MFMA, ds_read}, 8 x {MFMA, DMA}, 8 MFMA.
+    constexpr int SB = 32768, OPB = 16384;
+    const int nst = p.K / 32;
+    const int sw8 = (l31 >> 2) & 3;
+    const elem_t* a8[4];
+    const elem_t* b8[4];
+    {
+      const int r0 = tid >> 2, q = (tid & 3) ^ ((tid >> 4) & 3);   // row of round 0 and the LOGICAL slot this lane fetches
+      const int am = (abl & 8) ? 0 : m0, bn = (abl & 8) ? 0 : n0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a8[i] = A + (int64_t)min(am + i * 64 + r0, p.M - 1) * p.lda + q * 8;
+        b8[i] = B + (int64_t)min(bn + i * 64 + r0, p.N - 1) * p.ldb + q * 8;
+      }
+    }
+    auto src_off = [&](int st) -> int64_t { return (int64_t)st * 32; };
+    auto stage8 = [&](int st) {
+      char* base = smem + (st & 3) * SB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(a8[i] + src_off(st)), (lptr_t)(base + (i * 256 + wave * 64) * 16), 16, 0, ALG_AUX_A);
+        __builtin_amdgcn_global_load_lds((gptr_t)(b8[i] + src_off(st)), (lptr_t)(base + OPB + (i * 256 + wave * 64) * 16), 16, 0, ALG_AUX_B);
+      }
+    };
+    const int a_off8 = (wm * 128 + l31) * 64, b_off8 = (wn * 128 + l31) * 64;
+    auto load8 = [&](int st, bf16x8 (&af)[2][4], bf16x8 (&bfr)[2][4]) {
+      const char* As = smem + (st & 3) * SB;
+      const char* Bs = As + OPB;
+#pragma unroll
+      for (int ksl = 0; ksl < 2; ++ksl) {
+        const int so = ((2 * ksl + h2) ^ sw8) * 16;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bfr[ksl][nt] = *(const bf16x8*)(Bs + b_off8 + nt * 32 * 64 + so);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[ksl][mt] = *(const bf16x8*)(As + a_off8 + mt * 32 * 64 + so);
+      }
+    };
+    auto mma8 = [&](const bf16x8 (&af)[2][4], const bf16x8 (&bfr)[2][4]) {
+#pragma unroll
+      for (int ksl = 0; ksl < 2; ++ksl)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = fma_frag(bfr[ksl][nt], af[ksl][mt], acc[mt][nt]);
+    };
+    bf16x8 fa0[2][4], fb0[2][4], fa1[2][4], fb1[2][4];
+    // One code copy for every step: past the end of K the DMA re-fetches the last stage into a slot nobody reads again and
+    // the fragment reads fetch stale data into registers nobody uses (a few KiB of L2 traffic per tile; separate tail
+    // copies made hipcc shuffle the 256 accumulators through scratch).
+    auto step = [&](int j, bf16x8 (&ca)[2][4], bf16x8 (&cb)[2][4], bf16x8 (&na)[2][4], bf16x8 (&nb)[2][4]) {
+      asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef ALG_P8_NO_READS   // build-time ablations (results are garbage; timing shows what the loop is bound by)
+      load8(j + 1, na, nb);
+#endif
+#ifndef ALG_P8_NO_DMA
+      {
+        const int st = min(j + 4, nst - 1);
+        char* base = smem + (j & 3) * SB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_global_load_lds((gptr_t)(a8[i] + src_off(st)), (lptr_t)(base + (i * 256 + wave * 64) * 16), 16, 0, ALG_AUX_A);
+          __builtin_amdgcn_global_load_lds((gptr_t)(b8[i] + src_off(st)), (lptr_t)(base + OPB + (i * 256 + wave * 64) * 16), 16, 0, ALG_AUX_B);
+        }
+      }
+#endif
+      mma8(ca, cb);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    stage8(0);
+    stage8(1);   // K is a multiple of 64: at least two stages
+    stage8(min(2, nst - 1));
+    stage8(min(3, nst - 1));
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load8(0, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < nst; j += 2) {
+      step(j, fa0, fb0, fa1, fb1);
+      step(j + 1, fa1, fb1, fa0, fb0);
+    }
+    // the over-the-end DMA must have landed (and everybody must be past its last fragment read) before the epilogue
+    // parks the tile in the ring
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
   // ---- epilogue: bias, activation, gate, residual, 8-byte stores ----
   // lane owns row m = m0 + wm*128 + mt*32 + l31 and, per register quad g, columns n = nbase + 8g + 4h2 + (0..3)
   const bf16_t* bias = (const bf16_t*)p.bias;
@@ -525,16 +641,19 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
   // 16 bytes per lane along rows, and applies gate / residual and stores with 16-byte accesses -- 64 contiguous bytes per
   // row segment instead of 16.  Bank-conflict-free both ways (chunk XOR (row >> 2) & 3).  Needs 16-byte aligned rows of
   // C / R / gate and N % 8 == 0; anything else takes the element-exact path below.
-  if constexpr (PP) {
+  // tile-local origin of the wave's 32x32 block (mt, nt) in either layout
+  auto blk_row = [&](int mt) { return PP ? (mt >> 1) * 128 + wm * 64 + (mt & 1) * 32 : wm * 128 + mt * 32; };
+  auto blk_col = [&](int nt) { return PP ? nt * 128 + wn * 32 : wn * (NT * 32) + nt * 32; };
+  if constexpr (PP || PIPE == 8) {
     const bool staged = (p.N & 7) == 0 && (ldc & 7) == 0 && (p.strideC & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 &&
                         (col0 & 15) == 0 && !(abl & 32) &&
                         (!RES || ((ldr & 7) == 0 && (p.strideR & 7) == 0 && (((uintptr_t)p.R) & 15) == 0)) &&
                         (!(RES && p.gate) || ((p.strideGate & 7) == 0 && (gate_seg & 7) == 0 && (((uintptr_t)p.gate) & 15) == 0));
     if (staged) {
-      char* const my = smem + wave * 16384;
+      char* const my = smem + wave * (4 * NT * 2048);   // 16 KiB (8 waves) or 32 KiB (4 waves) of the free ring
       auto park_band = [&](auto mt_c) {
         constexpr int mt = decltype(mt_c)::value;
-        const int row = m0 + (mt >> 1) * 128 + wm * 64 + (mt & 1) * 32 + l31;
+        const int row = m0 + blk_row(mt) + l31;
         const int rowc = row < p.M ? row : p.M - 1;
         const float brow = (bias && bias_row) ? bf2f(bias[rowc]) : 0.0f;
         const float a_sc = FP8 ? p.a_scale[(int64_t)b * p.strideAScale + rowc] : 1.0f;
@@ -542,7 +661,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int n = n0 + nt * 128 + wn * 32 + 8 * g + 4 * h2;
+            const int n = n0 + blk_col(nt) + 8 * g + 4 * h2;
             float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f};
             if (n < p.N) {
               if (bias && !bias_row) unpack4(*(const uint2*)(bias + n), bv);
@@ -562,7 +681,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
             uint2 o;
             o.x = pack_bf2(v[0], v[1]);
             o.y = pack_bf2(v[2], v[3]);
-            *(uint2*)(my + (mt * 2 + nt) * 2048 + l31 * 64 + ((g ^ ((l31 >> 2) & 3)) * 16) + h2 * 8) = o;
+            *(uint2*)(my + (mt * NT + nt) * 2048 + l31 * 64 + ((g ^ ((l31 >> 2) & 3)) * 16) + h2 * 8) = o;
           }
       };
       park_band(IntC<0>{});
@@ -574,25 +693,26 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
       // sixteen serialised HBM round trips per tile (measured: 21.7 us of per-tile overhead with a residual vs 6.9 us
       // without, scripts/gemm_k_sweep.py).  A thread reads exactly the elements it later writes, so all sixteen loads
       // can go out first; the accumulators are parked, their registers are free.
-      uint4 rbuf[RES ? 16 : 1];
+      constexpr int NIT = 8 * NT;   // 32x32 blocks x two 16-row halves
+      uint4 rbuf[RES ? NIT : 1];
       if (RES) {
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-          const int blk = it >> 1, mt = blk >> 1, nt = blk & 1;
+        for (int it = 0; it < NIT; ++it) {
+          const int blk = it >> 1, mt = blk / NT, nt = blk % NT;
           const int rr = (it & 1) * 16 + (lane >> 2), ch = lane & 3;
-          const int row = m0 + (mt >> 1) * 128 + wm * 64 + (mt & 1) * 32 + rr;
-          const int c0 = n0 + nt * 128 + wn * 32 + ch * 8;
+          const int row = m0 + blk_row(mt) + rr;
+          const int c0 = n0 + blk_col(nt) + ch * 8;
           rbuf[it] = (row < p.M && c0 < p.N) ? *(const uint4*)(R + row * ldr + c0) : make_uint4(0, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int blk = it >> 1, mt = blk >> 1, nt = blk & 1;
+      for (int it = 0; it < NIT; ++it) {
+        const int blk = it >> 1, mt = blk / NT, nt = blk % NT;
         const int rr = (it & 1) * 16 + (lane >> 2), ch = lane & 3;
         const uint4 raw = *(const uint4*)(my + blk * 2048 + rr * 64 + ((ch ^ ((rr >> 2) & 3)) * 16));
-        const int row = m0 + (mt >> 1) * 128 + wm * 64 + (mt & 1) * 32 + rr;
-        const int c0 = n0 + nt * 128 + wn * 32 + ch * 8;
+        const int row = m0 + blk_row(mt) + rr;
+        const int c0 = n0 + blk_col(nt) + ch * 8;
         if (row < p.M && c0 < p.N) {
           uint4 outv = raw;
           if (RES) {
@@ -744,7 +864,7 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
 inline int gemm_pipe() {
   const char* e = getenv("ALG_GEMM_PIPE");
   const int v = e ? atoi(e) : 6;  // default: 8-wave ping-pong over half-tiles (fastest measured)
-  return (v == 0 || v == 6 || v == 7) ? v : 6;
+  return (v == 0 || v == 6 || v == 7 || v == 8) ? v : 6;
 }
 
 // persistent launch: one workgroup per CU walks the tile list (saves a workgroup launch + teardown per tile: at K = 3072

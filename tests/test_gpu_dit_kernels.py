@@ -26,7 +26,7 @@ def rel_err(got, ref):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.fixture(params=["7", "6", "0"], ids=["4waves-interleaved", "pingpong-halftiles", "dbufBK64"])
+@pytest.fixture(params=["8", "7", "6", "0"], ids=["4waves-bk32-ring", "4waves-interleaved", "pingpong-halftiles", "dbufBK64"])
 def gemm_pipe(request, monkeypatch):
     """Every GEMM test runs on both staging pipelines (the default 4-stage ring and the 2-stage A/B variant)."""
     monkeypatch.setenv("ALG_GEMM_PIPE", request.param)
@@ -297,11 +297,11 @@ def test_pingpong_gemm_race_screen(monkeypatch):
         a = torch.randn(M, K, generator=g, device="cuda").to(BF)
         w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(BF)
         outs = {}
-        for pipe in ("0", "6", "6", "6"):
+        for pipe in ("0", "6", "6", "6", "8", "8"):
             monkeypatch.setenv("ALG_GEMM_PIPE", pipe)
             c = torch.empty(M, N, dtype=BF, device="cuda")
             _lib.gemm(a, w, c, M, N, K, K, K, N)
             if pipe in outs:
                 assert torch.equal(c, outs["0"]), (M, N, K)
             outs.setdefault(pipe, c)
-        assert torch.equal(outs["6"], outs["0"]), (M, N, K)
+        assert torch.equal(outs["6"], outs["0"]) and torch.equal(outs["8"], outs["0"]), (M, N, K)
