@@ -13,7 +13,10 @@ import torch.distributed as dist
 
 
 def env_world():
-    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    """(rank, local_rank, world) of the torchrun environment.  ALG_DIST_ONE_GPU=1 (test hook: exercising the multi-process
+    launch path on a one-GPU box, together with ALG_DIST_BACKEND=gloo) maps every local rank to device 0."""
+    local = 0 if os.environ.get("ALG_DIST_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    return int(os.environ.get("RANK", "0")), local, int(os.environ.get("WORLD_SIZE", "1"))
 
 
 def init_distributed(backend=None):
@@ -23,7 +26,7 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("ALG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
