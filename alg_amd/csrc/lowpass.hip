@@ -370,8 +370,8 @@ extern "C" int alg_gaussian_blur(const void* in, void* out, int64_t planes, int 
     set_error("alg_gaussian_blur: bad argument (planes=%lld H=%d W=%d)", (long long)planes, H, W);
     return ALG_EINVAL;
   }
-  if (ksize <= 0 || (ksize & 1) == 0 || ksize > 255) {
-    set_error("alg_gaussian_blur: kernel size must be odd and in [1, 255], got %d", ksize);
+  if (ksize <= 0 || (ksize & 1) == 0) {
+    set_error("alg_gaussian_blur: kernel size must be odd and positive, got %d", ksize);
     return ALG_EINVAL;
   }
   if (!(sigma > 0.0f)) {
@@ -393,7 +393,9 @@ extern "C" int alg_gaussian_blur(const void* in, void* out, int64_t planes, int 
   if (planes == 0) return ALG_OK;
   const size_t lds = (((size_t)2 * H * W + ksize) * 4 + 15) & ~(size_t)15;
   hipStream_t s = (hipStream_t)stream;
-  if (lds > 160 * 1024 || force_global()) return gaussian_big(in, out, planes, H, W, ksize, sigma, dtype, s);
+  // kernels wider than 255 taps (an integer `lp_blur_kernel_size` on pixel-sized planes; reflect padding needs ksize / 2 <
+  // min(H, W), so such planes are at least 128 x 128) always take the global-memory passes, which have no tap-count limit
+  if (lds > 160 * 1024 || ksize > 255 || force_global()) return gaussian_big(in, out, planes, H, W, ksize, sigma, dtype, s);
   int rc;
   if (!force_v1()) {
     rc = gaussian_v2(in, out, planes, H, W, ksize, sigma, dtype, s);

@@ -84,18 +84,18 @@ __device__ __forceinline__ int reflect(int i, int n) {
 }
 
 // g[j] = exp(-0.5 (x / sigma)^2) / sum, as lowpass.hip's gaussian_kernel builds it
-__global__ void gauss_weights_kernel(float* g, int ksize, float sigma) {
-  __shared__ float raw[256];
+__global__ void gauss_weights_kernel(float* g, int ksize, float sigma) {   // one workgroup, any ksize
   const int tid = threadIdx.x;
-  if (tid < ksize) {
-    const float x = (float)tid - 0.5f * (float)(ksize - 1);
+  for (int j = tid; j < ksize; j += blockDim.x) {
+    const float x = (float)j - 0.5f * (float)(ksize - 1);
     const float q = __fdiv_rn(x, sigma);
-    raw[tid] = expf(__fmul_rn(-0.5f, __fmul_rn(q, q)));
+    g[j] = expf(__fmul_rn(-0.5f, __fmul_rn(q, q)));
   }
   __syncthreads();
   float tot = 0.0f;
-  for (int j = 0; j < ksize; ++j) tot = __fadd_rn(tot, raw[j]);
-  if (tid < ksize) g[tid] = __fdiv_rn(raw[tid], tot);
+  for (int j = 0; j < ksize; ++j) tot = __fadd_rn(tot, g[j]);   // the sequential sum, in every thread
+  __syncthreads();
+  for (int j = tid; j < ksize; j += blockDim.x) g[j] = __fdiv_rn(g[j], tot);
 }
 
 template <typename TI>
@@ -179,7 +179,7 @@ static int gaussian_big_t(const T* in, T* out, int64_t planes, int H, int W, int
   }
   float* ws = nullptr;
   const size_t n = (size_t)planes * H * W;
-  if (int rc = big::ws_alloc(&ws, n + 256, s, "alg_gaussian_blur")) return rc;
+  if (int rc = big::ws_alloc(&ws, n + (size_t)((ksize + 255) & ~255), s, "alg_gaussian_blur")) return rc;
   float* g = ws + n;
   hipLaunchKernelGGL(big::gauss_weights_kernel, dim3(1), dim3(256), 0, s, g, ksize, sigma);
   const dim3 grid((W + 255) / 256, H, (unsigned)planes);

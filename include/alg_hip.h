@@ -48,7 +48,9 @@ int alg_down_up(const void* in, void* out, int64_t planes, int H, int W, int h1,
                 int round_intermediate, void* stream);
 
 /* lp:40-47  torchvision gaussian_blur(kernel_size=[k,k], sigma=[s,s]): reflect pad k/2, separable
- * correlation with g = exp(-0.5 (x/s)^2)/sum.  ksize must be odd, ksize/2 < min(H, W), sigma > 0. */
+ * correlation with g = exp(-0.5 (x/s)^2)/sum.  ksize must be odd (any size: more than 255 taps run through the global-memory
+ * passes), ksize/2 < min(H, W), sigma > 0.  Weights are fp32 for every dtype (torchvision builds them in the image dtype:
+ * for bf16 tensors see DESIGN.md section 2, "Rounding semantics"). */
 int alg_gaussian_blur(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype,
                       void* stream);
 

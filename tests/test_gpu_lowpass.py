@@ -175,6 +175,18 @@ def test_gaussian_pixel_sized_planes(device):
     assert (np.abs(yb - refb) <= bf16_ulp(refb) + 1e-3).all()
 
 
+def test_gaussian_more_than_255_taps(device):
+    """An integer `lp_blur_kernel_size` larger than 255 (lp:44-46 accepts any size; reflect padding needs k // 2 < min(H, W)):
+    the global-memory passes have no tap-count limit."""
+    g = torch.Generator().manual_seed(30)
+    x = torch.randn(1, 2, 300, 340, generator=g)
+    y = lp_utils.apply_low_pass_filter(x.to(device), "gaussian_blur", 60.0, 301, 1.0).cpu().numpy()
+    ref = lp_oracle.gaussian_blur(x.numpy().astype(np.float64), 301, 60.0)
+    assert np.abs(y - ref).max() <= 1e-5
+    with pytest.raises(RuntimeError, match="Padding size"):
+        lp_utils.apply_low_pass_filter(x.to(device), "gaussian_blur", 60.0, 601, 1.0)
+
+
 def test_global_memory_path_is_bit_identical_to_the_lds_path(device, monkeypatch):
     """ALG_LOWPASS_FORCE_GLOBAL=1 (debug knob) sends LDS-sized planes through lowpass_big.hip: same bits."""
     g = torch.Generator().manual_seed(31)
