@@ -229,6 +229,12 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
 
 using namespace alg;
 
+namespace alg {
+int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq, int Skv,
+                        int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t vt_bs, int64_t vt_rs, int64_t o_bs,
+                        int64_t o_rs, float scale, hipStream_t stream);
+}
+
 static int flash_attn_d128_entry(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq,
                                  int Skv, int64_t q_bstride, int64_t q_rstride, int64_t k_bstride, int64_t k_rstride,
                                  int64_t vt_bstride, int64_t vt_rstride, int64_t o_bstride, int64_t o_rstride,
@@ -255,6 +261,11 @@ static int flash_attn_d128_entry(const void* q, const void* k, const void* vt, v
     set_error("alg_flash_attn_d128: vt row stride %lld must cover Skv rounded up to %d", (long long)vt_rstride,
               a128::KVB);
     return ALG_EINVAL;
+  }
+  if (!causal && kv_group == 1) {   // long self-attention: 64 queries per wave (attention128_q64.hip); 1 = not covered
+    const int rc = flash_attn_d128_q64(q, k, vt, o, batch, heads, Sq, Skv, q_bstride, q_rstride, k_bstride, k_rstride, vt_bstride,
+                                       vt_rstride, o_bstride, o_rstride, scale, (hipStream_t)stream);
+    if (rc <= 0) return rc;
   }
   a128::P p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;

@@ -48,6 +48,42 @@ def test_flash_attn_d128_matches_sdpa(B, H, Sq, Skv):
     assert (o.float() - ref).abs().mean().item() < 2e-3
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 1024), (2, 3, 257, 1000), (1, 1, 256, 513), (1, 2, 1300, 2050),
+                                          (1, 1, 64, 544), (1, 2, 520, 575)])
+def test_flash_attn_d128_q64_kernel(B, H, Sq, Skv, monkeypatch):
+    """The long self-attention form (attention128_q64.hip: 64 queries per wave, software-pipelined 32-key half-tiles, taken for
+    >= 8 KV tiles): against fp32 SDPA and against the 32-query kernel (ALG_ATTN128_Q64=0) on the same tensors.  Ragged key
+    counts: a last tile whose second half is partly (1000, 2050), entirely (513, 544: 1 / 32 keys) masked, or exactly half
+    (575 = 8 x 64 + 63), query blocks that end mid-wave, scores large enough to trip the lazy running max's exact path."""
+    D = H * 128
+    q, k, v = _rand((B, Sq, D), 11), _rand((B, Skv, D), 12), _rand((B, Skv, D), 13)
+    q[:, : Sq // 2] *= 6.0                       # half the queries: scores ~ +-25 -> row sums far beyond the first tile's
+    k[:, Skv // 3] *= 8.0                        # and one key that dominates late
+    s_pad = (Skv + 63) // 64 * 64
+    vt = make_vt(v, s_pad)
+    scale = 1.0 / math.sqrt(128)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ALG_ATTN128_Q64", flag)
+        o = torch.full((B, Sq, D), 7.0, dtype=BF, device=DEV)
+        _lib.flash_attn_d128(q, k, vt, o, B, H, Sq, Skv, Sq * D, D, Skv * D, D, D * s_pad, s_pad, Sq * D, D, scale)
+        outs[flag] = o
+    qh = q.float().view(B, Sq, H, 128).transpose(1, 2)
+    kh = k.float().view(B, Skv, H, 128).transpose(1, 2)
+    vh = v.float().view(B, Skv, H, 128).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(B, Sq, D)
+    for flag, o in outs.items():
+        assert bool(torch.isfinite(o.float()).all()), flag
+        assert (o.float() - ref).abs().max().item() < 3e-2, flag
+        assert (o.float() - ref).abs().mean().item() < 2e-3, flag
+    # same arithmetic per query (S^T = K Q^T, bf16 P, fp32 O); only the lazy max's offsets may differ (32- vs 64-key steps)
+    assert (outs["1"].float() - outs["0"].float()).abs().max().item() < 1.6e-2
+    monkeypatch.setenv("ALG_ATTN128_Q64", "1")
+    o2 = torch.empty_like(outs["1"])
+    _lib.flash_attn_d128(q, k, vt, o2, B, H, Sq, Skv, Sq * D, D, Skv * D, D, D * s_pad, s_pad, Sq * D, D, scale)
+    assert torch.equal(o2, outs["1"])             # deterministic
+
+
 def test_flash_attn_d128_rejects_bad_arguments():
     q = _rand((1, 64, 128), 4)
     with pytest.raises(_lib.AlgHipError):  # vt row stride shorter than Skv rounded up
