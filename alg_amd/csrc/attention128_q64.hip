@@ -64,6 +64,9 @@ struct P {
 #define ALG_FR3 "a[252:255]"
 template <int SLOT, int OFF>
 __device__ __forceinline__ void frag_read(uint32_t addr) {
+#ifdef ALG_Q64_NO_READS   // build-time ablations (garbage results; timing shows what the loop is bound by)
+  return;
+#endif
   if constexpr (SLOT == 0) asm volatile("ds_read_b128 " ALG_FR0 ", %0 offset:%1" ::"v"(addr), "n"(OFF) : ALG_FRAG_CLOBBER);
   if constexpr (SLOT == 1) asm volatile("ds_read_b128 " ALG_FR1 ", %0 offset:%1" ::"v"(addr), "n"(OFF) : ALG_FRAG_CLOBBER);
   if constexpr (SLOT == 2) asm volatile("ds_read_b128 " ALG_FR2 ", %0 offset:%1" ::"v"(addr), "n"(OFF) : ALG_FRAG_CLOBBER);
@@ -164,37 +167,50 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
   const int n_tiles = (Skv + KVB - 1) / KVB;
   const bool ragged = (Skv & (KVB - 1)) != 0;
 
-  // DMA.  K tile: 64 rows x 16 slots (256 B rows), four rounds of 16 rows; physical slot tid & 15 holds logical slot
-  // (tid & 15) ^ (row & 15).  V^T tile: 128 d-rows x 8 slots, four rounds of 32 rows, swizzle (row >> 1) & 7.  Tiles past the
-  // end re-fetch the last one (uniform instruction counts for the counted waits; nobody uses the data).
-  // The per-lane source offsets are RECOMPUTED from the thread id for every tile (a handful of VALU instructions): kept live
-  // across the loop they do not fit next to Q, both P buffers and the fragments, and a spilled value comes back through
-  // scratch_load + s_waitcnt vmcnt(0) -- which would drain the DMA queue eight times per tile.  The empty asm keeps hipcc
-  // from hoisting them.  Element offsets inside one (batch, head) fit 32 bits (checked on the host).
+  // DMA: buffer_load ... lds with the tile's origin in the SCALAR offset and a per-lane byte offset that never changes -- no
+  // vector arithmetic per tile (the global_load_lds form cost ~5 VALU instructions per DMA for its 64-bit lane addresses, in
+  // a loop whose vector pipe is the busy one), and rows past Skv read as zeros through the descriptor's bounds check instead
+  // of a per-lane clamp.  K tile: 64 rows x 16 slots (256 B rows), four rounds of 16 rows; physical slot tid & 15 holds
+  // logical slot (tid & 15) ^ (row & 15).  V^T tile: 128 d-rows x 8 slots, four rounds of 32 rows, swizzle (row >> 1) & 7.
+  // Tiles past the end re-fetch the last one (uniform instruction counts for the counted waits; nobody uses the data).
   const int k_rs = (int)p.k_rs, vt_rs = (int)p.vt_rs;
-  auto stage_k = [&](int tile) {
-    int tl = tid;
-    asm volatile("" : "+v"(tl));
-    const int kv0 = min(tile, n_tiles - 1) * KVB;
-    const int row = tl >> 4, slot = (tl & 15) ^ ((tl >> 4) & 15);
-    char* dst = k_ring + (tile & (NS - 1)) * K_TILE;
+  const __amdgpu_buffer_rsrc_t k_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (int)(((int64_t)(Skv - 1) * k_rs + 128) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)VT, 0, (int)((int64_t)128 * vt_rs * 2), 0x00020000);
+  int k_vo[4], v_vo[4];
+  {
+    const int row = tid >> 4, slot = (tid & 15) ^ ((tid >> 4) & 15);
+    const int vrow = tid >> 3, vslot = (tid & 7) ^ ((tid >> 4) & 7);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const uint32_t off = (uint32_t)min(kv0 + row + i * 16, Skv - 1) * (uint32_t)k_rs + (uint32_t)slot * 8u;
-      __builtin_amdgcn_global_load_lds((gptr_t)(K + off), (lptr_t)(dst + (i * 256 + wave * 64) * 16), 16, 0, 0);
+      k_vo[i] = ((row + i * 16) * k_rs + slot * 8) * 2;
+      v_vo[i] = ((vrow + i * 32) * vt_rs + vslot * 8) * 2;
+    }
+  }
+  // one DMA instruction of the pair [K(tk), V(tv)]: pieces 0 - 3 the K rounds, 4 - 7 the V^T rounds
+  auto stage_piece = [&](int tk, int tv, auto piece_c) {
+    constexpr int PC = decltype(piece_c)::value;
+    if constexpr (PC < 4) {
+      const int so = min(tk, n_tiles - 1) * KVB * k_rs * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(k_ring + (tk & (NS - 1)) * K_TILE + (PC * 256 + wave * 64) * 16), 16,
+                                               k_vo[PC], so, 0, 0);
+    } else {
+      const int so = min(tv, n_tiles - 1) * KVB * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(v_ring + (tv & (NS - 1)) * V_TILE + ((PC - 4) * 256 + wave * 64) * 16),
+                                               16, v_vo[PC - 4], so, 0, 0);
     }
   };
+  auto stage_k = [&](int tile) {
+    stage_piece(tile, 0, std::integral_constant<int, 0>{});
+    stage_piece(tile, 0, std::integral_constant<int, 1>{});
+    stage_piece(tile, 0, std::integral_constant<int, 2>{});
+    stage_piece(tile, 0, std::integral_constant<int, 3>{});
+  };
   auto stage_v = [&](int tile) {
-    int tl = tid;
-    asm volatile("" : "+v"(tl));
-    const int kv0 = min(tile, n_tiles - 1) * KVB;
-    const int row = tl >> 3, slot = (tl & 7) ^ ((tl >> 4) & 7);
-    char* dst = v_ring + (tile & (NS - 1)) * V_TILE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t off = (uint32_t)(row + i * 32) * (uint32_t)vt_rs + (uint32_t)(slot * 8 + kv0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(VT + off), (lptr_t)(dst + (i * 256 + wave * 64) * 16), 16, 0, 0);
-    }
+    stage_piece(0, tile, std::integral_constant<int, 4>{});
+    stage_piece(0, tile, std::integral_constant<int, 5>{});
+    stage_piece(0, tile, std::integral_constant<int, 6>{});
+    stage_piece(0, tile, std::integral_constant<int, 7>{});
   };
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
@@ -295,11 +311,13 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
       }
   };
   auto finish_softmax = [&](f32x16 (&s)[2], bf16x8 (&pf)[2][2], float (&psum)[2]) {
+    if (__any(!(psum[0] < 1.0995116e12f) || !(psum[1] < 1.0995116e12f))) {   // 2^40; also inf / NaN -- rare: one branch
 #pragma unroll
-    for (int qh = 0; qh < 2; ++qh) {
-      if (__any(!(psum[qh] < 1.0995116e12f))) fixup(qh, s[qh], pf[qh], psum[qh]);   // 2^40; also inf / NaN
-      l_run[qh] += psum[qh];
+      for (int qh = 0; qh < 2; ++qh)
+        if (__any(!(psum[qh] < 1.0995116e12f))) fixup(qh, s[qh], pf[qh], psum[qh]);
     }
+    l_run[0] += psum[0];
+    l_run[1] += psum[1];
   };
   // tile boundary, at the top of the EVEN half-tile u = 2 t: K(t+1) and V(t) have landed (one DMA group stays in flight) --
   // a region late for its own reads (K(t) sub 1, V(t-1) sub 1), but the fragment prefetch at the end of this region already
@@ -308,9 +326,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
   auto boundary = [&](int t) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    stage_k(t + 3);
-    stage_v(t + 2);
+    __builtin_amdgcn_sched_barrier(0);   // K(t + 3) and V(t + 2) go out piece by piece during the region (stage_piece)
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -334,19 +350,30 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
     const uint32_t vs_base = lds0 + NS * K_TILE + (vt_ & (NS - 1)) * V_TILE + v_row_off;
     // the NEXT region's K fragments (its steps 0 - 2 are fetched by this region's steps 13 - 15): half-tile u + 2 = (t + 1, CUR)
     const uint32_t kn_base = lds0 + ((t + 1) & (NS - 1)) * K_TILE + k_row_off + CUR * 8192;
+    // ... and its first V^T fragment (its step 1): the PV of half-tile u = (t, CUR)
+    const uint32_t vn_base = lds0 + NS * K_TILE + (t & (NS - 1)) * V_TILE + v_row_off;
+    constexpr int VNSUB = CUR;
     // Fragment reads and MFMAs are inline asm with hand-counted waits: hipcc answers every fragment dependence here with
     // s_waitcnt lgkmcnt(0) (a full LDS round trip every four steps), and moves O between the register files in front of the
     // (rare) rescale branch unless O is pinned to AccVGPRs.  LDS returns in order and nothing else uses the counter in the
     // loop: with three younger reads in flight, lgkmcnt(3) means "the fragment of this step has arrived".
+    // Step order: QK and PV steps ALTERNATE (even ST: k-step ST / 2 of S_next, odd ST: PV block (ST - 1) / 2), so the two
+    // S accumulators are touched every fourth MFMA instead of every second (no dependent-accumulate stall) .
     auto rd = [&](auto step_c) {   // the fragment of step ST (16 .. 18: steps 0 .. 2 of the next region) -> ring slot ST & 3
       constexpr int ST = decltype(step_c)::value;
-      if constexpr (ST < 8) {
-        frag_read<ST & 3, 0>(ks_base + (((2 * ST + h2) ^ k_sw) * 16));
-      } else if constexpr (ST < 16) {
-        constexpr int k2 = (ST - 8) >> 2, dt = (ST - 8) & 3;
-        frag_read<ST & 3, dt * 4096>(vs_base + (((2 * (2 * VSUB + k2) + h2) ^ v_sw) * 16));
+      if constexpr (ST >= 16) {
+        constexpr int S2 = ST - 16;   // next region: step 0 = its K k-step 0, step 1 = ITS V block 0, step 2 = its K k-step 1
+        if constexpr ((S2 & 1) == 0) {
+          frag_read<ST & 3, 0>(kn_base + (((2 * (S2 >> 1) + h2) ^ k_sw) * 16));
+        } else {
+          constexpr int k2 = (S2 >> 1) >> 2, dt = (S2 >> 1) & 3;
+          frag_read<ST & 3, dt * 4096>(vn_base + (((2 * (2 * VNSUB + k2) + h2) ^ v_sw) * 16));
+        }
+      } else if constexpr ((ST & 1) == 0) {
+        frag_read<ST & 3, 0>(ks_base + (((2 * (ST >> 1) + h2) ^ k_sw) * 16));
       } else {
-        frag_read<ST & 3, 0>(kn_base + (((2 * (ST - 16) + h2) ^ k_sw) * 16));
+        constexpr int k2 = (ST >> 1) >> 2, dt = (ST >> 1) & 3;
+        frag_read<ST & 3, dt * 4096>(vs_base + (((2 * (2 * VSUB + k2) + h2) ^ v_sw) * 16));
       }
     };
     const float mc[2] = {m_run[0] * c, m_run[1] * c};
@@ -358,33 +385,48 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
       // holds the matrix pipe, and the VALU work behind them then runs with the pipe idle.  So: MFMA, half of the score pair
       // (and the fragment read, whose address arithmetic is VALU too), MFMA, the other half -- each half fits the shadow.
       constexpr int qh = ST >> 3, g = (ST >> 2) & 1, jj = ST & 3;
+#ifndef ALG_Q64_NO_READS
       asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");   // reads ST + 1, ST + 2 in flight: fragment ST has arrived
-      if constexpr (ST < 8) {
+#endif
+      constexpr bool QK = (ST & 1) == 0;
+      constexpr int KS = ST >> 1;                       // k-step of S_next (QK steps)
+      constexpr int k2 = (ST >> 1) >> 2, dt = (ST >> 1) & 3;   // kv block and d-tile (PV steps)
+      if constexpr (QK) {
         // Register files, by hand: the Q fragments live in AccVGPRs and feed the MFMA from there, the scores land in
         // ArchVGPRs, where the VALU of the NEXT region reads them (a VALU operand cannot be an AccVGPR).  Left to itself hipcc
         // keeps Q in VGPRs, spills 37 of them to AGPRs and copies S out of AGPRs: 95 v_accvgpr_read per region next to 96
         // instructions of softmax.  The result is first read >= 16 MFMAs later (no XDL -> VALU hazard).
-        qk_mfma<ST & 3, ST == 0>(sn[0], qf[0][ST]);
+        qk_mfma<ST & 3, KS == 0>(sn[0], qf[0][KS]);
       } else {
-        constexpr int k2 = (ST - 8) >> 2, dt = (ST - 8) & 3;
         pv_mfma<dt, ST & 3>(o_acc[0][dt], pp[0][k2]);
       }
+#ifdef ALG_Q64_NO_SOFTMAX
+      const float a0 = 0.0f, a1 = 0.0f, p0 = 0.5f;
+#else
       const float a0 = sc[qh][8 * g + 2 * jj] * c - mc[qh];
       const float a1 = sc[qh][8 * g + 2 * jj + 1] * c - mc[qh];
       const float p0 = __builtin_amdgcn_exp2f(a0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (ST < 8) {
-        qk_mfma<ST & 3, ST == 0>(sn[1], qf[1][ST]);
+      if constexpr (QK) {
+        qk_mfma<ST & 3, KS == 0>(sn[1], qf[1][KS]);
       } else {
-        constexpr int k2 = (ST - 8) >> 2, dt = (ST - 8) & 3;
         pv_mfma<4 + dt, ST & 3>(o_acc[1][dt], pp[1][k2]);
       }
       rd(std::integral_constant<int, ST + 3>{});   // into the slot of step ST - 1 (both of its MFMAs have been issued)
+#ifndef ALG_Q64_NO_DMA
+      if constexpr (CUR == 0 && (ST & 1) == 1) stage_piece(t + 3, t + 2, std::integral_constant<int, (ST >> 1)>{});
+#endif
       {   // score pair ST of the softmax: query half ST >> 3, register quad g, pair jj
+#ifdef ALG_Q64_NO_SOFTMAX
+        pk[qh][g].w[jj] = 0x3f003f00u + (uint32_t)(a1 != 0.0f);
+        psum[qh] = 1.0f;
+#else
         const float p1 = __builtin_amdgcn_exp2f(a1);
         pk[qh][g].w[jj] = pack_bf2(p0, p1);
         psum[qh] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk[qh][g].w[jj]),
                                                   __builtin_bit_cast(bf2v, 0x3f803f80u), psum[qh], false);
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -426,9 +468,10 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
   __builtin_amdgcn_s_barrier();
   {
     const uint32_t kb = lds0 + 1 * K_TILE + k_row_off;             // region 1, steps 0 - 2: K(1) sub 0, ks = 0, 1, 2
+    const uint32_t vb = lds0 + NS * K_TILE + 0 * V_TILE + v_row_off;   // step 1: V(0) sub 0, kv block 0, d-tile 0
     frag_read<0, 0>(kb + (((0 + h2) ^ k_sw) * 16));
-    frag_read<1, 0>(kb + (((2 + h2) ^ k_sw) * 16));
-    frag_read<2, 0>(kb + (((4 + h2) ^ k_sw) * 16));
+    frag_read<1, 0>(vb + (((0 + h2) ^ v_sw) * 16));
+    frag_read<2, 0>(kb + (((2 + h2) ^ k_sw) * 16));
   }
   // u = 1, 2, ..., 2 n - 1; the S computed for u = 2 n (past the end) reads the re-fetched last tile and is dropped
   const int n_half = 2 * n_tiles;
@@ -472,7 +515,9 @@ int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, i
   const char* env = getenv("ALG_ATTN128_Q64");   // 0: keep attention128.hip's 32-query kernel (A/B runs, bit-level comparisons)
   const int enabled = env ? atoi(env) : 1;
   if (!enabled || (Skv + KVB - 1) / KVB < MIN_TILES) return 1;
-  if ((int64_t)Skv * k_rs >= (1ll << 31) || (int64_t)128 * vt_rs + Skv + 64 >= (1ll << 31)) return 1;   // 32-bit DMA offsets
+  // 31-bit BYTE offsets inside one (batch, head) for the buffer-load DMA; V^T rows cover whole 64-key tiles
+  if ((int64_t)(Skv + 64) * k_rs * 2 >= (1ll << 31) || (int64_t)129 * vt_rs * 2 >= (1ll << 31)) return 1;
+  if (vt_rs < (int64_t)((Skv + KVB - 1) / KVB) * KVB) return 1;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)flash_attn_d128_q64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
