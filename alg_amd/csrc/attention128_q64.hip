@@ -217,6 +217,12 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
   const int k_row_off = l31 * 256, k_sw = l31 & 15;
   const int v_row_off = l31 * 128, v_sw = (l31 >> 1) & 7;
   const float c = p.scale_log2;
+  // per-lane fragment addresses without the (slot, half, d-tile) part: kc[k-step], vc[32-key block of the 64-key tile]
+  uint32_t kc[8], vc[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kc[ks] = lds0 + k_row_off + (((2 * ks + h2) ^ k_sw) * 16);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vc[j] = lds0 + NS * K_TILE + v_row_off + (((2 * j + h2) ^ v_sw) * 16);
 
   f32x16 o_acc[2][4];
 #pragma unroll
@@ -337,8 +343,13 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
   // { fragment read for step + 3;  2 MFMAs;  one score pair of the softmax (2 fma, 2 exp2, pack, dot2) } with a scheduling
   // barrier after each step: hipcc's own ordering (and sched_group_barrier patterns) put every read right in front of its
   // MFMAs and the whole softmax behind them.
-  auto region = [&](int u, auto cur_c, f32x16 (&sc)[2], f32x16 (&sn)[2], bf16x8 (&pc)[2][2], const bf16x8 (&pp)[2][2]) {
+  // SL: the ring slot (tile & 3) of tile t = u >> 1 as a compile-time constant (the main loop is unrolled over four tiles), or
+  // -1 for the runtime form (remainder tiles).  With SL known every fragment address is a per-lane constant plus an
+  // IMMEDIATE offset (slot, half, d-tile): no vector add per read, and the DMA's LDS destination is an immediate M0.
+  auto region = [&](int u, auto cur_c, auto sl_c, f32x16 (&sc)[2], f32x16 (&sn)[2], bf16x8 (&pc)[2][2],
+                    const bf16x8 (&pp)[2][2]) {
     constexpr int CUR = decltype(cur_c)::value;
+    constexpr int SL = decltype(sl_c)::value;
     const int t = u >> 1;
     if (CUR == 0) boundary(t);
     if (ragged && t == n_tiles - 1) mask_tail(t * KVB + CUR * 32, sc);
@@ -361,7 +372,24 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
     // S accumulators are touched every fourth MFMA instead of every second (no dependent-accumulate stall) .
     auto rd = [&](auto step_c) {   // the fragment of step ST (16 .. 18: steps 0 .. 2 of the next region) -> ring slot ST & 3
       constexpr int ST = decltype(step_c)::value;
-      if constexpr (ST >= 16) {
+      if constexpr (SL >= 0) {
+        // slots: K of this region: tile t (CUR 0) or t + 1 (CUR 1); V: tile t - 1 or t; next region: K(t + 1), V(t)
+        constexpr int KSL = CUR == 0 ? SL : (SL + 1) & 3, VSL = CUR == 0 ? (SL + 3) & 3 : SL;
+        if constexpr (ST >= 16) {
+          constexpr int S2 = ST - 16;
+          if constexpr ((S2 & 1) == 0) {
+            frag_read<ST & 3, ((SL + 1) & 3) * K_TILE + CUR * 8192>(kc[S2 >> 1]);
+          } else {
+            constexpr int k2 = (S2 >> 1) >> 2, dt = (S2 >> 1) & 3;
+            frag_read<ST & 3, SL * V_TILE + dt * 4096>(vc[2 * VNSUB + k2]);
+          }
+        } else if constexpr ((ST & 1) == 0) {
+          frag_read<ST & 3, KSL * K_TILE + KSUB * 8192>(kc[ST >> 1]);
+        } else {
+          constexpr int k2 = (ST >> 1) >> 2, dt = (ST >> 1) & 3;
+          frag_read<ST & 3, VSL * V_TILE + dt * 4096>(vc[2 * VSUB + k2]);
+        }
+      } else if constexpr (ST >= 16) {
         constexpr int S2 = ST - 16;   // next region: step 0 = its K k-step 0, step 1 = ITS V block 0, step 2 = its K k-step 1
         if constexpr ((S2 & 1) == 0) {
           frag_read<ST & 3, 0>(kn_base + (((2 * (S2 >> 1) + h2) ^ k_sw) * 16));
@@ -473,13 +501,26 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
     frag_read<1, 0>(vb + (((0 + h2) ^ v_sw) * 16));
     frag_read<2, 0>(kb + (((2 + h2) ^ k_sw) * 16));
   }
-  // u = 1, 2, ..., 2 n - 1; the S computed for u = 2 n (past the end) reads the re-fetched last tile and is dropped
-  const int n_half = 2 * n_tiles;
-  for (int u = 1; u + 1 < n_half; u += 2) {
-    region(u, S1{}, so, se, po, pe);
-    region(u + 1, S0{}, se, so, pe, po);
+  // u = 1, 2, ..., 2 n - 1; the S computed for u = 2 n (past the end) reads the re-fetched last tile and is dropped.
+  // Pairs (2 t + 1, 2 t + 2) for t = 0 .. n - 2, four tiles per trip with their ring slots as constants, then the remainder
+  // and the last odd half-tile in the runtime-slot form.
+  using SLR = std::integral_constant<int, -1>;
+  int t = 0;
+  for (; t + 4 <= n_tiles - 1; t += 4) {   // t is a multiple of 4 here: tile t + i sits in slot i
+    region(2 * t + 1, S1{}, std::integral_constant<int, 0>{}, so, se, po, pe);
+    region(2 * t + 2, S0{}, std::integral_constant<int, 1>{}, se, so, pe, po);
+    region(2 * t + 3, S1{}, std::integral_constant<int, 1>{}, so, se, po, pe);
+    region(2 * t + 4, S0{}, std::integral_constant<int, 2>{}, se, so, pe, po);
+    region(2 * t + 5, S1{}, std::integral_constant<int, 2>{}, so, se, po, pe);
+    region(2 * t + 6, S0{}, std::integral_constant<int, 3>{}, se, so, pe, po);
+    region(2 * t + 7, S1{}, std::integral_constant<int, 3>{}, so, se, po, pe);
+    region(2 * t + 8, S0{}, std::integral_constant<int, 0>{}, se, so, pe, po);
   }
-  region(n_half - 1, S1{}, so, se, po, pe);
+  for (; t < n_tiles - 1; ++t) {
+    region(2 * t + 1, S1{}, SLR{}, so, se, po, pe);
+    region(2 * t + 2, S0{}, SLR{}, se, so, pe, po);
+  }
+  region(2 * n_tiles - 1, S1{}, SLR{}, so, se, po, pe);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   pv(n_tiles - 1, S1{}, po);

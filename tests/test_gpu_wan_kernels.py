@@ -49,12 +49,14 @@ def test_flash_attn_d128_matches_sdpa(B, H, Sq, Skv):
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 1024), (2, 3, 257, 1000), (1, 1, 256, 513), (1, 2, 1300, 2050),
-                                          (1, 1, 64, 544), (1, 2, 520, 575)])
+                                          (1, 1, 64, 544), (1, 2, 520, 575), (1, 1, 300, 640), (1, 2, 100, 700),
+                                          (1, 1, 200, 832)])
 def test_flash_attn_d128_q64_kernel(B, H, Sq, Skv, monkeypatch):
     """The long self-attention form (attention128_q64.hip: 64 queries per wave, software-pipelined 32-key half-tiles, taken for
     >= 8 KV tiles): against fp32 SDPA and against the 32-query kernel (ALG_ATTN128_Q64=0) on the same tensors.  Ragged key
     counts: a last tile whose second half is partly (1000, 2050), entirely (513, 544: 1 / 32 keys) masked, or exactly half
-    (575 = 8 x 64 + 63), query blocks that end mid-wave, scores large enough to trip the lazy running max's exact path."""
+    (575 = 8 x 64 + 63), query blocks that end mid-wave, scores large enough to trip the lazy running max's exact path; tile
+    counts that leave 0, 1, 2 and 3 tiles to the runtime-slot remainder of the four-tile unrolled main loop."""
     D = H * 128
     q, k, v = _rand((B, Sq, D), 11), _rand((B, Skv, D), 12), _rand((B, Skv, D), 13)
     q[:, : Sq // 2] *= 6.0                       # half the queries: scores ~ +-25 -> row sums far beyond the first tile's
