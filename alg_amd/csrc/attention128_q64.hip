@@ -430,10 +430,20 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
       }
 #ifdef ALG_Q64_NO_SOFTMAX
       const float a0 = 0.0f, a1 = 0.0f, p0 = 0.5f;
+#elif defined(ALG_Q64_DUMMY_VALU)   // the same VALU instructions on a register no MFMA ever wrote
+      float dm0 = mc[0], dm1 = mc[1];
+      asm volatile("" : "+v"(dm0), "+v"(dm1));
+      const float a0 = dm0 * c - mc[qh];
+      const float a1 = dm1 * c - mc[qh];
+      const float p0 = __builtin_amdgcn_exp2f(a0);
 #else
       const float a0 = sc[qh][8 * g + 2 * jj] * c - mc[qh];
       const float a1 = sc[qh][8 * g + 2 * jj + 1] * c - mc[qh];
+#ifdef ALG_Q64_NO_EXP
+      const float p0 = a0;
+#else
       const float p0 = __builtin_amdgcn_exp2f(a0);
+#endif
 #endif
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (QK) {
@@ -450,10 +460,22 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
         pk[qh][g].w[jj] = 0x3f003f00u + (uint32_t)(a1 != 0.0f);
         psum[qh] = 1.0f;
 #else
+#ifdef ALG_Q64_NO_EXP
+        const float p1 = a1;
+#else
         const float p1 = __builtin_amdgcn_exp2f(a1);
+#endif
+#ifdef ALG_Q64_NO_PACK
+        pk[qh][g].w[jj] = __float_as_uint(p0) ^ __float_as_uint(p1);
+#else
         pk[qh][g].w[jj] = pack_bf2(p0, p1);
+#endif
+#ifndef ALG_Q64_NO_DOT2
         psum[qh] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk[qh][g].w[jj]),
                                                   __builtin_bit_cast(bf2v, 0x3f803f80u), psum[qh], false);
+#else
+        psum[qh] = 1.0f;
+#endif
 #endif
       }
       __builtin_amdgcn_sched_barrier(0);
