@@ -1388,6 +1388,13 @@ static int attn_variant() {
 
 using namespace alg;
 
+namespace alg {
+// attention64_q64.hip: the 64-queries-per-wave form of the main launch for pre-scaled Q (0 = launched, 1 = not covered)
+int flash_attn_d64_q64(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S, int q_blocks,
+                       int64_t q_bs, int64_t q_rs, int64_t vt_bs, int64_t vt_rs, int64_t o_bs, int64_t o_rs, unsigned blocks,
+                       hipStream_t stream);
+}
+
 extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S,
                                   int64_t q_bstride, int64_t q_rstride, int64_t vt_bstride, int64_t vt_rstride,
                                   int64_t o_bstride, int64_t o_rstride, float scale, void* stream) {
@@ -1448,7 +1455,14 @@ extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* v
       }
       p.ws_o = ws, p.ws_ml = ws + rows * 64;
       if (variant == 41) {
-        hipLaunchKernelGGL((flash_attn_d64_kernel<41, 8>), dim3((unsigned)(8 * p.unit0)), blk, 0, s, p);
+        const int rq = p.unit0 > 0 ? flash_attn_d64_q64(q, k, vt, o, batch, heads, S, p.q_blocks, q_bstride, q_rstride, vt_bstride,
+                                                        vt_rstride, o_bstride, o_rstride, (unsigned)(8 * p.unit0), s)
+                                   : 0;
+        if (rq < 0 || rq > 1) {
+          (void)hipFreeAsync(ws, s);
+          return rq;
+        }
+        if (rq == 1) hipLaunchKernelGGL((flash_attn_d64_kernel<41, 8>), dim3((unsigned)(8 * p.unit0)), blk, 0, s, p);
         hipLaunchKernelGGL((flash_attn_d64_kernel<41, 8, true>), dim3((unsigned)(8 * tp.units * tp.split)), blk, 0, s, p);
       } else {
         hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8>), dim3((unsigned)(8 * p.unit0)), blk, 0, s, p);
@@ -1462,6 +1476,11 @@ extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* v
     }
   }
   const dim3 g((unsigned)grid);
+  if (variant == 41) {
+    const int rq = flash_attn_d64_q64(q, k, vt, o, batch, heads, S, p.q_blocks, q_bstride, q_rstride, vt_bstride, vt_rstride,
+                                      o_bstride, o_rstride, (unsigned)grid, s);
+    if (rq != 1) return rq;
+  }
   switch (variant) {
     case 0: hipLaunchKernelGGL(flash_attn_d64_kernel<0>, g, blk, 0, s, p); break;
     case 1: hipLaunchKernelGGL(flash_attn_d64_kernel<1>, g, blk, 0, s, p); break;

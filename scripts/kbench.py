@@ -83,6 +83,9 @@ def main():
                      2.0 * N * S * D * F4, "flop"),
         "attn": (lambda: _lib.flash_attn_d64(qk, qk, vt, att, N, H, S, S * 2 * D, 2 * D, D * S_pad, S_pad, S * D, D,
                                              0.125, k_off=D), 4.0 * N * H * S * S * 64, "flop"),
+        # the product's form: Q carries scale * log2(e) already (same tensors: only the score scale differs, timing case)
+        "attn_prescaled": (lambda: _lib.flash_attn_d64(qk, qk, vt, att, N, H, S, S * 2 * D, 2 * D, D * S_pad, S_pad, S * D, D,
+                                                       0.125, k_off=D, q_prescaled=True), 4.0 * N * H * S * S * 64, "flop"),
         "ln_mod": (lambda: _lib.layernorm_modulate(x, y, lnw, lnb, mod, mod, 12 * D, N, S, D, T, 1e-5, scale_off=2 * D,
                                                    shift_off=0), 2.0 * N * S * D * 2, "byte"),
         "qk_norm_rope": (lambda: _lib.qk_norm_rope_(qk, nq[0], nq[1], nq[2], nq[3], cos, sin, N, S, H, T, 1e-6),

@@ -261,6 +261,51 @@ def test_qk_norm_rope_scaled_and_prescaled_attention(device):
         assert torch.isfinite(got).all() and (got - ref).abs().max() <= 1e-2
 
 
+@pytest.mark.parametrize("Bn,S2,H2", [(1, 512, 2), (2, 1000, 3), (1, 513, 1), (1, 575, 2), (1, 640, 1), (1, 700, 2), (1, 832, 1),
+                                       (1, 2050, 2), (8, 1200, 1)])
+def test_flash_attention_d64_q64_kernel(device, monkeypatch, Bn, S2, H2):
+    """attention64_q64.hip (64 queries per wave; OPT-IN with ALG_ATTN64_Q64=1 for pre-scaled calls over >= 8 KV tiles: slower than
+    the default at d = 64, kept as the measured A/B reference) against fp32 SDPA and against attention.hip's 32-query kernel
+    (ALG_ATTN64_Q64=0) on the same tensors: ragged tails (second half-tile partly / wholly
+    masked), 0-3 tiles left to the runtime-slot remainder, rows whose first-tile max is beyond +-64 (non-zero offset: the
+    subtracting form) next to rows in the zero-offset form, late dominant keys (exact rescale path), query blocks ending
+    mid-wave; 8 x 1 heads = enough units for the split-KV tail plan to engage next to the q64 main launch."""
+    g = torch.Generator().manual_seed(S2 + H2)
+    c = 0.125 * 1.4426950408889634
+    q, k, v = rnd((Bn, S2, H2, 64), g), rnd((Bn, S2, H2, 64), g), rnd((Bn, S2, H2, 64), g)
+    q[:, : S2 // 3] *= 9.0                       # scores ~ +-70 in log2 units: non-zero offsets for a third of the rows
+    k[:, (2 * S2) // 3] *= 6.0                   # one late key that dominates
+    D = H2 * 64
+    S_pad = (S2 + 127) // 128 * 128
+    qs = (q.float() * c).to(BF)
+    # the reference takes the SAME rounded, pre-scaled Q the kernels see (scores in log2 units): with scores in the hundreds
+    # the rounding of q * c alone moves probabilities by tens of percent, which is not what this test is about
+    sc2 = torch.einsum("bqhd,bkhd->bhqk", qs.double(), k.double()) * math.log(2.0)
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc2, dim=-1), v.double())
+    qkb = torch.cat([qs.reshape(Bn, S2, D), k.reshape(Bn, S2, D)], dim=-1).contiguous().to(device)
+    vt = torch.zeros(Bn, D, S_pad, dtype=BF)
+    vt[:, :, torch.tensor([swap23(n) for n in range(S2)])] = v.reshape(Bn, S2, D).transpose(1, 2)
+    vt = vt.to(device)
+    outs, errs = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ALG_ATTN64_Q64", flag)
+        o = torch.full((Bn, S2, D), 3.0, dtype=BF, device=device)
+        _lib.flash_attn_d64(qkb, qkb, vt, o, Bn, H2, S2, S2 * 2 * D, 2 * D, D * S_pad, S_pad, S2 * D, D, 0.125, k_off=D,
+                            q_prescaled=True)
+        outs[flag] = o
+        got = o.cpu().reshape(Bn, S2, H2, 64).double()
+        assert torch.isfinite(got).all(), flag
+        errs[flag] = ((got - ref).abs().max().item(), (got - ref).abs().mean().item())
+    assert errs["0"][0] <= 3e-2 and errs["0"][1] <= 2e-3, errs
+    assert errs["1"][0] <= 3e-2 and errs["1"][1] <= 2e-3, errs
+    assert (outs["1"].float() - outs["0"].float()).abs().max().item() <= 3.2e-2
+    monkeypatch.setenv("ALG_ATTN64_Q64", "1")
+    o2 = torch.empty_like(outs["1"])
+    _lib.flash_attn_d64(qkb, qkb, vt, o2, Bn, H2, S2, S2 * 2 * D, 2 * D, D * S_pad, S_pad, S2 * D, D, 0.125, k_off=D,
+                        q_prescaled=True)
+    assert torch.equal(o2, outs["1"])
+
+
 def test_patchify_unpatchify_timestep(device):
     g = torch.Generator().manual_seed(6)
     n, Fr, C, H, W, p = 3, 2, 4, 6, 10, 2
