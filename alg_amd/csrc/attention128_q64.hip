@@ -86,13 +86,14 @@ __device__ __forceinline__ void qk_mfma(f32x16& s, const bf16x8 qv) {
   if constexpr (SLOT == 3) { ALG_QK(ALG_FR3) }
 #undef ALG_QK
 }
-// O lives in FIXED AccVGPRs: tile (qh, dt) = a[16 (4 qh + dt) .. + 15].  Every MFMA that accumulates into O names them, and
-// the (rare) exact-rescale path multiplies them in place inside one asm block -- otherwise hipcc keeps the O tiles that the
-// cold path touches in ArchVGPRs and copies them out of the AccVGPRs on the HOT path (64 v_accvgpr_read per region, issued
-// right behind MFMAs it cannot see inside the asm).
+// O is NOT a C++ value inside the loop: it lives in a[0:127] (tile (qh, dt) = a[16 (4 qh + dt) .. + 15]) and is named literally by
+// every asm that touches it (all of them list a0 - a127 as clobbers).  As an asm OPERAND pinned to those registers it is at
+// the allocator's mercy: in the d = 64 sibling hipcc kept such an O in ArchVGPRs between the asms -- 16 v_accvgpr_write in
+// front of every MFMA and reads right behind it, i.e. behind an MFMA it cannot see (wrong results, not just slow).
+#define ALG_O_CLOBBER "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
 template <int IDX, int SLOT>
-__device__ __forceinline__ void pv_mfma(f32x16& o, const bf16x8 pfrag) {
-#define ALG_PV2(LO, HI, FR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, " FR ", %1, %0" : "+{a[" #LO ":" #HI "]}"(o) : "v"(pfrag) : ALG_FRAG_CLOBBER);
+__device__ __forceinline__ void pv_mfma(const bf16x8 pfrag) {
+#define ALG_PV2(LO, HI, FR) asm volatile("v_mfma_f32_32x32x16_bf16 a[" #LO ":" #HI "], " FR ", %0, a[" #LO ":" #HI "]" ::"v"(pfrag) : ALG_O_CLOBBER, ALG_FRAG_CLOBBER);
 #define ALG_PV_CASE(I, LO, HI)                        \
   if constexpr (IDX == I) {                           \
     if constexpr (SLOT == 0) { ALG_PV2(LO, HI, ALG_FR0) } \
@@ -100,34 +101,438 @@ __device__ __forceinline__ void pv_mfma(f32x16& o, const bf16x8 pfrag) {
     if constexpr (SLOT == 2) { ALG_PV2(LO, HI, ALG_FR2) } \
     if constexpr (SLOT == 3) { ALG_PV2(LO, HI, ALG_FR3) } \
   }
-  ALG_PV_CASE(0, 0, 15) ALG_PV_CASE(1, 16, 31) ALG_PV_CASE(2, 32, 47) ALG_PV_CASE(3, 48, 63)
-  ALG_PV_CASE(4, 64, 79) ALG_PV_CASE(5, 80, 95) ALG_PV_CASE(6, 96, 111) ALG_PV_CASE(7, 112, 127)
+  ALG_PV_CASE(0, 0, 15) ALG_PV_CASE(1, 16, 31) ALG_PV_CASE(2, 32, 47) ALG_PV_CASE(3, 48, 63) ALG_PV_CASE(4, 64, 79) ALG_PV_CASE(5, 80, 95) ALG_PV_CASE(6, 96, 111) ALG_PV_CASE(7, 112, 127)
 #undef ALG_PV_CASE
 #undef ALG_PV2
 }
-#define ALG_RS1(R) "v_accvgpr_read_b32 %4, a" #R "\n\tv_mul_f32 %4, %4, %5\n\tv_accvgpr_write_b32 a" #R ", %4\n\t"
-#define ALG_RS16(B) ALG_RS1(B##0) ALG_RS1(B##1) ALG_RS1(B##2) ALG_RS1(B##3) ALG_RS1(B##4) ALG_RS1(B##5) ALG_RS1(B##6) ALG_RS1(B##7) ALG_RS1(B##8) ALG_RS1(B##9)
-// O[qh] *= alpha, all four d-tiles, in the AccVGPRs they are pinned to (two leading s_nop 15: the region's last MFMAs wrote
-// O a few cycles ago, and hipcc does not see an MFMA inside an asm)
-__device__ __forceinline__ void rescale_o(f32x16 (&o)[4], float alpha, int qh) {
+__device__ __forceinline__ void zero_o() {
+  asm volatile("v_accvgpr_write_b32 a0, 0\n\t"
+               "v_accvgpr_write_b32 a1, 0\n\t"
+               "v_accvgpr_write_b32 a2, 0\n\t"
+               "v_accvgpr_write_b32 a3, 0\n\t"
+               "v_accvgpr_write_b32 a4, 0\n\t"
+               "v_accvgpr_write_b32 a5, 0\n\t"
+               "v_accvgpr_write_b32 a6, 0\n\t"
+               "v_accvgpr_write_b32 a7, 0\n\t"
+               "v_accvgpr_write_b32 a8, 0\n\t"
+               "v_accvgpr_write_b32 a9, 0\n\t"
+               "v_accvgpr_write_b32 a10, 0\n\t"
+               "v_accvgpr_write_b32 a11, 0\n\t"
+               "v_accvgpr_write_b32 a12, 0\n\t"
+               "v_accvgpr_write_b32 a13, 0\n\t"
+               "v_accvgpr_write_b32 a14, 0\n\t"
+               "v_accvgpr_write_b32 a15, 0\n\t"
+               "v_accvgpr_write_b32 a16, 0\n\t"
+               "v_accvgpr_write_b32 a17, 0\n\t"
+               "v_accvgpr_write_b32 a18, 0\n\t"
+               "v_accvgpr_write_b32 a19, 0\n\t"
+               "v_accvgpr_write_b32 a20, 0\n\t"
+               "v_accvgpr_write_b32 a21, 0\n\t"
+               "v_accvgpr_write_b32 a22, 0\n\t"
+               "v_accvgpr_write_b32 a23, 0\n\t"
+               "v_accvgpr_write_b32 a24, 0\n\t"
+               "v_accvgpr_write_b32 a25, 0\n\t"
+               "v_accvgpr_write_b32 a26, 0\n\t"
+               "v_accvgpr_write_b32 a27, 0\n\t"
+               "v_accvgpr_write_b32 a28, 0\n\t"
+               "v_accvgpr_write_b32 a29, 0\n\t"
+               "v_accvgpr_write_b32 a30, 0\n\t"
+               "v_accvgpr_write_b32 a31, 0\n\t"
+               "v_accvgpr_write_b32 a32, 0\n\t"
+               "v_accvgpr_write_b32 a33, 0\n\t"
+               "v_accvgpr_write_b32 a34, 0\n\t"
+               "v_accvgpr_write_b32 a35, 0\n\t"
+               "v_accvgpr_write_b32 a36, 0\n\t"
+               "v_accvgpr_write_b32 a37, 0\n\t"
+               "v_accvgpr_write_b32 a38, 0\n\t"
+               "v_accvgpr_write_b32 a39, 0\n\t"
+               "v_accvgpr_write_b32 a40, 0\n\t"
+               "v_accvgpr_write_b32 a41, 0\n\t"
+               "v_accvgpr_write_b32 a42, 0\n\t"
+               "v_accvgpr_write_b32 a43, 0\n\t"
+               "v_accvgpr_write_b32 a44, 0\n\t"
+               "v_accvgpr_write_b32 a45, 0\n\t"
+               "v_accvgpr_write_b32 a46, 0\n\t"
+               "v_accvgpr_write_b32 a47, 0\n\t"
+               "v_accvgpr_write_b32 a48, 0\n\t"
+               "v_accvgpr_write_b32 a49, 0\n\t"
+               "v_accvgpr_write_b32 a50, 0\n\t"
+               "v_accvgpr_write_b32 a51, 0\n\t"
+               "v_accvgpr_write_b32 a52, 0\n\t"
+               "v_accvgpr_write_b32 a53, 0\n\t"
+               "v_accvgpr_write_b32 a54, 0\n\t"
+               "v_accvgpr_write_b32 a55, 0\n\t"
+               "v_accvgpr_write_b32 a56, 0\n\t"
+               "v_accvgpr_write_b32 a57, 0\n\t"
+               "v_accvgpr_write_b32 a58, 0\n\t"
+               "v_accvgpr_write_b32 a59, 0\n\t"
+               "v_accvgpr_write_b32 a60, 0\n\t"
+               "v_accvgpr_write_b32 a61, 0\n\t"
+               "v_accvgpr_write_b32 a62, 0\n\t"
+               "v_accvgpr_write_b32 a63, 0\n\t"
+               "v_accvgpr_write_b32 a64, 0\n\t"
+               "v_accvgpr_write_b32 a65, 0\n\t"
+               "v_accvgpr_write_b32 a66, 0\n\t"
+               "v_accvgpr_write_b32 a67, 0\n\t"
+               "v_accvgpr_write_b32 a68, 0\n\t"
+               "v_accvgpr_write_b32 a69, 0\n\t"
+               "v_accvgpr_write_b32 a70, 0\n\t"
+               "v_accvgpr_write_b32 a71, 0\n\t"
+               "v_accvgpr_write_b32 a72, 0\n\t"
+               "v_accvgpr_write_b32 a73, 0\n\t"
+               "v_accvgpr_write_b32 a74, 0\n\t"
+               "v_accvgpr_write_b32 a75, 0\n\t"
+               "v_accvgpr_write_b32 a76, 0\n\t"
+               "v_accvgpr_write_b32 a77, 0\n\t"
+               "v_accvgpr_write_b32 a78, 0\n\t"
+               "v_accvgpr_write_b32 a79, 0\n\t"
+               "v_accvgpr_write_b32 a80, 0\n\t"
+               "v_accvgpr_write_b32 a81, 0\n\t"
+               "v_accvgpr_write_b32 a82, 0\n\t"
+               "v_accvgpr_write_b32 a83, 0\n\t"
+               "v_accvgpr_write_b32 a84, 0\n\t"
+               "v_accvgpr_write_b32 a85, 0\n\t"
+               "v_accvgpr_write_b32 a86, 0\n\t"
+               "v_accvgpr_write_b32 a87, 0\n\t"
+               "v_accvgpr_write_b32 a88, 0\n\t"
+               "v_accvgpr_write_b32 a89, 0\n\t"
+               "v_accvgpr_write_b32 a90, 0\n\t"
+               "v_accvgpr_write_b32 a91, 0\n\t"
+               "v_accvgpr_write_b32 a92, 0\n\t"
+               "v_accvgpr_write_b32 a93, 0\n\t"
+               "v_accvgpr_write_b32 a94, 0\n\t"
+               "v_accvgpr_write_b32 a95, 0\n\t"
+               "v_accvgpr_write_b32 a96, 0\n\t"
+               "v_accvgpr_write_b32 a97, 0\n\t"
+               "v_accvgpr_write_b32 a98, 0\n\t"
+               "v_accvgpr_write_b32 a99, 0\n\t"
+               "v_accvgpr_write_b32 a100, 0\n\t"
+               "v_accvgpr_write_b32 a101, 0\n\t"
+               "v_accvgpr_write_b32 a102, 0\n\t"
+               "v_accvgpr_write_b32 a103, 0\n\t"
+               "v_accvgpr_write_b32 a104, 0\n\t"
+               "v_accvgpr_write_b32 a105, 0\n\t"
+               "v_accvgpr_write_b32 a106, 0\n\t"
+               "v_accvgpr_write_b32 a107, 0\n\t"
+               "v_accvgpr_write_b32 a108, 0\n\t"
+               "v_accvgpr_write_b32 a109, 0\n\t"
+               "v_accvgpr_write_b32 a110, 0\n\t"
+               "v_accvgpr_write_b32 a111, 0\n\t"
+               "v_accvgpr_write_b32 a112, 0\n\t"
+               "v_accvgpr_write_b32 a113, 0\n\t"
+               "v_accvgpr_write_b32 a114, 0\n\t"
+               "v_accvgpr_write_b32 a115, 0\n\t"
+               "v_accvgpr_write_b32 a116, 0\n\t"
+               "v_accvgpr_write_b32 a117, 0\n\t"
+               "v_accvgpr_write_b32 a118, 0\n\t"
+               "v_accvgpr_write_b32 a119, 0\n\t"
+               "v_accvgpr_write_b32 a120, 0\n\t"
+               "v_accvgpr_write_b32 a121, 0\n\t"
+               "v_accvgpr_write_b32 a122, 0\n\t"
+               "v_accvgpr_write_b32 a123, 0\n\t"
+               "v_accvgpr_write_b32 a124, 0\n\t"
+               "v_accvgpr_write_b32 a125, 0\n\t"
+               "v_accvgpr_write_b32 a126, 0\n\t"
+               "v_accvgpr_write_b32 a127, 0\n\t"
+               "s_nop 0" ::: ALG_O_CLOBBER);
+}
+// O[qh] *= alpha (leading s_nops: XDL write -> accvgpr_read hazard, invisible to hipcc)
+__device__ __forceinline__ void rescale_o(float alpha, int qh) {
   float tmp;
   if (qh == 0) {
     asm volatile("s_nop 15\n\ts_nop 15\n\t"
-                 ALG_RS16() ALG_RS16(1) ALG_RS16(2) ALG_RS16(3) ALG_RS16(4) ALG_RS16(5)
-                 ALG_RS1(60) ALG_RS1(61) ALG_RS1(62) ALG_RS1(63)
-                 : "+{a[0:15]}"(o[0]), "+{a[16:31]}"(o[1]), "+{a[32:47]}"(o[2]), "+{a[48:63]}"(o[3]), "=&v"(tmp)
-                 : "v"(alpha));
+                 "v_accvgpr_read_b32 %0, a0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a0, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a1\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a1, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a2\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a2, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a3\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a3, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a4\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a4, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a5\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a5, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a6\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a6, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a7\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a7, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a8\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a8, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a9\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a9, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a10\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a10, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a11\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a11, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a12\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a12, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a13\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a13, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a14\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a14, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a15\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a15, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a16\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a16, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a17\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a17, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a18\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a18, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a19\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a19, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a20\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a20, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a21\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a21, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a22\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a22, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a23\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a23, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a24\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a24, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a25\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a25, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a26\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a26, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a27\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a27, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a28\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a28, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a29\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a29, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a30\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a30, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a31\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a31, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a32\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a32, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a33\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a33, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a34\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a34, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a35\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a35, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a36\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a36, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a37\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a37, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a38\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a38, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a39\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a39, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a40\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a40, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a41\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a41, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a42\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a42, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a43\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a43, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a44\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a44, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a45\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a45, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a46\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a46, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a47\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a47, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a48\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a48, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a49\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a49, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a50\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a50, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a51\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a51, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a52\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a52, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a53\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a53, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a54\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a54, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a55\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a55, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a56\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a56, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a57\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a57, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a58\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a58, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a59\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a59, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a60\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a60, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a61\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a61, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a62\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a62, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a63\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a63, %0\n\t"
+                 "s_nop 0"
+                 : "=&v"(tmp) : "v"(alpha) : ALG_O_CLOBBER);
   } else {
     asm volatile("s_nop 15\n\ts_nop 15\n\t"
-                 ALG_RS1(64) ALG_RS1(65) ALG_RS1(66) ALG_RS1(67) ALG_RS1(68) ALG_RS1(69)
-                 ALG_RS16(7) ALG_RS16(8) ALG_RS16(9) ALG_RS16(10) ALG_RS16(11)
-                 ALG_RS1(120) ALG_RS1(121) ALG_RS1(122) ALG_RS1(123) ALG_RS1(124) ALG_RS1(125) ALG_RS1(126) ALG_RS1(127)
-                 : "+{a[64:79]}"(o[0]), "+{a[80:95]}"(o[1]), "+{a[96:111]}"(o[2]), "+{a[112:127]}"(o[3]), "=&v"(tmp)
-                 : "v"(alpha));
+                 "v_accvgpr_read_b32 %0, a64\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a64, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a65\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a65, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a66\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a66, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a67\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a67, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a68\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a68, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a69\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a69, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a70\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a70, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a71\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a71, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a72\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a72, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a73\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a73, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a74\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a74, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a75\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a75, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a76\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a76, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a77\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a77, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a78\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a78, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a79\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a79, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a80\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a80, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a81\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a81, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a82\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a82, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a83\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a83, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a84\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a84, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a85\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a85, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a86\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a86, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a87\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a87, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a88\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a88, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a89\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a89, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a90\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a90, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a91\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a91, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a92\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a92, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a93\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a93, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a94\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a94, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a95\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a95, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a96\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a96, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a97\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a97, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a98\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a98, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a99\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a99, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a100\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a100, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a101\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a101, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a102\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a102, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a103\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a103, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a104\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a104, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a105\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a105, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a106\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a106, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a107\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a107, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a108\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a108, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a109\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a109, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a110\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a110, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a111\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a111, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a112\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a112, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a113\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a113, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a114\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a114, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a115\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a115, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a116\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a116, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a117\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a117, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a118\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a118, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a119\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a119, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a120\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a120, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a121\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a121, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a122\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a122, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a123\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a123, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a124\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a124, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a125\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a125, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a126\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a126, %0\n\t"
+                 "v_accvgpr_read_b32 %0, a127\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a127, %0\n\t"
+                 "s_nop 0"
+                 : "=&v"(tmp) : "v"(alpha) : ALG_O_CLOBBER);
   }
 }
-#undef ALG_RS16
-#undef ALG_RS1
+// read one O tile out (after the loop; the caller has waited out the last MFMAs)
+template <int IDX>
+__device__ __forceinline__ void read_o(float (&f)[16]) {
+  if constexpr (IDX == 0)
+    asm volatile("v_accvgpr_read_b32 %0, a0\n\t"
+                 "v_accvgpr_read_b32 %1, a1\n\t"
+                 "v_accvgpr_read_b32 %2, a2\n\t"
+                 "v_accvgpr_read_b32 %3, a3\n\t"
+                 "v_accvgpr_read_b32 %4, a4\n\t"
+                 "v_accvgpr_read_b32 %5, a5\n\t"
+                 "v_accvgpr_read_b32 %6, a6\n\t"
+                 "v_accvgpr_read_b32 %7, a7\n\t"
+                 "v_accvgpr_read_b32 %8, a8\n\t"
+                 "v_accvgpr_read_b32 %9, a9\n\t"
+                 "v_accvgpr_read_b32 %10, a10\n\t"
+                 "v_accvgpr_read_b32 %11, a11\n\t"
+                 "v_accvgpr_read_b32 %12, a12\n\t"
+                 "v_accvgpr_read_b32 %13, a13\n\t"
+                 "v_accvgpr_read_b32 %14, a14\n\t"
+                 "v_accvgpr_read_b32 %15, a15\n\t"
+                 "s_nop 0"
+                 : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]) : : ALG_O_CLOBBER);
+  if constexpr (IDX == 1)
+    asm volatile("v_accvgpr_read_b32 %0, a16\n\t"
+                 "v_accvgpr_read_b32 %1, a17\n\t"
+                 "v_accvgpr_read_b32 %2, a18\n\t"
+                 "v_accvgpr_read_b32 %3, a19\n\t"
+                 "v_accvgpr_read_b32 %4, a20\n\t"
+                 "v_accvgpr_read_b32 %5, a21\n\t"
+                 "v_accvgpr_read_b32 %6, a22\n\t"
+                 "v_accvgpr_read_b32 %7, a23\n\t"
+                 "v_accvgpr_read_b32 %8, a24\n\t"
+                 "v_accvgpr_read_b32 %9, a25\n\t"
+                 "v_accvgpr_read_b32 %10, a26\n\t"
+                 "v_accvgpr_read_b32 %11, a27\n\t"
+                 "v_accvgpr_read_b32 %12, a28\n\t"
+                 "v_accvgpr_read_b32 %13, a29\n\t"
+                 "v_accvgpr_read_b32 %14, a30\n\t"
+                 "v_accvgpr_read_b32 %15, a31\n\t"
+                 "s_nop 0"
+                 : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]) : : ALG_O_CLOBBER);
+  if constexpr (IDX == 2)
+    asm volatile("v_accvgpr_read_b32 %0, a32\n\t"
+                 "v_accvgpr_read_b32 %1, a33\n\t"
+                 "v_accvgpr_read_b32 %2, a34\n\t"
+                 "v_accvgpr_read_b32 %3, a35\n\t"
+                 "v_accvgpr_read_b32 %4, a36\n\t"
+                 "v_accvgpr_read_b32 %5, a37\n\t"
+                 "v_accvgpr_read_b32 %6, a38\n\t"
+                 "v_accvgpr_read_b32 %7, a39\n\t"
+                 "v_accvgpr_read_b32 %8, a40\n\t"
+                 "v_accvgpr_read_b32 %9, a41\n\t"
+                 "v_accvgpr_read_b32 %10, a42\n\t"
+                 "v_accvgpr_read_b32 %11, a43\n\t"
+                 "v_accvgpr_read_b32 %12, a44\n\t"
+                 "v_accvgpr_read_b32 %13, a45\n\t"
+                 "v_accvgpr_read_b32 %14, a46\n\t"
+                 "v_accvgpr_read_b32 %15, a47\n\t"
+                 "s_nop 0"
+                 : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]) : : ALG_O_CLOBBER);
+  if constexpr (IDX == 3)
+    asm volatile("v_accvgpr_read_b32 %0, a48\n\t"
+                 "v_accvgpr_read_b32 %1, a49\n\t"
+                 "v_accvgpr_read_b32 %2, a50\n\t"
+                 "v_accvgpr_read_b32 %3, a51\n\t"
+                 "v_accvgpr_read_b32 %4, a52\n\t"
+                 "v_accvgpr_read_b32 %5, a53\n\t"
+                 "v_accvgpr_read_b32 %6, a54\n\t"
+                 "v_accvgpr_read_b32 %7, a55\n\t"
+                 "v_accvgpr_read_b32 %8, a56\n\t"
+                 "v_accvgpr_read_b32 %9, a57\n\t"
+                 "v_accvgpr_read_b32 %10, a58\n\t"
+                 "v_accvgpr_read_b32 %11, a59\n\t"
+                 "v_accvgpr_read_b32 %12, a60\n\t"
+                 "v_accvgpr_read_b32 %13, a61\n\t"
+                 "v_accvgpr_read_b32 %14, a62\n\t"
+                 "v_accvgpr_read_b32 %15, a63\n\t"
+                 "s_nop 0"
+                 : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]) : : ALG_O_CLOBBER);
+  if constexpr (IDX == 4)
+    asm volatile("v_accvgpr_read_b32 %0, a64\n\t"
+                 "v_accvgpr_read_b32 %1, a65\n\t"
+                 "v_accvgpr_read_b32 %2, a66\n\t"
+                 "v_accvgpr_read_b32 %3, a67\n\t"
+                 "v_accvgpr_read_b32 %4, a68\n\t"
+                 "v_accvgpr_read_b32 %5, a69\n\t"
+                 "v_accvgpr_read_b32 %6, a70\n\t"
+                 "v_accvgpr_read_b32 %7, a71\n\t"
+                 "v_accvgpr_read_b32 %8, a72\n\t"
+                 "v_accvgpr_read_b32 %9, a73\n\t"
+                 "v_accvgpr_read_b32 %10, a74\n\t"
+                 "v_accvgpr_read_b32 %11, a75\n\t"
+                 "v_accvgpr_read_b32 %12, a76\n\t"
+                 "v_accvgpr_read_b32 %13, a77\n\t"
+                 "v_accvgpr_read_b32 %14, a78\n\t"
+                 "v_accvgpr_read_b32 %15, a79\n\t"
+                 "s_nop 0"
+                 : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]) : : ALG_O_CLOBBER);
+  if constexpr (IDX == 5)
+    asm volatile("v_accvgpr_read_b32 %0, a80\n\t"
+                 "v_accvgpr_read_b32 %1, a81\n\t"
+                 "v_accvgpr_read_b32 %2, a82\n\t"
+                 "v_accvgpr_read_b32 %3, a83\n\t"
+                 "v_accvgpr_read_b32 %4, a84\n\t"
+                 "v_accvgpr_read_b32 %5, a85\n\t"
+                 "v_accvgpr_read_b32 %6, a86\n\t"
+                 "v_accvgpr_read_b32 %7, a87\n\t"
+                 "v_accvgpr_read_b32 %8, a88\n\t"
+                 "v_accvgpr_read_b32 %9, a89\n\t"
+                 "v_accvgpr_read_b32 %10, a90\n\t"
+                 "v_accvgpr_read_b32 %11, a91\n\t"
+                 "v_accvgpr_read_b32 %12, a92\n\t"
+                 "v_accvgpr_read_b32 %13, a93\n\t"
+                 "v_accvgpr_read_b32 %14, a94\n\t"
+                 "v_accvgpr_read_b32 %15, a95\n\t"
+                 "s_nop 0"
+                 : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]) : : ALG_O_CLOBBER);
+  if constexpr (IDX == 6)
+    asm volatile("v_accvgpr_read_b32 %0, a96\n\t"
+                 "v_accvgpr_read_b32 %1, a97\n\t"
+                 "v_accvgpr_read_b32 %2, a98\n\t"
+                 "v_accvgpr_read_b32 %3, a99\n\t"
+                 "v_accvgpr_read_b32 %4, a100\n\t"
+                 "v_accvgpr_read_b32 %5, a101\n\t"
+                 "v_accvgpr_read_b32 %6, a102\n\t"
+                 "v_accvgpr_read_b32 %7, a103\n\t"
+                 "v_accvgpr_read_b32 %8, a104\n\t"
+                 "v_accvgpr_read_b32 %9, a105\n\t"
+                 "v_accvgpr_read_b32 %10, a106\n\t"
+                 "v_accvgpr_read_b32 %11, a107\n\t"
+                 "v_accvgpr_read_b32 %12, a108\n\t"
+                 "v_accvgpr_read_b32 %13, a109\n\t"
+                 "v_accvgpr_read_b32 %14, a110\n\t"
+                 "v_accvgpr_read_b32 %15, a111\n\t"
+                 "s_nop 0"
+                 : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]) : : ALG_O_CLOBBER);
+  if constexpr (IDX == 7)
+    asm volatile("v_accvgpr_read_b32 %0, a112\n\t"
+                 "v_accvgpr_read_b32 %1, a113\n\t"
+                 "v_accvgpr_read_b32 %2, a114\n\t"
+                 "v_accvgpr_read_b32 %3, a115\n\t"
+                 "v_accvgpr_read_b32 %4, a116\n\t"
+                 "v_accvgpr_read_b32 %5, a117\n\t"
+                 "v_accvgpr_read_b32 %6, a118\n\t"
+                 "v_accvgpr_read_b32 %7, a119\n\t"
+                 "v_accvgpr_read_b32 %8, a120\n\t"
+                 "v_accvgpr_read_b32 %9, a121\n\t"
+                 "v_accvgpr_read_b32 %10, a122\n\t"
+                 "v_accvgpr_read_b32 %11, a123\n\t"
+                 "v_accvgpr_read_b32 %12, a124\n\t"
+                 "v_accvgpr_read_b32 %13, a125\n\t"
+                 "v_accvgpr_read_b32 %14, a126\n\t"
+                 "v_accvgpr_read_b32 %15, a127\n\t"
+                 "s_nop 0"
+                 : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]) : : ALG_O_CLOBBER);
+}
 
 __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -224,13 +629,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
 #pragma unroll
   for (int j = 0; j < 4; ++j) vc[j] = lds0 + NS * K_TILE + v_row_off + (((2 * j + h2) ^ v_sw) * 16);
 
-  f32x16 o_acc[2][4];
-#pragma unroll
-  for (int qh = 0; qh < 2; ++qh)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o_acc[qh][i][e] = 0.0f;
+  zero_o();
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
 
   // The KV tile is STAGED 64 keys at a time (whole 128-byte lines of V^T) but CONSUMED in 32-key halves u = 2 tile + sub: only
@@ -255,18 +654,21 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
     // hipcc does not see an MFMA inside the asm: cover the XDL-write -> VALU-read hazard (18 wait states) by hand
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   };
-  // O^T += V^T P^T over the 32 keys of half-tile (tile, SUB): kv blocks 2 SUB, 2 SUB + 1
+  // O^T += V^T P^T over the 32 keys of half-tile (tile, SUB), epilogue form: one fragment at a time through ring slot 0
   auto pv = [&](int tile, auto sub_c, const bf16x8 (&pf)[2][2]) {
     constexpr int SUB = decltype(sub_c)::value;
-    const char* Vs = v_ring + (tile & (NS - 1)) * V_TILE + v_row_off;
-#pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 vf = *(const bf16x8*)(Vs + dt * 4096 + (((2 * (2 * SUB + k2) + h2) ^ v_sw) * 16));
-#pragma unroll
-        for (int qh = 0; qh < 2; ++qh) o_acc[qh][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qh][k2], o_acc[qh][dt], 0, 0, 0);
-      }
+    const uint32_t vb = (tile & (NS - 1)) * V_TILE;
+    auto one = [&](auto k2_c, auto dt_c) {
+      constexpr int k2 = decltype(k2_c)::value, dt = decltype(dt_c)::value;
+      frag_read<0, dt * 4096>(vc[2 * SUB + k2] + vb);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pv_mfma<dt, 0>(pf[0][k2]);
+      pv_mfma<4 + dt, 0>(pf[1][k2]);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    one(I0{}, I0{}); one(I0{}, I1{}); one(I0{}, I2{}); one(I0{}, I3{});
+    one(I1{}, I0{}); one(I1{}, I1{}); one(I1{}, I2{}); one(I1{}, I3{});
   };
   typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
   // probabilities of one query half against the offset mc (= m_run * c), packed as the PV B operand; returns the row sum
@@ -304,7 +706,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
     const float alpha = __builtin_amdgcn_exp2f((m_run[qh] - m_new) * c);
     m_run[qh] = m_new;
     l_run[qh] *= alpha;
-    rescale_o(o_acc[qh], alpha, qh);
+    rescale_o(alpha, qh);
     psum = probs(s, m_new * c, pf);
   };
   auto mask_tail = [&](int kv_base, f32x16 (&s)[2]) {   // keys past Skv in the ragged last tile
@@ -426,7 +828,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
         // instructions of softmax.  The result is first read >= 16 MFMAs later (no XDL -> VALU hazard).
         qk_mfma<ST & 3, KS == 0>(sn[0], qf[0][KS]);
       } else {
-        pv_mfma<dt, ST & 3>(o_acc[0][dt], pp[0][k2]);
+        pv_mfma<dt, ST & 3>(pp[0][k2]);
       }
 #ifdef ALG_Q64_NO_SOFTMAX
       const float a0 = 0.0f, a1 = 0.0f, p0 = 0.5f;
@@ -449,7 +851,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
       if constexpr (QK) {
         qk_mfma<ST & 3, KS == 0>(sn[1], qf[1][KS]);
       } else {
-        pv_mfma<4 + dt, ST & 3>(o_acc[1][dt], pp[1][k2]);
+        pv_mfma<4 + dt, ST & 3>(pp[1][k2]);
       }
       rd(std::integral_constant<int, ST + 3>{});   // into the slot of step ST - 1 (both of its MFMAs have been issued)
 #ifndef ALG_Q64_NO_DMA
@@ -547,8 +949,15 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
   __builtin_amdgcn_s_barrier();
   pv(n_tiles - 1, S1{}, po);
 
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs wrote O a few cycles ago
 #pragma unroll
   for (int qh = 0; qh < 2; ++qh) {
+    float ot[4][16];
+    if (qh == 0) {
+      read_o<0>(ot[0]); read_o<1>(ot[1]); read_o<2>(ot[2]); read_o<3>(ot[3]);
+    } else {
+      read_o<4>(ot[0]); read_o<5>(ot[1]); read_o<6>(ot[2]); read_o<7>(ot[3]);
+    }
     const float l_tot = l_run[qh] + __shfl_xor(l_run[qh], 32, 64);
     const float inv = 1.0f / l_tot;
     const int q_row = q_row0 + qh * 32;
@@ -560,8 +969,8 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
         for (int g = 0; g < 4; ++g) {
           const int d = dt * 32 + 8 * g + 4 * h2;
           uint2 v;
-          v.x = pack_bf2(o_acc[qh][dt][4 * g] * inv, o_acc[qh][dt][4 * g + 1] * inv);
-          v.y = pack_bf2(o_acc[qh][dt][4 * g + 2] * inv, o_acc[qh][dt][4 * g + 3] * inv);
+          v.x = pack_bf2(ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv);
+          v.y = pack_bf2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
           *(uint2*)(op + d) = v;
         }
     }
