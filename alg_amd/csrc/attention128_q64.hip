@@ -839,8 +839,13 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
       const float a1 = dm1 * c - mc[qh];
       const float p0 = __builtin_amdgcn_exp2f(a0);
 #else
+#ifdef ALG_Q64_NO_FMA   // timing experiment: what a pre-scaled Q with a zero offset would save
+      const float a0 = sc[qh][8 * g + 2 * jj];
+      const float a1 = sc[qh][8 * g + 2 * jj + 1];
+#else
       const float a0 = sc[qh][8 * g + 2 * jj] * c - mc[qh];
       const float a1 = sc[qh][8 * g + 2 * jj + 1] * c - mc[qh];
+#endif
 #ifdef ALG_Q64_NO_EXP
       const float p0 = a0;
 #else
