@@ -58,14 +58,17 @@ def pmc_traffic(kernel_substr, profiles=("profiles/r2_pmc_summary.txt", "profile
         path = os.path.join(ROOT, profile)
         if not os.path.exists(path):
             continue
-        vals = {}
+        per_kernel = {}   # kernel name as printed -> {counter: mean}; the main launch is the one that fetches most
         with open(path) as f:
             for line in f:
-                if kernel_substr in line:
+                if kernel_substr in line and "mean=" in line:
                     for name in ("FETCH_SIZE", "WRITE_SIZE"):
                         if (" " + name + " ") in line:
-                            vals[name] = float(line.rsplit("mean=", 1)[1])
-        if len(vals) == 2:
+                            kname = line.split(name)[0].strip()
+                            per_kernel.setdefault(kname, {})[name] = float(line.rsplit("mean=", 1)[1])
+        full = [v for v in per_kernel.values() if len(v) == 2]
+        if full:
+            vals = max(full, key=lambda v: v["FETCH_SIZE"])
             return dict(bytes_per_launch=(2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
                         fetch_kib_raw=vals["FETCH_SIZE"], write_kib_raw=vals["WRITE_SIZE"], samples_per_launch=2,
                         source=profile)
