@@ -287,6 +287,8 @@ int gaussian_big(const void* in, void* out, int64_t planes, int H, int W, int ks
 int down_up_v2(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
                hipStream_t s);
 int gaussian_v2(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype, hipStream_t s);
+// register-blocked kernels for many-plane batches (lowpass_v3.hip); return 1 = shape not covered
+int gaussian_v3(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype, hipStream_t s);
 
 static bool force_v1() {  // debug knob: the one-plane-per-workgroup kernels of this file (bit-identity tests)
   const char* e = getenv("ALG_LOWPASS_V1");
@@ -398,6 +400,8 @@ extern "C" int alg_gaussian_blur(const void* in, void* out, int64_t planes, int 
   if (lds > 160 * 1024 || ksize > 255 || force_global()) return gaussian_big(in, out, planes, H, W, ksize, sigma, dtype, s);
   int rc;
   if (!force_v1()) {
+    rc = gaussian_v3(in, out, planes, H, W, ksize, sigma, dtype, s);
+    if (rc <= 0) return rc;
     rc = gaussian_v2(in, out, planes, H, W, ksize, sigma, dtype, s);
     if (rc <= 0) return rc;
   }

@@ -11,8 +11,9 @@ import bench  # noqa: E402
 
 dev = torch.device("cuda:0")
 res = {}
-for tag, env in (("v2", "0"), ("v1", "1")):
+for tag, env, env3 in (("v3", "0", "1"), ("v2", "0", "0"), ("v1", "1", "1")):
     os.environ["ALG_LOWPASS_V1"] = env
+    os.environ["ALG_LOWPASS_V3"] = env3
     res[tag] = {k: {"us": round(v["ms"] * 1e3, 2), "gbs": round(v["gbs"]), "hbm_frac": round(v["hbm_frac"], 3)}
                 for k, v in bench.filter_microbench(dev).items()}
 print(json.dumps(res, indent=1))

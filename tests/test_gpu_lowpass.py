@@ -213,6 +213,13 @@ def test_global_memory_path_is_bit_identical_to_the_lds_path(device, monkeypatch
     ((8, 20, 21, 60, 104), torch.float32, "gaussian_blur", (9, 7.5)),
     ((8, 13, 16, 60, 90), torch.bfloat16, "gaussian_blur", (13, 3.0)),
     ((2, 20, 21, 90, 160), torch.float32, "gaussian_blur", (19, 15.0)),   # k > 16: taps read from LDS
+    # register-blocked kernels (lowpass_v3.hip): W a multiple of 4, more than two planes per CU
+    ((8, 16, 13, 60, 88), torch.bfloat16, "gaussian_blur", (5, 2.0)),
+    ((4, 20, 21, 60, 104), torch.float32, "gaussian_blur", (3, 1.0)),
+    ((8, 16, 13, 32, 36), torch.float32, "gaussian_blur", (15, 4.0)),
+    ((8, 16, 13, 17, 20), torch.bfloat16, "gaussian_blur", (7, 1.5)),    # H not a multiple of the row block
+    ((8, 16, 13, 18, 24), torch.float32, "gaussian_blur", (17, 9.0)),    # pad = 8 = H / 2 - 1: mirrored rows overlap the far edge
+    ((8, 16, 13, 30, 44), torch.float32, "gaussian_blur", (11, 3.0)),
 ])
 def test_bandwidth_shaped_kernels_are_bit_identical_to_the_plane_per_workgroup_kernels(device, monkeypatch, shape, dtype,
                                                                                        kind, arg):
