@@ -289,6 +289,8 @@ int down_up_v2(const void* in, void* out, int64_t planes, int H, int W, int h1, 
 int gaussian_v2(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype, hipStream_t s);
 // register-blocked kernels for many-plane batches (lowpass_v3.hip); return 1 = shape not covered
 int gaussian_v3(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype, hipStream_t s);
+int down_up_v3(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
+               hipStream_t s);
 
 static bool force_v1() {  // debug knob: the one-plane-per-workgroup kernels of this file (bit-identity tests)
   const char* e = getenv("ALG_LOWPASS_V1");
@@ -342,6 +344,8 @@ extern "C" int alg_down_up(const void* in, void* out, int64_t planes, int H, int
   if (lds > 160 * 1024 || force_global()) return down_up_big(in, out, planes, H, W, h1, w1, dtype, round_intermediate ? 1 : 0, s);
   int rc;
   if (!force_v1()) {
+    rc = down_up_v3(in, out, planes, H, W, h1, w1, dtype, (dtype == ALG_BF16 && round_intermediate) ? 1 : 0, s);
+    if (rc <= 0) return rc;
     rc = down_up_v2(in, out, planes, H, W, h1, w1, dtype, (dtype == ALG_BF16 && round_intermediate) ? 1 : 0, s);
     if (rc <= 0) return rc;
   }

@@ -23,43 +23,12 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "lowpass_tabs.h"
 
 namespace alg {
 namespace v2 {
 
 constexpr int REG_TAPS = 12;
-
-__host__ __device__ inline int aa_taps(int in_size, int out_size) {
-  float scale = (float)in_size / (float)out_size;
-  float support = scale >= 1.0f ? scale : 1.0f;
-  return (int)ceilf(support) * 2 + 1;
-}
-
-// ---- tap tables: blob layout per table = xmin[n_out] | xsize[n_out] | w[n_out][taps] (ints / floats, 4 bytes each) --------
-struct Tab {
-  int off;   // word offset of the table inside the blob
-  int n_out, taps;
-  __host__ __device__ int words() const { return n_out * (2 + taps); }
-};
-
-struct Tabs {
-  Tab dw, dh, uw, uh;
-  int words;
-};
-
-static Tabs layout(int H, int W, int h1, int w1) {
-  Tabs t;
-  int o = 0;
-  auto mk = [&](int n_out, int in_size) {
-    Tab x;
-    x.off = o, x.n_out = n_out, x.taps = aa_taps(in_size, n_out);
-    o += x.words();
-    return x;
-  };
-  t.dw = mk(w1, W), t.dh = mk(h1, H), t.uw = mk(W, w1), t.uh = mk(H, h1);
-  t.words = (o + 3) & ~3;
-  return t;
-}
 
 // Host restatement of lowpass.hip build_taps: every operation is a single IEEE fp32 operation in the same order (this file
 // is compiled with -ffp-contract=off for host and device; x86-64 float arithmetic is SSE, no excess precision), so the
@@ -637,6 +606,9 @@ template <typename T>
 static int dispatch_g(const void* in, void* out, const GArgs& a, size_t lds, const Geo& geo, hipStream_t s) {
   ALG_V2_DISPATCH(launch_g, T, (const T*)in, (T*)out, a, lds, geo.grid, s)
 }
+
+// the same device blob for lowpass_v3.hip
+const uint32_t* lowpass_tables_for(int H, int W, int h1, int w1, const Tabs& t) { return tables_for(H, W, h1, w1, t); }
 
 }  // namespace v2
 

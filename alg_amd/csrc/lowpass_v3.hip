@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "lowpass_tabs.h"
 
 namespace alg {
 namespace v3 {
@@ -38,9 +39,25 @@ __device__ __forceinline__ void pk_fma_bv(v2f& acc, const v2f w, const v2f v) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(v));
 }
 
-// acc += (w.y, w.y) * v
-__device__ __forceinline__ void pk_fma_bw_hi(v2f& acc, const v2f w, const v2f v) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(v));
+// acc += (w.S, w.S) * v
+template <int S>
+__device__ __forceinline__ void pk_fma_bw(v2f& acc, const v2f w, const v2f v) {
+  if constexpr (S == 0)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(v));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(v));
+}
+__device__ __forceinline__ void pk_fma_bw_hi(v2f& acc, const v2f w, const v2f v) { pk_fma_bw<1>(acc, w, v); }
+
+// (w.S, w.S) * v
+template <int S>
+__device__ __forceinline__ v2f pk_mul_bw(const v2f w, const v2f v) {
+  v2f r;
+  if constexpr (S == 0)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "v"(v));
+  else
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(w), "v"(v));
+  return r;
 }
 
 template <typename T>
@@ -217,6 +234,233 @@ __global__ __launch_bounds__(NT) void gaussian_v3_kernel(const T* __restrict__ i
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// down_up: two antialiased bilinear resamples (H x W -> h1 x w1 -> H x W), each a W pass then an H pass (lowpass.hip
+// down_up_kernel; tables from the shared device blob).  Row strides in LDS are padded to a multiple of 4 floats (WS, VS) so
+// that every quad is one 16-byte access; pad columns and the slack behind the regions hold finite values (zero-filled
+// once, afterwards only ever overwritten by results of zero weights), because the tap loops run UNCONDITIONALLY over the
+// table's tap count: taps past a row's own count have weight 0 in the table.
+//   pass 1 (W, down): a lane owns output column o for good (weights in registers), walks rows; reads are plain LDS words.
+//   pass 2 (H, down): item = (output row, column quad); weights come in pairs from an 8-byte-aligned LDS record.
+//   pass 3 (W, up, 3 taps): a lane owns a quad of output columns for good (4 x (first tap, 3 weights) in registers).
+//   pass 4 (H, up, 3 taps): item = (output row, column quad); one 16-byte record {first row, w0, w1, w2} per output row;
+//                           the quad leaves straight for HBM.
+// LDS: X [H][WS] (later T3 [h1][WS]) | 16 | T1 [H][VS] | T2 [h1][VS] | 16 | dh_lo [h1] | dh_w [h1][TP] | uh_rec [H][4]
+// ---------------------------------------------------------------------------------------------------------------------
+struct DArgs {
+  int H, W, h1, w1, round_mid;
+  int64_t planes;
+  v2::Tabs tabs;
+};
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// a quad of results to HBM at a 4-byte-aligned element offset; `valid` = 4 or 2 elements
+template <typename T>
+__device__ __forceinline__ void store_quad(T* p, const v4f v, const bool whole) {
+  if constexpr (sizeof(T) == 4) {
+    if (whole) {
+      *(u32x4_a4*)p = u32x4_a4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    } else {
+      *(u32x2_a4*)p = u32x2_a4{__float_as_uint(v.x), __float_as_uint(v.y)};
+    }
+  } else {
+    if (whole) {
+      *(u32x2_a4*)p = u32x2_a4{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+    } else {
+      *(uint32_t*)p = pack_bf2(v.x, v.y);
+    }
+  }
+}
+
+template <typename T, int TDW, int NT>
+__global__ __launch_bounds__(NT) void down_up_v3_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                        const uint32_t* __restrict__ gblob, const DArgs a) {
+  typedef typename Chunk<T>::type chunk_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int H = a.H, W = a.W, h1 = a.h1, w1 = a.w1;
+  const int WS = (W + 3) & ~3, VS = (w1 + 3) & ~3, Q = WS >> 2, QV = VS >> 2;
+  const int n = H * W, nv = n >> 2;
+  const int tdh = a.tabs.dh.taps, TP = (tdh + 1) & ~1;
+  float* X = (float*)smem;
+  float* T1 = X + (size_t)H * WS + 16;
+  float* T2 = T1 + (size_t)H * VS;
+  int* dh_lo = (int*)(T2 + (size_t)h1 * VS + 16);
+  float* dh_w = (float*)(dh_lo + ((h1 + 3) & ~3));
+  float* uh_rec = dh_w + (((size_t)h1 * TP + 3) & ~(size_t)3);
+  float* T3 = X;
+  const int lds_floats = (int)(uh_rec + (size_t)H * 4 - X);
+
+  for (int i = tid; i < lds_floats; i += NT) X[i] = 0.0f;
+  __syncthreads();
+  {
+    const int* gmin = (const int*)gblob + a.tabs.dh.off;
+    const float* gw = (const float*)(gmin + 2 * h1);
+    for (int o = tid; o < h1; o += NT) dh_lo[o] = gmin[o];
+    for (int i = tid; i < h1 * tdh; i += NT) {
+      const int o = i / tdh, j = i - o * tdh;
+      dh_w[o * TP + j] = gw[i];
+    }
+    const int* umin = (const int*)gblob + a.tabs.uh.off;
+    const float* uw_ = (const float*)(umin + 2 * H);
+    for (int y = tid; y < H; y += NT) {
+      uh_rec[4 * y] = __int_as_float(umin[y]);
+      for (int j = 0; j < 3; ++j) uh_rec[4 * y + 1 + j] = uw_[y * 3 + j];
+    }
+  }
+  // pass 1 constants: output column o = tid % w1 of row group tid / w1
+  const int rstep1 = NT / w1, rg1 = tid / w1, o1 = tid - rg1 * w1;
+  int xm1;
+  float w1r[TDW];
+  {
+    const int* gmin = (const int*)gblob + a.tabs.dw.off;
+    const float* gw = (const float*)(gmin + 2 * w1);
+    xm1 = gmin[o1];
+#pragma unroll
+    for (int j = 0; j < TDW; ++j) w1r[j] = j < a.tabs.dw.taps ? gw[o1 * a.tabs.dw.taps + j] : 0.0f;
+  }
+  // pass 3 constants: output quad q3 = tid % Q of row group tid / Q
+  const int rstep3 = NT / Q, rg3 = tid / Q, q3 = tid - rg3 * Q;
+  int xm3[4];
+  float w3[4][3];
+  {
+    const int* gmin = (const int*)gblob + a.tabs.uw.off;
+    const float* gw = (const float*)(gmin + 2 * W);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x = 4 * q3 + i;
+      const bool live = x < W;
+      xm3[i] = live ? gmin[x] : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) w3[i][j] = live ? gw[x * 3 + j] : 0.0f;
+    }
+  }
+  // where the thread's chunks land: element pairs (e, e + 1) and (e + 2, e + 3) never straddle a row (W is even); bit 0 of
+  // pre_dst says that the second pair starts the next row
+  int pre_dst[MAXPRE];
+#pragma unroll
+  for (int k = 0; k < MAXPRE; ++k) {
+    const int e = (tid + k * NT) << 2, y = e / W, c = e - y * W;
+    pre_dst[k] = (y * WS + c) | (c + 2 >= W ? 1 : 0);
+  }
+  chunk_t pre[MAXPRE];
+  auto fetch = [&](const int64_t plane) {
+    const chunk_t* gp = (const chunk_t*)(in + plane * n);
+#pragma unroll
+    for (int k = 0; k < MAXPRE; ++k)
+      if (tid + k * NT < nv) pre[k] = gp[tid + k * NT];
+  };
+  __syncthreads();
+
+  int64_t plane = blockIdx.x;
+  if (plane < a.planes) fetch(plane);
+  for (; plane < a.planes; plane += gridDim.x) {
+#pragma unroll
+    for (int k = 0; k < MAXPRE; ++k)
+      if (tid + k * NT < nv) {
+        const v4f v = Chunk<T>::unpack(pre[k]);
+        const int d0 = pre_dst[k] & ~1, d1 = d0 + 2 + ((pre_dst[k] & 1) ? WS - W : 0);
+        *(v2f*)(X + d0) = v2f{v.x, v.y};
+        *(v2f*)(X + d1) = v2f{v.z, v.w};
+      }
+    __syncthreads();
+    if (plane + gridDim.x < a.planes) fetch(plane + gridDim.x);   // in flight during the four passes
+
+    // ---- pass 1: T1[r][o] = sum_j X[r][xmin[o] + j] w[o][j] ----
+    if (rg1 < rstep1) {
+      const float* s0 = X + xm1;
+      int r = rg1;
+      for (; r + rstep1 < H; r += 2 * rstep1) {   // two rows in flight
+        const float* sa = s0 + r * WS;
+        const float* sb = sa + rstep1 * WS;
+        float va[TDW], vb[TDW];
+#pragma unroll
+        for (int j = 0; j < TDW; ++j) va[j] = sa[j], vb[j] = sb[j];
+        float acca = va[0] * w1r[0], accb = vb[0] * w1r[0];
+#pragma unroll
+        for (int j = 1; j < TDW; ++j) acca = fmaf(va[j], w1r[j], acca), accb = fmaf(vb[j], w1r[j], accb);
+        T1[r * VS + o1] = acca;
+        T1[(r + rstep1) * VS + o1] = accb;
+      }
+      if (r < H) {
+        const float* sa = s0 + r * WS;
+        float va[TDW];
+#pragma unroll
+        for (int j = 0; j < TDW; ++j) va[j] = sa[j];
+        float acca = va[0] * w1r[0];
+#pragma unroll
+        for (int j = 1; j < TDW; ++j) acca = fmaf(va[j], w1r[j], acca);
+        T1[r * VS + o1] = acca;
+      }
+    }
+    __syncthreads();
+    // ---- pass 2: T2[o][c] = sum_j T1[xmin[o] + j][c] w[o][j], item = (o, column quad) ----
+    for (int it = tid; it < h1 * QV; it += NT) {
+      const int o = it / QV, qc = it - o * QV;
+      const int lo = dh_lo[o];
+      const float* src = T1 + (qc << 2);
+      const float* wrow = dh_w + o * TP;
+      v2f a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
+      for (int j = 0; j < TP; j += 2) {
+        const v2f wv = *(const v2f*)(wrow + j);
+        const v4f u0 = *(const v4f*)(src + min(lo + j, H - 1) * VS);
+        const v4f u1 = *(const v4f*)(src + min(lo + j + 1, H - 1) * VS);
+        pk_fma_bw<0>(a0, wv, v2f{u0.x, u0.y});
+        pk_fma_bw<0>(a1, wv, v2f{u0.z, u0.w});
+        pk_fma_bw<1>(a0, wv, v2f{u1.x, u1.y});
+        pk_fma_bw<1>(a1, wv, v2f{u1.z, u1.w});
+      }
+      v4f r4 = {a0.x, a0.y, a1.x, a1.y};
+      if (a.round_mid) r4 = v4f{rbf(r4.x), rbf(r4.y), rbf(r4.z), rbf(r4.w)};
+      *(v4f*)(T2 + o * VS + (qc << 2)) = r4;
+    }
+    __syncthreads();
+    // ---- pass 3: T3[h][x] = sum_j T2[h][xmin[x] + j] w[x][j] (X is dead: T3 lives there) ----
+    if (rg3 < rstep3) {
+      for (int h = rg3; h < h1; h += rstep3) {
+        const float* row = T2 + h * VS;
+        v4f o4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float* sp = row + xm3[i];
+          float acc = sp[0] * w3[i][0];
+          acc = fmaf(sp[1], w3[i][1], acc);
+          acc = fmaf(sp[2], w3[i][2], acc);
+          o4[i] = acc;
+        }
+        *(v4f*)(T3 + h * WS + (q3 << 2)) = o4;
+      }
+    }
+    __syncthreads();
+    // ---- pass 4: out[y][x] = sum_j T3[xmin[y] + j][x] w[y][j], item = (y, column quad) -> HBM ----
+    {
+      T* op = out + plane * n;
+      int y = tid / Q, q = tid - y * Q;
+      const int dy = NT / Q, dq = NT - dy * Q;
+      for (; y < H; ) {
+        const v4f rec = *(const v4f*)(uh_rec + 4 * y);
+        const int lo = __float_as_int(rec.x);
+        const float* src = T3 + (q << 2);
+        const v4f u0 = *(const v4f*)(src + lo * WS);
+        const v4f u1 = *(const v4f*)(src + min(lo + 1, h1 - 1) * WS);
+        const v4f u2 = *(const v4f*)(src + min(lo + 2, h1 - 1) * WS);
+        const v2f w01 = {rec.x, rec.y}, w12 = {rec.z, rec.w};   // (lo, w0), (w1, w2)
+        v2f a0 = pk_mul_bw<1>(w01, v2f{u0.x, u0.y}), a1 = pk_mul_bw<1>(w01, v2f{u0.z, u0.w});
+        pk_fma_bw<0>(a0, w12, v2f{u1.x, u1.y});
+        pk_fma_bw<0>(a1, w12, v2f{u1.z, u1.w});
+        pk_fma_bw<1>(a0, w12, v2f{u2.x, u2.y});
+        pk_fma_bw<1>(a1, w12, v2f{u2.z, u2.w});
+        store_quad<T>(op + (size_t)y * W + (q << 2), v4f{a0.x, a0.y, a1.x, a1.y}, (q << 2) + 4 <= W);
+        y += dy, q += dq;
+        if (q >= Q) q -= Q, ++y;
+      }
+    }
+    __syncthreads();   // T3 (= X) is free for the next plane
+  }
+}
+
 static int num_cus() {
   static int cus = 0;
   if (!cus) {
@@ -231,7 +475,7 @@ static int num_cus() {
 static int threads_override() {
   const char* e = getenv("ALG_LOWPASS_V3_THREADS");
   const int v = e ? atoi(e) : 0;
-  return (v == 256 || v == 512) ? v : 0;
+  return (v == 256 || v == 512 || v == 1024) ? v : 0;
 }
 
 template <typename T, int K, int NT>
@@ -272,6 +516,43 @@ static int dispatch_g(const void* in, void* out, const GArgs& a, int ksize, size
   }
 }
 
+
+template <typename T, int TDW, int NT>
+static int launch_d(const void* in, void* out, const uint32_t* blob, const DArgs& a, size_t lds, int wgs, hipStream_t s) {
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)down_up_v3_kernel<T, TDW, NT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", lds, hipGetErrorString(e));
+      return ALG_ELAUNCH;
+    }
+  }
+  const int64_t slots = (int64_t)num_cus() * wgs;
+  const unsigned grid = (unsigned)std::min<int64_t>(a.planes, slots);
+  hipLaunchKernelGGL((down_up_v3_kernel<T, TDW, NT>), dim3(grid), dim3(NT), lds, s, (const T*)in, (T*)out, blob, a);
+  return check_launch("alg_down_up");
+}
+
+template <typename T, int TDW>
+static int launch_d_nt(const void* in, void* out, const uint32_t* blob, const DArgs& a, size_t lds, int nt, int wgs,
+                       hipStream_t s) {
+  switch (nt) {
+    case 256: return launch_d<T, TDW, 256>(in, out, blob, a, lds, wgs, s);
+    case 512: return launch_d<T, TDW, 512>(in, out, blob, a, lds, wgs, s);
+    default: return launch_d<T, TDW, 1024>(in, out, blob, a, lds, wgs, s);
+  }
+}
+
+template <typename T>
+static int dispatch_d(const void* in, void* out, const uint32_t* blob, const DArgs& a, size_t lds, int nt, int wgs,
+                      hipStream_t s) {
+  const int taps = a.tabs.dw.taps;
+  if (taps <= 5) return launch_d_nt<T, 5>(in, out, blob, a, lds, nt, wgs, s);
+  if (taps <= 7) return launch_d_nt<T, 7>(in, out, blob, a, lds, nt, wgs, s);
+  if (taps <= 9) return launch_d_nt<T, 9>(in, out, blob, a, lds, nt, wgs, s);
+  return launch_d_nt<T, 11>(in, out, blob, a, lds, nt, wgs, s);
+}
+
 }  // namespace v3
 
 // Returns ALG_OK when the launch was made, 1 when this shape is not covered (the caller goes on to lowpass_v2.hip).
@@ -291,6 +572,7 @@ int gaussian_v3(const void* in, void* out, int64_t planes, int H, int W, int ksi
   const int items = H * (W >> 2);
   auto waste = [&](int nt) { return (double)((items + nt - 1) / nt * nt) / items; };
   int nt = threads_override();
+  if (nt == 1024) nt = 512;
   if (!nt) nt = waste(512) < waste(256) - 0.02 ? 512 : 256;
   if ((int64_t)nt * MAXPRE * 4 < (int64_t)H * W || (int64_t)nt * MAXHALO < (int64_t)H * 2 * pad) {
     nt = 512;
@@ -300,6 +582,44 @@ int gaussian_v3(const void* in, void* out, int64_t planes, int H, int W, int ksi
   a.H = H, a.W = W, a.sigma = sigma, a.planes = planes;
   return dtype == ALG_F32 ? dispatch_g<float>(in, out, a, ksize, lds, nt, s)
                           : dispatch_g<bf16_t>(in, out, a, ksize, lds, nt, s);
+}
+
+
+// down_up: returns ALG_OK when the launch was made, 1 when this shape is not covered (the caller goes on to lowpass_v2.hip)
+int down_up_v3(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
+               hipStream_t s) {
+  using namespace v3;
+  const char* off = getenv("ALG_LOWPASS_V3");
+  if (off && off[0] == '0') return 1;
+  const int n = H * W;
+  if ((W & 1) || (n & 3) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return 1;
+  if (planes <= 2 * (int64_t)num_cus()) return 1;             // few planes: latency-bound, the plane-per-workgroup kernels win
+  DArgs a;
+  a.H = H, a.W = W, a.h1 = h1, a.w1 = w1, a.round_mid = round_mid, a.planes = planes;
+  a.tabs = v2::layout(H, W, h1, w1);
+  if (a.tabs.uw.taps != 3 || a.tabs.uh.taps != 3 || a.tabs.dw.taps > 11 || a.tabs.dh.taps > 64) return 1;
+  const int WS = (W + 3) & ~3, VS = (w1 + 3) & ~3, TP = (a.tabs.dh.taps + 1) & ~1;
+  const size_t floats = (size_t)H * WS + 16 + (size_t)H * VS + (size_t)h1 * VS + 16 + ((h1 + 3) & ~3) +
+                        (((size_t)h1 * TP + 3) & ~(size_t)3) + (size_t)H * 4;
+  const size_t lds = floats * 4;
+  if (lds > 160 * 1024) return 1;
+  // thread count: enough prefetch registers for a plane, then the most resident waves per CU (ties: the smaller workgroup)
+  int nt = threads_override(), wgs = 0;
+  if (nt) {
+    wgs = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / nt));
+  } else {
+    int best_waves = -1;
+    for (int t : {256, 512, 1024}) {
+      if ((int64_t)t * MAXPRE * 4 < n || w1 > t || (WS >> 2) > t) continue;
+      const int g = std::min((int)((160 * 1024) / lds), 2048 / t);
+      if (g >= 1 && g * t / 64 > best_waves) best_waves = g * t / 64, nt = t, wgs = g;
+    }
+  }
+  if (!nt || (int64_t)nt * MAXPRE * 4 < n || w1 > nt || (WS >> 2) > nt) return 1;
+  const uint32_t* blob = v2::lowpass_tables_for(H, W, h1, w1, a.tabs);
+  if (!blob) return 1;
+  return dtype == ALG_F32 ? dispatch_d<float>(in, out, blob, a, lds, nt, wgs, s)
+                          : dispatch_d<bf16_t>(in, out, blob, a, lds, nt, wgs, s);
 }
 
 }  // namespace alg

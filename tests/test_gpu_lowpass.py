@@ -220,6 +220,13 @@ def test_global_memory_path_is_bit_identical_to_the_lds_path(device, monkeypatch
     ((8, 16, 13, 17, 20), torch.bfloat16, "gaussian_blur", (7, 1.5)),    # H not a multiple of the row block
     ((8, 16, 13, 18, 24), torch.float32, "gaussian_blur", (17, 9.0)),    # pad = 8 = H / 2 - 1: mirrored rows overlap the far edge
     ((8, 16, 13, 30, 44), torch.float32, "gaussian_blur", (11, 3.0)),
+    ((8, 16, 13, 60, 104), torch.float32, "down_up", 0.25),             # integer scale, 9 taps
+    ((8, 16, 13, 44, 76), torch.bfloat16, "down_up", 0.8125),           # 5 taps
+    ((8, 16, 13, 90, 160), torch.float32, "down_up", 0.625),
+    ((8, 16, 13, 30, 46), torch.bfloat16, "down_up", 0.5),              # W = 2 mod 4: chunks straddle rows, half quads
+    ((8, 16, 13, 31, 44), torch.float32, "down_up", 0.3),               # odd H, 9 / 11 taps
+    ((8, 16, 13, 18, 22), torch.float32, "down_up", 0.2),               # scale 5.5 / 6 -> 11 and 13 taps: W pass fits, H pass table-driven
+    ((8, 16, 13, 60, 90), torch.float32, "down_up", 0.34),
 ])
 def test_bandwidth_shaped_kernels_are_bit_identical_to_the_plane_per_workgroup_kernels(device, monkeypatch, shape, dtype,
                                                                                        kind, arg):
