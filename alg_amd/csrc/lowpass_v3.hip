@@ -17,6 +17,7 @@
 // pair's chain, which leave acc unchanged (they can turn an all-zero-products result -0 into +0; nothing else).
 // Shapes not covered (W not a multiple of 4, tap counts without an instantiation, halo too large) return 1 and take v2.
 #include <algorithm>
+#include <atomic>
 
 #include <math.h>
 #include <stdlib.h>
@@ -128,10 +129,15 @@ __global__ __launch_bounds__(NT) void gaussian_v3_kernel(const T* __restrict__ i
 
   // per-thread constants of the plane walk: where its chunks and halo elements sit (the same for every plane)
   int pre_dst[MAXPRE];
+  {
+    int y = (tid << 2) / W, c = (tid << 2) - y * W;
+    const int sy = (4 * NT) / W, sc = 4 * NT - sy * W;   // one division per thread; chunk k + 1 is 4 NT elements further
 #pragma unroll
-  for (int k = 0; k < MAXPRE; ++k) {
-    const int idx = tid + k * NT, e = idx << 2, y = e / W;
-    pre_dst[k] = y * XS + P4 + (e - y * W);
+    for (int k = 0; k < MAXPRE; ++k) {
+      pre_dst[k] = y * XS + P4 + c;
+      y += sy, c += sc;
+      if (c >= W) c -= W, ++y;
+    }
   }
   const int n_halo = H * 2 * PAD;
   int halo_src[MAXHALO], halo_dst[MAXHALO];
@@ -340,10 +346,15 @@ __global__ __launch_bounds__(NT) void down_up_v3_kernel(const T* __restrict__ in
   // where the thread's chunks land: element pairs (e, e + 1) and (e + 2, e + 3) never straddle a row (W is even); bit 0 of
   // pre_dst says that the second pair starts the next row
   int pre_dst[MAXPRE];
+  {
+    int y = (tid << 2) / W, c = (tid << 2) - y * W;
+    const int sy = (4 * NT) / W, sc = 4 * NT - sy * W;   // one division per thread; chunk k + 1 is 4 NT elements further
 #pragma unroll
-  for (int k = 0; k < MAXPRE; ++k) {
-    const int e = (tid + k * NT) << 2, y = e / W, c = e - y * W;
-    pre_dst[k] = (y * WS + c) | (c + 2 >= W ? 1 : 0);
+    for (int k = 0; k < MAXPRE; ++k) {
+      pre_dst[k] = (y * WS + c) | (c + 2 >= W ? 1 : 0);
+      y += sy, c += sc;
+      if (c >= W) c -= W, ++y;
+    }
   }
   chunk_t pre[MAXPRE];
   auto fetch = [&](const int64_t plane) {
@@ -472,25 +483,69 @@ static int num_cus() {
   return cus;
 }
 
+// planes a launch must have for these kernels to be used (fewer: the plane-per-workgroup kernels of lowpass.hip put up to
+// 1024 threads on a plane and have the lower latency; measured cross-over well below one plane per CU)
+static int64_t min_planes() {
+  const char* e = getenv("ALG_LOWPASS_V3_MIN_PLANES");
+  return e ? atoll(e) : num_cus() / 2;
+}
+
+static int wgs_cap() {   // tuning knob: resident workgroups per CU the persistent grid is sized for
+  const char* e = getenv("ALG_LOWPASS_V3_WGS");
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? v : 1 << 20;
+}
+
+// Workgroups of `kernel` a CU really holds (registers AND LDS): the persistent grid must not be larger than that, or the
+// surplus workgroups wait for a slot and run their planes as a tail (measured: C2 x 8 videos 26.8 us with five workgroups
+// per CU requested, four resident; 22.6 us with four).
+template <typename K>
+static int resident_wgs(K kernel, int nt, size_t lds) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kernel, nt, lds) != hipSuccess || n < 1) {
+    (void)hipGetLastError();
+    n = 1;
+  }
+  return n;
+}
+
 static int threads_override() {
   const char* e = getenv("ALG_LOWPASS_V3_THREADS");
   const int v = e ? atoi(e) : 0;
   return (v == 256 || v == 512 || v == 1024) ? v : 0;
 }
 
+// per kernel instantiation: raise the LDS limit when needed and ask the runtime how many workgroups a CU holds; both are
+// remembered for the largest LDS size seen (first calls may race: they compute the same values)
+struct Prep {
+  std::atomic<size_t> lds{0};
+  std::atomic<int> wgs{0};
+};
+
+template <typename K>
+static int prepare(Prep& p, K kernel, int nt, size_t lds, int* wgs) {
+  if (p.lds.load() != lds) {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", lds, hipGetErrorString(e));
+        return ALG_ELAUNCH;
+      }
+    }
+    p.wgs.store(resident_wgs(kernel, nt, lds));
+    p.lds.store(lds);
+  }
+  *wgs = std::min(std::max(p.wgs.load(), 1), wgs_cap());
+  return ALG_OK;
+}
+
 template <typename T, int K, int NT>
 static int launch_g(const void* in, void* out, const GArgs& a, size_t lds, hipStream_t s) {
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)gaussian_v3_kernel<T, K, NT>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", lds, hipGetErrorString(e));
-      return ALG_ELAUNCH;
-    }
-  }
-  const int wgs = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / NT));
-  const int64_t slots = (int64_t)num_cus() * wgs;
-  const unsigned grid = (unsigned)std::min<int64_t>(a.planes, slots);
+  static Prep prep;
+  int wgs = 1;
+  const int rc = prepare(prep, gaussian_v3_kernel<T, K, NT>, NT, lds, &wgs);
+  if (rc != ALG_OK) return rc;
+  const unsigned grid = (unsigned)std::min<int64_t>(a.planes, (int64_t)num_cus() * wgs);
   hipLaunchKernelGGL((gaussian_v3_kernel<T, K, NT>), dim3(grid), dim3(NT), lds, s, (const T*)in, (T*)out, a);
   return check_launch("alg_gaussian_blur");
 }
@@ -518,39 +573,34 @@ static int dispatch_g(const void* in, void* out, const GArgs& a, int ksize, size
 
 
 template <typename T, int TDW, int NT>
-static int launch_d(const void* in, void* out, const uint32_t* blob, const DArgs& a, size_t lds, int wgs, hipStream_t s) {
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)down_up_v3_kernel<T, TDW, NT>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", lds, hipGetErrorString(e));
-      return ALG_ELAUNCH;
-    }
-  }
-  const int64_t slots = (int64_t)num_cus() * wgs;
-  const unsigned grid = (unsigned)std::min<int64_t>(a.planes, slots);
+static int launch_d(const void* in, void* out, const uint32_t* blob, const DArgs& a, size_t lds, hipStream_t s) {
+  static Prep prep;
+  int wgs = 1;
+  const int rc = prepare(prep, down_up_v3_kernel<T, TDW, NT>, NT, lds, &wgs);
+  if (rc != ALG_OK) return rc;
+  const unsigned grid = (unsigned)std::min<int64_t>(a.planes, (int64_t)num_cus() * wgs);
   hipLaunchKernelGGL((down_up_v3_kernel<T, TDW, NT>), dim3(grid), dim3(NT), lds, s, (const T*)in, (T*)out, blob, a);
   return check_launch("alg_down_up");
 }
 
 template <typename T, int TDW>
-static int launch_d_nt(const void* in, void* out, const uint32_t* blob, const DArgs& a, size_t lds, int nt, int wgs,
+static int launch_d_nt(const void* in, void* out, const uint32_t* blob, const DArgs& a, size_t lds, int nt,
                        hipStream_t s) {
   switch (nt) {
-    case 256: return launch_d<T, TDW, 256>(in, out, blob, a, lds, wgs, s);
-    case 512: return launch_d<T, TDW, 512>(in, out, blob, a, lds, wgs, s);
-    default: return launch_d<T, TDW, 1024>(in, out, blob, a, lds, wgs, s);
+    case 256: return launch_d<T, TDW, 256>(in, out, blob, a, lds, s);
+    case 512: return launch_d<T, TDW, 512>(in, out, blob, a, lds, s);
+    default: return launch_d<T, TDW, 1024>(in, out, blob, a, lds, s);
   }
 }
 
 template <typename T>
-static int dispatch_d(const void* in, void* out, const uint32_t* blob, const DArgs& a, size_t lds, int nt, int wgs,
+static int dispatch_d(const void* in, void* out, const uint32_t* blob, const DArgs& a, size_t lds, int nt,
                       hipStream_t s) {
   const int taps = a.tabs.dw.taps;
-  if (taps <= 5) return launch_d_nt<T, 5>(in, out, blob, a, lds, nt, wgs, s);
-  if (taps <= 7) return launch_d_nt<T, 7>(in, out, blob, a, lds, nt, wgs, s);
-  if (taps <= 9) return launch_d_nt<T, 9>(in, out, blob, a, lds, nt, wgs, s);
-  return launch_d_nt<T, 11>(in, out, blob, a, lds, nt, wgs, s);
+  if (taps <= 5) return launch_d_nt<T, 5>(in, out, blob, a, lds, nt, s);
+  if (taps <= 7) return launch_d_nt<T, 7>(in, out, blob, a, lds, nt, s);
+  if (taps <= 9) return launch_d_nt<T, 9>(in, out, blob, a, lds, nt, s);
+  return launch_d_nt<T, 11>(in, out, blob, a, lds, nt, s);
 }
 
 }  // namespace v3
@@ -565,15 +615,14 @@ int gaussian_v3(const void* in, void* out, int64_t planes, int H, int W, int ksi
   if ((W & 3) || ksize < 3 || ksize > 19 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) || ((size_t)H * W * esz & 15))
     return 1;
   if (pad + 1 >= H || pad + 1 >= W) return 1;                 // the mirrored rows / columns must be distinct from the edge
-  if (planes <= 2 * (int64_t)num_cus()) return 1;             // few planes: latency-bound, the plane-per-workgroup kernels win
+  if (planes < min_planes()) return 1;
   const size_t lds = ((size_t)H * (W + 2 * p4) + (size_t)(H + 2 * pad) * W + ksize + 3) / 4 * 16;
   if (lds > 160 * 1024) return 1;
-  // thread count: the one that wastes fewer lanes in the last round of the W pass (H * W / 4 items)
-  const int items = H * (W >> 2);
-  auto waste = [&](int nt) { return (double)((items + nt - 1) / nt * nt) / items; };
+  // thread count (measured, Wan 480p planes): 512 when the launch has more than two planes per CU (16 instead of 8 waves per
+  // CU with two workgroups resident: 37 -> 33 us for 8 videos), 256 for a single video (9.8 vs 10.9 us)
   int nt = threads_override();
   if (nt == 1024) nt = 512;
-  if (!nt) nt = waste(512) < waste(256) - 0.02 ? 512 : 256;
+  if (!nt) nt = planes > 2 * (int64_t)num_cus() ? 512 : 256;
   if ((int64_t)nt * MAXPRE * 4 < (int64_t)H * W || (int64_t)nt * MAXHALO < (int64_t)H * 2 * pad) {
     nt = 512;
     if ((int64_t)nt * MAXPRE * 4 < (int64_t)H * W || (int64_t)nt * MAXHALO < (int64_t)H * 2 * pad) return 1;
@@ -593,7 +642,7 @@ int down_up_v3(const void* in, void* out, int64_t planes, int H, int W, int h1, 
   if (off && off[0] == '0') return 1;
   const int n = H * W;
   if ((W & 1) || (n & 3) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return 1;
-  if (planes <= 2 * (int64_t)num_cus()) return 1;             // few planes: latency-bound, the plane-per-workgroup kernels win
+  if (planes < min_planes()) return 1;
   DArgs a;
   a.H = H, a.W = W, a.h1 = h1, a.w1 = w1, a.round_mid = round_mid, a.planes = planes;
   a.tabs = v2::layout(H, W, h1, w1);
@@ -603,23 +652,21 @@ int down_up_v3(const void* in, void* out, int64_t planes, int H, int W, int h1, 
                         (((size_t)h1 * TP + 3) & ~(size_t)3) + (size_t)H * 4;
   const size_t lds = floats * 4;
   if (lds > 160 * 1024) return 1;
-  // thread count: enough prefetch registers for a plane, then the most resident waves per CU (ties: the smaller workgroup)
-  int nt = threads_override(), wgs = 0;
-  if (nt) {
-    wgs = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / nt));
-  } else {
-    int best_waves = -1;
+  // thread count (measured): the smallest workgroup whose prefetch registers hold a plane -- several small workgroups per
+  // CU overlap each other's barrier-separated passes -- unless LDS admits only one workgroup per CU: then the largest
+  int nt = threads_override();
+  const int by_lds = (int)((160 * 1024) / lds);
+  if (!nt) {
     for (int t : {256, 512, 1024}) {
       if ((int64_t)t * MAXPRE * 4 < n || w1 > t || (WS >> 2) > t) continue;
-      const int g = std::min((int)((160 * 1024) / lds), 2048 / t);
-      if (g >= 1 && g * t / 64 > best_waves) best_waves = g * t / 64, nt = t, wgs = g;
+      if (!nt || by_lds == 1) nt = t;
     }
   }
   if (!nt || (int64_t)nt * MAXPRE * 4 < n || w1 > nt || (WS >> 2) > nt) return 1;
   const uint32_t* blob = v2::lowpass_tables_for(H, W, h1, w1, a.tabs);
   if (!blob) return 1;
-  return dtype == ALG_F32 ? dispatch_d<float>(in, out, blob, a, lds, nt, wgs, s)
-                          : dispatch_d<bf16_t>(in, out, blob, a, lds, nt, wgs, s);
+  return dtype == ALG_F32 ? dispatch_d<float>(in, out, blob, a, lds, nt, s)
+                          : dispatch_d<bf16_t>(in, out, blob, a, lds, nt, s);
 }
 
 }  // namespace alg

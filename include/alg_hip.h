@@ -37,7 +37,9 @@ const char* alg_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Low-pass filters on [planes, H, W] contiguous planes (a 4-D/5-D tensor viewed per (H, W) plane,
- * lp:31-37).  One workgroup per plane, plane resident in LDS, taps computed in-kernel.
+ * lp:31-37).  Planes resident in LDS: one workgroup per plane for small calls, a persistent grid of
+ * register-blocked workgroups from 128 planes up (all bit-identical; planes beyond LDS size run
+ * through global-memory passes).
  * ---------------------------------------------------------------------------------------------- */
 
 /* lp:49-54  F.interpolate(bilinear, antialias) to (h1, w1) then back to (H, W).
