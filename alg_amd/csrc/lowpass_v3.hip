@@ -15,7 +15,8 @@
 // Arithmetic is the reference chain of lowpass.hip, operation for operation (acc = 0, then fma over ascending taps): a
 // packed fma is the same fused operation per half.  The only extra operations are fma(0, finite, acc) at the ends of a
 // pair's chain, which leave acc unchanged (they can turn an all-zero-products result -0 into +0; nothing else).
-// Shapes not covered (W not a multiple of 4, tap counts without an instantiation, halo too large) return 1 and take v2.
+// Shapes not covered (odd W, plane sizes that are not a multiple of 4 elements, tap counts without an instantiation, halo
+// too large) return 1 and take v2.
 #include <algorithm>
 #include <atomic>
 
@@ -83,6 +84,27 @@ struct Chunk<bf16_t> {
   static __device__ __forceinline__ uint2 pack(const v4f v) { return uint2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)}; }
 };
 
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// a quad of results to HBM at a 4-byte-aligned element offset; `valid` = 4 or 2 elements
+template <typename T>
+__device__ __forceinline__ void store_quad(T* p, const v4f v, const bool whole) {
+  if constexpr (sizeof(T) == 4) {
+    if (whole) {
+      *(u32x4_a4*)p = u32x4_a4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    } else {
+      *(u32x2_a4*)p = u32x2_a4{__float_as_uint(v.x), __float_as_uint(v.y)};
+    }
+  } else {
+    if (whole) {
+      *(u32x2_a4*)p = u32x2_a4{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+    } else {
+      *(uint32_t*)p = pack_bf2(v.x, v.y);
+    }
+  }
+}
+
 constexpr int MAXPRE = 8;    // 4-element chunks of the next plane a thread keeps in flight
 constexpr int MAXHALO = 4;   // mirrored halo elements a thread fetches per plane
 
@@ -104,11 +126,11 @@ __global__ __launch_bounds__(NT) void gaussian_v3_kernel(const T* __restrict__ i
   typedef typename Chunk<T>::type chunk_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
-  const int H = a.H, W = a.W, Q = W >> 2, XS = W + 2 * P4;
+  const int H = a.H, W = a.W, WS = (W + 3) & ~3, Q = WS >> 2, XS = WS + 2 * P4;   // W is even; W = 2 (mod 4): half a last quad
   const int n = H * W, nv = n >> 2;
   float* Xp = (float*)smem;
   float* Tm = Xp + (size_t)H * XS;
-  float* g = Tm + (size_t)(H + 2 * PAD) * W;
+  float* g = Tm + (size_t)(H + 2 * PAD) * WS;
 
   // g = exp(-0.5 (x/sigma)^2), x = -(k-1)/2 + j, normalised by the sequential sum (lowpass.hip gaussian_kernel)
   for (int j = tid; j < K; j += NT) {
@@ -134,7 +156,7 @@ __global__ __launch_bounds__(NT) void gaussian_v3_kernel(const T* __restrict__ i
     const int sy = (4 * NT) / W, sc = 4 * NT - sy * W;   // one division per thread; chunk k + 1 is 4 NT elements further
 #pragma unroll
     for (int k = 0; k < MAXPRE; ++k) {
-      pre_dst[k] = y * XS + P4 + c;
+      pre_dst[k] = (y * XS + P4 + c) | (c + 2 >= W ? 1 : 0);   // bit 0: the chunk's second pair starts the next row
       y += sy, c += sc;
       if (c >= W) c -= W, ++y;
     }
@@ -166,7 +188,12 @@ __global__ __launch_bounds__(NT) void gaussian_v3_kernel(const T* __restrict__ i
   for (; plane < a.planes; plane += gridDim.x) {
 #pragma unroll
     for (int k = 0; k < MAXPRE; ++k)
-      if (tid + k * NT < nv) *(v4f*)(Xp + pre_dst[k]) = Chunk<T>::unpack(pre[k]);
+      if (tid + k * NT < nv) {
+        const v4f v = Chunk<T>::unpack(pre[k]);
+        const int d0 = pre_dst[k] & ~1, d1 = d0 + 2 + ((pre_dst[k] & 1) ? XS - W : 0);
+        *(v2f*)(Xp + d0) = v2f{v.x, v.y};
+        *(v2f*)(Xp + d1) = v2f{v.z, v.w};
+      }
 #pragma unroll
     for (int k = 0; k < MAXHALO; ++k)
       if (tid + k * NT < n_halo) Xp[halo_dst[k]] = load_as_float<T>(&hpre[k], 0);
@@ -195,9 +222,9 @@ __global__ __launch_bounds__(NT) void gaussian_v3_kernel(const T* __restrict__ i
         }
         const v4f o = {a01.y, a01.x, a23.y, a23.x};
         float* dst = Tm + (q << 2);
-        *(v4f*)(dst + (y + PAD) * W) = o;
-        if (y >= 1 && y <= PAD) *(v4f*)(dst + (PAD - y) * W) = o;                              // mirrored above row 0
-        if (y >= H - 1 - PAD && y <= H - 2) *(v4f*)(dst + (PAD + 2 * (H - 1) - y) * W) = o;    // mirrored below row H - 1
+        *(v4f*)(dst + (y + PAD) * WS) = o;
+        if (y >= 1 && y <= PAD) *(v4f*)(dst + (PAD - y) * WS) = o;                              // mirrored above row 0
+        if (y >= H - 1 - PAD && y <= H - 2) *(v4f*)(dst + (PAD + 2 * (H - 1) - y) * WS) = o;    // mirrored below row H - 1
         y += dy, q += dq;
         if (q >= Q) q -= Q, ++y;
       }
@@ -217,7 +244,7 @@ __global__ __launch_bounds__(NT) void gaussian_v3_kernel(const T* __restrict__ i
         for (int r = 0; r < R; ++r) acc[r][0] = v2f{0.0f, 0.0f}, acc[r][1] = v2f{0.0f, 0.0f};
 #pragma unroll
         for (int s = 0; s < R + K - 1; ++s) {
-          const v4f v = *(const v4f*)(src + min(y0 + s, last_row) * W);   // padded row y0 + s = original row y0 + s - PAD
+          const v4f v = *(const v4f*)(src + min(y0 + s, last_row) * WS);   // padded row y0 + s = original row y0 + s - PAD
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const int i = s - r;
@@ -230,8 +257,8 @@ __global__ __launch_bounds__(NT) void gaussian_v3_kernel(const T* __restrict__ i
 #pragma unroll
         for (int r = 0; r < R; ++r)
           if (y0 + r < H)
-            *(chunk_t*)(op + (size_t)(y0 + r) * W + (q << 2)) =
-                Chunk<T>::pack(v4f{acc[r][0].x, acc[r][0].y, acc[r][1].x, acc[r][1].y});
+            store_quad<T>(op + (size_t)(y0 + r) * W + (q << 2), v4f{acc[r][0].x, acc[r][0].y, acc[r][1].x, acc[r][1].y},
+                          (q << 2) + 4 <= W);
         yg += dy, q += dq;
         if (q >= Q) q -= Q, ++yg;
       }
@@ -258,27 +285,6 @@ struct DArgs {
   int64_t planes;
   v2::Tabs tabs;
 };
-
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
-
-// a quad of results to HBM at a 4-byte-aligned element offset; `valid` = 4 or 2 elements
-template <typename T>
-__device__ __forceinline__ void store_quad(T* p, const v4f v, const bool whole) {
-  if constexpr (sizeof(T) == 4) {
-    if (whole) {
-      *(u32x4_a4*)p = u32x4_a4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    } else {
-      *(u32x2_a4*)p = u32x2_a4{__float_as_uint(v.x), __float_as_uint(v.y)};
-    }
-  } else {
-    if (whole) {
-      *(u32x2_a4*)p = u32x2_a4{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
-    } else {
-      *(uint32_t*)p = pack_bf2(v.x, v.y);
-    }
-  }
-}
 
 template <typename T, int TDW, int NT>
 __global__ __launch_bounds__(NT) void down_up_v3_kernel(const T* __restrict__ in, T* __restrict__ out,
@@ -610,13 +616,12 @@ int gaussian_v3(const void* in, void* out, int64_t planes, int H, int W, int ksi
   using namespace v3;
   const char* off = getenv("ALG_LOWPASS_V3");
   if (off && off[0] == '0') return 1;
-  const size_t esz = dtype == ALG_F32 ? 4 : 2;
   const int pad = ksize / 2, p4 = (pad + 3) & ~3;
-  if ((W & 3) || ksize < 3 || ksize > 19 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) || ((size_t)H * W * esz & 15))
-    return 1;
+  if ((W & 1) || ((H * W) & 3) || ksize < 3 || ksize > 19 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return 1;
   if (pad + 1 >= H || pad + 1 >= W) return 1;                 // the mirrored rows / columns must be distinct from the edge
   if (planes < min_planes()) return 1;
-  const size_t lds = ((size_t)H * (W + 2 * p4) + (size_t)(H + 2 * pad) * W + ksize + 3) / 4 * 16;
+  const int ws = (W + 3) & ~3;
+  const size_t lds = ((size_t)H * (ws + 2 * p4) + (size_t)(H + 2 * pad) * ws + ksize + 3) / 4 * 16;
   if (lds > 160 * 1024) return 1;
   // thread count (measured, Wan 480p planes): 512 when the launch has more than two planes per CU (16 instead of 8 waves per
   // CU with two workgroups resident: 37 -> 33 us for 8 videos), 256 for a single video (9.8 vs 10.9 us)

@@ -220,6 +220,8 @@ def test_global_memory_path_is_bit_identical_to_the_lds_path(device, monkeypatch
     ((8, 16, 13, 17, 20), torch.bfloat16, "gaussian_blur", (7, 1.5)),    # H not a multiple of the row block
     ((8, 16, 13, 18, 24), torch.float32, "gaussian_blur", (17, 9.0)),    # pad = 8 = H / 2 - 1: mirrored rows overlap the far edge
     ((8, 16, 13, 30, 44), torch.float32, "gaussian_blur", (11, 3.0)),
+    ((8, 16, 13, 30, 46), torch.float32, "gaussian_blur", (5, 1.2)),     # W = 2 mod 4: padded rows, half quads
+    ((8, 16, 13, 34, 50), torch.bfloat16, "gaussian_blur", (9, 2.5)),
     ((8, 16, 13, 60, 104), torch.float32, "down_up", 0.25),             # integer scale, 9 taps
     ((8, 16, 13, 44, 76), torch.bfloat16, "down_up", 0.8125),           # 5 taps
     ((8, 16, 13, 90, 160), torch.float32, "down_up", 0.625),
