@@ -31,6 +31,33 @@ def test_down_up_f32_golden_vectors(device, golden_dir):
         assert err <= 3e-6, (m["name"], err)  # fp32 rounding (fma vs mul+add ordering)
 
 
+def test_register_blocked_kernels_against_golden_vectors_and_oracle(device, golden_dir, monkeypatch):
+    """lowpass_v3.hip takes calls of 128 planes and more; here the plane threshold is dropped to 1 so that the
+    reference-generated golden vectors (small plane counts) and the oracle cases run through it directly, not only through
+    its bit-identity with the plane-per-workgroup kernels."""
+    monkeypatch.setenv("ALG_LOWPASS_V3_MIN_PLANES", "1")
+    with open(os.path.join(golden_dir, "lp_misc.json")) as f:
+        meta = json.load(f)["down_up_meta"]
+    vec = np.load(os.path.join(golden_dir, "down_up_vectors.npz"))
+    for m in meta:
+        x = torch.from_numpy(vec[m["name"] + "_in"]).to(device)
+        y = lp_utils.apply_low_pass_filter(x, "down_up", 0.0, 0, m["factor"])
+        err = np.abs(y.cpu().numpy() - vec[m["name"] + "_out"]).max()
+        assert err <= 3e-6, (m["name"], err)
+    g = torch.Generator().manual_seed(7)
+    for shape, factor in (((1, 16, 13, 60, 90), 0.25), ((1, 20, 21, 60, 104), 0.4), ((1, 16, 1, 90, 160), 0.625),
+                          ((1, 16, 3, 32, 32), 0.25), ((1, 2, 12, 18), 0.5)):
+        x = torch.randn(shape, generator=g)
+        y = lp_utils.apply_low_pass_filter(x.to(device), "down_up", 0.0, 0, factor).cpu().numpy()
+        assert np.abs(y - lp_oracle.down_up(x.numpy(), factor, np.float32)).max() <= 3e-6, (shape, factor)
+    for shape, k, sigma in (((1, 20, 21, 60, 104), 9, 15.0), ((1, 16, 3, 32, 32), 5, 1.5), ((1, 16, 13, 60, 90), 7, 2.0),
+                            ((2, 3, 12, 18), 3, 0.8)):
+        x = torch.randn(shape, generator=g)
+        y = lp_utils.apply_low_pass_filter(x.to(device), "gaussian_blur", sigma, k, 1.0).cpu().numpy()
+        ref = lp_oracle.gaussian_blur(x.numpy().astype(np.float64), lp_oracle.gaussian_kernel_size(k, shape[-2]), sigma)
+        assert np.abs(y - ref).max() <= 1e-5, (shape, k, sigma)
+
+
 @pytest.mark.parametrize("shape,factor", [((1, 16, 13, 60, 90), 0.25), ((1, 20, 21, 60, 104), 0.4),
                                           ((1, 16, 1, 90, 160), 0.625), ((1, 16, 3, 32, 32), 0.25),
                                           ((2, 3, 7, 5), 0.1), ((1, 2, 13, 17), 0.5), ((3, 1, 1, 2, 60, 90)[1:], 0.9)])
