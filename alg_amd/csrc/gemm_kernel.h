@@ -63,12 +63,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ float act_apply(float x, int act) {
   if (act == ALG_ACT_GELU_TANH) {
-    // 0.5 x (1 + tanh(u)) == x / (1 + exp(-2u)),  u = sqrt(2/pi) (x + 0.044715 x^3)
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return x * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(-2.0f * 1.4426950408889634f * u));
+    // 0.5 x (1 + tanh(u)) == x / (1 + exp(-2u)),  u = sqrt(2/pi) (x + 0.044715 x^3).  The reciprocal is the hardware's
+    // v_rcp_f32 (1 ulp): the correctly rounded one costs ten more instructions per output in an epilogue that is VALU-bound,
+    // and the result is rounded to bf16 (2^-9) right after.
+    // exp(-2u) = exp2(x (k1 + k2 x^2)), k1 = -2 log2(e) sqrt(2/pi), k2 = 0.044715 k1: three operations for the argument
+    const float k1 = -2.0f * 1.4426950408889634f * 0.7978845608028654f, k2 = 0.044715f * k1;
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * fmaf(k2, x * x, k1)));
   }
   if (act == ALG_ACT_SILU) {
-    return x * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
   }
   return x;
 }
@@ -651,31 +654,53 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
                         (!(RES && p.gate) || ((p.strideGate & 7) == 0 && (gate_seg & 7) == 0 && (((uintptr_t)p.gate) & 15) == 0));
     if (staged) {
       char* const my = smem + wave * (4 * NT * 2048);   // 16 KiB (8 waves) or 32 KiB (4 waves) of the free ring
-      auto park_band = [&](auto mt_c) {
-        constexpr int mt = decltype(mt_c)::value;
+      // Epilogue operands first, ALL of them, before any arithmetic: the column bias (and fp8 column scales) of the wave's
+      // NT x 4 quads are the same for its four row bands, the row bias / row scale is one value per band.  Loaded where they
+      // were used (inside the quad loop, under `n < N`) every quad waited for its own L2 round trip: 32 serialised loads
+      // per wave and tile.
+      uint2 bcol[NT][4];
+      float4 scol[FP8 ? NT : 1][FP8 ? 4 : 1];
+      float brow4[4], a_sc4[4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + blk_col(nt) + 8 * g + 4 * h2;
+          const int nc = n < p.N ? n : 0;                       // p.N is a multiple of 8 here: column 0 always exists
+          bcol[nt][g] = (bias && !bias_row) ? *(const uint2*)(bias + nc) : make_uint2(0u, 0u);
+          if constexpr (FP8) scol[nt][g] = *(const float4*)(p.b_scale + (int64_t)b * p.strideBScale + nc);
+        }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
         const int row = m0 + blk_row(mt) + l31;
         const int rowc = row < p.M ? row : p.M - 1;
-        const float brow = (bias && bias_row) ? bf2f(bias[rowc]) : 0.0f;
-        const float a_sc = FP8 ? p.a_scale[(int64_t)b * p.strideAScale + rowc] : 1.0f;
+        brow4[mt] = (bias && bias_row) ? bf2f(bias[rowc]) : 0.0f;
+        a_sc4[mt] = FP8 ? p.a_scale[(int64_t)b * p.strideAScale + rowc] : 1.0f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // BR: per-row bias (the V^T projection) -- a workgroup-uniform choice, so the other form does not pay for an add of 0
+      auto park_band = [&](auto mt_c, auto br_c) {
+        constexpr int mt = decltype(mt_c)::value;
+        constexpr bool BR = decltype(br_c)::value != 0;
+        const float brow = brow4[mt];
+        const float a_sc = a_sc4[mt];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int n = n0 + blk_col(nt) + 8 * g + 4 * h2;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f};
-            if (n < p.N) {
-              if (bias && !bias_row) unpack4(*(const uint2*)(bias + n), bv);
-              if (FP8) {
-                const float4 s4 = *(const float4*)(p.b_scale + (int64_t)b * p.strideBScale + n);
-                sv[0] = s4.x * a_sc; sv[1] = s4.y * a_sc; sv[2] = s4.z * a_sc; sv[3] = s4.w * a_sc;
-              }
+            float bv[4], sv[4] = {1.f, 1.f, 1.f, 1.f};
+            unpack4(bcol[nt][g], bv);
+            if constexpr (FP8) {
+              const float4 s4 = scol[nt][g];
+              sv[0] = s4.x * a_sc; sv[1] = s4.y * a_sc; sv[2] = s4.z * a_sc; sv[3] = s4.w * a_sc;
             }
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float dot = FP8 ? acc[mt][nt][4 * g + i] * sv[i] : acc[mt][nt][4 * g + i];
-              float x = rbf(dot + bv[i] + brow);
-              if (ACT != ALG_ACT_NONE) x = rbf(act_apply(x, ACT));
+              // nn.Linear's bf16 result is the rounding pack_bf2 applies below; an activation works on that rounded value
+              float x = BR ? dot + bv[i] + brow : dot + bv[i];
+              if (ACT != ALG_ACT_NONE) x = act_apply(rbf(x), ACT);
               v[i] = x;
             }
             uint2 o;
@@ -684,15 +709,27 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
             *(uint2*)(my + (mt * NT + nt) * 2048 + l31 * 64 + ((g ^ ((l31 >> 2) & 3)) * 16) + h2 * 8) = o;
           }
       };
-      park_band(IntC<0>{});
-      park_band(IntC<1>{});
-      park_band(IntC<2>{});
-      park_band(IntC<3>{});
+      // (only the plain kernel is built in both forms: the per-row bias belongs to the V^T projection, which has neither
+      // activation nor residual, and a second copy of those longer epilogues costs more in code size than the add)
+      constexpr bool BR_SPLIT = !RES && ACT == ALG_ACT_NONE;
+      if (!BR_SPLIT || (bias && bias_row)) {
+        park_band(IntC<0>{}, IntC<1>{});
+        park_band(IntC<1>{}, IntC<1>{});
+        park_band(IntC<2>{}, IntC<1>{});
+        park_band(IntC<3>{}, IntC<1>{});
+      } else if constexpr (BR_SPLIT) {
+        park_band(IntC<0>{}, IntC<0>{});
+        park_band(IntC<1>{}, IntC<0>{});
+        park_band(IntC<2>{}, IntC<0>{});
+        park_band(IntC<3>{}, IntC<0>{});
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave reads back only what it wrote itself
       // The residual may alias C (in-place update), so hipcc keeps every R load behind the previous iteration's store:
       // sixteen serialised HBM round trips per tile (measured: 21.7 us of per-tile overhead with a residual vs 6.9 us
       // without, scripts/gemm_k_sweep.py).  A thread reads exactly the elements it later writes, so all sixteen loads
-      // can go out first; the accumulators are parked, their registers are free.
+      // can go out first; the accumulators are parked, their registers are free.  (Issuing them BEFORE the park, to hide
+      // their latency under its arithmetic, needs 64 more live registers: 19 spills, and a kernel with scratch ran 10 %
+      // slower -- measured.)
       constexpr int NIT = 8 * NT;   // 32x32 blocks x two 16-row halves
       uint4 rbuf[RES ? NIT : 1];
       if (RES) {
@@ -843,10 +880,12 @@ __global__ __launch_bounds__(2 * WNW * 64) void gemm_bf16_kernel(const alg_gemm_
       }
     }
   };
+#ifndef ALG_EPI_STAGED_ONLY   // analysis builds (instruction counts of the staged epilogue alone) leave the fallback out
   epilogue_band(IntC<0>{});
   epilogue_band(IntC<1>{});
   epilogue_band(IntC<2>{});
   epilogue_band(IntC<3>{});
+#endif
   };  // do_tile
 
   // ---- logical workgroup -> (batch, m_tile, n_tile): XCD-contiguous, grouped along M ----
