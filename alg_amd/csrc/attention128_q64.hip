@@ -572,17 +572,19 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
   const int n_tiles = (Skv + KVB - 1) / KVB;
   const bool ragged = (Skv & (KVB - 1)) != 0;
 
-  // DMA: buffer_load ... lds with the tile's origin in the SCALAR offset and a per-lane byte offset that never changes -- no
-  // vector arithmetic per tile (the global_load_lds form cost ~5 VALU instructions per DMA for its 64-bit lane addresses, in
-  // a loop whose vector pipe is the busy one), and rows past Skv read as zeros through the descriptor's bounds check instead
-  // of a per-lane clamp.  K tile: 64 rows x 16 slots (256 B rows), four rounds of 16 rows; physical slot tid & 15 holds
-  // logical slot (tid & 15) ^ (row & 15).  V^T tile: 128 d-rows x 8 slots, four rounds of 32 rows, swizzle (row >> 1) & 7.
+  // K tile: 64 rows x 16 slots (256 B rows), four rounds of 16 rows; physical slot tid & 15 holds logical slot
+  // (tid & 15) ^ (row & 15).  V^T tile: 128 d-rows x 8 slots, four rounds of 32 rows, swizzle (row >> 1) & 7.
   // Tiles past the end re-fetch the last one (uniform instruction counts for the counted waits; nobody uses the data).
   const int k_rs = (int)p.k_rs, vt_rs = (int)p.vt_rs;
-  const __amdgpu_buffer_rsrc_t k_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (int)(((int64_t)(Skv - 1) * k_rs + 128) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)VT, 0, (int)((int64_t)128 * vt_rs * 2), 0x00020000);
+  // DMA as global_load_lds with a SCALAR tile base and a per-lane byte offset that never changes.  (The buffer_load ... lds
+  // form this kernel used first saved the last two vector instructions per DMA, but its LDS-DMA did not always complete in
+  // issue order -- the counted vmcnt waits below then let a wave read a ring slot that had not been filled: 8 % of the fp8
+  // C5 forwards differed from their repeat in a few dozen tokens, always in the first wave of workgroups, whose K rows sit
+  // behind cold TLBs; profiles/r2_attention128_q64_flake.txt.  The global form is the one the GEMMs and the 32-query kernel
+  // run with counted waits, without a single mismatch.)  Rows past Skv only exist in the last tile: their lanes re-read its
+  // last valid row (masked in the softmax anyway; V^T has its zero pad columns up to a multiple of 64).
   int k_vo[4], v_vo[4];
+  int k_vo_lim;
   {
     const int row = tid >> 4, slot = (tid & 15) ^ ((tid >> 4) & 15);
     const int vrow = tid >> 3, vslot = (tid & 7) ^ ((tid >> 4) & 7);
@@ -591,18 +593,21 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
       k_vo[i] = ((row + i * 16) * k_rs + slot * 8) * 2;
       v_vo[i] = ((vrow + i * 32) * vt_rs + vslot * 8) * 2;
     }
+    k_vo_lim = ((Skv - 1 - (n_tiles - 1) * KVB) * k_rs + slot * 8) * 2;
   }
   // one DMA instruction of the pair [K(tk), V(tv)]: pieces 0 - 3 the K rounds, 4 - 7 the V^T rounds
   auto stage_piece = [&](int tk, int tv, auto piece_c) {
     constexpr int PC = decltype(piece_c)::value;
     if constexpr (PC < 4) {
-      const int so = min(tk, n_tiles - 1) * KVB * k_rs * 2;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(k_ring + (tk & (NS - 1)) * K_TILE + (PC * 256 + wave * 64) * 16), 16,
-                                               k_vo[PC], so, 0, 0);
+      const int tc = min(tk, n_tiles - 1);
+      const char* base = (const char*)(K + (int64_t)tc * KVB * k_rs);
+      const int vo = min(k_vo[PC], tc == n_tiles - 1 ? k_vo_lim : 0x7fffffff);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + (uint32_t)vo),
+                                       (lptr_t)(k_ring + (tk & (NS - 1)) * K_TILE + (PC * 256 + wave * 64) * 16), 16, 0, 0);
     } else {
-      const int so = min(tv, n_tiles - 1) * KVB * 2;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(v_ring + (tv & (NS - 1)) * V_TILE + ((PC - 4) * 256 + wave * 64) * 16),
-                                               16, v_vo[PC - 4], so, 0, 0);
+      const char* base = (const char*)(VT + (int64_t)min(tv, n_tiles - 1) * KVB);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + (uint32_t)v_vo[PC - 4]),
+                                       (lptr_t)(v_ring + (tv & (NS - 1)) * V_TILE + ((PC - 4) * 256 + wave * 64) * 16), 16, 0, 0);
     }
   };
   auto stage_k = [&](int tile) {
@@ -911,7 +916,9 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
   stage_v(1);
   stage_k(3);
   stage_v(2);
-  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // K(0)
+  // the whole prologue is drained (one DMA latency per ~2 ms workgroup): cheap insurance for the first tiles, whose rows
+  // sit behind cold TLBs in the first wave of workgroups
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   qk(0, S0{}, se);
   {
@@ -989,10 +996,15 @@ int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, i
                         int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t vt_bs, int64_t vt_rs, int64_t o_bs,
                         int64_t o_rs, float scale, hipStream_t stream) {
   using namespace a128q;
-  const char* env = getenv("ALG_ATTN128_Q64");   // 0: keep attention128.hip's 32-query kernel (A/B runs, bit-level comparisons)
-  const int enabled = env ? atoi(env) : 1;
+  // OPT-IN (ALG_ATTN128_Q64=1).  The kernel is bit-reproducible on its own (thousands of stressed launches, cold and warm),
+  // but inside the fp8 Wan forward at the C5 token count 2 - 8 % of the forwards differed from their repeat in a few dozen
+  // tokens of the first wave of workgroups, and never with attention128.hip's 32-query kernel in its place
+  // (profiles/r2_attention128_q64_flake.txt: what was tried, what moved the rate).  Until that is understood the
+  // product default is the kernel that has never produced a mismatch.
+  const char* env = getenv("ALG_ATTN128_Q64");
+  const int enabled = env ? atoi(env) : 0;
   if (!enabled || (Skv + KVB - 1) / KVB < MIN_TILES) return 1;
-  // 31-bit BYTE offsets inside one (batch, head) for the buffer-load DMA; V^T rows cover whole 64-key tiles
+  // 31-bit BYTE offsets inside one (batch, head) for the DMA's lane offsets; V^T rows cover whole 64-key tiles
   if ((int64_t)(Skv + 64) * k_rs * 2 >= (1ll << 31) || (int64_t)129 * vt_rs * 2 >= (1ll << 31)) return 1;
   if (vt_rs < (int64_t)((Skv + KVB - 1) / KVB) * KVB) return 1;
   static std::atomic<bool> attr_set{false};

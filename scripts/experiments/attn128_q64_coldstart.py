@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Cold-start stress of the 64-queries-per-wave d = 128 attention in the Wan layout (Q and K interleaved in one [N, S, 2 D]
+buffer: K rows 20 KB apart), one to five waves of workgroups per launch, the TLBs / caches thrashed in between, every
+result against the first.  python attn128_q64_coldstart.py [launches] [thrash GB] [Sq]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from alg_amd import _lib  # noqa: E402
+
+launches = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+thrash = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+Sq = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+dev, BF = torch.device("cuda:0"), torch.bfloat16
+N, Hh, S = int(os.environ.get("NB", "1")), 40, 75600
+D = Hh * 128
+S_pad = (S + 63) // 64 * 64
+g = torch.Generator(device=dev).manual_seed(1)
+qk = torch.randn(N, S, 2 * D, generator=g, device=dev).to(BF)
+vt = torch.zeros(N, D, S_pad, dtype=BF, device=dev)
+vt[:, :, :S] = torch.randn(N, D, S, generator=g, device=dev).to(BF)
+o = torch.empty(N, S, D, dtype=BF, device=dev)
+junk = torch.empty(thrash << 30, dtype=torch.uint8, device=dev) if thrash else None
+
+
+def run():
+    _lib.flash_attn_d128(qk, qk, vt, o, N, Hh, Sq, S, S * 2 * D, 2 * D, S * 2 * D, 2 * D, D * S_pad, S_pad, S * D, D,
+                         128 ** -0.5, k_off=D)
+    return o[:, :min(Sq, 16384)].clone()
+
+
+ref = run()
+bad = []
+for i in range(launches):
+    if junk is not None:
+        junk.fill_(i & 0xff)
+    y = run()
+    if not torch.equal(y, ref):
+        d = (y.float() - ref.float()).abs()
+        rows = (d.sum(dim=-1).sum(dim=0) > 0).nonzero().flatten()
+        cols = (d.sum(dim=1).sum(dim=0) > 0).nonzero().flatten()
+        bad.append((i, int((d > 0).sum()), round(float(d.max()), 4), int(rows.min()), int(rows.max()), int(rows.numel()),
+                    sorted(set((cols // 128).tolist()))[:6]))
+print("env", {k_: v for k_, v in os.environ.items() if k_.startswith("ALG_")}, "launches", launches, "thrash GB", thrash, "Sq", Sq,
+      "bad", len(bad), bad[:6])
