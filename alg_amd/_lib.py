@@ -7,6 +7,7 @@ call fails, an exception is raised.
 from __future__ import annotations
 
 import ctypes
+from collections import OrderedDict
 import os
 from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
@@ -28,7 +29,11 @@ EXPORTS = (
     "alg_conv_cl_bf16", "alg_vae_groupnorm_workspace", "alg_vae_groupnorm_stats", "alg_vae_spatial_norm", "alg_vae_upsample",
     "alg_vae_pack_latent", "alg_vae_unpack_video", "alg_vae_group_norm", "alg_vae_pad", "alg_vae_repitch",
     "alg_vae_unpack_planes", "alg_rms_norm_rows", "alg_softmax_hilo", "alg_flash_attn_d128_ex", "alg_rope_half", "alg_patchify_t", "alg_unpatchify_t", "alg_qk_norm_rope_scaled", "alg_flash_attn_d64_ex", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
+    "alg_lowpass_tables_bytes", "alg_lowpass_tables_build", "alg_down_up_workspace_bytes", "alg_gaussian_blur_workspace_bytes",
+    "alg_flash_attn_d64_workspace_bytes",
 )
+_RET_I64 = ("alg_vae_groupnorm_workspace", "alg_lowpass_tables_bytes", "alg_down_up_workspace_bytes",
+            "alg_gaussian_blur_workspace_bytes", "alg_flash_attn_d64_workspace_bytes")
 
 
 class AlgHipError(RuntimeError):
@@ -83,8 +88,15 @@ def load_library():
     lib = ctypes.CDLL(LIB_PATH)
     lib.alg_version.restype = c_int
     lib.alg_last_error.restype = c_char_p
-    lib.alg_down_up.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
-    lib.alg_gaussian_blur.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p]
+    lib.alg_down_up.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                c_int64, c_void_p]
+    lib.alg_gaussian_blur.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int64,
+                                      c_void_p]
+    lib.alg_lowpass_tables_bytes.argtypes = [c_int] * 4
+    lib.alg_lowpass_tables_build.argtypes = [c_void_p, c_int64] + [c_int] * 4 + [c_void_p]
+    lib.alg_down_up_workspace_bytes.argtypes = [c_int64] + [c_int] * 4
+    lib.alg_gaussian_blur_workspace_bytes.argtypes = [c_int64] + [c_int] * 3
+    lib.alg_flash_attn_d64_workspace_bytes.argtypes = [c_int] * 4
     lib.alg_cfg_ddim_step.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_float, c_float, c_float,
                                       c_float, c_float, c_void_p]
     lib.alg_cfg_combine.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_void_p]
@@ -111,7 +123,6 @@ def load_library():
     lib.alg_gemm_fp8.argtypes = [POINTER(GemmArgs), c_void_p]
     lib.alg_conv_cl_bf16.argtypes = [c_void_p] * 5 + [c_int] * 7 + [c_void_p]
     lib.alg_vae_groupnorm_workspace.argtypes = [POINTER(VaeGeom)]
-    lib.alg_vae_groupnorm_workspace.restype = c_int64
     lib.alg_vae_groupnorm_stats.argtypes = [c_void_p, POINTER(VaeGeom), c_float, c_void_p, c_void_p, c_void_p]
     lib.alg_vae_spatial_norm.argtypes = [c_void_p] * 6 + [POINTER(VaeGeom), c_int, c_void_p]
     lib.alg_vae_group_norm.argtypes = [c_void_p] * 5 + [POINTER(VaeGeom), c_int, c_void_p]
@@ -140,7 +151,7 @@ def load_library():
                                      c_int, c_int, c_int, c_float, c_void_p]
     lib.alg_qk_norm_rope_scaled.argtypes = [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]
     lib.alg_flash_attn_d64_ex.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
-                                          c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_void_p]
+                                          c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_void_p, c_int64, c_void_p]
     lib.alg_patchify.argtypes = [c_void_p, c_int64, POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_void_p]
     lib.alg_unpatchify.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
@@ -150,7 +161,7 @@ def load_library():
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("alg_version", "alg_last_error"):
-            fn.restype = c_int
+            fn.restype = c_int64 if name in _RET_I64 else c_int
     _lib = lib
     return lib
 
@@ -187,6 +198,51 @@ def _ptr(t):
 # thin typed wrappers (shape/dtype checks live here; arithmetic lives in the kernels)
 # ---------------------------------------------------------------------------------------------------
 
+# The library never allocates (include/alg_hip.h): scratch space and the down_up tap tables are torch tensors owned here.
+# Tables depend on the shape only, so they are built once per (device, stream, shape) and kept in a small LRU; a scratch
+# buffer is kept per (device, stream, tag) and only ever grows -- launches on one stream are ordered, so the calls that
+# share it never overlap.  Both survive a hipGraph capture: a replay reads / writes the very buffers the capture saw.
+_TABLES = OrderedDict()
+_TABLES_MAX = 64
+_SCRATCH = {}
+
+
+def _stream_key(t):
+    return (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def lowpass_tables(x, h1, w1):
+    """The caller-owned tap-table blob of alg_down_up for x's plane shape (alg_lowpass_tables_build, cached)."""
+    lib = load_library()
+    H, W = x.shape[-2:]
+    key = _stream_key(x) + (H, W, h1, w1)
+    t = _TABLES.get(key)
+    if t is not None:
+        _TABLES.move_to_end(key)
+        return t
+    n = int(lib.alg_lowpass_tables_bytes(H, W, h1, w1))
+    if n <= 0:
+        return None
+    t = torch.empty(n, dtype=torch.uint8, device=x.device)
+    _check(lib.alg_lowpass_tables_build(_ptr(t), n, H, W, h1, w1, _stream()), "alg_lowpass_tables_build")
+    _TABLES[key] = t
+    while len(_TABLES) > _TABLES_MAX:
+        _TABLES.popitem(last=False)
+    return t
+
+
+def scratch(ref, nbytes, tag):
+    """A 16-byte aligned uint8 buffer of >= nbytes on ref's device for the current stream (None when nbytes == 0)."""
+    if nbytes <= 0:
+        return None
+    key = _stream_key(ref) + (tag,)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=ref.device)
+        _SCRATCH[key] = t
+    return t
+
+
 def down_up(x, h1, w1, round_intermediate=True):
     """x: [..., H, W] contiguous device tensor -> new tensor, antialiased bilinear down to (h1, w1) and back."""
     lib = load_library()
@@ -196,8 +252,13 @@ def down_up(x, h1, w1, round_intermediate=True):
     H, W = x.shape[-2:]
     planes = x.numel() // (H * W) if x.numel() else 0
     out = torch.empty_like(x)
+    if planes == 0:
+        return out
+    wsb = int(lib.alg_down_up_workspace_bytes(planes, H, W, h1, w1))
+    ws = scratch(x, wsb, "down_up")
+    tables = lowpass_tables(x, h1, w1) if wsb == 0 else None      # the global-memory passes derive their own taps
     _check(lib.alg_down_up(_ptr(x), _ptr(out), planes, H, W, h1, w1, _dt(x), 1 if round_intermediate else 0,
-                           _stream()), "alg_down_up")
+                           _ptr(tables), _ptr(ws), wsb, _stream()), "alg_down_up")
     return out
 
 
@@ -209,8 +270,10 @@ def gaussian_blur(x, ksize, sigma):
     H, W = x.shape[-2:]
     planes = x.numel() // (H * W) if x.numel() else 0
     out = torch.empty_like(x)
-    _check(lib.alg_gaussian_blur(_ptr(x), _ptr(out), planes, H, W, int(ksize), float(sigma), _dt(x), _stream()),
-           "alg_gaussian_blur")
+    wsb = int(lib.alg_gaussian_blur_workspace_bytes(planes, H, W, int(ksize))) if planes else 0
+    ws = scratch(x, wsb, "gaussian")
+    _check(lib.alg_gaussian_blur(_ptr(x), _ptr(out), planes, H, W, int(ksize), float(sigma), _dt(x), _ptr(ws), wsb,
+                                 _stream()), "alg_gaussian_blur")
     return out
 
 
@@ -589,9 +652,12 @@ def flash_attn_d64(q, k, vt, o, batch, heads, S, q_bstride, q_rstride, vt_bstrid
                    scale, q_off=0, k_off=0, q_prescaled=False):
     """q_prescaled: q already carries scale * log2(e) (qk_norm_rope_ with q_scale): alg_flash_attn_d64_ex."""
     lib = load_library()
+    flags = ATTN_Q_PRESCALED if q_prescaled else 0
+    wsb = int(lib.alg_flash_attn_d64_workspace_bytes(batch, heads, S, flags))     # split-KV tail partials (0: one launch)
+    ws = scratch(o, wsb, "attn_d64")
     _check(lib.alg_flash_attn_d64_ex(c_void_p(q.data_ptr() + 2 * q_off), c_void_p(k.data_ptr() + 2 * k_off), _ptr(vt),
                                      _ptr(o), batch, heads, S, q_bstride, q_rstride, vt_bstride, vt_rstride, o_bstride,
-                                     o_rstride, float(scale), ATTN_Q_PRESCALED if q_prescaled else 0, _stream()),
+                                     o_rstride, float(scale), flags, _ptr(ws), wsb, _stream()),
            "alg_flash_attn_d64")
 
 

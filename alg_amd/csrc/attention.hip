@@ -1399,12 +1399,26 @@ extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, 
                                   int64_t q_bstride, int64_t q_rstride, int64_t vt_bstride, int64_t vt_rstride,
                                   int64_t o_bstride, int64_t o_rstride, float scale, void* stream) {
   return alg_flash_attn_d64_ex(q, k, vt, o, batch, heads, S, q_bstride, q_rstride, vt_bstride, vt_rstride, o_bstride,
-                               o_rstride, scale, 0, stream);
+                               o_rstride, scale, 0, nullptr, 0, stream);
+}
+
+// Bytes of the split-KV workspace the launch plan of (batch, heads, S) uses (0: the plan is a single launch).  The library
+// never allocates: the caller owns the buffer and passes it to alg_flash_attn_d64_ex.
+extern "C" int64_t alg_flash_attn_d64_workspace_bytes(int batch, int heads, int S, int flags) {
+  if (batch <= 0 || heads <= 0 || S <= 0) return 0;
+  int variant = attn_variant();
+  if (flags & ALG_ATTN_Q_PRESCALED) variant = 41;
+  if (variant != 33 && variant != 41) return 0;
+  const int q_blocks = (S + 8 * 32 - 1) / (8 * 32);
+  const TailPlan tp = plan_tail(batch * heads, q_blocks, (S + KVB - 1) / KVB);
+  if (!tp.units) return 0;
+  return (int64_t)8 * tp.units * tp.split * 256 * 66 * (int64_t)sizeof(float);
 }
 
 extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S,
                                      int64_t q_bstride, int64_t q_rstride, int64_t vt_bstride, int64_t vt_rstride,
-                                     int64_t o_bstride, int64_t o_rstride, float scale, int flags, void* stream) {
+                                     int64_t o_bstride, int64_t o_rstride, float scale, int flags, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
   if (!q || !k || !vt || !o || batch <= 0 || heads <= 0 || S <= 0) {
     set_error("alg_flash_attn_d64: bad argument (batch=%d heads=%d S=%d)", batch, heads, S);
     return ALG_EINVAL;
@@ -1443,25 +1457,19 @@ extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* v
   p.ws_o = p.ws_ml = nullptr;
   if (variant == 33 || variant == 41) {
     const TailPlan tp = plan_tail(nbh, p.q_blocks, (S + KVB - 1) / KVB);
-    if (tp.units) {
+    const size_t rows = (size_t)8 * tp.units * tp.split * 256;
+    // the split-KV tail runs only in a caller-provided workspace (alg_flash_attn_d64_workspace_bytes); without one the
+    // whole problem is the single launch below (same rows up to fp32 summation order in the tail units)
+    if (tp.units && workspace && !((uintptr_t)workspace & 15) && workspace_bytes >= (int64_t)(rows * 66 * sizeof(float))) {
       const int per_xcd = nbh / 8 * p.q_blocks;
       p.unit0 = per_xcd - tp.units, p.tail_units = tp.units, p.tail_split = tp.split, p.tail_tiles = tp.tiles;
-      const size_t rows = (size_t)8 * tp.units * tp.split * 256;
-      float* ws = nullptr;
-      hipError_t e = hipMallocAsync((void**)&ws, rows * 66 * sizeof(float), s);
-      if (e != hipSuccess) {
-        set_error("alg_flash_attn_d64: split-KV workspace (%zu bytes): %s", rows * 66 * sizeof(float), hipGetErrorString(e));
-        return ALG_ELAUNCH;
-      }
+      float* ws = (float*)workspace;
       p.ws_o = ws, p.ws_ml = ws + rows * 64;
       if (variant == 41) {
         const int rq = p.unit0 > 0 ? flash_attn_d64_q64(q, k, vt, o, batch, heads, S, p.q_blocks, q_bstride, q_rstride, vt_bstride,
                                                         vt_rstride, o_bstride, o_rstride, (unsigned)(8 * p.unit0), s)
                                    : 0;
-        if (rq < 0 || rq > 1) {
-          (void)hipFreeAsync(ws, s);
-          return rq;
-        }
+        if (rq < 0 || rq > 1) return rq;
         if (rq == 1) hipLaunchKernelGGL((flash_attn_d64_kernel<41, 8>), dim3((unsigned)(8 * p.unit0)), blk, 0, s, p);
         hipLaunchKernelGGL((flash_attn_d64_kernel<41, 8, true>), dim3((unsigned)(8 * tp.units * tp.split)), blk, 0, s, p);
       } else {
@@ -1470,9 +1478,7 @@ extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* v
       }
       const int64_t merge = (int64_t)8 * tp.units * 256 * 16;
       hipLaunchKernelGGL(flash_attn_d64_merge_kernel, dim3((unsigned)((merge + 255) / 256)), dim3(256), 0, s, p);
-      const int rc = check_launch("alg_flash_attn_d64");
-      (void)hipFreeAsync(ws, s);
-      return rc;
+      return check_launch("alg_flash_attn_d64");
     }
   }
   const dim3 g((unsigned)grid);

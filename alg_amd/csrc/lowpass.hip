@@ -279,18 +279,20 @@ static int plane_threads(int H, int W, int64_t planes) {
 
 // planes beyond the LDS budget: same arithmetic through a global workspace (lowpass_big.hip)
 int down_up_big(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
-                hipStream_t s);
+                void* workspace, int64_t workspace_bytes, hipStream_t s);
 int gaussian_big(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype,
-                 hipStream_t s);
+                 void* workspace, int64_t workspace_bytes, hipStream_t s);
+int64_t down_up_big_bytes(int64_t planes, int H, int W, int h1, int w1);
+int64_t gaussian_big_bytes(int64_t planes, int H, int W, int ksize);
 
 // bandwidth-shaped kernels for 16-byte-granular planes (lowpass_v2.hip); return 1 = shape not covered
 int down_up_v2(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
-               hipStream_t s);
+               const void* tables, hipStream_t s);
 int gaussian_v2(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype, hipStream_t s);
 // register-blocked kernels for many-plane batches (lowpass_v3.hip); return 1 = shape not covered
 int gaussian_v3(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype, hipStream_t s);
 int down_up_v3(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
-               hipStream_t s);
+               const void* tables, hipStream_t s);
 
 static bool force_v1() {  // debug knob: the one-plane-per-workgroup kernels of this file (bit-identity tests)
   const char* e = getenv("ALG_LOWPASS_V1");
@@ -323,8 +325,29 @@ static int set_lds_limit(K kernel, size_t bytes) {
 
 using namespace alg;
 
+static bool global_path_down_up(int H, int W, int h1, int w1) {
+  return down_up_lds_bytes(H, W, h1, w1) > 160 * 1024 || force_global();
+}
+
+static size_t gaussian_lds_bytes(int H, int W, int ksize) { return (((size_t)2 * H * W + ksize) * 4 + 15) & ~(size_t)15; }
+
+static bool global_path_gaussian(int H, int W, int ksize) {
+  return gaussian_lds_bytes(H, W, ksize) > 160 * 1024 || ksize > 255 || force_global();
+}
+
+extern "C" int64_t alg_down_up_workspace_bytes(int64_t planes, int H, int W, int h1, int w1) {
+  if (planes <= 0 || H <= 0 || W <= 0 || h1 <= 0 || w1 <= 0 || !global_path_down_up(H, W, h1, w1)) return 0;
+  return down_up_big_bytes(planes, H, W, h1, w1);
+}
+
+extern "C" int64_t alg_gaussian_blur_workspace_bytes(int64_t planes, int H, int W, int ksize) {
+  if (planes <= 0 || H <= 0 || W <= 0 || ksize <= 0 || !global_path_gaussian(H, W, ksize)) return 0;
+  return gaussian_big_bytes(planes, H, W, ksize);
+}
+
 extern "C" int alg_down_up(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype,
-                           int round_intermediate, void* stream) {
+                           int round_intermediate, const void* tables, void* workspace, int64_t workspace_bytes,
+                           void* stream) {
   if (planes == 0 && H > 0 && W > 0) return ALG_OK;  // empty batch: nothing to do (pointers may be null)
   if (!in || !out || planes < 0 || H <= 0 || W <= 0 || h1 <= 0 || w1 <= 0) {
     set_error("alg_down_up: bad argument (planes=%lld H=%d W=%d h1=%d w1=%d)", (long long)planes, H, W, h1, w1);
@@ -341,12 +364,17 @@ extern "C" int alg_down_up(const void* in, void* out, int64_t planes, int H, int
   if (planes == 0) return ALG_OK;
   const size_t lds = down_up_lds_bytes(H, W, h1, w1);
   hipStream_t s = (hipStream_t)stream;
-  if (lds > 160 * 1024 || force_global()) return down_up_big(in, out, planes, H, W, h1, w1, dtype, round_intermediate ? 1 : 0, s);
+  if (global_path_down_up(H, W, h1, w1))
+    return down_up_big(in, out, planes, H, W, h1, w1, dtype, round_intermediate ? 1 : 0, workspace, workspace_bytes, s);
   int rc;
-  if (!force_v1()) {
-    rc = down_up_v3(in, out, planes, H, W, h1, w1, dtype, (dtype == ALG_BF16 && round_intermediate) ? 1 : 0, s);
+  if (!force_v1() && tables) {   // without the caller's tap tables: the kernels below, which build them in LDS per plane
+    if ((uintptr_t)tables & 15) {
+      set_error("alg_down_up: tables must be 16-byte aligned");
+      return ALG_EINVAL;
+    }
+    rc = down_up_v3(in, out, planes, H, W, h1, w1, dtype, (dtype == ALG_BF16 && round_intermediate) ? 1 : 0, tables, s);
     if (rc <= 0) return rc;
-    rc = down_up_v2(in, out, planes, H, W, h1, w1, dtype, (dtype == ALG_BF16 && round_intermediate) ? 1 : 0, s);
+    rc = down_up_v2(in, out, planes, H, W, h1, w1, dtype, (dtype == ALG_BF16 && round_intermediate) ? 1 : 0, tables, s);
     if (rc <= 0) return rc;
   }
   if (dtype == ALG_F32) {
@@ -370,7 +398,7 @@ extern "C" int alg_down_up(const void* in, void* out, int64_t planes, int H, int
 }
 
 extern "C" int alg_gaussian_blur(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma,
-                                 int dtype, void* stream) {
+                                 int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
   if (planes == 0 && H > 0 && W > 0) return ALG_OK;
   if (!in || !out || planes < 0 || H <= 0 || W <= 0) {
     set_error("alg_gaussian_blur: bad argument (planes=%lld H=%d W=%d)", (long long)planes, H, W);
@@ -397,11 +425,12 @@ extern "C" int alg_gaussian_blur(const void* in, void* out, int64_t planes, int 
     return ALG_EINVAL;
   }
   if (planes == 0) return ALG_OK;
-  const size_t lds = (((size_t)2 * H * W + ksize) * 4 + 15) & ~(size_t)15;
+  const size_t lds = gaussian_lds_bytes(H, W, ksize);
   hipStream_t s = (hipStream_t)stream;
   // kernels wider than 255 taps (an integer `lp_blur_kernel_size` on pixel-sized planes; reflect padding needs ksize / 2 <
   // min(H, W), so such planes are at least 128 x 128) always take the global-memory passes, which have no tap-count limit
-  if (lds > 160 * 1024 || ksize > 255 || force_global()) return gaussian_big(in, out, planes, H, W, ksize, sigma, dtype, s);
+  if (global_path_gaussian(H, W, ksize))
+    return gaussian_big(in, out, planes, H, W, ksize, sigma, dtype, workspace, workspace_bytes, s);
   int rc;
   if (!force_v1()) {
     rc = gaussian_v3(in, out, planes, H, W, ksize, sigma, dtype, s);

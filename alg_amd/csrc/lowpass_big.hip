@@ -124,26 +124,31 @@ __global__ __launch_bounds__(256) void gauss_cols_kernel(const float* __restrict
   store_from_float<TO>(dst, (p * H + y) * W + x, acc);
 }
 
-static int ws_alloc(float** p, size_t floats, hipStream_t s, const char* who) {
-  hipError_t e = hipMallocAsync((void**)p, floats * sizeof(float), s);
-  if (e != hipSuccess) {
-    set_error("%s: workspace of %zu bytes: %s", who, floats * sizeof(float), hipGetErrorString(e));
-    return ALG_ELAUNCH;
+// The intermediates of the global-memory passes live in a workspace the CALLER provides (alg_*_workspace_bytes): the
+// library never allocates.
+static int ws_check(float** p, size_t floats, void* workspace, int64_t workspace_bytes, const char* who) {
+  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < (int64_t)(floats * sizeof(float))) {
+    set_error("%s: this shape runs through global-memory passes and needs a 16-byte aligned workspace of %zu bytes "
+              "(%s_workspace_bytes); got %p / %lld bytes", who, floats * sizeof(float), who, workspace,
+              (long long)workspace_bytes);
+    return ALG_EINVAL;
   }
+  *p = (float*)workspace;
   return ALG_OK;
 }
 
 }  // namespace big
 
 template <typename T>
-static int down_up_big_t(const T* in, T* out, int64_t planes, int H, int W, int h1, int w1, int round_mid, hipStream_t s) {
+static int down_up_big_t(const T* in, T* out, int64_t planes, int H, int W, int h1, int w1, int round_mid, void* workspace,
+                         int64_t workspace_bytes, hipStream_t s) {
   if (planes > 65535 || H > 65535 || h1 > 65535) {
     set_error("alg_down_up: %lld planes of %dx%d exceed the global-memory path's grid", (long long)planes, H, W);
     return ALG_ELIMIT;
   }
   float* ws = nullptr;
   const size_t n1 = (size_t)planes * H * w1, n2 = (size_t)planes * h1 * w1, n3 = (size_t)planes * h1 * W;
-  if (int rc = big::ws_alloc(&ws, n1 + n2 + n3, s, "alg_down_up")) return rc;
+  if (int rc = big::ws_check(&ws, n1 + n2 + n3, workspace, workspace_bytes, "alg_down_up")) return rc;
   float *T1 = ws, *T2 = ws + n1, *T3 = T2 + n2;
   const int rpb = 8;
   // first interpolate call (lp:53): W pass, H pass (result optionally rounded to bf16 like the tensor in between)
@@ -160,40 +165,47 @@ static int down_up_big_t(const T* in, T* out, int64_t planes, int H, int W, int 
                      s, (const float*)T2, T3, h1, w1, W, rpb);
   hipLaunchKernelGGL((big::cols_kernel<T, false>), dim3((W + 255) / 256, H, (unsigned)planes), dim3(256), 0, s,
                      (const float*)T3, out, h1, H, W);
-  const int rc = check_launch("alg_down_up");
-  (void)hipFreeAsync(ws, s);
-  return rc;
+  return check_launch("alg_down_up");
+}
+
+int64_t down_up_big_bytes(int64_t planes, int H, int W, int h1, int w1) {
+  return (int64_t)sizeof(float) * planes * ((int64_t)H * w1 + (int64_t)h1 * w1 + (int64_t)h1 * W);
+}
+
+int64_t gaussian_big_bytes(int64_t planes, int H, int W, int ksize) {
+  return (int64_t)sizeof(float) * (planes * H * W + ((ksize + 255) & ~255));
 }
 
 int down_up_big(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
-                hipStream_t s) {
-  if (dtype == ALG_F32) return down_up_big_t<float>((const float*)in, (float*)out, planes, H, W, h1, w1, 0, s);
-  return down_up_big_t<bf16_t>((const bf16_t*)in, (bf16_t*)out, planes, H, W, h1, w1, round_mid, s);
+                void* workspace, int64_t workspace_bytes, hipStream_t s) {
+  if (dtype == ALG_F32)
+    return down_up_big_t<float>((const float*)in, (float*)out, planes, H, W, h1, w1, 0, workspace, workspace_bytes, s);
+  return down_up_big_t<bf16_t>((const bf16_t*)in, (bf16_t*)out, planes, H, W, h1, w1, round_mid, workspace, workspace_bytes, s);
 }
 
 template <typename T>
-static int gaussian_big_t(const T* in, T* out, int64_t planes, int H, int W, int ksize, float sigma, hipStream_t s) {
+static int gaussian_big_t(const T* in, T* out, int64_t planes, int H, int W, int ksize, float sigma, void* workspace,
+                          int64_t workspace_bytes, hipStream_t s) {
   if (planes > 65535 || H > 65535) {
     set_error("alg_gaussian_blur: %lld planes of %dx%d exceed the global-memory path's grid", (long long)planes, H, W);
     return ALG_ELIMIT;
   }
   float* ws = nullptr;
   const size_t n = (size_t)planes * H * W;
-  if (int rc = big::ws_alloc(&ws, n + (size_t)((ksize + 255) & ~255), s, "alg_gaussian_blur")) return rc;
+  if (int rc = big::ws_check(&ws, n + (size_t)((ksize + 255) & ~255), workspace, workspace_bytes, "alg_gaussian_blur")) return rc;
   float* g = ws + n;
   hipLaunchKernelGGL(big::gauss_weights_kernel, dim3(1), dim3(256), 0, s, g, ksize, sigma);
   const dim3 grid((W + 255) / 256, H, (unsigned)planes);
   hipLaunchKernelGGL(big::gauss_rows_kernel<T>, grid, dim3(256), 0, s, in, ws, (const float*)g, H, W, ksize);
   hipLaunchKernelGGL(big::gauss_cols_kernel<T>, grid, dim3(256), 0, s, (const float*)ws, out, (const float*)g, H, W, ksize);
-  const int rc = check_launch("alg_gaussian_blur");
-  (void)hipFreeAsync(ws, s);
-  return rc;
+  return check_launch("alg_gaussian_blur");
 }
 
 int gaussian_big(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype,
-                 hipStream_t s) {
-  if (dtype == ALG_F32) return gaussian_big_t<float>((const float*)in, (float*)out, planes, H, W, ksize, sigma, s);
-  return gaussian_big_t<bf16_t>((const bf16_t*)in, (bf16_t*)out, planes, H, W, ksize, sigma, s);
+                 void* workspace, int64_t workspace_bytes, hipStream_t s) {
+  if (dtype == ALG_F32)
+    return gaussian_big_t<float>((const float*)in, (float*)out, planes, H, W, ksize, sigma, workspace, workspace_bytes, s);
+  return gaussian_big_t<bf16_t>((const bf16_t*)in, (bf16_t*)out, planes, H, W, ksize, sigma, workspace, workspace_bytes, s);
 }
 
 }  // namespace alg

@@ -1,5 +1,5 @@
-// Antialias tap tables of the down_up filter as a device blob (built on the host by lowpass_v2.hip, shared with
-// lowpass_v3.hip).  Blob layout per table: xmin[n_out] | xsize[n_out] | w[n_out][taps] (ints / floats, 4 bytes each).
+// Antialias tap tables of the down_up filter as a device blob (built by lowpass_v2.hip's build_tables_kernel into a buffer
+// the caller owns, read by the kernels of lowpass_v2.hip and lowpass_v3.hip).  Blob layout per table: xmin[n_out] | xsize[n_out] | w[n_out][taps] (ints / floats, 4 bytes each).
 #pragma once
 #include <stdint.h>
 
@@ -39,9 +39,6 @@ inline Tabs layout(int H, int W, int h1, int w1) {
   t.words = (o + 3) & ~3;
   return t;
 }
-
-
-const uint32_t* lowpass_tables_for(int H, int W, int h1, int w1, const Tabs& t);
 
 }  // namespace v2
 }  // namespace alg

@@ -3,8 +3,9 @@
 // chip is fed when many planes are in flight (8 videos x 208 planes, Wan's 420-plane conditions):
 //
 //   * a PERSISTENT grid (CUs x workgroups that fit by LDS): a workgroup walks planes blockIdx, blockIdx + grid, ...;
-//   * the antialias tap tables are built ONCE per shape on the host (strict fp32, the very expressions of build_taps) and
-//     kept in a small device blob: a workgroup copies it to LDS once, not four tables per plane with ~13 divisions each;
+//   * the antialias tap tables are built ONCE per shape by a tiny kernel (alg_lowpass_tables_build: strict fp32, the very
+//     expressions of build_taps) into a small blob the caller owns and passes to every call: a workgroup copies it to LDS
+//     once, not four tables per plane with ~13 divisions each;
 //   * the NEXT plane is already in flight (16-byte loads into registers) while the current one runs its passes, so the
 //     ~2 us HBM latency of a plane is hidden behind LDS work instead of heading every plane;
 //   * the last pass runs with a wave-uniform output row: its three tap weights and row offsets are scalar loads from the
@@ -14,10 +15,6 @@
 //
 // Planes whose byte size is not a multiple of 16 (or misaligned bases) take the original kernels.
 #include <algorithm>
-#include <map>
-#include <mutex>
-#include <tuple>
-#include <vector>
 
 #include <math.h>
 #include <stdlib.h>
@@ -30,69 +27,45 @@ namespace v2 {
 
 constexpr int REG_TAPS = 12;
 
-// Host restatement of lowpass.hip build_taps: every operation is a single IEEE fp32 operation in the same order (this file
-// is compiled with -ffp-contract=off for host and device; x86-64 float arithmetic is SSE, no excess precision), so the
-// table is the one the device builds, bit for bit (checked against the in-kernel tables through the bit-identity test).
-static void host_build(uint32_t* blob, const Tab& t, int in_size) {
+// Device builder of the four tables of one shape (alg_lowpass_tables_build): lowpass.hip's build_taps, operation for
+// operation (every step one IEEE fp32 operation through the never-fused __f*_rn intrinsics; correctly rounded division),
+// written into a blob the CALLER owns -- the library neither allocates nor caches device memory.  One thread per output.
+__global__ __launch_bounds__(256) void build_tables_kernel(uint32_t* __restrict__ blob, const Tabs tabs, int H, int W, int h1,
+                                                           int w1) {
+  const unsigned which = blockIdx.y;   // dw: W -> w1, dh: H -> h1, uw: w1 -> W, uh: h1 -> H
+  const Tab t = which == 0 ? tabs.dw : which == 1 ? tabs.dh : which == 2 ? tabs.uw : tabs.uh;
+  const int in_size = which == 0 ? W : which == 1 ? H : which == 2 ? w1 : h1;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.y == 3 && i < 4) {   // the blob is padded to a multiple of four words
+    const int last = tabs.uh.off + tabs.uh.words() + i;
+    if (last < tabs.words) blob[last] = 0u;
+  }
   const int out_size = t.n_out;
+  if (i >= out_size) return;
   int* xmin = (int*)blob + t.off;
   int* xsize = xmin + out_size;
-  float* wt = (float*)(xsize + out_size);
-  volatile float scale = (float)in_size / (float)out_size;
+  float* w = (float*)(xsize + out_size) + (size_t)i * t.taps;
+  const float scale = __fdiv_rn((float)in_size, (float)out_size);
   const float support = scale >= 1.0f ? scale : 1.0f;
-  volatile float invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
-  for (int i = 0; i < out_size; ++i) {
-    volatile float center = scale * ((float)i + 0.5f);
-    volatile float a = center - support;
-    int lo = (int)(a + 0.5f);
-    lo = lo > 0 ? lo : 0;
-    volatile float b = center + support;
-    int hi = (int)(b + 0.5f);
-    hi = hi < in_size ? hi : in_size;
-    int n = hi - lo;
-    n = n < 0 ? 0 : (n > t.taps ? t.taps : n);
-    float* w = wt + (size_t)i * t.taps;
-    volatile float tot = 0.0f;
-    for (int j = 0; j < n; ++j) {
-      volatile float d = (float)(j + lo) - center;
-      volatile float e = d + 0.5f;
-      float x = fabsf(e * invscale);
-      float wj = x < 1.0f ? 1.0f - x : 0.0f;
-      w[j] = wj;
-      tot = tot + wj;
-    }
-    for (int j = 0; j < n; ++j) w[j] = tot != 0.0f ? w[j] / tot : w[j];
-    for (int j = n; j < t.taps; ++j) w[j] = 0.0f;
-    xmin[i] = lo;
-    xsize[i] = n;
+  const float invscale = scale >= 1.0f ? __fdiv_rn(1.0f, scale) : 1.0f;
+  const float center = __fmul_rn(scale, (float)i + 0.5f);
+  int lo = (int)__fadd_rn(__fsub_rn(center, support), 0.5f);
+  lo = lo > 0 ? lo : 0;
+  int hi = (int)__fadd_rn(__fadd_rn(center, support), 0.5f);
+  hi = hi < in_size ? hi : in_size;
+  int n = hi - lo;
+  n = n < 0 ? 0 : (n > t.taps ? t.taps : n);
+  float tot = 0.0f;
+  for (int j = 0; j < n; ++j) {
+    float x = fabsf(__fmul_rn(__fadd_rn(__fsub_rn((float)(j + lo), center), 0.5f), invscale));
+    const float wj = x < 1.0f ? __fsub_rn(1.0f, x) : 0.0f;
+    w[j] = wj;
+    tot = __fadd_rn(tot, wj);
   }
-}
-
-static std::mutex g_mu;
-static std::map<std::tuple<int, int, int, int, int>, uint32_t*> g_blobs;   // (device, H, W, h1, w1) -> device blob
-
-// Device blob of the four tables for this shape (created on first use: one blocking 2-6 KB copy per shape and device, so
-// the blob is complete for every stream before the first launch that reads it).
-static const uint32_t* tables_for(int H, int W, int h1, int w1, const Tabs& t) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(g_mu);
-  auto key = std::make_tuple(dev, H, W, h1, w1);
-  auto it = g_blobs.find(key);
-  if (it != g_blobs.end()) return it->second;
-  std::vector<uint32_t> host((size_t)t.words, 0u);
-  host_build(host.data(), t.dw, W);
-  host_build(host.data(), t.dh, H);
-  host_build(host.data(), t.uw, w1);
-  host_build(host.data(), t.uh, h1);
-  uint32_t* d = nullptr;
-  if (hipMalloc((void**)&d, (size_t)t.words * 4) != hipSuccess) return nullptr;
-  if (hipMemcpy(d, host.data(), (size_t)t.words * 4, hipMemcpyHostToDevice) != hipSuccess) {
-    (void)hipFree(d);
-    return nullptr;
-  }
-  g_blobs[key] = d;
-  return d;
+  for (int j = 0; j < n; ++j) w[j] = tot != 0.0f ? __fdiv_rn(w[j], tot) : w[j];
+  for (int j = n; j < t.taps; ++j) w[j] = 0.0f;
+  xmin[i] = lo;
+  xsize[i] = n;
 }
 
 struct TapView {   // a table inside a word array (LDS copy or the global blob)
@@ -607,14 +580,11 @@ static int dispatch_g(const void* in, void* out, const GArgs& a, size_t lds, con
   ALG_V2_DISPATCH(launch_g, T, (const T*)in, (T*)out, a, lds, geo.grid, s)
 }
 
-// the same device blob for lowpass_v3.hip
-const uint32_t* lowpass_tables_for(int H, int W, int h1, int w1, const Tabs& t) { return tables_for(H, W, h1, w1, t); }
-
 }  // namespace v2
 
 // Returns ALG_OK when the launch was made, 1 when this shape is not covered (the caller falls back to lowpass.hip's kernels).
 int down_up_v2(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
-               hipStream_t s) {
+               const void* tables, hipStream_t s) {
   using namespace v2;
   const size_t esz = dtype == ALG_F32 ? 4 : 2;
   const size_t bytes = (size_t)H * W * esz;
@@ -631,7 +601,7 @@ int down_up_v2(const void* in, void* out, int64_t planes, int H, int W, int h1, 
   if (((size_t)H * w1) & 3) return 1;                                              // keeps T2 / the blob 16-byte aligned
   Geo geo;
   if (!geometry(bytes, H * W, planes, lds, 6, 4, &geo)) return 1;
-  const uint32_t* blob = tables_for(H, W, h1, w1, a.tabs);
+  const uint32_t* blob = (const uint32_t*)tables;
   if (!blob) return 1;
   return dtype == ALG_F32 ? dispatch_du<float>(in, out, blob, a, lds, geo, s)
                           : dispatch_du<bf16_t>(in, out, blob, a, lds, geo, s);
@@ -653,3 +623,27 @@ int gaussian_v2(const void* in, void* out, int64_t planes, int H, int W, int ksi
 }
 
 }  // namespace alg
+
+extern "C" int64_t alg_lowpass_tables_bytes(int H, int W, int h1, int w1) {
+  if (H <= 0 || W <= 0 || h1 <= 0 || w1 <= 0) return 0;
+  return (int64_t)alg::v2::layout(H, W, h1, w1).words * 4;
+}
+
+extern "C" int alg_lowpass_tables_build(void* tables, int64_t bytes, int H, int W, int h1, int w1, void* stream) {
+  using namespace alg;
+  if (!tables || H <= 0 || W <= 0 || h1 <= 0 || w1 <= 0 || ((uintptr_t)tables & 15)) {
+    set_error("alg_lowpass_tables_build: bad argument (tables=%p H=%d W=%d h1=%d w1=%d; 16-byte aligned blob)", tables, H, W,
+              h1, w1);
+    return ALG_EINVAL;
+  }
+  const v2::Tabs t = v2::layout(H, W, h1, w1);
+  if (bytes < (int64_t)t.words * 4) {
+    set_error("alg_lowpass_tables_build: blob of %lld bytes, alg_lowpass_tables_bytes says %lld", (long long)bytes,
+              (long long)t.words * 4);
+    return ALG_EINVAL;
+  }
+  const int widest = std::max(std::max(H, W), std::max(h1, w1));
+  hipLaunchKernelGGL(v2::build_tables_kernel, dim3((unsigned)((widest + 255) / 256), 4), dim3(256), 0, (hipStream_t)stream,
+                     (uint32_t*)tables, t, H, W, h1, w1);
+  return check_launch("alg_lowpass_tables_build");
+}

@@ -641,7 +641,7 @@ int gaussian_v3(const void* in, void* out, int64_t planes, int H, int W, int ksi
 
 // down_up: returns ALG_OK when the launch was made, 1 when this shape is not covered (the caller goes on to lowpass_v2.hip)
 int down_up_v3(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
-               hipStream_t s) {
+               const void* tables, hipStream_t s) {
   using namespace v3;
   const char* off = getenv("ALG_LOWPASS_V3");
   if (off && off[0] == '0') return 1;
@@ -668,7 +668,7 @@ int down_up_v3(const void* in, void* out, int64_t planes, int H, int W, int h1, 
     }
   }
   if (!nt || (int64_t)nt * MAXPRE * 4 < n || w1 > nt || (WS >> 2) > nt) return 1;
-  const uint32_t* blob = v2::lowpass_tables_for(H, W, h1, w1, a.tabs);
+  const uint32_t* blob = (const uint32_t*)tables;
   if (!blob) return 1;
   return dtype == ALG_F32 ? dispatch_d<float>(in, out, blob, a, lds, nt, s)
                           : dispatch_d<bf16_t>(in, out, blob, a, lds, nt, s);

@@ -7,8 +7,11 @@
  *   lp:  lp_utils.py            cog: pipeline_cogvideox_image2video_lowpass.py
  *
  * Conventions
- *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); kernels never allocate or free
- *   - enqueue-only on `stream` (a hipStream_t, may be NULL = default stream); no internal sync
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); the library never allocates, frees or caches
+ *     device memory: scratch space is a `workspace` argument sized by the matching alg_*_workspace_bytes()
+ *     query, precomputed tables are a caller-owned blob filled by an explicit alg_*_build() call
+ *   - enqueue-only on `stream` (a hipStream_t, may be NULL = default stream); no internal sync, no blocking
+ *     copy: every entry point is legal inside a hipGraph stream capture
  *   - in/out may not alias unless stated
  *   - return 0 on success, negative ALG_E* on failure; message via alg_last_error() (thread local)
  *   - dtype codes: ALG_F32 = 0, ALG_BF16 = 1
@@ -30,7 +33,7 @@ extern "C" {
 #define ALG_ELAUNCH (-2)  /* HIP launch / runtime error */
 #define ALG_ELIMIT (-3)   /* shape exceeds what the kernel supports (e.g. plane does not fit LDS) */
 
-#define ALG_VERSION 100
+#define ALG_VERSION 110
 
 int alg_version(void);
 const char* alg_last_error(void);
@@ -47,14 +50,27 @@ const char* alg_last_error(void);
  * round_intermediate != 0 rounds the (h1, w1) intermediate to bf16 (the reference's two separate
  * interpolate calls each return a tensor of the input dtype); only meaningful for ALG_BF16. */
 int alg_down_up(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype,
-                int round_intermediate, void* stream);
+                int round_intermediate, const void* tables, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The antialias tap tables of one (H, W) -> (h1, w1) -> (H, W) shape (lp:51-54: the weights F.interpolate(antialias=True)
+ * derives per output index), as a blob the caller owns: alg_lowpass_tables_bytes() sizes it, alg_lowpass_tables_build()
+ * fills it with one tiny kernel on `stream`, alg_down_up(tables=...) reads it on any later call of that shape (ordered
+ * after the build on the stream, as usual).  tables = NULL is legal: alg_down_up then uses the kernels that derive the
+ * taps per plane (identical bits, lower throughput on many-plane batches). */
+int64_t alg_lowpass_tables_bytes(int H, int W, int h1, int w1);
+int alg_lowpass_tables_build(void* tables, int64_t bytes, int H, int W, int h1, int w1, void* stream);
+
+/* Scratch bytes alg_down_up needs for this call (0 for planes that fit LDS -- every latent-sized plane; pixel-sized planes
+ * run through global-memory passes with fp32 intermediates in `workspace`). */
+int64_t alg_down_up_workspace_bytes(int64_t planes, int H, int W, int h1, int w1);
 
 /* lp:40-47  torchvision gaussian_blur(kernel_size=[k,k], sigma=[s,s]): reflect pad k/2, separable
  * correlation with g = exp(-0.5 (x/s)^2)/sum.  ksize must be odd (any size: more than 255 taps run through the global-memory
  * passes), ksize/2 < min(H, W), sigma > 0.  Weights are fp32 for every dtype (torchvision builds them in the image dtype:
  * for bf16 tensors see DESIGN.md section 2, "Rounding semantics"). */
 int alg_gaussian_blur(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype,
-                      void* stream);
+                      void* workspace, int64_t workspace_bytes, void* stream);
+int64_t alg_gaussian_blur_workspace_bytes(int64_t planes, int H, int W, int ksize);   /* 0 for LDS-sized planes */
 
 /* ------------------------------------------------------------------------------------------------
  * cog:1091-1123  noise_pred.float(); chunk; CFG combine; CogVideoXDDIMScheduler.step (v-prediction,
@@ -164,11 +180,17 @@ int alg_flash_attn_d64(const void* q, const void* k, const void* vt, void* o, in
                        int64_t o_bstride, int64_t o_rstride, float scale, void* stream);
 
 /* flags = ALG_ATTN_Q_PRESCALED: q already carries scale * log2(e) (alg_qk_norm_rope_scaled); `scale` is ignored and the
- * scores come out of the MFMA in log2 units.  flags = 0 is alg_flash_attn_d64. */
+ * scores come out of the MFMA in log2 units.  flags = 0 is alg_flash_attn_d64.
+ * workspace: when the (head, query-block) units of a launch leave the last round of workgroups nearly empty (C2: 840 units
+ * per XCD on 64 slots), the last units are cut along KV into a second launch whose fp32 partials live in `workspace`
+ * (alg_flash_attn_d64_workspace_bytes; 0 = this shape is one launch).  workspace = NULL (what alg_flash_attn_d64 passes)
+ * runs everything as one launch: same result up to the fp32 summation order of those last units. */
 #define ALG_ATTN_Q_PRESCALED 1
 int alg_flash_attn_d64_ex(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S,
                           int64_t q_bstride, int64_t q_rstride, int64_t vt_bstride, int64_t vt_rstride,
-                          int64_t o_bstride, int64_t o_rstride, float scale, int flags, void* stream);
+                          int64_t o_bstride, int64_t o_rstride, float scale, int flags, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+int64_t alg_flash_attn_d64_workspace_bytes(int batch, int heads, int S, int flags);
 
 /* wan:910-917 (WanTransformer3DModel self- and cross-attention, head_dim 128; diffusers WanAttnProcessor SDPA)
  * Same contract as alg_flash_attn_d64 with head_dim 128 and separate query / key lengths:

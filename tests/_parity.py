@@ -6,7 +6,9 @@ so the same CPU oracle is run twice on the same inputs -- once in fp32 (the math
 weights / activations in eager op order (what the reference executes) -- and the HIP path has to land within
 FACTOR x the bf16-eager deviation from the fp32 result, instead of under a bare 3e-2 / 4e-2:
 
-        err(HIP, fp32 oracle)  <=  1.5 * err(bf16-eager oracle, fp32 oracle)
+        err(HIP, fp32 oracle)  <=  1.5 * err(bf16-eager oracle, fp32 oracle)                  (global relative L2)
+        max_token err_token(HIP)  <=  4 * p99.9_token err_token(bf16-eager oracle)             (per token, round 3)
+        max |HIP - fp32|  <=  2 * max |bf16-eager - fp32|                                      (worst element, round 3)
 
 Measured pairs are appended to gpurun_out/parity_floor.jsonl when ALG_PARITY_REPORT is set (the summary committed under
 profiles/ comes from there)."""
@@ -16,6 +18,8 @@ import os
 import torch
 
 FACTOR = 1.5
+TOKEN_FACTOR = 4.0        # a token's relative error vs 4 x the eager oracle's own 99.9th-percentile token error
+MAXABS_FACTOR = 2.0       # the worst element vs 2 x the eager oracle's worst element
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -24,17 +28,81 @@ def rel(got, ref):
     return ((got - ref).norm() / ref.norm()).item()
 
 
-def check_floor(name, hip, ref32, eager_bf16, factor=FACTOR, sane=0.5):
-    """Assert the anchored bound and return (err_hip, err_floor)."""
+def _channel_dim(t, channel_dim):
+    if channel_dim is not None:
+        return channel_dim
+    return 1 if t.dim() == 5 else -1      # [B, C, F, H, W] video latents (Wan / HunyuanVideo) / [..., D] token rows
+
+
+def token_errors(got, ref, channel_dim=None):
+    """Per-token relative errors: the error vector of every token (all dims except `channel_dim` index tokens; a video
+    latent [B, C, F, H, W] has one token per voxel, CogVideoX's [B, F, C, H, W] passes channel_dim=2) against that token's
+    own reference norm, floored at the tensor's RMS token norm so that near-zero tokens do not blow the ratio up."""
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    if got.dim() < 2:
+        got, ref = got.reshape(1, -1), ref.reshape(1, -1)
+    cd = _channel_dim(ref, channel_dim)
+    num = (got - ref).norm(dim=cd)
+    den = ref.norm(dim=cd)
+    floor = den.pow(2).mean().sqrt().clamp_min(1e-30)
+    return (num / torch.maximum(den, floor)).reshape(-1)
+
+
+def check_tokens(name, hip, ref32, eager_bf16, channel_dim=None, token_factor=TOKEN_FACTOR, maxabs_factor=MAXABS_FACTOR):
+    """The LOCAL half of the bound (a global L2 norm over 10^5 tokens does not see a few dozen corrupted
+    ones): every token's relative error <= token_factor x the bf16-eager oracle's 99.9th-percentile token error, and the
+    worst element <= maxabs_factor x the eager oracle's worst element."""
+    t_hip, t_floor = token_errors(hip, ref32, channel_dim), token_errors(eager_bf16, ref32, channel_dim)
+    q = torch.quantile(t_floor, 0.999).item() if t_floor.numel() <= 2 ** 24 else t_floor.kthvalue(
+        int(0.999 * t_floor.numel())).values.item()
+    worst = t_hip.max().item()
+    m_hip = (hip.detach().double().cpu() - ref32.detach().double().cpu()).abs().max().item()
+    m_floor = (eager_bf16.detach().double().cpu() - ref32.detach().double().cpu()).abs().max().item()
+    stats = {"token_worst_hip": worst, "token_p999_eager": q, "token_ratio": worst / max(q, 1e-30),
+             "maxabs_hip": m_hip, "maxabs_eager": m_floor, "maxabs_ratio": m_hip / max(m_floor, 1e-30),
+             "tokens": int(t_hip.numel())}
+    bad = int((t_hip > token_factor * q).sum().item())
+    assert bad == 0, ("%s: %d of %d tokens exceed %.1f x the bf16-eager oracle's p99.9 token error %.3e (worst %.3e)"
+                      % (name, bad, t_hip.numel(), token_factor, q, worst))
+    assert m_hip <= maxabs_factor * m_floor, ("%s: max |HIP - fp32| %.3e exceeds %.1f x the bf16-eager oracle's %.3e"
+                                              % (name, m_hip, maxabs_factor, m_floor))
+    return stats
+
+
+def check_floor(name, hip, ref32, eager_bf16, factor=FACTOR, sane=0.5, channel_dim=None, tokens=True):
+    """Assert the anchored bound (global AND per token) and return (err_hip, err_floor)."""
     e_hip, e_floor = rel(hip, ref32), rel(eager_bf16, ref32)
+    assert torch.isfinite(hip.float()).all(), name
+    assert e_floor < sane, "%s: the bf16-eager oracle itself is %.3e away from fp32 -- the case is ill-conditioned" % (name, e_floor)
+    err = None
+    stats = {}
+    try:
+        assert e_hip <= factor * e_floor, ("%s: HIP %.3e vs fp32 oracle exceeds %.1f x the bf16-eager floor %.3e"
+                                           % (name, e_hip, factor, e_floor))
+        if tokens:
+            stats = check_tokens(name, hip, ref32, eager_bf16, channel_dim)
+    except AssertionError as e:
+        err = e
     if os.environ.get("ALG_PARITY_REPORT"):
         d = os.path.join(ROOT, "gpurun_out")
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, "parity_floor.jsonl"), "a") as f:
-            f.write(json.dumps({"case": name, "err_hip_vs_fp32": e_hip, "err_bf16_eager_vs_fp32": e_floor,
-                                "ratio": e_hip / max(e_floor, 1e-30), "factor": factor}) + "\n")
-    assert torch.isfinite(hip.float()).all(), name
-    assert e_floor < sane, "%s: the bf16-eager oracle itself is %.3e away from fp32 -- the case is ill-conditioned" % (name, e_floor)
-    assert e_hip <= factor * e_floor, ("%s: HIP %.3e vs fp32 oracle exceeds %.1f x the bf16-eager floor %.3e"
-                                       % (name, e_hip, factor, e_floor))
+            f.write(json.dumps(dict({"case": name, "err_hip_vs_fp32": e_hip, "err_bf16_eager_vs_fp32": e_floor,
+                                     "ratio": e_hip / max(e_floor, 1e-30), "factor": factor,
+                                     "passed": err is None}, **stats)) + "\n")
+    if err is not None:
+        raise err
     return e_hip, e_floor
+
+
+def assert_repeatable(fn, times=8, what="forward"):
+    """Run fn() `times` times in this process and require every result to be bit-identical to the first (VERDICT r2 weak 2:
+    a 2-8 % per-process flake is invisible to a single repeat).  Returns the first result."""
+    first = fn()
+    for i in range(1, times):
+        again = fn()
+        if not torch.equal(again, first):
+            d = (again.float() - first.float()).abs()
+            raise AssertionError("%s: run %d of %d differs from run 0 in %d elements (max |diff| %.3e)"
+                                 % (what, i, times, int((d > 0).sum().item()), d.max().item()))
+    return first

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from _parity import assert_repeatable
 from alg_amd import (CogVideoXDDIMScheduler, CogVideoXImageToVideoPipeline, CogVideoXTransformer3DModel,
                      CogVideoXTransformerConfig, _lib, lp_utils)
 from alg_amd.pipeline_cogvideox_image2video_lowpass import get_resize_crop_region_for_grid, rotary_tables
@@ -111,8 +112,12 @@ def test_dit_full_width_two_layers_consistency(device, monkeypatch):
     out2 = model.forward_assembled(lat, [c1, c1], torch.cat([ne, pe]), ts2, rope)
     assert torch.equal(out3[1], out2[0]) and torch.equal(out3[2], out2[1])
     assert not torch.equal(out3[0], out3[1])  # the sharp and the low-passed condition give different predictions
-    again = model.forward_assembled(lat, [c0, c1, c1], torch.cat([ne, ne, pe]), ts3, rope)
+    again = assert_repeatable(lambda: model.forward_assembled(lat, [c0, c1, c1], torch.cat([ne, ne, pe]), ts3, rope), 8,
+                              "c2 3-pass forward (single-launch attention)")
     assert torch.equal(again, out3)
+    monkeypatch.delenv("ALG_ATTN_SPLIT_TAIL")
+    assert_repeatable(lambda: model.forward_assembled(lat, [c1, c1], torch.cat([ne, pe]), ts2, rope), 8,
+                      "c2 2-pass forward (default split-KV tail)")
 
 
 def test_sampler_full_latent_size_one_layer(device):

@@ -10,6 +10,7 @@ finite, run-to-run bit-identical, a sample's prediction independent of its posit
 import pytest
 import torch
 
+from _parity import assert_repeatable
 from alg_amd import (HunyuanVideoTransformer3DModel, HunyuanVideoTransformerConfig, WanTransformer3DModel, WanTransformerConfig,
                      lp_utils)
 
@@ -56,9 +57,8 @@ def test_wan_14b_width_full_token_count(name, F, H, W, fp8):
     ts = torch.full((3,), 900.0, device=DEV)
     run = lambda m, x, t, i: m(hidden_states=x, timestep=ts[:x.shape[0]], encoder_hidden_states=t,
                                encoder_hidden_states_image=i, return_dict=False)[0]
-    out3 = run(model, x3, t3, i3)
+    out3 = assert_repeatable(lambda: run(model, x3, t3, i3), 8, name + " 3-pass forward")   # deterministic: 8 runs, bit-equal
     assert out3.shape == (3, 16, F, H, W) and out3.dtype == BF and bool(torch.isfinite(out3.float()).all())
-    assert torch.equal(run(model, x3, t3, i3), out3)                              # deterministic
     out2 = run(model, x2, t2, i2)
     # batch-position / batch-size invariance: samples 1, 2 of the 3-pass batch are samples 0, 1 of the 2-pass batch
     for a, b in ((out3[1], out2[0]), (out3[2], out2[1])):
@@ -89,9 +89,8 @@ def test_hunyuan_13b_width_c4_token_count():
     run = lambda x_, txt_, mask_, pooled_, t_, g_: model(
         hidden_states=x_, timestep=t_, encoder_hidden_states=txt_, encoder_attention_mask=mask_.to(BF),
         pooled_projections=pooled_, guidance=g_, return_dict=False)[0]
-    out = run(x, txt, mask, pooled, t, guid)
+    out = assert_repeatable(lambda: run(x, txt, mask, pooled, t, guid), 8, "c4 forward")       # deterministic: 8 runs
     assert out.shape == (1, 16, F, H, W) and out.dtype == BF and bool(torch.isfinite(out.float()).all())
-    assert torch.equal(run(x, txt, mask, pooled, t, guid), out)                   # deterministic
     assert 0.05 < out.float().std().item() < 50.0
     # padded prompt tokens are outside the contract: garbage there must not reach the latents (bit for bit)
     txt2 = txt.clone()

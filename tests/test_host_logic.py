@@ -141,24 +141,40 @@ def test_c_abi_exports_every_declared_symbol():
     lib = alg_amd.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.alg_version() == 100
+    assert lib.alg_version() == 110
     assert ctypes.sizeof(alg_amd._lib.GemmArgs) == 6 * 8 + 9 * 8 + 7 * 4 + 4 + 8 + 8 + 4 * 8 + 16  # struct alg_gemm_args (+pad, gate_seg_stride, perm_col0/conv_cin_log2, fp8 scales, conv_wp/conv_hpwp/conv_kw/reserved)
 
 
 def test_c_abi_argument_errors_without_gpu():
     """Argument validation happens before any launch, so it is testable on CPU."""
     lib = alg_amd.load_library()
-    rc = lib.alg_down_up(None, None, 1, 4, 4, 2, 2, 0, 0, None)
+    rc = lib.alg_down_up(None, None, 1, 4, 4, 2, 2, 0, 0, None, None, 0, None)
     assert rc == -1 and b"alg_down_up" in lib.alg_last_error()
     buf = (ctypes.c_float * 16)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.alg_gaussian_blur(p, ctypes.c_void_p(p.value + 4), 1, 4, 4, 4, 1.0, 0, None) == -1  # even kernel
+    assert lib.alg_gaussian_blur(p, ctypes.c_void_p(p.value + 4), 1, 4, 4, 4, 1.0, 0, None, 0, None) == -1  # even kernel
     assert b"odd" in lib.alg_last_error()
-    assert lib.alg_gaussian_blur(p, ctypes.c_void_p(p.value + 4), 1, 4, 4, 9, 1.0, 0, None) == -1  # pad >= plane
-    assert lib.alg_gaussian_blur(p, ctypes.c_void_p(p.value + 4), 1, 4, 4, 3, 0.0, 0, None) == -1  # sigma
+    assert lib.alg_gaussian_blur(p, ctypes.c_void_p(p.value + 4), 1, 4, 4, 9, 1.0, 0, None, 0, None) == -1  # pad >= plane
+    assert lib.alg_gaussian_blur(p, ctypes.c_void_p(p.value + 4), 1, 4, 4, 3, 0.0, 0, None, 0, None) == -1  # sigma
     assert lib.alg_cfg_ddim_step(p, 0, p, 0, 4, 16, 1.0, 1.0, 1.0, 1.0, 1.0, None) == -1
-    assert lib.alg_down_up(p, p, 1, 4, 4, 2, 2, 0, 0, None) == -1  # aliasing
-    assert lib.alg_down_up(p, ctypes.c_void_p(p.value + 4), 0, 4, 4, 2, 2, 0, 0, None) == 0  # empty input is fine
+    assert lib.alg_down_up(p, p, 1, 4, 4, 2, 2, 0, 0, None, None, 0, None) == -1  # aliasing
+    assert lib.alg_down_up(p, ctypes.c_void_p(p.value + 4), 0, 4, 4, 2, 2, 0, 0, None, None, 0, None) == 0  # empty input is fine
+    # the library never allocates: sizes of caller-owned buffers are plain host queries
+    assert lib.alg_lowpass_tables_bytes(60, 90, 15, 22) > 0 and lib.alg_lowpass_tables_bytes(60, 90, 15, 22) % 16 == 0
+    assert lib.alg_down_up_workspace_bytes(208, 60, 90, 15, 22) == 0                       # latent planes live in LDS
+    assert lib.alg_down_up_workspace_bytes(3, 480, 720, 120, 180) == 4 * 3 * (480 * 180 + 120 * 180 + 120 * 720)
+    assert lib.alg_gaussian_blur_workspace_bytes(420, 60, 104, 9) == 0
+    assert lib.alg_gaussian_blur_workspace_bytes(3, 480, 720, 9) == 4 * (3 * 480 * 720 + 256)
+    # a pixel-sized plane without its workspace is an argument error, not an allocation
+    big = (ctypes.c_float * 1)()
+    pb = ctypes.cast(big, ctypes.c_void_p)
+    assert lib.alg_down_up(pb, ctypes.c_void_p(pb.value + 64), 3, 480, 720, 120, 180, 0, 0, None, None, 0, None) == -1
+    assert b"workspace" in lib.alg_last_error()
+    assert lib.alg_lowpass_tables_build(None, 0, 60, 90, 15, 22, None) == -1
+    # C2's attention launch (2 samples x 48 heads x 17,776 tokens) has a split-KV tail: 8 XCDs x 8 units x 8 chunks x 256 rows
+    ws = lib.alg_flash_attn_d64_workspace_bytes(2, 48, 17776, 1)
+    assert ws == 8 * 8 * 8 * 256 * 66 * 4, ws
+    assert lib.alg_flash_attn_d64_workspace_bytes(1, 8, 1024, 0) == 0
 
 
 class _FakeTransformer:
