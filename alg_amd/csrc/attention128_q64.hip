@@ -534,6 +534,13 @@ __device__ __forceinline__ void read_o(float (&f)[16]) {
                  : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]) : : ALG_O_CLOBBER);
 }
 
+// MODE (round-3 experiment arms, selected at run time by ALG_ATTN128_Q64 = 1 / 2 / 3 / 4):
+//   1  the round-2 kernel: counted vmcnt(8) at the tile boundary (three DMA groups in the ring, one may still be in flight)
+//   2  vmcnt(0) at the tile boundary: no reliance on LDS-DMA completing in issue order (the group issued one tile ago is
+//      ~2,000 cycles old by then)
+//   3  MODE 1 + every wave drains its output stores and writes the L2 back (agent-scope release) before it ends
+//   4  both
+template <int MODE>
 __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const k_ring = smem;
@@ -737,7 +744,10 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
   // reaches into K(t+1).  Every wave is past its reads of K(t-1) and V(t-2) (each was consumed by an MFMA behind a counted
   // wait), so after the barrier their slots take K(t+3) and V(t+2).
   auto boundary = [&](int t) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (MODE == 2 || MODE == 4)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);   // K(t + 3) and V(t + 2) go out piece by piece during the region (stage_piece)
   };
@@ -987,6 +997,11 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
         }
     }
   }
+  if constexpr (MODE == 3 || MODE == 4) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
 }
 
 }  // namespace a128q
@@ -1009,9 +1024,9 @@ int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, i
   if (vt_rs < (int64_t)((Skv + KVB - 1) / KVB) * KVB) return 1;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)flash_attn_d128_q64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
-        hipSuccess)
-      return 1;
+    for (const void* fn : {(const void*)flash_attn_d128_q64_kernel<1>, (const void*)flash_attn_d128_q64_kernel<2>,
+                           (const void*)flash_attn_d128_q64_kernel<3>, (const void*)flash_attn_d128_q64_kernel<4>})
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return 1;
     attr_set = true;
   }
   P p;
@@ -1022,7 +1037,13 @@ int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, i
   p.scale_log2 = scale * 1.4426950408889634f;
   const int64_t grid = (int64_t)((batch * heads + 7) / 8) * 8 * p.q_blocks;
   if (grid > 0x7fffffff) return 1;
-  hipLaunchKernelGGL(flash_attn_d128_q64_kernel, dim3((unsigned)grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  const dim3 g((unsigned)grid), blk(NW * 64);
+  switch (enabled) {
+    case 2: hipLaunchKernelGGL(flash_attn_d128_q64_kernel<2>, g, blk, LDS_BYTES, stream, p); break;
+    case 3: hipLaunchKernelGGL(flash_attn_d128_q64_kernel<3>, g, blk, LDS_BYTES, stream, p); break;
+    case 4: hipLaunchKernelGGL(flash_attn_d128_q64_kernel<4>, g, blk, LDS_BYTES, stream, p); break;
+    default: hipLaunchKernelGGL(flash_attn_d128_q64_kernel<1>, g, blk, LDS_BYTES, stream, p); break;
+  }
   return check_launch("alg_flash_attn_d128");
 }
 

@@ -10,12 +10,13 @@ int launch_gemm_p0(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg
 int launch_gemm_p6(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p7(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
+int launch_gemm_p9(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 static int gemm_pipe() {
   const char* e = getenv("ALG_GEMM_PIPE");
   const int v = e ? atoi(e) : 6;  // default: 8-wave ping-pong over half-tiles (fastest measured)
-  return (v == 0 || v == 6 || v == 7 || v == 8) ? v : 6;
+  return (v == 0 || v == 6 || v == 7 || v == 8 || v == 9) ? v : 6;
 }
 }  // namespace alg
 
@@ -123,6 +124,10 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
     case 0: return launch_gemm_p0(a, m_tiles, n_tiles, nwg, s);   // 2-stage ring, 8 waves
     case 7: return launch_gemm_p7(a, m_tiles, n_tiles, nwg, s);   // 4 waves, every memory op behind an MFMA
     case 8: return launch_gemm_p8(a, m_tiles, n_tiles, nwg, s);   // 4 waves, 4-stage BK = 32 ring, never drains
+    case 9:   // 4 waves, hand-written asm main loop; needs two k-tiles and 32-bit byte offsets inside a 256-row panel
+      if (a->K >= 128 && 256 * a->lda * 2 + (int64_t)a->K * 2 < (1ll << 32) && 256 * a->ldb * 2 + (int64_t)a->K * 2 < (1ll << 32))
+        return launch_gemm_p9(a, m_tiles, n_tiles, nwg, s);
+      return launch_gemm_p6(a, m_tiles, n_tiles, nwg, s);
     default: return launch_gemm_p6(a, m_tiles, n_tiles, nwg, s);  // 8-wave ping-pong over half-tiles
   }
 }

@@ -54,25 +54,31 @@ DEFAULT_PROMPT_TEMPLATE = {   # hy:84-100
 
 def _expand_input_ids_with_image_tokens(text_input_ids, prompt_attention_mask, max_sequence_length, image_token_index,
                                         image_emb_len, image_emb_start, image_emb_end, pad_token_id):
-    """hy:107-146: make room for the image embeddings -- every `<image>` placeholder becomes `image_emb_len` image tokens at
-    [image_emb_start, image_emb_end), the text slides right; attention mask and position ids follow."""
-    special_image_token_mask = text_input_ids == image_token_index
-    num_special_image_tokens = torch.sum(special_image_token_mask, dim=-1)
-    batch_indices, non_image_indices = torch.where(text_input_ids != image_token_index)
-    max_expanded_length = max_sequence_length + (num_special_image_tokens.max() * (image_emb_len - 1))
-    new_token_positions = torch.cumsum((special_image_token_mask * (image_emb_len - 1) + 1), -1) - 1
-    text_to_overwrite = new_token_positions[batch_indices, non_image_indices]
-    expanded_input_ids = torch.full((text_input_ids.shape[0], int(max_expanded_length)), pad_token_id,
-                                    dtype=text_input_ids.dtype, device=text_input_ids.device)
-    expanded_input_ids[batch_indices, text_to_overwrite] = text_input_ids[batch_indices, non_image_indices]
-    expanded_input_ids[batch_indices, image_emb_start:image_emb_end] = image_token_index
-    expanded_attention_mask = torch.zeros((text_input_ids.shape[0], int(max_expanded_length)),
-                                          dtype=prompt_attention_mask.dtype, device=prompt_attention_mask.device)
-    attn_batch_indices, attention_indices = torch.where(expanded_input_ids != pad_token_id)
-    expanded_attention_mask[attn_batch_indices, attention_indices] = 1.0
-    expanded_attention_mask = expanded_attention_mask.to(prompt_attention_mask.dtype)
-    position_ids = (expanded_attention_mask.cumsum(-1) - 1).masked_fill_((expanded_attention_mask == 0), 1)
-    return {"input_ids": expanded_input_ids, "attention_mask": expanded_attention_mask, "position_ids": position_ids}
+    """Token ids / mask / positions of the Llava prompt once every `<image>` placeholder has grown into `image_emb_len` image
+    tokens (behaviour of hy:107-146, restated): a token's new index is the running sum of the widths in front of it
+    (placeholder: image_emb_len, anything else: 1); the image span is the template's [image_emb_start, image_emb_end); whatever
+    is not the pad id is attended to; positions count attended tokens, masked ones sit at position 1."""
+    ids = text_input_ids
+    rows, _ = ids.shape
+    is_image = ids == image_token_index
+    width = torch.where(is_image, image_emb_len, 1)
+    start = width.cumsum(dim=-1) - width                                   # first slot of every token after the expansion
+    total = int(max_sequence_length + is_image.sum(dim=-1).max() * (image_emb_len - 1))
+    # text tokens scatter to their slots; placeholders are parked in an extra trailing column that is cut off again
+    out = ids.new_full((rows, total + 1), pad_token_id)
+    out.scatter_(1, torch.where(is_image, total, start), ids)
+    out = out[:, :total]
+    out[:, image_emb_start:image_emb_end] = image_token_index
+    attend = (out != pad_token_id).to(prompt_attention_mask.dtype)
+    position_ids = (attend.cumsum(dim=-1) - 1).masked_fill(attend == 0, 1)
+    return {"input_ids": out, "attention_mask": attend, "position_ids": position_ids}
+
+
+def _drop_window(length, first, window_start, window):
+    """Column indices [rows, length - first - window] of `first .. length` with the `window` columns from window_start[row] on
+    left out -- the gather form of cat([x[first:ws], x[ws + window:]]) for a per-row ws."""
+    j = first + torch.arange(length - first - window, device=window_start.device)[None, :]
+    return j + window * (j >= window_start[:, None])
 
 
 @dataclass
@@ -289,78 +295,57 @@ class HunyuanVideoImageToVideoPipeline:
 
     def _get_llama_prompt_embeds(self, image, prompt, prompt_template, num_videos_per_prompt=1, device=None, dtype=None,
                                  max_sequence_length=256, num_hidden_layers_to_skip=2, image_embed_interleave=2):
-        """hy:282-420, line for line: fill the template, tokenise to crop_start + max_sequence_length, expand the `<image>`
-        placeholder to 576 image tokens, run the Llava encoder with the image's pixel values, take hidden state -(skip + 1),
-        cut the template / assistant header out and put every `image_embed_interleave`-th image token in front."""
+        """The Llava prompt embedding of hy:282-420 (same inputs, same outputs; the index arithmetic is restated in closed form):
+
+          1. the prompt goes into the template and is tokenised to crop_start + max_sequence_length tokens;
+          2. the one `<image>` placeholder grows into image_emb_len image tokens, the encoder runs on ids + pixel values, the
+             hidden state `num_hidden_layers_to_skip` layers before the last is the embedding;
+          3. output row = [every image_embed_interleave-th image token | user text], where "user text" is everything behind the
+             template's first crop_start tokens except the four tokens of the assistant header, which end at the LAST
+             double-return token of the row (a single prompt so long that the header was truncated away has only three of
+             them: the window then ends at the sequence end).  Text indices live in expanded coordinates (+ image_emb_len - 1), mask
+             indices in the tokenizer's."""
         if self.text_encoder is None or self.tokenizer is None or self.image_processor is None:
             raise _lib.AlgHipError("no Llava prompt encoder / tokenizer / image processor is attached: pass prompt_embeds and "
                                    "prompt_attention_mask")
         device = device or self._execution_device
         dtype = dtype or self.text_encoder.dtype
-        prompt = [prompt] if isinstance(prompt, str) else prompt
-        prompt = [prompt_template["template"].format(p) for p in prompt]
-        crop_start = prompt_template.get("crop_start", None)
-        image_emb_len = prompt_template.get("image_emb_len", 576)
-        image_emb_start = prompt_template.get("image_emb_start", 5)
-        image_emb_end = prompt_template.get("image_emb_end", 581)
-        double_return_token_id = prompt_template.get("double_return_token_id", 271)
-        if crop_start is None:
-            prompt_template_input = self.tokenizer(prompt_template["template"], padding="max_length", return_tensors="pt",
-                                                   return_length=False, return_overflowing_tokens=False,
-                                                   return_attention_mask=False)
-            crop_start = prompt_template_input["input_ids"].shape[-1]
-            crop_start -= 5   # <|start_header_id|>, <|end_header_id|>, assistant, <|eot_id|>, and the placeholder {}
-        max_sequence_length += crop_start
-        text_inputs = self.tokenizer(prompt, max_length=max_sequence_length, padding="max_length", truncation=True,
-                                     return_tensors="pt", return_length=False, return_overflowing_tokens=False,
-                                     return_attention_mask=True)
-        text_input_ids = text_inputs.input_ids.to(device=device)
-        prompt_attention_mask = text_inputs.attention_mask.to(device=device)
-        image_embeds = self.image_processor(image, return_tensors="pt")
-        image_embeds = (image_embeds["pixel_values"] if isinstance(image_embeds, dict) else image_embeds.pixel_values).to(device)
-        image_token_index = self.text_encoder.config.image_token_index
-        pad_token_id = self.text_encoder.config.pad_token_id
-        expanded_inputs = _expand_input_ids_with_image_tokens(text_input_ids, prompt_attention_mask, max_sequence_length,
-                                                              image_token_index, image_emb_len, image_emb_start,
-                                                              image_emb_end, pad_token_id)
-        prompt_embeds = self.text_encoder(**expanded_inputs, pixel_values=image_embeds,
-                                          output_hidden_states=True).hidden_states[-(num_hidden_layers_to_skip + 1)]
-        prompt_embeds = prompt_embeds.to(dtype=dtype)
-        if crop_start is not None and crop_start > 0:
-            text_crop_start = crop_start - 1 + image_emb_len
-            batch_indices, last_double_return_token_indices = torch.where(text_input_ids == double_return_token_id)
-            if last_double_return_token_indices.shape[0] == 3:   # in case the prompt is too long
-                last_double_return_token_indices = torch.cat(
-                    (last_double_return_token_indices, torch.tensor([text_input_ids.shape[-1]], device=device)))
-                batch_indices = torch.cat((batch_indices, torch.tensor([0], device=device)))
-            last_double_return_token_indices = last_double_return_token_indices.reshape(text_input_ids.shape[0], -1)[:, -1]
-            batch_indices = batch_indices.reshape(text_input_ids.shape[0], -1)[:, -1]
-            assistant_crop_start = last_double_return_token_indices - 1 + image_emb_len - 4
-            assistant_crop_end = last_double_return_token_indices - 1 + image_emb_len
-            attention_mask_assistant_crop_start = last_double_return_token_indices - 4
-            attention_mask_assistant_crop_end = last_double_return_token_indices
-            prompt_embed_list, prompt_attention_mask_list, image_embed_list, image_attention_mask_list = [], [], [], []
-            for i in range(text_input_ids.shape[0]):
-                prompt_embed_list.append(torch.cat([prompt_embeds[i, text_crop_start:assistant_crop_start[i].item()],
-                                                    prompt_embeds[i, assistant_crop_end[i].item():]]))
-                prompt_attention_mask_list.append(torch.cat([
-                    prompt_attention_mask[i, crop_start:attention_mask_assistant_crop_start[i].item()],
-                    prompt_attention_mask[i, attention_mask_assistant_crop_end[i].item():]]))
-                image_embed_list.append(prompt_embeds[i, image_emb_start:image_emb_end])
-                image_attention_mask_list.append(
-                    torch.ones(image_embed_list[-1].shape[0]).to(prompt_embeds.device).to(prompt_attention_mask.dtype))
-            prompt_embed_list = torch.stack(prompt_embed_list)
-            prompt_attention_mask_list = torch.stack(prompt_attention_mask_list)
-            image_embed_list = torch.stack(image_embed_list)
-            image_attention_mask_list = torch.stack(image_attention_mask_list)
-            if 0 < image_embed_interleave < 6:
-                image_embed_list = image_embed_list[:, ::image_embed_interleave, :]
-                image_attention_mask_list = image_attention_mask_list[:, ::image_embed_interleave]
-            assert (prompt_embed_list.shape[0] == prompt_attention_mask_list.shape[0]
-                    and image_embed_list.shape[0] == image_attention_mask_list.shape[0])
-            prompt_embeds = torch.cat([image_embed_list, prompt_embed_list], dim=1)
-            prompt_attention_mask = torch.cat([image_attention_mask_list, prompt_attention_mask_list], dim=1)
-        return prompt_embeds, prompt_attention_mask
+        tpl = prompt_template
+        texts = [tpl["template"].format(p) for p in ([prompt] if isinstance(prompt, str) else prompt)]
+        n_img, img_lo, img_hi = tpl.get("image_emb_len", 576), tpl.get("image_emb_start", 5), tpl.get("image_emb_end", 581)
+        dr_id = tpl.get("double_return_token_id", 271)
+        crop_start = tpl.get("crop_start", None)
+        if crop_start is None:   # measure the template: its own tokens minus <|start_header_id|>, <|end_header_id|>, assistant, <|eot_id|>, {}
+            crop_start = self.tokenizer(tpl["template"], padding="max_length", return_tensors="pt", return_length=False,
+                                        return_overflowing_tokens=False, return_attention_mask=False)["input_ids"].shape[-1] - 5
+        seq_len = max_sequence_length + crop_start
+        tok = self.tokenizer(texts, max_length=seq_len, padding="max_length", truncation=True, return_tensors="pt",
+                             return_length=False, return_overflowing_tokens=False, return_attention_mask=True)
+        ids, mask = tok.input_ids.to(device=device), tok.attention_mask.to(device=device)
+        pixels = self.image_processor(image, return_tensors="pt")
+        pixels = (pixels["pixel_values"] if isinstance(pixels, dict) else pixels.pixel_values).to(device)
+        enc_cfg = self.text_encoder.config
+        expanded = _expand_input_ids_with_image_tokens(ids, mask, seq_len, enc_cfg.image_token_index, n_img, img_lo, img_hi,
+                                                       enc_cfg.pad_token_id)
+        hidden = self.text_encoder(**expanded, pixel_values=pixels,
+                                   output_hidden_states=True).hidden_states[-(num_hidden_layers_to_skip + 1)].to(dtype=dtype)
+        if crop_start <= 0:
+            return hidden, mask
+        L = ids.shape[-1]
+        is_dr = ids == dr_id
+        last_dr = L - 1 - is_dr.flip(-1).to(torch.int64).argmax(dim=-1)             # last double return of every row ...
+        if int(is_dr.sum()) == 3:       # ... or the end: a single prompt so long that its assistant header was truncated away
+            last_dr = torch.full_like(last_dr, L)                                    # (the reference's test, hy:361-370)
+        shift = n_img - 1                                                            # text index -> expanded index
+        keep_h = _drop_window(hidden.shape[1], crop_start + shift, last_dr - 4 + shift, 4)
+        keep_m = _drop_window(L, crop_start, last_dr - 4, 4)
+        text = hidden.gather(1, keep_h[:, :, None].expand(-1, -1, hidden.shape[-1]))
+        text_mask = mask.gather(1, keep_m)
+        image_part = hidden[:, img_lo:img_hi]
+        if 0 < image_embed_interleave < 6:
+            image_part = image_part[:, ::image_embed_interleave]
+        image_mask = torch.ones(image_part.shape[:2], dtype=mask.dtype, device=hidden.device)
+        return torch.cat([image_part, text], dim=1), torch.cat([image_mask, text_mask], dim=1)
 
     def encode_prompt(self, image, prompt, prompt_2=None, prompt_template=DEFAULT_PROMPT_TEMPLATE, num_videos_per_prompt=1,
                       prompt_embeds=None, pooled_prompt_embeds=None, prompt_attention_mask=None, device=None, dtype=None,

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""In-process run-to-run determinism of the C5 (Wan 14B fp8, 3 x 75,600 tokens) 2-block forward: N forwards against the
+majority result, with the d = 128 attention arm given by ALG_ATTN128_Q64 (0 = 32-query kernel, 1-4 = q64 arms).
+python scripts/experiments/c5_loop.py [forwards] [fp8 0|1]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from alg_amd import WanTransformer3DModel, WanTransformerConfig  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+fp8 = bool(int(sys.argv[2])) if len(sys.argv) > 2 else True
+DEV, BF = "cuda:0", torch.bfloat16
+F, H, W = 21, 90, 160
+model = WanTransformer3DModel.from_synthetic(WanTransformerConfig(num_layers=2), seed=21, device=DEV, fp8=fp8)
+g = torch.Generator(device=DEV).manual_seed(5)
+x = torch.randn(3, 36, F, H, W, generator=g, device=DEV).to(BF)
+txt = torch.randn(3, 512, 4096, generator=g, device=DEV).to(BF)
+img = torch.randn(3, 257, 1280, generator=g, device=DEV).to(BF)
+ts = torch.full((3,), 900.0, device=DEV)
+run = lambda: model(hidden_states=x, timestep=ts, encoder_hidden_states=txt, encoder_hidden_states_image=img,
+                    return_dict=False)[0]
+outs = [run() for _ in range(3)]
+torch.cuda.synchronize()
+ref = outs[0] if torch.equal(outs[0], outs[1]) or torch.equal(outs[0], outs[2]) else outs[1]
+bad = [i for i, o in enumerate(outs) if not torch.equal(o, ref)]
+events = []
+t0 = time.time()
+for i in range(3, reps):
+    y = run()
+    if not torch.equal(y, ref):
+        d = (y.float() - ref.float()).abs()
+        nz = (d > 0).nonzero()
+        events.append({"forward": i, "elements": int((d > 0).sum()), "max": float(d.max()),
+                       "per_sample": [int((d[k] > 0).sum()) for k in range(3)],
+                       "frames": sorted(set(nz[:, 2].tolist()))[:8], "tokens": int((d.amax(dim=1) > 0).sum())})
+        bad.append(i)
+torch.cuda.synchronize()
+print(json.dumps({"arm": os.environ.get("ALG_ATTN128_Q64", "0"), "fp8": fp8, "forwards": reps, "mismatching": len(bad),
+                  "s_per_forward": (time.time() - t0) / max(reps - 3, 1), "events": events[:12]}))

@@ -82,3 +82,39 @@ def test_llama_prompt_embeds_cropping_and_interleave():
     # row 1 (2 text tokens): kept 3..5 -> 6..8, header 6..9 cut, last double return 10 and two pads -> 13..15
     assert emb[1, :, 0].tolist() == [1.0, 3.0, 6.0, 7.0, 8.0, 13.0, 14.0, 15.0]
     assert mask[1].tolist() == [1, 1, 1, 1, 1, 1, 0, 0]
+
+
+def test_llama_prompt_embeds_truncated_prompt_and_two_placeholder_expansion():
+    """A single prompt so long that the assistant header is truncated away keeps only three double returns: the cut-out
+    window then ends at the sequence end (hy:361-370).  And the id expansion in its general form: two placeholders."""
+    image_len, start, end, crop = 4, 1, 5, 3
+    DR = 271
+
+    class Tok:
+        def __call__(self, prompt, max_length=None, **kw):
+            row = [1, 99, DR, DR, DR] + [50 + i for i in range(40)] + [6, 7, 8, 9, DR]   # three double returns up front, as
+            ids = torch.tensor([row[:max_length]])                                      # in the published template
+            return SimpleNamespace(input_ids=ids, attention_mask=(ids != 0).long())
+
+    class Enc:
+        dtype = torch.float32
+        config = SimpleNamespace(image_token_index=99, pad_token_id=0)
+
+        def __call__(self, input_ids, attention_mask, position_ids, pixel_values, output_hidden_states):
+            L = input_ids.shape[1]
+            h = torch.arange(L, dtype=torch.float32)[None, :, None].expand(1, L, 2).clone()
+            return SimpleNamespace(hidden_states=[h * 0, h * 0, h, h * 0, h * 0])
+
+    proc = lambda image, return_tensors: SimpleNamespace(pixel_values=torch.zeros(1, 3, 4, 4))
+    pipe = HunyuanVideoImageToVideoPipeline(text_encoder=Enc(), tokenizer=Tok(), image_processor=proc)
+    tpl = {"template": "sys {}", "crop_start": crop, "image_emb_start": start, "image_emb_end": end, "image_emb_len": image_len,
+           "double_return_token_id": DR}
+    emb, mask = pipe._get_llama_prompt_embeds(None, "a very long prompt", tpl, max_sequence_length=10,
+                                              device=torch.device("cpu"), image_embed_interleave=2)
+    # 13 tokens survive the truncation (positions 0-12, expanded 0-15); text positions 3..8 stay (expanded 6..11), the window
+    # [L - 4, L) = 9..12 (expanded 12..15) goes
+    assert emb[0, :, 0].tolist() == [1.0, 3.0, 6.0, 7.0, 8.0, 9.0, 10.0, 11.0]
+    assert mask[0].tolist() == [1] * 8
+    ids = torch.tensor([[11, 99, 12, 99, 13, 0]])
+    out = _expand_input_ids_with_image_tokens(ids, (ids != 0).long(), 6, 99, 3, 1, 4, 0)
+    assert out["input_ids"].tolist() == [[11, 99, 99, 99, 12, 0, 0, 0, 13, 0]]      # the 2nd span is the template's business
