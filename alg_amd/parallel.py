@@ -6,10 +6,18 @@ The reference has no distributed code at all; this is the build's own addition. 
 """
 from __future__ import annotations
 
+import datetime
 import os
 
 import torch
 import torch.distributed as dist
+
+# A rank with fewer videos than its neighbours (jobs % world != 0) waits in the final barrier while the others still render:
+# a C4 / C5 video is 9-13 minutes, the default NCCL watchdog aborts a waiting rank after 10.  Collectives here are a handful
+# per process lifetime, so a generous limit costs nothing (ALG_DIST_TIMEOUT_S overrides it).
+DIST_TIMEOUT_S = 6 * 3600
+# tensors below this size are copied out of their broadcast bucket: a bias or norm weight a model keeps must not pin 1 GiB
+SMALL_TENSOR_BYTES = 1 << 20
 
 
 def env_world():
@@ -29,7 +37,8 @@ def init_distributed(backend=None):
             backend = os.environ.get("ALG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        timeout = datetime.timedelta(seconds=int(os.environ.get("ALG_DIST_TIMEOUT_S", DIST_TIMEOUT_S)))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local_rank, world
 
 
@@ -80,9 +89,17 @@ def broadcast_loaded_state_dict(sd, device, src=0, bucket_bytes=1 << 30):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return sd
     rank = dist.get_rank()
-    meta = [[(k, tuple(v.shape), v.dtype) for k, v in sd.items()]] if rank == src else [None]
+    # ``sd`` may be an exception on rank ``src`` (the caller caught a failed read): the status travels first, so every rank
+    # raises instead of sitting in a broadcast until the watchdog fires
+    if rank == src:
+        meta = [("error", repr(sd))] if isinstance(sd, BaseException) else \
+            [("ok", [(k, tuple(v.shape), v.dtype) for k, v in sd.items()])]
+    else:
+        meta = [None]
     dist.broadcast_object_list(meta, src=src)
-    meta = meta[0]
+    status, meta = meta[0]
+    if status != "ok":
+        raise RuntimeError("rank %d failed to load the weights it was to broadcast: %s" % (src, meta))
     out = {}
     by_dtype = {}
     for k, shape, dt in meta:
@@ -97,6 +114,10 @@ def broadcast_loaded_state_dict(sd, device, src=0, bucket_bytes=1 << 30):
                 group.append(items[i])
                 nbytes += -(-_numel(items[i][1]) * esize // 16) * 16      # keep every tensor 16-byte aligned in the bucket
                 i += 1
+            if nbytes == 0:                                                # only zero-element tensors: nothing to send
+                for k, shape in group:
+                    out[k] = torch.empty(shape, dtype=dt, device=device)
+                continue
             flat = torch.empty(nbytes, device=device, dtype=torch.uint8)
             if rank == src:
                 off = 0
@@ -108,7 +129,8 @@ def broadcast_loaded_state_dict(sd, device, src=0, bucket_bytes=1 << 30):
             off = 0
             for k, shape in group:
                 nb = _numel(shape) * esize
-                out[k] = flat[off:off + nb].view(dt).view(shape)
+                t = flat[off:off + nb].view(dt).view(shape)
+                out[k] = t.clone() if nb < SMALL_TENSOR_BYTES and nb < nbytes else t   # small tensors do not pin the bucket
                 off += -(-nb // 16) * 16
     return {k: out[k] for k, _, _ in meta}
 

@@ -109,9 +109,14 @@ def read_shards(root, device=None):
     from . import parallel
     sd = None
     if dist.get_rank() == 0:
-        sd = {}
-        for shard in shards:
-            sd.update(load_file(shard))
+        try:
+            sd = {}
+            for shard in shards:
+                sd.update(load_file(shard))
+            if not shards:
+                raise FileNotFoundError("no *.safetensors under %s" % root)
+        except Exception as e:      # a missing / corrupt shard: tell the waiting ranks instead of leaving them in a broadcast
+            sd = e
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and
                                                                       dist.get_backend() == "nccl") else torch.device("cpu")

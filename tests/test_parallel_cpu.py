@@ -240,3 +240,43 @@ def test_cfg_pair_merge_moves_bits_not_sums():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def _loaded_worker(rank, world, port, out, fail):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_distributed(backend="gloo")
+    g = torch.Generator().manual_seed(9)
+    full = {"w": torch.randn(700, 800, generator=g).to(torch.bfloat16), "bias": torch.randn(33, generator=g),
+            "empty": torch.zeros(0, 4), "ids": torch.arange(5)}
+    sd = (FileNotFoundError("shard missing") if fail else full) if rank == 0 else None
+    try:
+        got = parallel.broadcast_loaded_state_dict(sd, "cpu", bucket_bytes=1 << 16)
+        ok = all(torch.equal(got[k], full[k]) and got[k].dtype == full[k].dtype for k in full)
+        # a small tensor owns its storage (it does not pin the bucket it travelled in); the big one may be a view
+        small_own = got["bias"].untyped_storage().nbytes() <= 33 * 4 + 16
+        out.put((rank, "ok", ok and small_own and list(got) == list(full)))
+    except RuntimeError as e:
+        out.put((rank, "raised", "shard missing" in str(e)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [False, True])
+def test_loaded_state_dict_broadcast_status_small_tensors_and_empty_buckets(fail):
+    """rank 0 failing to read its shards makes EVERY rank raise (no rank is left in a broadcast); zero-element
+    tensors produce no 0-byte collective; small tensors are copied out of their bucket."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loaded_worker, args=(r, 2, port, q, fail)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, "raised" if fail else "ok", True), (1, "raised" if fail else "ok", True)]
+
+
+def test_process_group_timeout_outlasts_a_video():
+    assert parallel.DIST_TIMEOUT_S >= 3600      # C4 / C5: 9-13 minutes per video; ranks with fewer jobs wait in the barrier
