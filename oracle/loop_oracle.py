@@ -44,6 +44,25 @@ def apply_low_pass_filter_torch(t, filter_type, blur_sigma, blur_kernel_size, re
     return x.view(shape) if t.ndim == 5 else x
 
 
+def gaussian_blur_torch(x, ksize, sigma):
+    """torchvision.transforms.functional.gaussian_blur(x, [k, k], [s, s]) as the reference executes it on the CPU (lp:40-47):
+    the k x k kernel is the outer product of g = exp(-0.5 (i / s)^2) / sum over i = -(k-1)/2 .. (k-1)/2 (built in x's dtype),
+    the planes are reflect-padded by k // 2 and run through ONE depthwise F.conv2d (ATen's threaded CPU convolution).  Used by
+    bench.py's cpu_baseline leg (a threaded baseline next to the single-threaded numpy statement in lp_oracle.gaussian_blur,
+    which it matches to fp32 rounding: tests/test_oracle_golden.py)."""
+    lim = (ksize - 1) * 0.5
+    i = torch.linspace(-lim, lim, steps=ksize, dtype=x.dtype)
+    g = torch.exp(-0.5 * (i / sigma) ** 2)
+    g = g / g.sum()
+    k2 = torch.outer(g, g)
+    shape = x.shape
+    planes = x.reshape(-1, 1, shape[-2], shape[-1])
+    pad = ksize // 2
+    y = F.conv2d(F.pad(planes.transpose(0, 1), (pad, pad, pad, pad), mode="reflect"),
+                 k2[None, None].expand(planes.shape[0], 1, ksize, ksize), groups=planes.shape[0])
+    return y.transpose(0, 1).reshape(shape)
+
+
 def prepare_lp_latent(image_latents, filter_type, sigma, ksize, factor):
     """cog:684-701: [B,F,C,H,W] -> permute -> contiguous -> filter -> permute back -> contiguous."""
     perm = image_latents.permute(0, 2, 1, 3, 4).contiguous()

@@ -22,6 +22,14 @@ trips (K / 64 - 2); wm, wn wave coordinates; wave1k = lds base + wave * 1024; t0
 """
 import os
 
+# experiment knobs (scripts/experiments/p9_build_variant.sh): timing ablations produce garbage results
+NO_DMA = os.environ.get("P9_NO_DMA") == "1"          # no LDS-DMA inside the loop (the prologue's two k-tiles are re-read)
+NO_READS = os.environ.get("P9_NO_READS") == "1"      # no fragment reads inside the loop
+NO_BARRIER = os.environ.get("P9_NO_BARRIER") == "1"  # no s_barrier inside the loop
+B_FAST = os.environ.get("P9_B_FAST") == "1"          # B(kt + 2): one DMA per MFMA gap right behind the barrier (more slack)
+A_GAPS = os.environ.get("P9_A_GAPS", "")             # comma list of the eight gaps (0..47) that carry the A DMAs
+BUF = os.environ.get("P9_BUF") == "1"                # DMA as buffer_load ... lds: k advances in the scalar offset (no v_add per DMA)
+
 FB = lambda s, nt: "v[%d:%d]" % (192 + 32 * s + 4 * nt, 192 + 32 * s + 4 * nt + 3)
 FA = lambda s, mt: "v[%d:%d]" % (208 + 32 * s + 4 * mt, 208 + 32 * s + 4 * mt + 3)
 ACC = lambda mt, nt: "a[%d:%d]" % (16 * (4 * mt + nt), 16 * (4 * mt + nt) + 15)
@@ -39,11 +47,18 @@ P, SA, SB, DA, T, T2, MA, MB, DB, CNT = ("%%[t%d]" % i for i in range(10))
 #  CNT remaining steady-state trips
 
 
+SPREAD = os.environ.get("P9_SPREAD", "1") == "1"   # one memory instruction per MFMA gap, counted lgkmcnt waits
+
+# fragment read order of a k-step = order of first use by the MFMAs (mt outer, nt inner): MFMA (mt, nt) needs B[nt] and A[mt]
+READ_ORDER = (("b", 0), ("a", 0), ("b", 1), ("b", 2), ("b", 3), ("a", 1), ("a", 2), ("a", 3)) if SPREAD else \
+    (("b", 0), ("b", 1), ("b", 2), ("b", 3), ("a", 0), ("a", 1), ("a", 2), ("a", 3))
+READ_IDX = {f: i for i, f in enumerate(READ_ORDER)}
+
+
 def reads(ks, s):
-    """the eight fragment reads of k-step ks into set s: B first (the MFMA order needs them first)"""
-    out = ["ds_read_b128 %s, %s offset:%d" % (FB(s, nt), ADB(ks), nt * 4096) for nt in range(4)]
-    out += ["ds_read_b128 %s, %s offset:%d" % (FA(s, mt), ADA(ks), mt * 4096) for mt in range(4)]
-    return out
+    """the eight fragment reads of k-step ks into set s, in READ_ORDER"""
+    return ["ds_read_b128 %s, %s offset:%d" % ((FB(s, i), ADB(ks), i * 4096) if op == "b" else (FA(s, i), ADA(ks), i * 4096))
+            for op, i in READ_ORDER]
 
 
 def dma(panel, i):
@@ -53,8 +68,16 @@ def dma(panel, i):
     off = OFFA(i) if panel == "a" else OFFB(i)
     base = "%[pa]" if panel == "a" else "%[pb]"
     dst = DA if panel == "a" else DB
-    return ("s_add_u32 m0, %s, %d" % (dst, (i >> 2) * SLOT + (i & 3) * 4096),
-            ["global_load_lds_dwordx4 %s, %s" % (off, base), "v_add_u32 %s, 0x80, %s" % (off, off)])
+    m0 = "s_add_u32 m0, %s, %d" % (dst, (i >> 2) * SLOT + (i & 3) * 4096)
+    if BUF:
+        # the k-tile's byte offset rides in the scalar offset (MA / MB), advanced once per panel behind its eighth DMA
+        ko = MA if panel == "a" else MB
+        desc = "%[da]" if panel == "a" else "%[db]"
+        rest = ["buffer_load_dwordx4 %s, %s, %s offen lds" % (off, desc, ko)]
+        if i == 7:
+            rest.append("s_add_u32 %s, %s, 0x80" % (ko, ko))
+        return (m0, rest)
+    return (m0, ["global_load_lds_dwordx4 %s, %s" % (off, base), "v_add_u32 %s, 0x80, %s" % (off, off)])
 
 
 def gap(m0_sets, mids, posts):
@@ -97,8 +120,11 @@ def ktile(dma_on, barrier_on):
     m0s = [[] for _ in range(64)]
     mids = [[] for _ in range(64)]
     posts = [[] for _ in range(64)]
+    read_gaps = [[] for _ in range(4)]   # per k-step: the (relative) gaps that carry the NEXT k-step's fragment reads
 
     def put_dma(j, panel, i):
+        if NO_DMA:
+            return
         m0, rest = dma(panel, i)
         m0s[j].append(m0)
         posts[j] += rest
@@ -106,33 +132,45 @@ def ktile(dma_on, barrier_on):
     pre = []
     if dma_on:
         pre += slot_math_top()
-        # A(kt + 2): eight DMAs behind MFMAs 3, 7, ..., 31 of k-steps 0 and 1 (their two slots were free all along)
+        # A(kt + 2): eight DMAs in k-steps 0 and 1 (their two slots were free all along)
+        a_gaps = [int(x) for x in A_GAPS.split(",")] if A_GAPS else \
+            ([4 * i + 1 for i in range(8)] if SPREAD else [4 * i + 3 for i in range(8)])
         for i in range(8):
-            put_dma(4 * i + 3, "a", i)
-    for ks in range(3):   # k-steps 0-2 prefetch k-steps 1-3 of the same k-tile
-        for r, ins in enumerate(reads(ks + 1, (ks + 1) & 1)):
-            mids[16 * ks + 1 + r].append(ins)
-    if barrier_on:
-        # k-step 3 prefetches k-step 0 of the NEXT k-tile (set 0) and, the old k-tile's slots being free, stages B(kt + 2)
-        for r, ins in enumerate(reads(0, 0)):
-            mids[48 + 1 + r].append(ins)
-        if dma_on:
-            for i in range(8):
-                put_dma(48 + 1 + 2 * i, "b", i)
+            put_dma(a_gaps[i], "a", i)
+    for ks in range(4):   # k-steps 0-2 prefetch k-steps 1-3 of the same k-tile, k-step 3 k-step 0 of the NEXT k-tile
+        if ks == 3 and not barrier_on:
+            continue
+        # spread: one read every other gap (the DMAs take the odd gaps); k-step 2 stays dense so that every read of this
+        # k-tile has returned by the barrier at the top of k-step 3 (its lgkmcnt(0) then costs nothing)
+        gaps = [2 * r for r in range(8)] if (SPREAD and ks != 2) else [1 + r for r in range(8)]
+        read_gaps[ks] = gaps
+        for r, ins in enumerate(reads((ks + 1) & 3, (ks + 1) & 1)):
+            if not NO_READS:
+                mids[16 * ks + gaps[r]].append(ins)
+    if barrier_on and dma_on:
+        for i in range(8):   # the old k-tile's slots are free behind the barrier: B(kt + 2)
+            put_dma(48 + (i if B_FAST else 1 + 2 * i), "b", i)
     body = list(pre)
     for j in range(64):
         ks, q = j >> 4, j & 15
         mt, nt = q >> 2, q & 3
         s = ks & 1
-        if q == 0:
-            if ks == 3 and barrier_on:
-                # every fragment read of this k-tile has returned; B of the next k-tile and everything older has landed (at
-                # most the eight A DMAs issued above are still in flight): publish / free through ONE barrier
-                body.append("s_waitcnt vmcnt(%d) lgkmcnt(0)" % (8 if dma_on else 0))
+        if q == 0 and ks == 3 and barrier_on:
+            # every fragment read of this k-tile has returned; B of the next k-tile and everything older has landed (at
+            # most the eight A DMAs issued above are still in flight): publish / free through ONE barrier
+            body.append("s_waitcnt vmcnt(%d) lgkmcnt(0)" % (8 if dma_on and not NO_DMA else 0))
+            if not NO_BARRIER:
                 body.append("s_barrier")
-                body += slot_math_advance() if dma_on else advance_no_dma()
-            else:
+            body += slot_math_advance() if dma_on else advance_no_dma()
+        elif not SPREAD:
+            if q == 0:
                 body.append("s_waitcnt lgkmcnt(0)")
+        elif q in (0, 1, 2, 3, 4, 8, 12) and not (ks == 3 and barrier_on) and not NO_READS:
+            # LDS returns in order: the fragment this MFMA needs is read number `need` of its k-step's eight; younger reads
+            # (the rest of those eight + what this k-step has issued for the next one) may stay in flight
+            need = max(READ_IDX[("b", nt)], READ_IDX[("a", mt)])
+            issued_here = sum(1 for g in read_gaps[ks] if g < q)
+            body.append("s_waitcnt lgkmcnt(%d)" % min(15, 7 - need + issued_here))
         body.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (ACC(mt, nt), FB(s, nt), FA(s, mt), ACC(mt, nt)))
         body += gap(m0s[j], mids[j], posts[j])
     return body
@@ -156,6 +194,8 @@ def setup():
 
 def prologue():
     out = setup()
+    if BUF:
+        out += ["s_mov_b32 %s, 0" % MA, "s_mov_b32 %s, 0" % MB]
     # k-tiles 0 and 1: slots 0-3 and 4-7, order A(0) B(0) A(1) B(1)
     for kt in range(2):
         out += ["s_add_u32 %s, %%[wave1k], %d" % (DA, (4 * kt) * SLOT), "s_add_u32 %s, %%[wave1k], %d" % (DB, (4 * kt + 2) * SLOT)]
@@ -186,7 +226,7 @@ def emit():
 def main():
     lines = emit()
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(here, "..", "alg_amd", "csrc", "gemm_p9_loop.inc")
+    path = os.environ.get("P9_OUT") or os.path.join(here, "..", "alg_amd", "csrc", "gemm_p9_loop.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by scripts/gen_gemm_p9.py -- do not edit.  The main loop of GEMM schedule 9 as one asm statement.\n")
         f.write("#define ALG_GEMM_P9_LOOP_ASM \\\n")

@@ -95,6 +95,14 @@ def test_gaussian_matches_independent_formulation():
         assert abs(g.sum() - 1) < 1e-12 and np.allclose(g, g[::-1])
         ref = ndimage.correlate1d(ndimage.correlate1d(x, g, axis=-1, mode="mirror"), g, axis=-2, mode="mirror")
         assert np.abs(lp_oracle.gaussian_blur(x, k, sigma) - ref).max() < 1e-13
+    # the threaded torch statement bench.py times as the CPU baseline (torchvision's own op order: k x k kernel, one depthwise
+    # conv2d) agrees with the separable numpy one to fp32 rounding
+    import torch
+    from oracle import loop_oracle
+    xt = torch.from_numpy(x.astype(np.float32))
+    for k, sigma in ((9, 15.0), (3, 0.7), (13, 4.2)):
+        got = loop_oracle.gaussian_blur_torch(xt, k, sigma).numpy()
+        assert np.abs(got - lp_oracle.gaussian_blur(x, k, sigma)).max() < 2e-6
     # kernel-size rule (lp_utils.py:41-46): float = fraction of H, int = absolute, even -> +1
     assert lp_oracle.gaussian_kernel_size(0.02734375, 60) == 1
     assert lp_oracle.gaussian_kernel_size(0.02734375, 480) == 13
