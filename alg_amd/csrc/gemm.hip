@@ -1,5 +1,5 @@
 // C ABI entry of the bf16 GEMM: argument validation and schedule dispatch.  The kernel template lives in gemm_kernel.h; one
-// translation unit per schedule (gemm_p0.hip, gemm_p6.hip, gemm_p7.hip, gemm_p8.hip) instantiates it.
+// translation unit per schedule (gemm_p0.hip, gemm_p6.hip, gemm_p7.hip, gemm_p8.hip, gemm_p9.hip) instantiates it.
 #include <stdlib.h>
 
 #include "common.h"
@@ -15,8 +15,10 @@ int launch_gemm_p6_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t
 int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 static int gemm_pipe() {
   const char* e = getenv("ALG_GEMM_PIPE");
-  const int v = e ? atoi(e) : 6;  // default: 8-wave ping-pong over half-tiles (fastest measured)
-  return (v == 0 || v == 6 || v == 7 || v == 8 || v == 9) ? v : 6;
+  // default: schedule 9 (4 waves, asm main loop; round 3: faster than the 8-wave ping-pong on all five C2 shapes); calls it
+  // cannot take (K < 128, byte offsets past 32 bits) and the fp8 / convolution operands run schedule 6
+  const int v = e ? atoi(e) : 9;
+  return (v == 0 || v == 6 || v == 7 || v == 8 || v == 9) ? v : 9;
 }
 }  // namespace alg
 
@@ -61,31 +63,6 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
     set_error("alg_gemm_bf16: gate needs a residual");
     return ALG_EINVAL;
   }
-  if ((int64_t)a->M * a->ldc >= (1ll << 31) || (a->R && (int64_t)a->M * a->ldr >= (1ll << 31))) {
-    // The epilogue addresses C / R with 32-bit element offsets inside one batch item.  Taller operands (two or three CFG
-    // samples of a 75,600- or 118,800-token sequence flattened into M) are cut along M into tile-aligned slabs, one launch
-    // each on the same stream: rows are independent, every per-row operand just moves with the slab.
-    const int64_t ld = (a->R && a->ldr > a->ldc) ? a->ldr : a->ldc;
-    const int64_t rows = ((1ll << 31) - 1) / ld / BM * BM;
-    if (a->conv_wp || rows <= 0) {
-      set_error("alg_gemm_bf16: M*ldc must stay below 2^31 (32-bit epilogue offsets)");
-      return ALG_ELIMIT;
-    }
-    const int64_t esz = fp8 ? 1 : 2;
-    for (int64_t m0 = 0; m0 < a->M; m0 += rows) {
-      alg_gemm_args c = *a;
-      c.M = (int32_t)((a->M - m0) < rows ? (a->M - m0) : rows);
-      c.A = (const char*)a->A + m0 * a->lda * esz;
-      c.C = (char*)a->C + m0 * a->ldc * 2;
-      if (a->R) c.R = (const char*)a->R + m0 * a->ldr * 2;
-      if (a->bias && (a->flags & ALG_GEMM_BIAS_PER_ROW)) c.bias = (const char*)a->bias + m0 * 2;
-      if (a->a_scale) c.a_scale = a->a_scale + m0;
-      c.seg_split = a->seg_split > m0 ? (int32_t)(a->seg_split - m0) : 0;   // rows >= seg_split take gate[1]
-      const int rc = gemm_entry(&c, stream, fp8);
-      if (rc != ALG_OK) return rc;
-    }
-    return ALG_OK;
-  }
   // 8-byte epilogue accesses need 8-byte aligned quads whenever N is a multiple of 4
   if ((a->N & 3) == 0) {
     const bool bad = (a->ldc & 3) || (a->strideC & 3) || ((uintptr_t)a->C & 7) ||
@@ -110,6 +87,35 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
                 (long long)a->lda, a->conv_wp, a->conv_hpwp);
       return ALG_EINVAL;
     }
+  }
+  if ((int64_t)a->M * a->ldc >= (1ll << 31) || (a->R && (int64_t)a->M * a->ldr >= (1ll << 31))) {
+    // Every argument check above has run on the WHOLE call, so a slab can only fail at launch (no error after
+    // earlier slabs have already written C, which may alias R).  Per-row operands are A, C, R, a per-row bias, a_scale and
+    // seg_split: each moves with the slab.  `gate` is per BATCH item (two segments), never per row: a caller that flattens
+    // several samples into M shares one gate pair between them -- per-sample gates go through `batch` / strideGate.
+    // The epilogue addresses C / R with 32-bit element offsets inside one batch item.  Taller operands (two or three CFG
+    // samples of a 75,600- or 118,800-token sequence flattened into M) are cut along M into tile-aligned slabs, one launch
+    // each on the same stream: rows are independent, every per-row operand just moves with the slab.
+    const int64_t ld = (a->R && a->ldr > a->ldc) ? a->ldr : a->ldc;
+    const int64_t rows = ((1ll << 31) - 1) / ld / BM * BM;
+    if (a->conv_wp || rows <= 0) {
+      set_error("alg_gemm_bf16: M*ldc must stay below 2^31 (32-bit epilogue offsets)");
+      return ALG_ELIMIT;
+    }
+    const int64_t esz = fp8 ? 1 : 2;
+    for (int64_t m0 = 0; m0 < a->M; m0 += rows) {
+      alg_gemm_args c = *a;
+      c.M = (int32_t)((a->M - m0) < rows ? (a->M - m0) : rows);
+      c.A = (const char*)a->A + m0 * a->lda * esz;
+      c.C = (char*)a->C + m0 * a->ldc * 2;
+      if (a->R) c.R = (const char*)a->R + m0 * a->ldr * 2;
+      if (a->bias && (a->flags & ALG_GEMM_BIAS_PER_ROW)) c.bias = (const char*)a->bias + m0 * 2;
+      if (a->a_scale) c.a_scale = a->a_scale + m0;
+      c.seg_split = a->seg_split > m0 ? (int32_t)(a->seg_split - m0) : 0;   // rows >= seg_split take gate[1]
+      const int rc = gemm_entry(&c, stream, fp8);
+      if (rc != ALG_OK) return rc;
+    }
+    return ALG_OK;
   }
   const int m_tiles = (a->M + BM - 1) / BM, n_tiles = (a->N + BN - 1) / BN;
   const int64_t nwg = (int64_t)m_tiles * n_tiles * a->batch;

@@ -115,8 +115,26 @@ def addr_math():
     return out
 
 
-def ktile(dma_on, barrier_on):
-    """one k-tile: 64 MFMAs; the instructions of gap j go out right behind MFMA j (0..63)"""
+RES_COPIES = 8        # residual variant: the first eight steady-state k-tiles each fetch four of the 32 residual quads
+RES_GAPS = (3, 7, 11, 15)
+RS = MA               # running scalar byte offset of the residual row block (MA / MB are only used by the BUF experiment)
+
+
+def res_loads(c):
+    """the four residual loads of copy c (row block j = c: m-tile c >> 1, 16-row half c & 1; one per n-tile), then the row
+    block advances.  Quad index it = ((mt * 4 + nt) << 1) | half, as the staged epilogue numbers them."""
+    mt, half = c >> 1, c & 1
+    out = []
+    for nt in range(4):
+        it = ((mt * 4 + nt) << 1) | half
+        out.append("buffer_load_dwordx4 %%[r%d], %%[rvoff], %%[rs], %s offen offset:%d" % (it, RS, nt * 64))
+    return out
+
+
+def ktile(dma_on, barrier_on, res_copy=None):
+    """one k-tile: 64 MFMAs; the instructions of gap j go out right behind MFMA j (0..63).  res_copy = c: this k-tile also
+    fetches residual row block c (four buffer loads in otherwise empty gaps; they are older than nothing the barrier of
+    THIS k-tile needs, so its counted wait lets twelve instead of eight loads stay in flight)"""
     m0s = [[] for _ in range(64)]
     mids = [[] for _ in range(64)]
     posts = [[] for _ in range(64)]
@@ -150,6 +168,10 @@ def ktile(dma_on, barrier_on):
     if barrier_on and dma_on:
         for i in range(8):   # the old k-tile's slots are free behind the barrier: B(kt + 2)
             put_dma(48 + (i if B_FAST else 1 + 2 * i), "b", i)
+    if res_copy is not None:
+        for g, ins in zip(RES_GAPS, res_loads(res_copy)):
+            posts[g].append(ins)
+        posts[RES_GAPS[-1]].append("s_add_u32 %s, %s, %%[ldr16]" % (RS, RS))
     body = list(pre)
     for j in range(64):
         ks, q = j >> 4, j & 15
@@ -158,7 +180,7 @@ def ktile(dma_on, barrier_on):
         if q == 0 and ks == 3 and barrier_on:
             # every fragment read of this k-tile has returned; B of the next k-tile and everything older has landed (at
             # most the eight A DMAs issued above are still in flight): publish / free through ONE barrier
-            body.append("s_waitcnt vmcnt(%d) lgkmcnt(0)" % (8 if dma_on and not NO_DMA else 0))
+            body.append("s_waitcnt vmcnt(%d) lgkmcnt(0)" % ((12 if res_copy is not None else 8) if dma_on and not NO_DMA else 0))
             if not NO_BARRIER:
                 body.append("s_barrier")
             body += slot_math_advance() if dma_on else advance_no_dma()
@@ -211,12 +233,30 @@ def prologue():
     return out
 
 
-def emit():
+def emit(res=False):
     lines = []
     lines += prologue()
-    lines += ["s_mov_b32 %s, %%[nloop]" % CNT, "s_cmp_eq_u32 %s, 0" % CNT, "s_cbranch_scc1 2f", "1:"]
-    lines += ktile(True, True)
-    lines += ["s_sub_u32 %s, %s, 1" % (CNT, CNT), "s_cmp_lg_u32 %s, 0" % CNT, "s_cbranch_scc1 1b", "2:"]
+    if not res:
+        lines += ["s_mov_b32 %s, %%[nloop]" % CNT, "s_cmp_eq_u32 %s, 0" % CNT, "s_cbranch_scc1 2f", "1:"]
+        lines += ktile(True, True)
+        lines += ["s_sub_u32 %s, %s, 1" % (CNT, CNT), "s_cmp_lg_u32 %s, 0" % CNT, "s_cbranch_scc1 1b", "2:"]
+    else:
+        # Residual variant (C = R + ...): the tile's residual (32 quads per lane, 128 KiB per workgroup) is fetched INSIDE the
+        # K loop, four quads per k-tile over the first eight steady-state k-tiles.  Fetched in one go -- behind the loop, or in
+        # front of it -- every CU asks for its 128 KiB in the same microsecond (32 MB per round of tiles) and the burst is on
+        # the critical path either way (vmcnt retires in order: a counted wait covers everything older).  Short K: whatever
+        # the loop did not get to is fetched by the catch-up chain (labels 1xx) in front of the last two k-tiles.
+        lines += ["s_mov_b32 %s, %%[rsoff]" % RS]
+        lines += ["s_mov_b32 %s, %%[nloop]" % CNT, "s_cmp_eq_u32 %s, 0" % CNT, "s_cbranch_scc1 100f"]
+        for c in range(RES_COPIES):
+            lines += ktile(True, True, res_copy=c)
+            lines += ["s_sub_u32 %s, %s, 1" % (CNT, CNT), "s_cmp_eq_u32 %s, 0" % CNT, "s_cbranch_scc1 %df" % (101 + c)]
+        lines += ["1:"]
+        lines += ktile(True, True)
+        lines += ["s_sub_u32 %s, %s, 1" % (CNT, CNT), "s_cmp_lg_u32 %s, 0" % CNT, "s_cbranch_scc1 1b", "s_branch 2f"]
+        for c in range(RES_COPIES):
+            lines += ["%d:" % (100 + c)] + res_loads(c) + ["s_add_u32 %s, %s, %%[ldr16]" % (RS, RS)]
+        lines += ["%d:" % (100 + RES_COPIES), "2:"]
     lines += ktile(False, True)     # last but one: nothing left to stage, the wait drains
     lines += ktile(False, False)    # last
     lines += ["s_nop 15", "s_nop 15"]   # the last MFMAs' results before any v_accvgpr_read of the epilogue
@@ -229,10 +269,11 @@ def main():
     path = os.environ.get("P9_OUT") or os.path.join(here, "..", "alg_amd", "csrc", "gemm_p9_loop.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by scripts/gen_gemm_p9.py -- do not edit.  The main loop of GEMM schedule 9 as one asm statement.\n")
-        f.write("#define ALG_GEMM_P9_LOOP_ASM \\\n")
-        for ln in lines:
-            f.write('  "%s\\n\\t" \\\n' % ln)
-        f.write('  ""\n')
+        for name, ls in (("ALG_GEMM_P9_LOOP_ASM", lines), ("ALG_GEMM_P9_LOOP_ASM_RES", emit(res=True))):
+            f.write("#define %s \\\n" % name)
+            for ln in ls:
+                f.write('  "%s\\n\\t" \\\n' % ln)
+            f.write('  ""\n')
         regs = ["a%d" % i for i in range(256)] + ["v%d" % i for i in range(160, 256)]
         f.write("#define ALG_GEMM_P9_CLOBBERS \\\n  " + ", ".join('"%s"' % r for r in regs) + '\n')
         f.write("#define ALG_GEMM_P9_ACC_CLOBBERS \\\n  " + ", ".join('"a%d"' % i for i in range(256)) + '\n')

@@ -81,3 +81,48 @@ def test_gemm_fp8_epilogues():
     perm = torch.tensor([(i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1) for i in range(s_pad)], device=DEV)
     got = vt[:, :, perm[:S]].transpose(1, 2)
     assert (got.float() - lin.float()).abs().max().item() <= 2.0 ** -5
+
+
+def test_tall_operand_is_cut_into_slabs_with_every_per_row_operand_following():
+    """M * ldc >= 2^31 (CFG samples of a 75,600- / 118,800-token sequence flattened into M): alg_gemm_* validates the whole
+    call, then launches tile-aligned slabs.  Per-row operands (A, C, R in place, the fp8 row scales, the segment split of the
+    fp32 gate) must move with the slab: the tall call equals two independent calls on row ranges that stay below the limit."""
+    M, N, K = 600_000, 4096, 128
+    split = 560_000                                     # inside the second slab (slabs are 524,032 rows at ldc = 4096)
+    assert M * N >= 2 ** 31
+    g = torch.Generator(device=DEV).manual_seed(21)
+    a = torch.randn(M, K, generator=g, device=DEV).to(BF)
+    w, bias = _rand((N, K), 22, 0.06), _rand((N,), 23, 0.1)
+    qa, sa = quant(a)
+    qw, sw = quant(w)
+    del a
+    gate = torch.randn(1, 2, N, generator=g, device=DEV)
+    r = torch.randn(M, N, generator=g, device=DEV, dtype=BF)
+    kw = dict(bias=bias, ldr=N, gate=gate, flags=_lib.GEMM_GATE_F32, b_scale=sw)
+    tall = r.clone()
+    _lib.gemm(qa, qw, tall, M, N, K, K, K, N, R=tall, seg_split=split, a_scale=sa, **kw)
+    want = r.clone()
+    del r
+    h = 300_000
+    _lib.gemm(qa, qw, want, h, N, K, K, K, N, R=want, seg_split=split, a_scale=sa, **kw)
+    _lib.gemm(qa, qw, want, M - h, N, K, K, K, N, R=want, seg_split=split - h, a_scale=sa, a_off=h * K, c_off=h * N,
+              r_off=h * N, a_scale_off=h, **kw)
+    assert torch.equal(tall, want)
+    # the two gate segments really differ across the split, and rows on both sides of a slab boundary were written
+    rows = torch.tensor([0, 524_031, 524_032, split - 1, split, M - 1], device=DEV)
+    lin = ((qa[rows].view(F8).float() * sa[rows, None]) @ (qw.view(F8).float() * sw[:, None]).t() + bias.float()).to(BF)
+    seg = (rows >= split).long()
+    assert torch.isfinite(tall[rows].float()).all() and not torch.equal(gate[0, 0], gate[0, 1])
+    assert lin.shape == (6, N) and seg.tolist() == [0, 0, 0, 0, 1, 1]
+
+
+def test_bad_arguments_of_a_tall_call_are_refused_before_any_slab_runs():
+    """A mis-aligned residual pitch on a call that needs slabs: refused up front, C untouched."""
+    M, N, K = 600_000, 4096, 128
+    qa = torch.zeros(M, K, dtype=torch.uint8, device=DEV)
+    qw = torch.zeros(N, K, dtype=torch.uint8, device=DEV)
+    sa, sw = torch.ones(M, device=DEV), torch.ones(N, device=DEV)
+    c = torch.full((M, N), 3.0, dtype=BF, device=DEV)
+    with pytest.raises(_lib.AlgHipError):
+        _lib.gemm(qa, qw, c, M, N, K, K, K, N, R=c, ldr=N + 2, a_scale=sa, b_scale=sw)
+    assert bool((c[:1024] == 3.0).all()) and bool((c[-1024:] == 3.0).all())
