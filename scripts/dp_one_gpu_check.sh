@@ -16,6 +16,18 @@ d = json.loads(open("$O/dp2_bench.json").read().strip().splitlines()[-1])
 print({k: d[k] for k in ("n_gpus", "value", "ms_per_step", "scaling")}, d["config"]["parallelism"])
 assert d["n_gpus"] == 2
 PY
+# the other multi-GPU workloads of BASELINE.json: config 4 = HunyuanVideo, 8-way data parallel (here 2 ranks,
+# weights through the RCCL-shaped broadcast), config 5 = Wan 14B fp8 with the CFG pair on a GPU pair (one all-gather per step)
+for leg in "c4 --gpus 2" "c5 --gpus 2 --cfg-split" "c3 --gpus 2"; do
+  tag=$(echo $leg | tr -d ' -')
+  timeout 1200 python bench.py --workload $leg --layers 2 --steps 2 --warmup 1 --no-cpu-baseline > $O/dp2_$tag.json 2> $O/dp2_$tag.err
+  echo "bench --workload $leg exit $?"; python - <<PY
+import json
+d = json.loads(open("$O/dp2_$tag.json").read().strip().splitlines()[-1])
+print("$leg", {k: d[k] for k in ("n_gpus", "value", "ms_per_step", "scaling")}, d["config"]["parallelism"])
+assert d["n_gpus"] == 2 and d["finite"]
+PY
+done
 cat > /tmp/dp/c.yaml <<Y
 model: {path: CogVideoX-toy, dtype: bfloat16, synthetic_config: {num_layers: 2, num_attention_heads: 8, text_embed_dim: 128, max_text_seq_length: 16, sample_height: 8, sample_width: 12, sample_frames: 9, time_embed_dim: 64}}
 generation: {num_inference_steps: 3, height: 64, width: 96, num_frames: 9, guidance_scale: 6.0}

@@ -26,9 +26,10 @@ def rel_err(got, ref):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.fixture(params=["8", "7", "6", "0"], ids=["4waves-bk32-ring", "4waves-interleaved", "pingpong-halftiles", "dbufBK64"])
+@pytest.fixture(params=["9", "8", "7", "6", "0"],
+                ids=["4waves-asm-loop", "4waves-bk32-ring", "4waves-interleaved", "pingpong-halftiles", "dbufBK64"])
 def gemm_pipe(request, monkeypatch):
-    """Every GEMM test runs on both staging pipelines (the default 4-stage ring and the 2-stage A/B variant)."""
+    """Every GEMM test runs on every built schedule (9 = the default since round 3; 6 = the fp8 / convolution schedule)."""
     monkeypatch.setenv("ALG_GEMM_PIPE", request.param)
     return request.param
 
@@ -342,7 +343,7 @@ def test_pingpong_gemm_race_screen(monkeypatch):
         a = torch.randn(M, K, generator=g, device="cuda").to(BF)
         w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(BF)
         outs = {}
-        for pipe in ("0", "6", "6", "6", "8", "8"):
+        for pipe in ("0", "6", "6", "9", "9", "9", "8", "8"):
             monkeypatch.setenv("ALG_GEMM_PIPE", pipe)
             c = torch.empty(M, N, dtype=BF, device="cuda")
             _lib.gemm(a, w, c, M, N, K, K, K, N)
@@ -350,3 +351,45 @@ def test_pingpong_gemm_race_screen(monkeypatch):
                 assert torch.equal(c, outs["0"]), (M, N, K)
             outs.setdefault(pipe, c)
         assert torch.equal(outs["6"], outs["0"]) and torch.equal(outs["8"], outs["0"]), (M, N, K)
+        assert torch.equal(outs["9"], outs["0"]), (M, N, K)
+
+
+@pytest.mark.parametrize("form", ["plain", "gelu", "vt", "res", "res_gate_seg", "res_gate_f32", "res_gate_f32_straddle"])
+def test_schedule9_equals_the_drain_and_barrier_schedule_bit_for_bit(monkeypatch, form):
+    """Schedule 9 (hand-written asm K loop, accumulators in AGPRs, residual quads fetched INSIDE the loop over its first eight
+    steady-state k-tiles, the rest by a catch-up chain) against schedule 0 (compiler-scheduled, drain + barrier per k-tile):
+    same accumulation order, so equal bits.  K / 64 = 2 .. 13 enters the catch-up chain at each of its labels (0 .. 8 k-tiles
+    short of the eight fetching ones) and runs past it; the shapes have edge tiles in M and N; every store-loop variant
+    (no gate, bf16 gate with a per-row segment select, fp32 gate on one segment, the generic loop for a straddled tile)."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    rn = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g, device="cuda") * sc).to(BF)
+    for M, N, K in [(300, 520, 64 * k) for k in range(2, 14)] + [(1111, 96, 3072), (2100, 1024, 64 * 23)]:
+        a, w, bias, x0 = rn(M, K), rn(N, K, sc=0.05), rn(N), rn(M, N)
+        gate, gate32, brow = rn(1, 2 * N, sc=0.5), torch.randn(1, 2 * N, generator=g, device="cuda"), rn(M)
+
+        def run():
+            if form == "vt":
+                npad = (N + 63) // 64 * 64
+                c = torch.zeros(M, npad, dtype=BF, device="cuda")
+                _lib.gemm(a, w, c, M, N, K, K, K, npad, bias=brow, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
+                return c
+            if form in ("plain", "gelu"):
+                c = torch.full((M, N), 7.0, dtype=BF, device="cuda")
+                _lib.gemm(a, w, c, M, N, K, K, K, N, bias=bias, act=_lib.ACT_GELU_TANH if form == "gelu" else _lib.ACT_NONE)
+                return c
+            x = x0.clone()
+            kw = {}
+            if form == "res_gate_seg":
+                kw = dict(gate=gate, strideGate=2 * N, seg_split=M // 3)
+            elif form == "res_gate_f32":
+                kw = dict(gate=gate32, strideGate=2 * N, seg_split=1 << 30, flags=_lib.GEMM_GATE_F32)
+            elif form == "res_gate_f32_straddle":
+                kw = dict(gate=gate32, strideGate=2 * N, seg_split=100, flags=_lib.GEMM_GATE_F32)
+            _lib.gemm(a, w, x, M, N, K, K, K, N, bias=bias, R=x, ldr=N, **kw)
+            return x
+
+        monkeypatch.setenv("ALG_GEMM_PIPE", "0")
+        want = run()
+        monkeypatch.setenv("ALG_GEMM_PIPE", "9")
+        for _ in range(2):
+            assert torch.equal(run(), want), (form, M, N, K)
