@@ -40,6 +40,10 @@
 //       was produced (alg_qk_norm_rope_scaled: no extra rounding); not selectable by ALG_ATTN_VARIANT
 //   34  33 with Q pre-scaled by scale*log2(e) in registers and the offset snapped to zero when the first tile's max allows
 //       it: p = exp2(s) with no per-score fma (+2 %; one more bf16 rounding of q, so opt-in)
+//   42/43  (round 3, ALG_ATTN_PP=1/2) variant 41's arithmetic with the two waves of a SIMD half a tile apart (ping-pong over
+//       workgroup barriers: one wave's softmax under its partner's PV + QK MFMAs; 43 adds s_setprio around the MFMA phase).
+//       Bit-identical to 41; measured 1097 / 1096 against 1103-1111 TFLOP/s, same clock (1.86 GHz) and power (1310-1320 W):
+//       the phase order across waves is not what limits the kernel (profiles/r3_attention_d64_pingpong.txt)
 // Measured on MI355X at the C2 shape (2 x 48 heads x 17,776 tokens, profiles/): 1: 860-915 TFLOP/s,
 // 0: 875, 2: 830, 3: 867, 4: 861, 5: 836, 6: 804, 7: 599, 8: 899, 9: 893, 12: 860, 13: 880, 14: 865, 15: 835, 16: 875.
 // All of them sit at 1225-1330 W with the clock pulled down to 1.9-2.2 GHz (profiles/r1_power_and_issue_rates.txt):
@@ -502,6 +506,64 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
     };
     for (int t = 0; t < n_loop; ++t) tile(t, BoolC<false>{});
     if (ragged) tile(n_tiles - 1, BoolC<true>{});
+  } else if (VARIANT == 42 || VARIANT == 43) {
+    // Ping-pong (round 3): the two waves that share a SIMD (w and w + 4) run HALF A TILE APART.  A wave alternates a VALU
+    // phase (softmax(t): exp2, pack, row sums) with an MFMA phase (PV(t), then QK(t + 1)); every phase boundary is a
+    // workgroup barrier, group B (waves 4-7) starts one phase late, so while one wave of a SIMD feeds the matrix pipe its
+    // partner runs its softmax.  In the straight loop (variant 41) the per-tile barrier lines all eight waves up in the SAME
+    // phase: per wave-tile the SIMD then spends MFMA time + VALU time (measured 900 cycles against 512 of MFMA).
+    //   phase 2u     (even): A = PV(u-1), QK(u)       B = softmax(u-1)        every wave issues its share of K(u+1), V(u)
+    //   phase 2u + 1 (odd) : A = softmax(u)           B = PV(u-1), QK(u)      then vmcnt(0): K(u+1), V(u) have landed
+    // K(t) is read in phases 2t (A) and 2t + 1 (B), V(t) in 2t + 2 and 2t + 3: K(t + 2) / V(t + 1) reuse the slots of K(t) /
+    // V(t - 1) from phase 2t + 2 on -- the two-slot rings of the straight loop suffice.  43 = 42 under s_setprio (MFMA phase).
+    const int T = n_tiles;
+    const bool grpB = NW == 8 && wave >= 4;
+    auto dma_even = [&](int u) {   // at the start of even phase 2u
+      if (u + 1 < T) stage_k((u + 1) & 1, (u + 1) * KVB);
+      if (u < T) stage_v(u & 1, u * KVB);
+    };
+    auto qk = [&](int t, f32x16 (&s)[2]) {
+      qk_tile(k_ring + (t & 1) * ATT_TILE, qf, f, s);
+      if (ragged && t == T - 1) mask_tail(s, t * KVB, S, h2);
+    };
+    f32x16 s[2];
+    bf16x8 pf[4];
+    stage_k(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // opens phase 0
+    dma_even(0);
+    if (!grpB) {
+      qk(0, s);
+      __syncthreads();                     // opens phase 1
+      for (int t = 0; t < T; ++t) {
+        softmax_tile_zero(s, m_run, l_run, o_acc, pf);            // phase 2t + 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                   // opens phase 2t + 2
+        dma_even(t + 1);
+        if (VARIANT == 43) __builtin_amdgcn_s_setprio(1);
+        pv_tile(v_ring + (t & 1) * ATT_TILE, pf, f, o_acc);
+        if (t + 1 < T) qk(t + 1, s);
+        if (VARIANT == 43) __builtin_amdgcn_s_setprio(0);
+        __syncthreads();                   // opens phase 2t + 3
+      }
+      __syncthreads();                     // group B's last phase
+    } else {
+      __syncthreads();                     // opens phase 1
+      qk(0, s);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                     // opens phase 2
+      for (int t = 0; t < T; ++t) {
+        dma_even(t + 1);
+        softmax_tile_zero(s, m_run, l_run, o_acc, pf);            // phase 2t + 2
+        __syncthreads();                   // opens phase 2t + 3
+        if (VARIANT == 43) __builtin_amdgcn_s_setprio(1);
+        pv_tile(v_ring + (t & 1) * ATT_TILE, pf, f, o_acc);
+        if (t + 1 < T) qk(t + 1, s);
+        if (VARIANT == 43) __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                   // opens phase 2t + 4
+      }
+    }
   } else if (VARIANT < 2 || VARIANT >= 10) {
     // VARIANT >= 16 (measurement only, wrong results, NOT reachable from the C ABI -- instantiate by hand): ablation
     // bits 1 no DMA after tile 0, 2 no LDS fragment reads, 4 no exp2, 8 no per-tile wait + barrier.  Round-1 readings
@@ -1395,6 +1457,20 @@ int flash_attn_d64_q64(const void* q, const void* k, const void* vt, void* o, in
                        hipStream_t stream);
 }
 
+// main launch of the pre-scaled form: the straight loop (41) or the ping-pong loop (42; 43 = under s_setprio), ALG_ATTN_PP
+static int attn_pp() {
+  const char* e = getenv("ALG_ATTN_PP");
+  const int v = e ? atoi(e) : 0;
+  return (v == 1 || v == 2) ? v : 0;
+}
+static void launch_main41(dim3 g, dim3 blk, hipStream_t s, const alg::AttnP& p) {
+  switch (attn_pp()) {
+    case 1: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<42, 8>), g, blk, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<43, 8>), g, blk, 0, s, p); break;
+    default: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<41, 8>), g, blk, 0, s, p); break;
+  }
+}
+
 extern "C" int alg_flash_attn_d64(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S,
                                   int64_t q_bstride, int64_t q_rstride, int64_t vt_bstride, int64_t vt_rstride,
                                   int64_t o_bstride, int64_t o_rstride, float scale, void* stream) {
@@ -1470,7 +1546,7 @@ extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* v
                                                         vt_rstride, o_bstride, o_rstride, (unsigned)(8 * p.unit0), s)
                                    : 0;
         if (rq < 0 || rq > 1) return rq;
-        if (rq == 1) hipLaunchKernelGGL((flash_attn_d64_kernel<41, 8>), dim3((unsigned)(8 * p.unit0)), blk, 0, s, p);
+        if (rq == 1) launch_main41(dim3((unsigned)(8 * p.unit0)), blk, s, p);
         hipLaunchKernelGGL((flash_attn_d64_kernel<41, 8, true>), dim3((unsigned)(8 * tp.units * tp.split)), blk, 0, s, p);
       } else {
         hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8>), dim3((unsigned)(8 * p.unit0)), blk, 0, s, p);
@@ -1502,7 +1578,7 @@ extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* v
     case 33: hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8>), g, blk, 0, s, p); break;
     case 34: hipLaunchKernelGGL((flash_attn_d64_kernel<34, 8>), g, blk, 0, s, p); break;
     case 36: hipLaunchKernelGGL((flash_attn_d64_kernel<36, 8>), g, blk, 0, s, p); break;
-    case 41: hipLaunchKernelGGL((flash_attn_d64_kernel<41, 8>), g, blk, 0, s, p); break;
+    case 41: launch_main41(g, blk, s, p); break;
     case 17: hipLaunchKernelGGL((flash_attn_d64_kernel<17, 8>), g, blk, 0, s, p); break;  // no DMA after tile 0
     case 18: hipLaunchKernelGGL((flash_attn_d64_kernel<18, 8>), g, blk, 0, s, p); break;  // no LDS fragment reads
     case 19: hipLaunchKernelGGL((flash_attn_d64_kernel<19, 8>), g, blk, 0, s, p); break;  // neither

@@ -393,3 +393,27 @@ def test_schedule9_equals_the_drain_and_barrier_schedule_bit_for_bit(monkeypatch
         monkeypatch.setenv("ALG_GEMM_PIPE", "9")
         for _ in range(2):
             assert torch.equal(run(), want), (form, M, N, K)
+
+
+@pytest.mark.parametrize("S", [64, 100, 1000, 4097])
+def test_pingpong_attention_equals_the_straight_loop_bit_for_bit(monkeypatch, S):
+    """ALG_ATTN_PP=1/2 (flash_attn_d64_kernel<42/43>): the same per-wave arithmetic as the default pre-scaled kernel with the
+    two waves of a SIMD half a tile apart -- only the order of phases ACROSS waves differs, so the output bits must not."""
+    H, D, N = 6, 64, 2
+    s_pad = (S + 127) // 128 * 128
+    g = torch.Generator(device="cuda").manual_seed(S)
+    qk = (torch.randn(N, S, 2 * H * D, generator=g, device="cuda") * 0.5).to(BF)
+    vt = torch.zeros(N, H * D, s_pad, dtype=BF, device="cuda")
+    vt[:, :, :S] = torch.randn(N, H * D, S, generator=g, device="cuda").to(BF)
+
+    def run():
+        o = torch.empty(N, S, H * D, dtype=BF, device="cuda")
+        _lib.flash_attn_d64(qk, qk, vt, o, N, H, S, S * 2 * H * D, 2 * H * D, H * D * s_pad, s_pad, S * H * D, H * D, 0.125,
+                            k_off=H * D, q_prescaled=True)
+        return o
+
+    monkeypatch.setenv("ALG_ATTN_PP", "0")
+    want = run()
+    for pp in ("1", "2"):
+        monkeypatch.setenv("ALG_ATTN_PP", pp)
+        assert torch.equal(run(), want), pp
