@@ -234,6 +234,17 @@ def prologue():
 
 
 def emit(res=False):
+    global BUF
+    buf_saved = BUF
+    if res:
+        BUF = False   # the BUF experiment (scalar k offset) only exists for the plain statement: its MA / MB are RS here
+    try:
+        return _emit(res)
+    finally:
+        BUF = buf_saved
+
+
+def _emit(res):
     lines = []
     lines += prologue()
     if not res:
