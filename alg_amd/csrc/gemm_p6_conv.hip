@@ -17,7 +17,7 @@ int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_
     attr_set = true;
   }
   const dim3 grid(gemm_grid(nwg)), block(512);
-  const int gm = gemm_group_m();
+  const int gm = gemm_group_m(6);
   if (a->R)
     hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, true, 6, 4, false, true>), grid, block, GEMM_LDS, s, *a, m_tiles,
                        n_tiles, gm);
