@@ -52,6 +52,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "attn_pipe_loop.inc"
 
 namespace alg {
 
@@ -1414,6 +1415,182 @@ __global__ __launch_bounds__(256) void flash_attn_d64_merge_kernel(const AttnP p
   *(uint2*)(p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + h * 64 + d4 * 4) = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pipelined form (round 3, ALG_ATTN_PP=3): the steady-state KV loop is ONE generated asm statement (attn_pipe_loop.inc,
+// scripts/gen_attn_pipe.py) in which every MFMA is followed, in program order of the SAME wave, by the softmax work of one
+// score pair and one fragment read -- the only arrangement in which matrix and vector work overlap on this part
+// (profiles/r3_attention_d64_mix_microbench.txt).  This kernel is the frame around it: the same workgroup -> (head, q block)
+// map, Q / K / V^T layouts and finish as flash_attn_d64_kernel<41>, a C++ loop that runs tile 0 (where the running offset is
+// established and snapped to zero), the last few tiles (ragged tail) and any tile on which the statement bails out (row sum
+// outside [0, 2^40): the exact max / rescale path), all under the statement's collective protocol:
+//     top of iteration t:  s_waitcnt vmcnt(0); s_barrier; DMA K(t+2) -> K slot (t+2) & 3, V^T(t+1) -> V slot (t+1) & 3
+// so that the waves of a workgroup may be inside or outside the statement independently.  The straight form of an iteration
+// reads K(t), V^T(t); the pipelined form K(t+1), V^T(t-1): four-slot rings keep all of them resident.
+// Row sums are plain fp32 adds of the unrounded probabilities inside the statement (v_dot2c does not hide behind an MFMA),
+// the bf16-rounded dot2 sums of softmax_tile_zero outside it.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flash_attn_d64_pipe_kernel(const AttnP p) {
+  // four waves x 32 queries: the statement names v[64:165] and a[0:79], and hipcc only grants an 8-wave workgroup 128 + 128
+  // registers per lane; two of these workgroups (2 x 64 KiB of LDS) share a CU
+  constexpr int NW = 4;
+  __shared__ __attribute__((aligned(16))) char smem[8 * ATT_TILE];
+  char* const k_ring = smem;
+  char* const v_ring = smem + 4 * ATT_TILE;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int nbh = p.batch * p.heads;
+  // p.q_blocks counts 256-query units (the unit of flash_attn_d64_kernel and of the split-KV tail plan); a unit is two of this
+  // kernel's 128-query workgroups, neighbours in the grid
+  int bh, qb;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int idx = bid >> 3;
+    const int unit = idx >> 1;
+    const int slot = unit / p.q_blocks;
+    qb = (unit - slot * p.q_blocks) * 2 + (idx & 1);
+    bh = slot * 8 + xcd;
+    if (bh >= nbh) return;
+  }
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int S = p.S;
+  const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* K = p.k + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
+  const int T = (S + KVB - 1) / KVB;
+  const bool ragged = (S & (KVB - 1)) != 0;
+  f32x16 oa[2];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) oa[i >> 4][i & 15] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+
+  // Everything lane-derived is rebuilt from a lane id (LaneCtx): the C++ loops in front of and behind the statement each build
+  // their own from a freshly laundered id, so that none of it is live across the statement (values that are compete with its
+  // 32 O operands for v[0:63], and hipcc then parks them in AccVGPRs beyond a79: 328 registers, one wave per SIMD)
+  struct LaneCtx {
+    int lane, l31, h2, tid, srow, sslot, q_row;
+    Frag f;
+  };
+  auto make_ctx = [&](int lane) -> LaneCtx {
+    LaneCtx c;
+    c.lane = lane, c.l31 = lane & 31, c.h2 = lane >> 5, c.tid = wave * 64 + lane;
+    c.srow = c.tid >> 3, c.sslot = (c.tid & 7) ^ ((c.tid >> 4) & 7);
+    c.q_row = qb * (NW * 32) + wave * 32 + c.l31;
+    c.f.row_off = c.l31 * 128, c.f.sw = (c.l31 >> 1) & 7, c.f.h2 = c.h2;
+    return c;
+  };
+  auto fresh_lane = [&]() -> int {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+  };
+  auto stage_k = [&](const LaneCtx& c, int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16_t* ks = K + (int64_t)min(t * KVB + c.srow + 32 * i, S - 1) * p.q_rs + c.sslot * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + (t & 3) * ATT_TILE + (i * 4 + wave) * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_v = [&](const LaneCtx& c, int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(VT + (int64_t)(c.srow + 32 * i) * p.vt_rs + c.sslot * 8 + min(t, T - 1) * KVB),
+                                       (lptr_t)(v_ring + (t & 3) * ATT_TILE + (i * 4 + wave) * 1024), 16, 0, 0);
+  };
+  // iterations [t, t_end) in the straight form: protocol (unless the first one's is already done), QK(t) -> softmax -> PV(t)
+  auto straight = [&](const LaneCtx& c, int t, int t_end, bool top_done) {
+    bf16x8 qf[4];
+    const bf16_t* qp = Q + (int64_t)min(c.q_row, S - 1) * p.q_rs + c.h2 * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    for (; t < t_end; ++t) {
+      if (!top_done) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the previous iteration's four DMAs
+        __syncthreads();
+        stage_k(c, t + 3);   // past the end the source rows are clamped (K) / lie in the padded pitch (V^T): the DMA count per
+        stage_v(c, t + 2);   // iteration must not depend on t, the counted wait above relies on it
+      }
+      top_done = false;
+      f32x16 s[2];
+      qk_tile(k_ring + (t & 3) * ATT_TILE, qf, c.f, s);
+      if (ragged && t == T - 1) mask_tail(s, t * KVB, S, c.h2);
+      bf16x8 pf[4];
+      softmax_tile_zero(s, m_run, l_run, oa, pf);
+      pv_tile(v_ring + (t & 3) * ATT_TILE, pf, c.f, oa);
+    }
+  };
+
+  // the statement only runs iterations t whose DMA target K(t + 3) is a whole tile (its sources are not clamped) and whose
+  // tile t + 1 needs no mask
+  const int tend = ragged ? T - 4 : T - 3;
+  int t = 1;
+  bool top_done = false;
+  {
+    const LaneCtx c = make_ctx(fresh_lane());
+    stage_k(c, 0);
+    stage_k(c, 1);
+    stage_v(c, 0);
+    stage_v(c, 0);       // (filler: four DMAs per batch)
+    stage_k(c, 2);       // the batch "iteration -1" would have issued: K(2), V(1)
+    stage_v(c, 1);
+    straight(c, 0, 1, false);     // tile 0: establishes the running offset (snapped to zero when its scores allow)
+  }
+  if (1 + 4 <= tend && __all(m_run == 0.0f)) {
+    const LaneCtx c = make_ctx(fresh_lane());
+    auto sreg = [](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
+    auto uniform64 = [](const void* ptr) -> uint64_t {
+      const uint64_t v = (uint64_t)(uintptr_t)ptr;
+      return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    const uint32_t kl = (uint32_t)(uintptr_t)(lptr_t)k_ring, vl = (uint32_t)(uintptr_t)(lptr_t)v_ring;
+    const int fl0 = c.f.row_off + (((0 + c.h2) ^ c.f.sw) * 16), fl1 = c.f.row_off + (((2 + c.h2) ^ c.f.sw) * 16);
+    const int fl2 = c.f.row_off + (((4 + c.h2) ^ c.f.sw) * 16), fl3 = c.f.row_off + (((6 + c.h2) ^ c.f.sw) * 16);
+    const int lk0 = kl + fl0, lk1 = kl + fl1, lk2 = kl + fl2, lk3 = kl + fl3;
+    const int lv0 = vl + fl0, lv1 = vl + fl1, lv2 = vl + fl2, lv3 = vl + fl3;
+    int kvo0 = (int)(((int64_t)((t + 3) * KVB + c.srow) * p.q_rs + c.sslot * 8) * 2);
+    int kvo1 = (int)(((int64_t)((t + 3) * KVB + c.srow + 32) * p.q_rs + c.sslot * 8) * 2);
+    int vvo0 = (int)(((int64_t)c.srow * p.vt_rs + c.sslot * 8 + (t + 2) * KVB) * 2);
+    int vvo1 = (int)(((int64_t)(c.srow + 32) * p.vt_rs + c.sslot * 8 + (t + 2) * KVB) * 2);
+    const int qvo = (int)(((int64_t)min(c.q_row, S - 1) * p.q_rs + c.h2 * 8) * 2);
+    const uint64_t kb = uniform64(K), vb = uniform64(VT), qbs = uniform64(Q);
+    const int kstep = sreg((int)(KVB * p.q_rs * 2)), tend_s = sreg(tend);
+    const int wk = sreg((int)kl + wave * 1024), wv = sreg((int)vl + wave * 1024);
+    int ts = sreg(t), code;
+    float o[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) o[i] = oa[i >> 4][i & 15];
+    asm volatile(ALG_ATTN_PIPE_LOOP_ASM
+                 : ALG_ATTN_PIPE_O_OPERANDS(o), [l] "+v"(l_run), [t] "+s"(ts), [code] "=&s"(code), [kvo0] "+v"(kvo0),
+                   [kvo1] "+v"(kvo1), [vvo0] "+v"(vvo0), [vvo1] "+v"(vvo1)
+                 : [lk0] "v"(lk0), [lk1] "v"(lk1), [lk2] "v"(lk2), [lk3] "v"(lk3), [lv0] "v"(lv0), [lv1] "v"(lv1),
+                   [lv2] "v"(lv2), [lv3] "v"(lv3), [qvo] "v"(qvo), [kb] "s"(kb), [vb] "s"(vb), [qb] "s"(qbs),
+                   [kstep] "s"(kstep), [tend] "s"(tend_s), [wk] "s"(wk), [wv] "s"(wv)
+                 : "memory", "vcc", "scc", ALG_ATTN_PIPE_CLOBBERS);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) oa[i >> 4][i & 15] = o[i];
+    t = ts;
+    top_done = code != 0;   // 1: iteration t's protocol is done, softmax(t) is not: tile t is redone below
+  }
+  LaneCtx c = make_ctx(fresh_lane());
+  straight(c, t, T, top_done);   // the tiles behind the statement (or all of them but tile 0)
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (c.q_row < S) {
+    bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)c.q_row * p.o_rs + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * c.h2;
+        uint2 v;
+        v.x = pack_bf2(oa[dt][4 * g] * inv, oa[dt][4 * g + 1] * inv);
+        v.y = pack_bf2(oa[dt][4 * g + 2] * inv, oa[dt][4 * g + 3] * inv);
+        *(uint2*)(op + d) = v;
+      }
+  }
+}
+
 // Workgroup-count quantisation (measured, scripts/attn_tail_probe.py): every XCD runs 64 workgroups at a time (32 CUs x
 // 2), a workgroup takes ~0.64 ms at S = 17,776, and a 2-sample C2 launch is 840 units per XCD = 13.125 rounds: the
 // fourteenth round keeps 8 of 64 slots busy and costs 1.5-5 % of the launch depending on the box.  When the last round is at most 1/4 full its units
@@ -1457,16 +1634,18 @@ int flash_attn_d64_q64(const void* q, const void* k, const void* vt, void* o, in
                        hipStream_t stream);
 }
 
-// main launch of the pre-scaled form: the straight loop (41) or the ping-pong loop (42; 43 = under s_setprio), ALG_ATTN_PP
+// main launch of the pre-scaled form (ALG_ATTN_PP): 3 = the pipelined kernel (default since round 3: asm steady-state loop, every
+// MFMA followed by one score pair of the softmax; +5 % in the bench), 0 = the straight loop (41), 1 / 2 = the ping-pong loops
 static int attn_pp() {
   const char* e = getenv("ALG_ATTN_PP");
-  const int v = e ? atoi(e) : 0;
-  return (v == 1 || v == 2) ? v : 0;
+  const int v = e ? atoi(e) : 3;
+  return (v >= 0 && v <= 3) ? v : 3;
 }
 static void launch_main41(dim3 g, dim3 blk, hipStream_t s, const alg::AttnP& p) {
   switch (attn_pp()) {
     case 1: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<42, 8>), g, blk, 0, s, p); break;
     case 2: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<43, 8>), g, blk, 0, s, p); break;
+    case 3: hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel, dim3(g.x * 2), dim3(256), 0, s, p); break;   // two 128-query workgroups per unit
     default: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<41, 8>), g, blk, 0, s, p); break;
   }
 }

@@ -549,8 +549,12 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const P p) 
       const float x1 = ZERO ? sc[qh][8 * g + 2 * jj + 1] : sc[qh][8 * g + 2 * jj + 1] - m_run[qh];
       const float p0 = __builtin_amdgcn_exp2f(x0), p1 = __builtin_amdgcn_exp2f(x1);
       pk[qh][g].w[jj] = pack_bf2(p0, p1);
-      psum[qh] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk[qh][g].w[jj]), __builtin_bit_cast(bf2v, 0x3f803f80u),
-                                                psum[qh], false);
+#ifndef ALG_Q64_ROWSUM_ADD   // (default: the dot2 form)
+      psum[qh] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk[qh][g].w[jj]), __builtin_bit_cast(bf2v, 0x3f803f80u), psum[qh], false);
+#else   // experiment (round 3): plain fp32 adds -- v_dot2c costs +7 ns per MFMA in an MFMA's shadow (scripts/micro/attn_mix.hip), but
+        // this kernel did not get faster with them (1051 vs 1098 TFLOP/s for the default) and the d = 64 form returned NaN: not adopted
+      psum[qh] += p0 + p1;
+#endif
     };
     auto step = [&](auto step_c) {
       constexpr int ST = decltype(step_c)::value;

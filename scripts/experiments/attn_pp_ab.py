@@ -21,7 +21,8 @@ vt[:, :, :S] = torch.randn(N, H * D, S, generator=g, device=dev).to(BF)
 
 
 def run(pp, small=None):
-    os.environ["ALG_ATTN_PP"] = str(pp)
+    os.environ["ALG_ATTN_PP"] = str(pp if pp < 10 else 0)
+    os.environ["ALG_ATTN64_Q64"] = "1" if pp == 64 else "0"      # pp = 64: the 64-queries-per-wave kernel
     s = small or S
     att = torch.empty(N, s, H * D, dtype=BF, device=dev)
     _lib.flash_attn_d64(qk, qk, vt, att, N, H, s, S * 2 * H * D, 2 * H * D, H * D * S_pad, S_pad, s * H * D, H * D, 0.125,
@@ -43,11 +44,18 @@ def timeit(pp, iters=6):
 
 
 bad = 0
-for small in (64, 100, 256, 1000, 4097, S):
+PPS = tuple(int(x) for x in os.environ.get('PPS', '1,2').split(','))
+for small in (64, 100, 256, 640, 1000, 4097, S):
     ref = run(0, small)
-    for pp in (1, 2):
+    for pp in PPS:
         for rep in range(2):
             got = run(pp, small)
+            if pp in (3, 64):   # row sums of unrounded probabilities inside the statement: close, not bit-equal
+                err = (got.float() - ref.float()).abs().max().item()
+                print('pp', pp, 'S', small, 'max abs diff vs straight', err, flush=True)
+                if not (err < 2e-2):
+                    bad += 1
+                break
             if not torch.equal(got, ref):
                 d = (got.float() - ref.float()).abs()
                 bad += 1
@@ -55,6 +63,6 @@ for small in (64, 100, 256, 1000, 4097, S):
                 break
 print("ping-pong vs straight loop: %d mismatching" % bad, flush=True)
 for r in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
-    for pp in (0, 1, 2):
+    for pp in (0,) + PPS:
         ms, tf = timeit(pp)
         print("round %d ALG_ATTN_PP=%d  %.3f ms  %.1f TFLOP/s" % (r, pp, ms, tf), flush=True)

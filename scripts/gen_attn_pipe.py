@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Generates alg_amd/csrc/attn_pipe_loop.inc: the steady-state KV loop of the d = 64 attention as ONE inline-asm statement.
+
+Why (profiles/r3_attention_d64_mix_microbench.txt): on gfx950 matrix and vector work of DIFFERENT waves of a SIMD do not
+overlap, vector work issued by the SAME wave right behind its own MFMA does -- 1 MFMA + {2 v_exp, 1 v_cvt_pk_bf16_f32, 2 v_add,
+1 ds_read_b128} costs 18.3 ns of SIMD time against 16.3 ns for the MFMA alone, while the straight loop of attention.hip (QK ->
+softmax -> PV, each phase on its own) spends 28.6 ns per MFMA.  (v_dot2c_f32_bf16 does NOT hide: +7 ns per MFMA; plain adds do.)
+
+The loop is software-pipelined over KV tiles of 64: iteration t issues, per wave (32 queries; a workgroup is four waves = 128 queries, two workgroups per CU),
+    PV(t-1): O^T += V(t-1)^T P(t-1)^T      8 MFMAs, A = V^T fragments from LDS, B = P(t-1) (registers), C/D = a[0:31]
+    QK(t+1): S(t+1)^T = K(t+1) Q^T         8 MFMAs, A = K fragments from LDS,   B = Q (registers), first k-step from C = 0
+    softmax(t): P(t) = bf16(exp2(S(t))), row sum     16 score pairs, ONE PAIR PER MFMA GAP: exp, exp, cvt_pk (of the previous
+                                                     pair), add, add -- none of it depends on this iteration's MFMAs
+Scores arrive in log2 units with the running offset at zero (attention.hip, softmax_tile_zero's common path): the statement is
+entered only by waves whose offsets are all zero and leaves as soon as a tile's row sum leaves [0, 2^40) -- the exact path
+(tile max, rescale) stays in C++.
+
+Collective protocol (identical in the C++ loop around the statement, so waves of one workgroup may be in either): at the top
+of iteration t   s_waitcnt vmcnt(4); s_barrier;  DMA K(t+3) -> K slot (t+3) & 3, V^T(t+2) -> V slot (t+2) & 3   (2 KiB = two
+instructions per wave and tile each; the counted wait leaves the previous iteration's four in flight: two tiles of prefetch).
+Iteration t reads K(t+1), V(t-1) (pipelined form) or K(t), V(t) (straight form): all resident in the 4-slot rings.
+
+Unrolled x 4 (ring slot = t & 3 as immediates; the S / P register roles alternate with t & 1).  Entered at t = 1 (mod 4) through
+a warm-up (QK(t) on its own; no PV: the caller has finished tile t-1), runs whole groups of four while t + 4 <= t_end, then
+drains PV of its last tile.  Register plan (named literally, clobbered):
+    v[64:95]  SA   v[96:127] SB     score tiles (sub-tile 0: +0..15, sub-tile 1: +16..31); roles alternate
+    v[128:143] PA  v[144:159] PB    packed probabilities: register n = pair (S[2n], S[2n+1])
+    v160 tile sum, v[161:164] exp results in flight, v165 scratch
+    a[0:31]   O^T accumulators (two 32x32 tiles)
+    a[32:63]  eight fragment buffers (ring, one per MFMA, read four MFMAs ahead; ds_read_b128 straight into AccVGPRs)
+    a[64:79]  Q fragments (loaded by the statement: four 16-byte pieces per lane)
+(102 ArchVGPRs + 80 AccVGPRs: with hipcc's own registers the kernel stays at 256 per lane = two waves per SIMD)
+Operands: o0..o31 "+v" (O^T elements, moved to / from a[0:31]), l "+v" running row sum, t "+s" iteration index (in: first
+iteration, = 1 mod 4; out: the iteration the caller continues with), code "=s" (0: t's top-of-iteration protocol NOT done,
+caller continues normally; 1: row-sum check failed in iteration t -- its protocol, PV(t-1) and QK(t+1) are done, softmax(t)
+is not: the caller redoes tile t from QK), lk0..lk3 / lv0..lv3 "v" LDS byte address of the lane's K / V^T fragment per
+k-step (ring base included; slot and sub-tile are immediates), kvo0/1, vvo0/1 "+v" DMA byte offsets of this lane (rows srow,
+srow + 32) into the K / V^T panels AT TILE (t + 3) / (t + 2) of the entry iteration (advanced inside), qvo "v" byte offset of the lane's Q row, kb / vb /
+qb "s" 64-bit panel bases, kstep "s" bytes per K tile, tend "s" (whole groups of four run while t + 4 <= tend; the caller guarantees t + 3 < T inside),
+wk / wv "s" = LDS byte address of the K / V^T ring + wave * 1024 (DMA destination of this wave).
+"""
+import os
+
+SA, SB, PA, PB = 64, 96, 128, 144
+TS, E0, E1, E2, E3, SCR = 160, 161, 162, 163, 164, 165
+OACC, FR, Q = 0, 32, 64        # AccVGPRs: O^T tiles, fragment ring, Q fragments
+TILE = 8192
+
+v = lambda i: "v%d" % i
+vr = lambda i, n: "v[%d:%d]" % (i, i + n - 1)
+ar = lambda i, n: "a[%d:%d]" % (i, i + n - 1)
+
+
+def frag_read(buf, which, slot, half, kstep):
+    """ds_read_b128 of one fragment: K (which = 'k') sub-tile `half` k-step `kstep`, or V^T d-tile `half` kv block `kstep`"""
+    # address = lane part(kstep) (carries the ring base) + slot * TILE + half * 4096
+    return "ds_read_b128 %s, %%[l%s%d] offset:%d" % (ar(FR + 4 * buf, 4), which, kstep, slot * TILE + half * 4096)
+
+
+def softmax_gap(S, P, n, first, last_of_tile=False):
+    """VALU work of one MFMA gap: exp2 of pair n (if n < 16), pack + row sum of pair n - 1 (if n >= 1).
+    Pair n lives in E0/E1 (n even) or E2/E3 (n odd) until it is packed in the next gap."""
+    out = []
+    ea, eb = (E0, E1) if n % 2 == 0 else (E2, E3)
+    pa, pb = (E2, E3) if n % 2 == 0 else (E0, E1)   # previous pair
+    if n >= 1:
+        out.append("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(P + n - 1), v(pa), v(pb)))
+        if n - 1 == 0:
+            out.append("v_add_f32 %s, %s, %s" % (v(TS), v(pa), v(pb)))
+        else:
+            out.append("v_add_f32 %s, %s, %s" % (v(SCR), v(pa), v(pb)))
+            out.append("v_add_f32 %s, %s, %s" % (v(TS), v(TS), v(SCR)))
+    if n < 16:
+        out.append("v_exp_f32 %s, %s" % (v(ea), v(S + 2 * n)))
+        out.append("v_exp_f32 %s, %s" % (v(eb), v(S + 2 * n + 1)))
+    return out
+
+
+def top_protocol(phase):
+    """top of iteration t (t & 3 == phase): all but the previous iteration's four DMAs have landed (K(t+1), V(t) and older),
+    everybody is done with iteration t - 1; then this wave's share of K(t+3) and V^T(t+2) -- two tiles ahead, into the slots of
+    K(t-1) / V^T(t-2): two 1 KiB pieces each (four waves stage an 8 KiB tile)"""
+    ks, vs = (phase + 3) & 3, (phase + 2) & 3
+    out = ["s_waitcnt vmcnt(4) lgkmcnt(0)", "s_barrier"]
+    for r in range(2):
+        out += ["s_add_u32 m0, %%[wk], %d" % (ks * TILE + r * 4096), "s_nop 0",
+                "global_load_lds_dwordx4 %%[kvo%d], %%[kb]" % r]
+    for r in range(2):
+        out += ["s_add_u32 m0, %%[wv], %d" % (vs * TILE + r * 4096), "s_nop 0",
+                "global_load_lds_dwordx4 %%[vvo%d], %%[vb]" % r]
+    out += ["v_add_u32 %[kvo0], %[kstep], %[kvo0]", "v_add_u32 %[kvo1], %[kstep], %[kvo1]",
+            "v_add_u32 %[vvo0], 0x80, %[vvo0]", "v_add_u32 %[vvo1], 0x80, %[vvo1]"]
+    return out
+
+
+def iteration(phase, X, Y, U, W, pv=True, softmax=True, qk=True):
+    """one pipelined iteration at ring phase t & 3 == phase.  MFMA stream (16, or 8 without PV): the four PV MFMAs of kv blocks
+    0, 1 first (their V^T fragments do not depend on this iteration's barrier), then QK and PV alternating, QK last."""
+    kslot, vslot = (phase + 1) & 3, (phase - 1) & 3
+    mf = []   # (kind, half, kstep)
+    if pv:
+        mf += [("v", 0, 0), ("v", 1, 0), ("v", 0, 1), ("v", 1, 1)]
+        rest_v = [("v", 0, 2), ("v", 1, 2), ("v", 0, 3), ("v", 1, 3)]
+    else:
+        rest_v = []
+    qks = [("k", s, ks) for ks in range(4) for s in range(2)] if qk else []
+    # alternate: QK, PV, QK, PV, ... then the remaining QKs
+    i = 0
+    while rest_v or qks[i:]:
+        if qks[i:]:
+            mf.append(qks[i]); i += 1
+        if rest_v:
+            mf.append(rest_v.pop(0))
+    n_m = len(mf)
+    lines = []
+    AHEAD = 4
+    def read(j):
+        kind, half, kstep = mf[j]
+        return frag_read(j % 8, kind, kslot if kind == "k" else vslot, half, kstep)
+    for j in range(min(AHEAD, n_m)):
+        lines.append(read(j))
+    pair = 0
+    n_pairs = 16 if softmax else 0
+    # pairs per gap: spread 17 VALU groups (16 exps + the trailing pack) over the gaps
+    per_gap = max(1, 16 // n_m) if softmax else 0
+    seen_first = {"k0": False, "k1": False}
+    for j, (kind, half, kstep) in enumerate(mf):
+        outstanding = min(AHEAD, n_m - j) - 1          # reads issued after read j that may still be in flight
+        lines.append("s_waitcnt lgkmcnt(%d)" % outstanding)
+        fr = ar(FR + 4 * (j % 8), 4)
+        if kind == "k":
+            acc = vr(Y + 16 * half, 16)
+            c = acc if seen_first["k%d" % half] else "0"
+            seen_first["k%d" % half] = True
+            lines.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, fr, ar(Q + 4 * kstep, 4), c))
+        else:
+            acc = ar(16 * half, 16)
+            lines.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, fr, vr(U + 4 * kstep, 4), acc))
+        if j + AHEAD < n_m:
+            lines.append(read(j + AHEAD))
+        for g in range(per_gap):
+            if softmax and pair <= 16:
+                if g > 0:
+                    lines.append("s_nop 1")     # the pack below reads what the two exps just above wrote (trans -> VALU use)
+                lines += softmax_gap(X, W, pair, pair == 0)
+                pair += 1
+    while softmax and pair <= 16:
+        lines.append("s_nop 1")
+        lines += softmax_gap(X, W, pair, False)
+        pair += 1
+    return lines
+
+
+def check_and_count(fail_label):
+    """row-sum check of the iteration just issued, then t += 1"""
+    return ["v_cmp_ngt_f32 vcc, 0x53800000, %s" % v(TS), "s_nop 4", "s_cbranch_vccnz %s" % fail_label,   # !(2^40 > sum)
+            "v_add_f32 %%[l], %%[l], %s" % v(TS), "s_add_u32 %[t], %[t], 1"]
+
+
+def emit():
+    L = []
+    # ---- entry: O -> a[0:31], Q fragments, constants ----
+    L += ["v_accvgpr_write_b32 a%d, %%[o%d]" % (i, i) for i in range(32)]
+    L += ["global_load_dwordx4 %s, %%[qvo], %%[qb] offset:%d" % (ar(Q + 4 * ks, 4), 32 * ks) for ks in range(4)]
+    roles = {1: (SA, SB, PA, PB), 2: (SB, SA, PB, PA), 3: (SA, SB, PA, PB), 0: (SB, SA, PB, PA)}
+    # ---- warm-up at phase 1: top protocol, QK(t) alone into X = SA (K(t) sits in slot 1 = the "next" slot of phase 0) ----
+    L += ["s_waitcnt vmcnt(0)"]   # Q (and, once, whatever the caller had in flight)
+    L += top_protocol(1)
+    X, Y, U, W = roles[1]
+    L += iteration(0, Y, X, U, W, pv=False, softmax=False)      # phase 0's "next" K slot is slot 1: S(t) -> SA
+    L += ["s_nop 15", "s_nop 15"]                                  # S(t) complete before the first exp reads it
+    L += iteration(1, X, Y, U, W, pv=False)                       # QK(t+1) -> SB under softmax(t) -> PB
+    L += check_and_count("90f")
+    L += ["s_branch 12f"]
+    # ---- the loop: phases 1, 2, 3, 0 ----
+    L += ["11:"]
+    for ph in (1, 2, 3, 0):
+        if ph == 2:
+            L += ["12:"]
+        X, Y, U, W = roles[ph]
+        L += top_protocol(ph)
+        L += iteration(ph, X, Y, U, W)
+        L += check_and_count("90f")
+    # after phase 0: t = 1 (mod 4) again.  Another whole group?  (t + 4 <= tend)
+    L += ["s_add_u32 %[code], %[t], 4", "s_cmp_le_u32 %[code], %[tend]", "s_cbranch_scc1 11b"]
+    # ---- drain: PV of the last tile (P in PB after phase 0: W of phase 0 = PA? roles[0] = (SB, SA, PB, PA): W = PA) ----
+    X, Y, U, W = roles[0]
+    L += iteration(1, Y, X, W, U, pv=True, softmax=False, qk=False)   # phase-1 slots: V slot (1 - 1) & 3 = 0 = slot of tile t - 1
+    L += ["s_mov_b32 %[code], 0", "s_branch 99f"]
+    # ---- failed row-sum check in iteration t: its MFMAs are issued; leave with code 1 ----
+    L += ["90:", "s_mov_b32 %[code], 1"]
+    L += ["99:", "s_nop 15", "s_nop 15"]
+    L += ["v_accvgpr_read_b32 %%[o%d], a%d" % (i, i) for i in range(32)]
+    L += ["s_waitcnt lgkmcnt(0)"]
+    return L
+
+
+def main():
+    lines = emit()
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.environ.get("ATTN_PIPE_OUT") or os.path.join(here, "..", "alg_amd", "csrc", "attn_pipe_loop.inc")
+    with open(path, "w") as f:
+        f.write("// GENERATED by scripts/gen_attn_pipe.py -- do not edit.  Steady-state KV loop of the pipelined d = 64 attention.\n")
+        f.write("#define ALG_ATTN_PIPE_LOOP_ASM \\\n")
+        for ln in lines:
+            f.write('  "%s\\n\\t" \\\n' % ln)
+        f.write('  ""\n')
+        regs = ["a%d" % i for i in range(80)] + ["v%d" % i for i in range(64, 166)]
+        f.write("#define ALG_ATTN_PIPE_CLOBBERS \\\n  " + ", ".join('"%s"' % r for r in regs) + '\n')
+        f.write("#define ALG_ATTN_PIPE_O_OPERANDS(o) \\\n  " +
+                ", ".join('[o%d] "+v"(o[%d])' % (i, i) for i in range(32)) + '\n')
+    print("wrote", os.path.normpath(path), len(lines), "lines,", sum(1 for l in lines if l.startswith("v_mfma")), "MFMAs")
+
+
+if __name__ == "__main__":
+    main()

@@ -417,3 +417,48 @@ def test_pingpong_attention_equals_the_straight_loop_bit_for_bit(monkeypatch, S)
     for pp in ("1", "2"):
         monkeypatch.setenv("ALG_ATTN_PP", pp)
         assert torch.equal(run(), want), pp
+
+
+@pytest.mark.parametrize("Bn,S2,H2", [(1, 512, 2), (2, 1000, 3), (1, 513, 1), (1, 640, 1), (1, 832, 1), (1, 2050, 2), (1, 4097, 1),
+                                       (8, 1200, 1)])
+def test_pipelined_attention_kernel(device, monkeypatch, Bn, S2, H2):
+    """flash_attn_d64_pipe_kernel (ALG_ATTN_PP=3, the default main launch of the pre-scaled call): the asm steady-state loop
+    (entered at tile 1 by waves whose running offsets are all zero, whole groups of four tiles) inside its C++ frame, against
+    fp32 SDPA and against the straight loop (ALG_ATTN_PP=0) on the same tensors.  Rows whose first-tile max is beyond +-64 keep a
+    non-zero offset (those waves never enter the statement while their neighbours in the workgroup do: mixed mode under one
+    barrier / DMA protocol); a late dominant key makes a row sum leave [0, 2^40) INSIDE the statement (it bails out, the tile is
+    redone on the exact path); ragged tails; S = 512 / 513 stay below the statement's minimum of eight tiles; 8 x 1 heads let
+    the split-KV tail plan engage next to the pipelined main launch.  Run-to-run identical."""
+    g = torch.Generator().manual_seed(S2 + H2)
+    c = 0.125 * 1.4426950408889634
+    q, k, v = rnd((Bn, S2, H2, 64), g), rnd((Bn, S2, H2, 64), g), rnd((Bn, S2, H2, 64), g)
+    q[:, : S2 // 5] *= 9.0                       # scores ~ +-70 in log2 units: non-zero offsets for a fifth of the rows
+    k[:, (2 * S2) // 3] *= 6.0                   # one late key that dominates
+    D = H2 * 64
+    S_pad = (S2 + 127) // 128 * 128
+    qs = (q.float() * c).to(BF)
+    sc2 = torch.einsum("bqhd,bkhd->bhqk", qs.double(), k.double()) * math.log(2.0)
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc2, dim=-1), v.double())
+    qkb = torch.cat([qs.reshape(Bn, S2, D), k.reshape(Bn, S2, D)], dim=-1).contiguous().to(device)
+    vt = torch.zeros(Bn, D, S_pad, dtype=BF)
+    vt[:, :, torch.tensor([swap23(n) for n in range(S2)])] = v.reshape(Bn, S2, D).transpose(1, 2)
+    vt = vt.to(device)
+    outs, errs = {}, {}
+    for pp in ("3", "0"):
+        monkeypatch.setenv("ALG_ATTN_PP", pp)
+        o = torch.full((Bn, S2, D), 3.0, dtype=BF, device=device)
+        _lib.flash_attn_d64(qkb, qkb, vt, o, Bn, H2, S2, S2 * 2 * D, 2 * D, D * S_pad, S_pad, S2 * D, D, 0.125, k_off=D,
+                            q_prescaled=True)
+        outs[pp] = o
+        got = o.cpu().reshape(Bn, S2, H2, 64).double()
+        assert torch.isfinite(got).all(), pp
+        errs[pp] = ((got - ref).abs().max().item(), (got - ref).abs().mean().item())
+    assert errs["0"][0] <= 3e-2 and errs["0"][1] <= 2e-3, errs
+    assert errs["3"][0] <= 3e-2 and errs["3"][1] <= 2e-3, errs
+    assert errs["3"][1] <= 1.25 * errs["0"][1] + 1e-5, errs       # not worse than the straight loop on average
+    monkeypatch.setenv("ALG_ATTN_PP", "3")
+    for _ in range(3):
+        o2 = torch.empty_like(outs["3"])
+        _lib.flash_attn_d64(qkb, qkb, vt, o2, Bn, H2, S2, S2 * 2 * D, 2 * D, D * S_pad, S_pad, S2 * D, D, 0.125, k_off=D,
+                            q_prescaled=True)
+        assert torch.equal(o2, outs["3"])
