@@ -76,24 +76,35 @@ def softmax_gap(S, P, n, first, last_of_tile=False):
     return out
 
 
-def top_protocol(phase):
+def top_protocol(phase, spread=False):
     """top of iteration t (t & 3 == phase): all but the previous iteration's four DMAs have landed (K(t+1), V(t) and older),
     everybody is done with iteration t - 1; then this wave's share of K(t+3) and V^T(t+2) -- two tiles ahead, into the slots of
-    K(t-1) / V^T(t-2): two 1 KiB pieces each (four waves stage an 8 KiB tile)"""
+    K(t-1) / V^T(t-2): two 1 KiB pieces each (four waves stage an 8 KiB tile).
+    spread: returns (head, groups) -- the four DMAs go out one per MFMA gap behind the barrier instead of as a block"""
     ks, vs = (phase + 3) & 3, (phase + 2) & 3
-    out = ["s_waitcnt vmcnt(4) lgkmcnt(0)", "s_barrier"]
+    head = ["s_waitcnt vmcnt(4)", "s_barrier"]
+    groups = []
     for r in range(2):
-        out += ["s_add_u32 m0, %%[wk], %d" % (ks * TILE + r * 4096), "s_nop 0",
-                "global_load_lds_dwordx4 %%[kvo%d], %%[kb]" % r]
+        groups.append(["s_add_u32 m0, %%[wk], %d" % (ks * TILE + r * 4096), "s_nop 0",
+                       "global_load_lds_dwordx4 %%[kvo%d], %%[kb]" % r, "v_add_u32 %%[kvo%d], %%[kstep], %%[kvo%d]" % (r, r)])
     for r in range(2):
-        out += ["s_add_u32 m0, %%[wv], %d" % (vs * TILE + r * 4096), "s_nop 0",
-                "global_load_lds_dwordx4 %%[vvo%d], %%[vb]" % r]
-    out += ["v_add_u32 %[kvo0], %[kstep], %[kvo0]", "v_add_u32 %[kvo1], %[kstep], %[kvo1]",
-            "v_add_u32 %[vvo0], 0x80, %[vvo0]", "v_add_u32 %[vvo1], 0x80, %[vvo1]"]
-    return out
+        groups.append(["s_add_u32 m0, %%[wv], %d" % (vs * TILE + r * 4096), "s_nop 0",
+                       "global_load_lds_dwordx4 %%[vvo%d], %%[vb]" % r, "v_add_u32 %%[vvo%d], 0x80, %%[vvo%d]" % (r, r)])
+    if spread:
+        return head, groups
+    return head + [ln for g in groups for ln in g]
 
 
-def iteration(phase, X, Y, U, W, pv=True, softmax=True, qk=True):
+def first_reads(phase):
+    """the first four fragment reads of a full iteration at `phase`: V^T(t-1) kv blocks 0, 1 for both d-tiles.  They do not
+    depend on the iteration's barrier (V^T(t-1) landed two iterations earlier), so the PREVIOUS iteration issues them behind its
+    twelfth MFMA (buffers 0-3 are free from there on) and the LDS latency hides under the top-of-iteration wait + barrier."""
+    vslot = (phase - 1) & 3
+    return [frag_read(j, "v", vslot, half, kstep) for j, (half, kstep) in enumerate([(0, 0), (1, 0), (0, 1), (1, 1)])]
+
+
+def iteration(phase, X, Y, U, W, pv=True, softmax=True, qk=True, reads_in_flight=False, prefetch_next=None, dma_groups=None,
+              pre_exp=False):
     """one pipelined iteration at ring phase t & 3 == phase.  MFMA stream (16, or 8 without PV): the four PV MFMAs of kv blocks
     0, 1 first (their V^T fragments do not depend on this iteration's barrier), then QK and PV alternating, QK last."""
     kslot, vslot = (phase + 1) & 3, (phase - 1) & 3
@@ -117,15 +128,16 @@ def iteration(phase, X, Y, U, W, pv=True, softmax=True, qk=True):
     def read(j):
         kind, half, kstep = mf[j]
         return frag_read(j % 8, kind, kslot if kind == "k" else vslot, half, kstep)
-    for j in range(min(AHEAD, n_m)):
-        lines.append(read(j))
-    pair = 0
+    if not reads_in_flight:
+        for j in range(min(AHEAD, n_m)):
+            lines.append(read(j))
+    pair = 1 if (softmax and pre_exp) else 0     # pre_exp: the caller has issued the two exps of pair 0 (softmax_pre)
     n_pairs = 16 if softmax else 0
     # pairs per gap: spread 17 VALU groups (16 exps + the trailing pack) over the gaps
     per_gap = max(1, 16 // n_m) if softmax else 0
     seen_first = {"k0": False, "k1": False}
     for j, (kind, half, kstep) in enumerate(mf):
-        outstanding = min(AHEAD, n_m - j) - 1          # reads issued after read j that may still be in flight
+        outstanding = (AHEAD if prefetch_next is not None else min(AHEAD, n_m - j)) - 1   # reads issued after read j
         lines.append("s_waitcnt lgkmcnt(%d)" % outstanding)
         fr = ar(FR + 4 * (j % 8), 4)
         if kind == "k":
@@ -138,6 +150,10 @@ def iteration(phase, X, Y, U, W, pv=True, softmax=True, qk=True):
             lines.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, fr, vr(U + 4 * kstep, 4), acc))
         if j + AHEAD < n_m:
             lines.append(read(j + AHEAD))
+        elif prefetch_next is not None and j + AHEAD - n_m < AHEAD:
+            lines.append(first_reads(prefetch_next)[j + AHEAD - n_m])   # next iteration's reads 0..3 behind MFMAs 12..15
+        if dma_groups and j < len(dma_groups):
+            lines += dma_groups[j]                                       # one DMA per gap behind the barrier
         for g in range(per_gap):
             if softmax and pair <= 16:
                 if g > 0:
@@ -149,6 +165,11 @@ def iteration(phase, X, Y, U, W, pv=True, softmax=True, qk=True):
         lines += softmax_gap(X, W, pair, False)
         pair += 1
     return lines
+
+
+def softmax_pre(S):
+    """the two exps of score pair 0, issued AHEAD of the top-of-iteration wait + barrier (the scores are complete)"""
+    return ["v_exp_f32 %s, %s" % (v(E0), v(S)), "v_exp_f32 %s, %s" % (v(E1), v(S + 1))]
 
 
 def check_and_count(fail_label):
@@ -164,12 +185,12 @@ def emit():
     L += ["global_load_dwordx4 %s, %%[qvo], %%[qb] offset:%d" % (ar(Q + 4 * ks, 4), 32 * ks) for ks in range(4)]
     roles = {1: (SA, SB, PA, PB), 2: (SB, SA, PB, PA), 3: (SA, SB, PA, PB), 0: (SB, SA, PB, PA)}
     # ---- warm-up at phase 1: top protocol, QK(t) alone into X = SA (K(t) sits in slot 1 = the "next" slot of phase 0) ----
-    L += ["s_waitcnt vmcnt(0)"]   # Q (and, once, whatever the caller had in flight)
+    L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"]   # Q (and, once, whatever the caller had in flight)
     L += top_protocol(1)
     X, Y, U, W = roles[1]
     L += iteration(0, Y, X, U, W, pv=False, softmax=False)      # phase 0's "next" K slot is slot 1: S(t) -> SA
     L += ["s_nop 15", "s_nop 15"]                                  # S(t) complete before the first exp reads it
-    L += iteration(1, X, Y, U, W, pv=False)                       # QK(t+1) -> SB under softmax(t) -> PB
+    L += iteration(1, X, Y, U, W, pv=False, prefetch_next=2)      # QK(t+1) -> SB under softmax(t) -> PB
     L += check_and_count("90f")
     L += ["s_branch 12f"]
     # ---- the loop: phases 1, 2, 3, 0 ----
@@ -178,14 +199,15 @@ def emit():
         if ph == 2:
             L += ["12:"]
         X, Y, U, W = roles[ph]
-        L += top_protocol(ph)
-        L += iteration(ph, X, Y, U, W)
+        head, groups = top_protocol(ph, spread=True)
+        L += softmax_pre(X) + head
+        L += iteration(ph, X, Y, U, W, reads_in_flight=True, prefetch_next=(ph + 1) & 3, dma_groups=groups, pre_exp=True)
         L += check_and_count("90f")
     # after phase 0: t = 1 (mod 4) again.  Another whole group?  (t + 4 <= tend)
     L += ["s_add_u32 %[code], %[t], 4", "s_cmp_le_u32 %[code], %[tend]", "s_cbranch_scc1 11b"]
     # ---- drain: PV of the last tile (P in PB after phase 0: W of phase 0 = PA? roles[0] = (SB, SA, PB, PA): W = PA) ----
     X, Y, U, W = roles[0]
-    L += iteration(1, Y, X, W, U, pv=True, softmax=False, qk=False)   # phase-1 slots: V slot (1 - 1) & 3 = 0 = slot of tile t - 1
+    L += iteration(1, Y, X, W, U, pv=True, softmax=False, qk=False, reads_in_flight=True)   # V slot (1 - 1) & 3 = slot of tile t - 1
     L += ["s_mov_b32 %[code], 0", "s_branch 99f"]
     # ---- failed row-sum check in iteration t: its MFMAs are issued; leave with code 1 ----
     L += ["90:", "s_mov_b32 %[code], 1"]
