@@ -1429,10 +1429,13 @@ __global__ __launch_bounds__(256) void flash_attn_d64_merge_kernel(const AttnP p
 // Row sums are plain fp32 adds of the unrounded probabilities inside the statement (v_dot2c does not hide behind an MFMA),
 // the bf16-rounded dot2 sums of softmax_tile_zero outside it.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void flash_attn_d64_pipe_kernel(const AttnP p) {
-  // four waves x 32 queries: the statement names v[64:165] and a[0:79], and hipcc only grants an 8-wave workgroup 128 + 128
-  // registers per lane; two of these workgroups (2 x 64 KiB of LDS) share a CU
-  constexpr int NW = 4;
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void flash_attn_d64_pipe_kernel(const AttnP p) {
+  // NW = 4 (default): four waves x 32 queries, the statement names v[64:165] and a[0:79] (252 registers), two of these
+  // workgroups (2 x 64 KiB of LDS) share a CU.  NW = 8 (ALG_ATTN_PP=4): one 256-query unit per workgroup, half the L2 -> LDS
+  // traffic per MFMA; hipcc grants an 8-wave workgroup 128 + 128 registers per lane, so that form of the statement lives in
+  // v[26:127] and takes O in AccVGPR operands.
+  constexpr int ROUNDS = 8 / NW;
   __shared__ __attribute__((aligned(16))) char smem[8 * ATT_TILE];
   char* const k_ring = smem;
   char* const v_ring = smem + 4 * ATT_TILE;
@@ -1445,9 +1448,9 @@ __global__ __launch_bounds__(256) void flash_attn_d64_pipe_kernel(const AttnP p)
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     const int idx = bid >> 3;
-    const int unit = idx >> 1;
+    const int unit = NW == 4 ? idx >> 1 : idx;
     const int slot = unit / p.q_blocks;
-    qb = (unit - slot * p.q_blocks) * 2 + (idx & 1);
+    qb = NW == 4 ? (unit - slot * p.q_blocks) * 2 + (idx & 1) : unit - slot * p.q_blocks;
     bh = slot * 8 + xcd;
     if (bh >= nbh) return;
   }
@@ -1485,16 +1488,16 @@ __global__ __launch_bounds__(256) void flash_attn_d64_pipe_kernel(const AttnP p)
   };
   auto stage_k = [&](const LaneCtx& c, int t) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bf16_t* ks = K + (int64_t)min(t * KVB + c.srow + 32 * i, S - 1) * p.q_rs + c.sslot * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + (t & 3) * ATT_TILE + (i * 4 + wave) * 1024), 16, 0, 0);
+    for (int i = 0; i < ROUNDS; ++i) {
+      const bf16_t* ks = K + (int64_t)min(t * KVB + c.srow + NW * 8 * i, S - 1) * p.q_rs + c.sslot * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + (t & 3) * ATT_TILE + (i * NW + wave) * 1024), 16, 0, 0);
     }
   };
   auto stage_v = [&](const LaneCtx& c, int t) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(VT + (int64_t)(c.srow + 32 * i) * p.vt_rs + c.sslot * 8 + min(t, T - 1) * KVB),
-                                       (lptr_t)(v_ring + (t & 3) * ATT_TILE + (i * 4 + wave) * 1024), 16, 0, 0);
+    for (int i = 0; i < ROUNDS; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(VT + (int64_t)(c.srow + NW * 8 * i) * p.vt_rs + c.sslot * 8 + min(t, T - 1) * KVB),
+                                       (lptr_t)(v_ring + (t & 3) * ATT_TILE + (i * NW + wave) * 1024), 16, 0, 0);
   };
   // iterations [t, t_end) in the straight form: protocol (unless the first one's is already done), QK(t) -> softmax -> PV(t)
   auto straight = [&](const LaneCtx& c, int t, int t_end, bool top_done) {
@@ -1504,7 +1507,10 @@ __global__ __launch_bounds__(256) void flash_attn_d64_pipe_kernel(const AttnP p)
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
     for (; t < t_end; ++t) {
       if (!top_done) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the previous iteration's four DMAs
+        if constexpr (ROUNDS == 2)
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the previous iteration's DMAs (2 * ROUNDS per wave)
+        else
+          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __syncthreads();
         stage_k(c, t + 3);   // past the end the source rows are clamped (K) / lie in the padded pitch (V^T): the DMA count per
         stage_v(c, t + 2);   // iteration must not depend on t, the counted wait above relies on it
@@ -1548,9 +1554,7 @@ __global__ __launch_bounds__(256) void flash_attn_d64_pipe_kernel(const AttnP p)
     const int lk0 = kl + fl0, lk1 = kl + fl1, lk2 = kl + fl2, lk3 = kl + fl3;
     const int lv0 = vl + fl0, lv1 = vl + fl1, lv2 = vl + fl2, lv3 = vl + fl3;
     int kvo0 = (int)(((int64_t)((t + 3) * KVB + c.srow) * p.q_rs + c.sslot * 8) * 2);
-    int kvo1 = (int)(((int64_t)((t + 3) * KVB + c.srow + 32) * p.q_rs + c.sslot * 8) * 2);
     int vvo0 = (int)(((int64_t)c.srow * p.vt_rs + c.sslot * 8 + (t + 2) * KVB) * 2);
-    int vvo1 = (int)(((int64_t)(c.srow + 32) * p.vt_rs + c.sslot * 8 + (t + 2) * KVB) * 2);
     const int qvo = (int)(((int64_t)min(c.q_row, S - 1) * p.q_rs + c.h2 * 8) * 2);
     const uint64_t kb = uniform64(K), vb = uniform64(VT), qbs = uniform64(Q);
     const int kstep = sreg((int)(KVB * p.q_rs * 2)), tend_s = sreg(tend);
@@ -1559,13 +1563,25 @@ __global__ __launch_bounds__(256) void flash_attn_d64_pipe_kernel(const AttnP p)
     float o[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) o[i] = oa[i >> 4][i & 15];
-    asm volatile(ALG_ATTN_PIPE_LOOP_ASM
-                 : ALG_ATTN_PIPE_O_OPERANDS(o), [l] "+v"(l_run), [t] "+s"(ts), [code] "=&s"(code), [kvo0] "+v"(kvo0),
-                   [kvo1] "+v"(kvo1), [vvo0] "+v"(vvo0), [vvo1] "+v"(vvo1)
-                 : [lk0] "v"(lk0), [lk1] "v"(lk1), [lk2] "v"(lk2), [lk3] "v"(lk3), [lv0] "v"(lv0), [lv1] "v"(lv1),
-                   [lv2] "v"(lv2), [lv3] "v"(lv3), [qvo] "v"(qvo), [kb] "s"(kb), [vb] "s"(vb), [qb] "s"(qbs),
-                   [kstep] "s"(kstep), [tend] "s"(tend_s), [wk] "s"(wk), [wv] "s"(wv)
-                 : "memory", "vcc", "scc", ALG_ATTN_PIPE_CLOBBERS);
+    if constexpr (NW == 4) {
+      int kvo1 = (int)(((int64_t)((t + 3) * KVB + c.srow + 32) * p.q_rs + c.sslot * 8) * 2);
+      int vvo1 = (int)(((int64_t)(c.srow + 32) * p.vt_rs + c.sslot * 8 + (t + 2) * KVB) * 2);
+      asm volatile(ALG_ATTN_PIPE_LOOP_ASM
+                   : ALG_ATTN_PIPE_O_OPERANDS(o), [l] "+v"(l_run), [t] "+s"(ts), [code] "=&s"(code), [kvo0] "+v"(kvo0),
+                     [kvo1] "+v"(kvo1), [vvo0] "+v"(vvo0), [vvo1] "+v"(vvo1)
+                   : [lk0] "v"(lk0), [lk1] "v"(lk1), [lk2] "v"(lk2), [lk3] "v"(lk3), [lv0] "v"(lv0), [lv1] "v"(lv1),
+                     [lv2] "v"(lv2), [lv3] "v"(lv3), [qvo] "v"(qvo), [kb] "s"(kb), [vb] "s"(vb), [qb] "s"(qbs),
+                     [kstep] "s"(kstep), [tend] "s"(tend_s), [wk] "s"(wk), [wv] "s"(wv)
+                   : "memory", "vcc", "scc", ALG_ATTN_PIPE_CLOBBERS);
+    } else {
+      asm volatile(ALG_ATTN_PIPE8_LOOP_ASM
+                   : ALG_ATTN_PIPE8_O_OPERANDS(o), [l] "+v"(l_run), [t] "+s"(ts), [code] "=&s"(code), [kvo0] "+v"(kvo0),
+                     [vvo0] "+v"(vvo0)
+                   : [lk0] "v"(lk0), [lk1] "v"(lk1), [lk2] "v"(lk2), [lk3] "v"(lk3), [lv0] "v"(lv0), [lv1] "v"(lv1),
+                     [lv2] "v"(lv2), [lv3] "v"(lv3), [qvo] "v"(qvo), [kb] "s"(kb), [vb] "s"(vb), [qb] "s"(qbs),
+                     [kstep] "s"(kstep), [tend] "s"(tend_s), [wk] "s"(wk), [wv] "s"(wv)
+                   : "memory", "vcc", "scc", ALG_ATTN_PIPE8_CLOBBERS);
+    }
 #pragma unroll
     for (int i = 0; i < 32; ++i) oa[i >> 4][i & 15] = o[i];
     t = ts;
@@ -1634,18 +1650,20 @@ int flash_attn_d64_q64(const void* q, const void* k, const void* vt, void* o, in
                        hipStream_t stream);
 }
 
-// main launch of the pre-scaled form (ALG_ATTN_PP): 3 = the pipelined kernel (default since round 3: asm steady-state loop, every
-// MFMA followed by one score pair of the softmax; +5 % in the bench), 0 = the straight loop (41), 1 / 2 = the ping-pong loops
+// main launch of the pre-scaled form (ALG_ATTN_PP): 4 = the pipelined kernel, one 8-wave workgroup per 256-query unit (default
+// since round 3: asm steady-state loop, every MFMA followed by one score pair of the softmax; +8 % on the kernel), 3 = the same
+// with 4-wave workgroups (twice the L2 -> LDS traffic per MFMA: +4 %), 0 = the straight loop (41), 1 / 2 = the ping-pong loops
 static int attn_pp() {
   const char* e = getenv("ALG_ATTN_PP");
-  const int v = e ? atoi(e) : 3;
-  return (v >= 0 && v <= 3) ? v : 3;
+  const int v = e ? atoi(e) : 4;
+  return (v >= 0 && v <= 4) ? v : 4;
 }
 static void launch_main41(dim3 g, dim3 blk, hipStream_t s, const alg::AttnP& p) {
   switch (attn_pp()) {
     case 1: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<42, 8>), g, blk, 0, s, p); break;
     case 2: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<43, 8>), g, blk, 0, s, p); break;
-    case 3: hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel, dim3(g.x * 2), dim3(256), 0, s, p); break;   // two 128-query workgroups per unit
+    case 3: hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel<4>, dim3(g.x * 2), dim3(256), 0, s, p); break;   // two 128-query workgroups per unit
+    case 4: hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel<8>, g, dim3(512), 0, s, p); break;             // experiment: one 8-wave workgroup per unit
     default: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<41, 8>), g, blk, 0, s, p); break;
   }
 }

@@ -301,7 +301,7 @@ class C2(Workload):
     name = "c2"
     metric = "frames/sec (whole node) CogVideoX-5B-I2V 49f x 50-step ALG"
     frames, steps_per_video = 49, 50
-    attn_kernel = "flash_attn_d64_pipe_kernel"   # main launch of the pre-scaled call (ALG_ATTN_PP=3, the default)
+    attn_kernel = "flash_attn_d64_pipe_kernel"   # main launch of the pre-scaled call (ALG_ATTN_PP=4, the default)
     S, D, Hn, T = 17776, 3072, 48, 226
     describe = ("BASELINE config 2: CogVideoX-5B-I2V bf16, 49 frames @ 480x720, 50 steps, ALG interval down_up "
                 "(resize_factor 0.25, interval [0, 0.04]), guidance 6.0; one video per GPU")

@@ -41,9 +41,22 @@ wk / wv "s" = LDS byte address of the K / V^T ring + wave * 1024 (DMA destinatio
 """
 import os
 
-SA, SB, PA, PB = 64, 96, 128, 144
-TS, E0, E1, E2, E3, SCR = 160, 161, 162, 163, 164, 165
 OACC, FR, Q = 0, 32, 64        # AccVGPRs: O^T tiles, fragment ring, Q fragments
+NW = 4                         # waves per workgroup (configure())
+
+
+def configure(nw):
+    """4-wave form: ArchVGPRs v[64:165], O exchanged through 32 "+v" operands, two DMA pieces per wave, tile and operand.
+    8-wave form (one 256-query unit per workgroup, half the L2 -> LDS traffic per MFMA): hipcc grants such a workgroup 128 + 128
+    registers per lane, so the statement's ArchVGPRs are v[26:127] and O travels in 32 "+a" operands (v_accvgpr_mov)."""
+    global SA, SB, PA, PB, TS, E0, E1, E2, E3, SCR, NW, VBASE
+    NW = nw
+    VBASE = 64 if nw == 4 else 26
+    SA, SB, PA, PB = VBASE, VBASE + 32, VBASE + 64, VBASE + 80
+    TS, E0, E1, E2, E3, SCR = (VBASE + 96 + i for i in range(6))
+
+
+configure(4)
 TILE = 8192
 
 v = lambda i: "v%d" % i
@@ -82,12 +95,13 @@ def top_protocol(phase, spread=False):
     K(t-1) / V^T(t-2): two 1 KiB pieces each (four waves stage an 8 KiB tile).
     spread: returns (head, groups) -- the four DMAs go out one per MFMA gap behind the barrier instead of as a block"""
     ks, vs = (phase + 3) & 3, (phase + 2) & 3
-    head = ["s_waitcnt vmcnt(4)", "s_barrier"]
+    rounds = 8 // NW
+    head = ["s_waitcnt vmcnt(%d)" % (2 * rounds), "s_barrier"]
     groups = []
-    for r in range(2):
+    for r in range(rounds):
         groups.append(["s_add_u32 m0, %%[wk], %d" % (ks * TILE + r * 4096), "s_nop 0",
                        "global_load_lds_dwordx4 %%[kvo%d], %%[kb]" % r, "v_add_u32 %%[kvo%d], %%[kstep], %%[kvo%d]" % (r, r)])
-    for r in range(2):
+    for r in range(rounds):
         groups.append(["s_add_u32 m0, %%[wv], %d" % (vs * TILE + r * 4096), "s_nop 0",
                        "global_load_lds_dwordx4 %%[vvo%d], %%[vb]" % r, "v_add_u32 %%[vvo%d], 0x80, %%[vvo%d]" % (r, r)])
     if spread:
@@ -181,7 +195,7 @@ def check_and_count(fail_label):
 def emit():
     L = []
     # ---- entry: O -> a[0:31], Q fragments, constants ----
-    L += ["v_accvgpr_write_b32 a%d, %%[o%d]" % (i, i) for i in range(32)]
+    L += [("v_accvgpr_write_b32 a%d, %%[o%d]" if NW == 4 else "v_accvgpr_mov_b32 a%d, %%[o%d]") % (i, i) for i in range(32)]
     L += ["global_load_dwordx4 %s, %%[qvo], %%[qb] offset:%d" % (ar(Q + 4 * ks, 4), 32 * ks) for ks in range(4)]
     roles = {1: (SA, SB, PA, PB), 2: (SB, SA, PB, PA), 3: (SA, SB, PA, PB), 0: (SB, SA, PB, PA)}
     # ---- warm-up at phase 1: top protocol, QK(t) alone into X = SA (K(t) sits in slot 1 = the "next" slot of phase 0) ----
@@ -212,26 +226,29 @@ def emit():
     # ---- failed row-sum check in iteration t: its MFMAs are issued; leave with code 1 ----
     L += ["90:", "s_mov_b32 %[code], 1"]
     L += ["99:", "s_nop 15", "s_nop 15"]
-    L += ["v_accvgpr_read_b32 %%[o%d], a%d" % (i, i) for i in range(32)]
+    L += [("v_accvgpr_read_b32 %%[o%d], a%d" if NW == 4 else "v_accvgpr_mov_b32 %%[o%d], a%d") % (i, i) for i in range(32)]
     L += ["s_waitcnt lgkmcnt(0)"]
     return L
 
 
 def main():
-    lines = emit()
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.environ.get("ATTN_PIPE_OUT") or os.path.join(here, "..", "alg_amd", "csrc", "attn_pipe_loop.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by scripts/gen_attn_pipe.py -- do not edit.  Steady-state KV loop of the pipelined d = 64 attention.\n")
-        f.write("#define ALG_ATTN_PIPE_LOOP_ASM \\\n")
-        for ln in lines:
-            f.write('  "%s\\n\\t" \\\n' % ln)
-        f.write('  ""\n')
-        regs = ["a%d" % i for i in range(80)] + ["v%d" % i for i in range(64, 166)]
-        f.write("#define ALG_ATTN_PIPE_CLOBBERS \\\n  " + ", ".join('"%s"' % r for r in regs) + '\n')
-        f.write("#define ALG_ATTN_PIPE_O_OPERANDS(o) \\\n  " +
-                ", ".join('[o%d] "+v"(o[%d])' % (i, i) for i in range(32)) + '\n')
-    print("wrote", os.path.normpath(path), len(lines), "lines,", sum(1 for l in lines if l.startswith("v_mfma")), "MFMAs")
+        for nw, tag in ((4, ""), (8, "8")):
+            configure(nw)
+            lines = emit()
+            f.write("#define ALG_ATTN_PIPE%s_LOOP_ASM \\\n" % tag)
+            for ln in lines:
+                f.write('  "%s\\n\\t" \\\n' % ln)
+            f.write('  ""\n')
+            regs = ["a%d" % i for i in range(80)] + ["v%d" % i for i in range(VBASE, VBASE + 102)]
+            f.write("#define ALG_ATTN_PIPE%s_CLOBBERS \\\n  " % tag + ", ".join('"%s"' % r for r in regs) + '\n')
+            f.write("#define ALG_ATTN_PIPE%s_O_OPERANDS(o) \\\n  " % tag +
+                    ", ".join('[o%d] "+%s"(o[%d])' % (i, "v" if nw == 4 else "a", i) for i in range(32)) + '\n')
+            print("wrote", os.path.normpath(path), "form", nw, len(lines), "lines,", sum(1 for l in lines if l.startswith("v_mfma")), "MFMAs")
+    configure(4)
 
 
 if __name__ == "__main__":

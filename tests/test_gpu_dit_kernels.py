@@ -422,7 +422,7 @@ def test_pingpong_attention_equals_the_straight_loop_bit_for_bit(monkeypatch, S)
 @pytest.mark.parametrize("Bn,S2,H2", [(1, 512, 2), (2, 1000, 3), (1, 513, 1), (1, 640, 1), (1, 832, 1), (1, 2050, 2), (1, 4097, 1),
                                        (8, 1200, 1)])
 def test_pipelined_attention_kernel(device, monkeypatch, Bn, S2, H2):
-    """flash_attn_d64_pipe_kernel (ALG_ATTN_PP=3, the default main launch of the pre-scaled call): the asm steady-state loop
+    """flash_attn_d64_pipe_kernel (ALG_ATTN_PP=4, the default main launch of the pre-scaled call, and its 4-wave form 3): the asm steady-state loop
     (entered at tile 1 by waves whose running offsets are all zero, whole groups of four tiles) inside its C++ frame, against
     fp32 SDPA and against the straight loop (ALG_ATTN_PP=0) on the same tensors.  Rows whose first-tile max is beyond +-64 keep a
     non-zero offset (those waves never enter the statement while their neighbours in the workgroup do: mixed mode under one
@@ -444,7 +444,7 @@ def test_pipelined_attention_kernel(device, monkeypatch, Bn, S2, H2):
     vt[:, :, torch.tensor([swap23(n) for n in range(S2)])] = v.reshape(Bn, S2, D).transpose(1, 2)
     vt = vt.to(device)
     outs, errs = {}, {}
-    for pp in ("3", "0"):
+    for pp in ("4", "3", "0"):
         monkeypatch.setenv("ALG_ATTN_PP", pp)
         o = torch.full((Bn, S2, D), 3.0, dtype=BF, device=device)
         _lib.flash_attn_d64(qkb, qkb, vt, o, Bn, H2, S2, S2 * 2 * D, 2 * D, D * S_pad, S_pad, S2 * D, D, 0.125, k_off=D,
@@ -454,11 +454,13 @@ def test_pipelined_attention_kernel(device, monkeypatch, Bn, S2, H2):
         assert torch.isfinite(got).all(), pp
         errs[pp] = ((got - ref).abs().max().item(), (got - ref).abs().mean().item())
     assert errs["0"][0] <= 3e-2 and errs["0"][1] <= 2e-3, errs
-    assert errs["3"][0] <= 3e-2 and errs["3"][1] <= 2e-3, errs
-    assert errs["3"][1] <= 1.25 * errs["0"][1] + 1e-5, errs       # not worse than the straight loop on average
-    monkeypatch.setenv("ALG_ATTN_PP", "3")
+    for pp in ("4", "3"):
+        assert errs[pp][0] <= 3e-2 and errs[pp][1] <= 2e-3, errs
+        assert errs[pp][1] <= 1.25 * errs["0"][1] + 1e-5, errs       # not worse than the straight loop on average
+    assert torch.equal(outs["4"], outs["3"])                         # same arithmetic per query row in both workgroup shapes
+    monkeypatch.setenv("ALG_ATTN_PP", "4")
     for _ in range(3):
-        o2 = torch.empty_like(outs["3"])
+        o2 = torch.empty_like(outs["4"])
         _lib.flash_attn_d64(qkb, qkb, vt, o2, Bn, H2, S2, S2 * 2 * D, 2 * D, D * S_pad, S_pad, S2 * D, D, 0.125, k_off=D,
                             q_prescaled=True)
-        assert torch.equal(o2, outs["3"])
+        assert torch.equal(o2, outs["4"])
