@@ -233,6 +233,9 @@ namespace alg {
 int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq, int Skv,
                         int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t vt_bs, int64_t vt_rs, int64_t o_bs,
                         int64_t o_rs, float scale, hipStream_t stream);
+int flash_attn_d128_pipe(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq, int Skv,
+                         int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t vt_bs, int64_t vt_rs, int64_t o_bs,
+                         int64_t o_rs, float scale, hipStream_t stream);
 }
 
 static int flash_attn_d128_entry(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq,
@@ -261,6 +264,11 @@ static int flash_attn_d128_entry(const void* q, const void* k, const void* vt, v
     set_error("alg_flash_attn_d128: vt row stride %lld must cover Skv rounded up to %d", (long long)vt_rstride,
               a128::KVB);
     return ALG_EINVAL;
+  }
+  if (!causal && kv_group == 1) {   // long self-attention: the pipelined kernel (attention128_pipe.hip; opt-in), 1 = not covered
+    const int rp = flash_attn_d128_pipe(q, k, vt, o, batch, heads, Sq, Skv, q_bstride, q_rstride, k_bstride, k_rstride, vt_bstride,
+                                        vt_rstride, o_bstride, o_rstride, scale, (hipStream_t)stream);
+    if (rp <= 0) return rp;
   }
   if (!causal && kv_group == 1) {   // long self-attention: 64 queries per wave (attention128_q64.hip); 1 = not covered
     const int rc = flash_attn_d128_q64(q, k, vt, o, batch, heads, Sq, Skv, q_bstride, q_rstride, k_bstride, k_rstride, vt_bstride,

@@ -86,6 +86,45 @@ def test_flash_attn_d128_q64_kernel(B, H, Sq, Skv, monkeypatch):
     assert torch.equal(o2, outs["1"])             # deterministic
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 1024), (2, 3, 257, 1000), (1, 1, 256, 833), (1, 2, 1300, 2050),
+                                          (1, 1, 64, 1100), (1, 2, 520, 767), (1, 1, 300, 768), (1, 2, 100, 1279),
+                                          (1, 1, 200, 4097)])
+def test_flash_attn_d128_pipelined_kernel(B, H, Sq, Skv, monkeypatch):
+    """attention128_pipe.hip (ALG_ATTN128_PIPE=1: generated asm steady-state loop -- PV(t-1) / QK(t+1) / softmax(t) pipelined, every
+    MFMA followed in the same wave by a slice of the softmax and a fragment read -- inside a C++ frame, taken for >= 12 KV tiles of
+    non-causal, ungrouped attention) against fp32 SDPA and against attention128.hip on the same tensors.  Ragged key counts (the
+    statement never sees the masked tile), scores large enough for the lazy running max's exact path INSIDE the statement's
+    range (it bails out, the tile is redone in C++), a late dominant key, query blocks that end mid-wave, tile counts that
+    leave 0-3 tiles behind the four-tile groups; run-to-run identical."""
+    D = H * 128
+    q, k, v = _rand((B, Sq, D), 11), _rand((B, Skv, D), 12), _rand((B, Skv, D), 13)
+    q[:, : Sq // 2] *= 6.0                       # half the queries: scores ~ +-25 -> row sums far beyond the first tile's
+    k[:, (2 * Skv) // 3] *= 8.0                  # and one key that dominates late
+    s_pad = (Skv + 63) // 64 * 64
+    vt = make_vt(v, s_pad)
+    scale = 1.0 / math.sqrt(128)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ALG_ATTN128_PIPE", flag)
+        o = torch.full((B, Sq, D), 7.0, dtype=BF, device=DEV)
+        _lib.flash_attn_d128(q, k, vt, o, B, H, Sq, Skv, Sq * D, D, Skv * D, D, D * s_pad, s_pad, Sq * D, D, scale)
+        outs[flag] = o
+    qh = q.float().view(B, Sq, H, 128).transpose(1, 2)
+    kh = k.float().view(B, Skv, H, 128).transpose(1, 2)
+    vh = v.float().view(B, Skv, H, 128).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(B, Sq, D)
+    for flag, o in outs.items():
+        assert bool(torch.isfinite(o.float()).all()), flag
+        assert (o.float() - ref).abs().max().item() < 3e-2, flag
+        assert (o.float() - ref).abs().mean().item() < 2e-3, flag
+    assert (outs["1"].float() - outs["0"].float()).abs().max().item() < 1.6e-2
+    monkeypatch.setenv("ALG_ATTN128_PIPE", "1")
+    for _ in range(3):
+        o2 = torch.empty_like(outs["1"])
+        _lib.flash_attn_d128(q, k, vt, o2, B, H, Sq, Skv, Sq * D, D, Skv * D, D, D * s_pad, s_pad, Sq * D, D, scale)
+        assert torch.equal(o2, outs["1"])             # deterministic
+
+
 def test_flash_attn_d128_rejects_bad_arguments():
     q = _rand((1, 64, 128), 4)
     with pytest.raises(_lib.AlgHipError):  # vt row stride shorter than Skv rounded up
