@@ -9,8 +9,10 @@
 //     top of iteration t:  s_waitcnt vmcnt(8); s_barrier; DMA K(t+3) -> K slot (t+3) & 3, V^T(t+2) -> V slot (t+2) & 3
 // so the waves of a workgroup may be inside or outside the statement independently.  Four waves x 32 queries per workgroup,
 // one wave per SIMD (the statement names v[64:169] and a[0:127]; O^T travels in 64 operands); K / V^T through two four-slot
-// rings of 16 KiB tiles (128 KiB of LDS).  Used for non-causal, ungrouped attention over at least MIN_TILES KV tiles; OPT-IN
-// (ALG_ATTN128_PIPE=1) until measured on the C3-C5 workloads.
+// rings of 16 KiB tiles (128 KiB of LDS).  Used for non-causal, ungrouped attention over at least MIN_TILES KV tiles.  DEFAULT
+// (ALG_ATTN128_PIPE=0 switches back to attention128.hip): C3 +4.4 %, C4 +5.9 %, C5 +4.8 % frames/s
+// (profiles/r3_attention128_pipe_ab.txt); 0 of 600 fp8 C5 forwards in three fresh processes differ run to run
+// (profiles/r3_attention128_pipe_determinism.jsonl) -- the test the 64-query kernel fails.
 #include <stdlib.h>
 
 #include <atomic>
@@ -275,7 +277,7 @@ int flash_attn_d128_pipe(const void* q, const void* k, const void* vt, void* o, 
                          int64_t o_rs, float scale, hipStream_t stream) {
   using namespace a128p;
   const char* env = getenv("ALG_ATTN128_PIPE");
-  if (!env || env[0] != '1' || (Skv + KVB - 1) / KVB < MIN_TILES) return 1;
+  if ((env && env[0] == '0') || (Skv + KVB - 1) / KVB < MIN_TILES) return 1;   // default since round 3; ALG_ATTN128_PIPE=0: attention128.hip
   // 31-bit BYTE offsets inside one (batch, head) for the DMA's lane offsets; V^T rows cover whole 64-key tiles
   if ((int64_t)(Skv + 64) * k_rs * 2 >= (1ll << 31) || (int64_t)129 * vt_rs * 2 >= (1ll << 31) ||
       (int64_t)Sq * q_rs * 2 >= (1ll << 31))
