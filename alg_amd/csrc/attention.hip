@@ -53,6 +53,7 @@
 
 #include "common.h"
 #include "attn_pipe_loop.inc"
+#include "attn_pipe64_loop.inc"
 
 namespace alg {
 
@@ -1607,6 +1608,171 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_pipe_kernel(const Attn
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pipelined form with 64 QUERIES PER WAVE (ALG_ATTN_PP=5; attn_pipe64_loop.inc, scripts/gen_attn_pipe64.py): four waves = one
+// 256-query unit per workgroup, one wave per SIMD; every K / V^T fragment read from LDS feeds two MFMAs (one per 32-query half),
+// i.e. half the fragment traffic per MFMA of flash_attn_d64_pipe_kernel.  Same frame, protocol and bail-out rules; the wave
+// carries two independent softmax states (one per half), the statement needs both offsets at zero.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flash_attn_d64_pipe64_kernel(const AttnP p) {
+  constexpr int NW = 4;
+  __shared__ __attribute__((aligned(16))) char smem[8 * ATT_TILE];
+  char* const k_ring = smem;
+  char* const v_ring = smem + 4 * ATT_TILE;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int nbh = p.batch * p.heads;
+  int bh, qb;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int unit = bid >> 3;
+    const int slot = unit / p.q_blocks;
+    qb = unit - slot * p.q_blocks;
+    bh = slot * 8 + xcd;
+    if (bh >= nbh) return;
+  }
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int S = p.S;
+  const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* K = p.k + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
+  const int T = (S + KVB - 1) / KVB;
+  const bool ragged = (S & (KVB - 1)) != 0;
+  f32x16 oa[2][2];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) oa[i >> 5][(i >> 4) & 1][i & 15] = 0.0f;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+
+  struct LaneCtx {
+    int lane, l31, h2, tid, srow, sslot, q_row;   // q_row: of half 0; half 1 is 32 rows further
+    Frag f;
+  };
+  auto make_ctx = [&](int lane) -> LaneCtx {
+    LaneCtx c;
+    c.lane = lane, c.l31 = lane & 31, c.h2 = lane >> 5, c.tid = wave * 64 + lane;
+    c.srow = c.tid >> 3, c.sslot = (c.tid & 7) ^ ((c.tid >> 4) & 7);
+    c.q_row = qb * 256 + wave * 64 + c.l31;
+    c.f.row_off = c.l31 * 128, c.f.sw = (c.l31 >> 1) & 7, c.f.h2 = c.h2;
+    return c;
+  };
+  auto fresh_lane = [&]() -> int {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+  };
+  auto stage_k = [&](const LaneCtx& c, int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16_t* ks = K + (int64_t)min(t * KVB + c.srow + 32 * i, S - 1) * p.q_rs + c.sslot * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + (t & 3) * ATT_TILE + (i * NW + wave) * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_v = [&](const LaneCtx& c, int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(VT + (int64_t)(c.srow + 32 * i) * p.vt_rs + c.sslot * 8 + min(t, T - 1) * KVB),
+                                       (lptr_t)(v_ring + (t & 3) * ATT_TILE + (i * NW + wave) * 1024), 16, 0, 0);
+  };
+  auto straight = [&](const LaneCtx& c, int t, int t_end, bool top_done) {
+    for (; t < t_end; ++t) {
+      if (!top_done) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();
+        stage_k(c, t + 3);
+        stage_v(c, t + 2);
+      }
+      top_done = false;
+#pragma unroll
+      for (int qh = 0; qh < 2; ++qh) {
+        bf16x8 qf[4];
+        const bf16_t* qp = Q + (int64_t)min(c.q_row + 32 * qh, S - 1) * p.q_rs + c.h2 * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+        f32x16 s[2];
+        qk_tile(k_ring + (t & 3) * ATT_TILE, qf, c.f, s);
+        if (ragged && t == T - 1) mask_tail(s, t * KVB, S, c.h2);
+        bf16x8 pf[4];
+        softmax_tile_zero(s, m_run[qh], l_run[qh], oa[qh], pf);
+        pv_tile(v_ring + (t & 3) * ATT_TILE, pf, c.f, oa[qh]);
+      }
+    }
+  };
+
+  const int tend = ragged ? T - 4 : T - 3;
+  int t = 1;
+  bool top_done = false;
+  {
+    const LaneCtx c = make_ctx(fresh_lane());
+    stage_k(c, 0);
+    stage_k(c, 1);
+    stage_v(c, 0);
+    stage_v(c, 0);       // (filler: four DMAs per batch)
+    stage_k(c, 2);
+    stage_v(c, 1);
+    straight(c, 0, 1, false);
+  }
+  if (1 + 4 <= tend && __all(m_run[0] == 0.0f && m_run[1] == 0.0f)) {
+    const LaneCtx c = make_ctx(fresh_lane());
+    auto sreg = [](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
+    auto uniform64 = [](const void* ptr) -> uint64_t {
+      const uint64_t v = (uint64_t)(uintptr_t)ptr;
+      return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    const uint32_t kl = (uint32_t)(uintptr_t)(lptr_t)k_ring, vl = (uint32_t)(uintptr_t)(lptr_t)v_ring;
+    const int fl0 = c.f.row_off + (((0 + c.h2) ^ c.f.sw) * 16), fl1 = c.f.row_off + (((2 + c.h2) ^ c.f.sw) * 16);
+    const int fl2 = c.f.row_off + (((4 + c.h2) ^ c.f.sw) * 16), fl3 = c.f.row_off + (((6 + c.h2) ^ c.f.sw) * 16);
+    const int lk0 = kl + fl0, lk1 = kl + fl1, lk2 = kl + fl2, lk3 = kl + fl3;
+    const int lv0 = vl + fl0, lv1 = vl + fl1, lv2 = vl + fl2, lv3 = vl + fl3;
+    int kvo0 = (int)(((int64_t)((t + 3) * KVB + c.srow) * p.q_rs + c.sslot * 8) * 2);
+    int kvo1 = (int)(((int64_t)((t + 3) * KVB + c.srow + 32) * p.q_rs + c.sslot * 8) * 2);
+    int vvo0 = (int)(((int64_t)c.srow * p.vt_rs + c.sslot * 8 + (t + 2) * KVB) * 2);
+    int vvo1 = (int)(((int64_t)(c.srow + 32) * p.vt_rs + c.sslot * 8 + (t + 2) * KVB) * 2);
+    const int qvo0 = (int)(((int64_t)min(c.q_row, S - 1) * p.q_rs + c.h2 * 8) * 2);
+    const int qvo1 = (int)(((int64_t)min(c.q_row + 32, S - 1) * p.q_rs + c.h2 * 8) * 2);
+    const uint64_t kb = uniform64(K), vb = uniform64(VT), qbs = uniform64(Q);
+    const int kstep = sreg((int)(KVB * p.q_rs * 2)), tend_s = sreg(tend);
+    const int wk = sreg((int)kl + wave * 1024), wv = sreg((int)vl + wave * 1024);
+    int ts = sreg(t), code;
+    float o[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) o[i] = oa[i >> 5][(i >> 4) & 1][i & 15];
+    asm volatile(ALG_ATTN_PIPE64_LOOP_ASM
+                 : ALG_ATTN_PIPE64_O_OPERANDS(o), [l0] "+v"(l_run[0]), [l1] "+v"(l_run[1]), [t] "+s"(ts), [code] "=&s"(code),
+                   [kvo0] "+v"(kvo0), [kvo1] "+v"(kvo1), [vvo0] "+v"(vvo0), [vvo1] "+v"(vvo1)
+                 : [lk0] "v"(lk0), [lk1] "v"(lk1), [lk2] "v"(lk2), [lk3] "v"(lk3), [lv0] "v"(lv0), [lv1] "v"(lv1),
+                   [lv2] "v"(lv2), [lv3] "v"(lv3), [qvo0] "v"(qvo0), [qvo1] "v"(qvo1), [kb] "s"(kb), [vb] "s"(vb), [qb] "s"(qbs),
+                   [kstep] "s"(kstep), [tend] "s"(tend_s), [wk] "s"(wk), [wv] "s"(wv)
+                 : "memory", "vcc", "scc", ALG_ATTN_PIPE64_CLOBBERS);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) oa[i >> 5][(i >> 4) & 1][i & 15] = o[i];
+    t = ts;
+    top_done = code != 0;
+  }
+  LaneCtx c = make_ctx(fresh_lane());
+  straight(c, t, T, top_done);
+
+#pragma unroll
+  for (int qh = 0; qh < 2; ++qh) {
+    const float l_tot = l_run[qh] + __shfl_xor(l_run[qh], 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q_row = c.q_row + 32 * qh;
+    if (q_row < S) {
+      bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * c.h2;
+          uint2 v;
+          v.x = pack_bf2(oa[qh][dt][4 * g] * inv, oa[qh][dt][4 * g + 1] * inv);
+          v.y = pack_bf2(oa[qh][dt][4 * g + 2] * inv, oa[qh][dt][4 * g + 3] * inv);
+          *(uint2*)(op + d) = v;
+        }
+    }
+  }
+}
+
 // Workgroup-count quantisation (measured, scripts/attn_tail_probe.py): every XCD runs 64 workgroups at a time (32 CUs x
 // 2), a workgroup takes ~0.64 ms at S = 17,776, and a 2-sample C2 launch is 840 units per XCD = 13.125 rounds: the
 // fourteenth round keeps 8 of 64 slots busy and costs 1.5-5 % of the launch depending on the box.  When the last round is at most 1/4 full its units
@@ -1656,7 +1822,7 @@ int flash_attn_d64_q64(const void* q, const void* k, const void* vt, void* o, in
 static int attn_pp() {
   const char* e = getenv("ALG_ATTN_PP");
   const int v = e ? atoi(e) : 4;
-  return (v >= 0 && v <= 4) ? v : 4;
+  return (v >= 0 && v <= 5) ? v : 4;
 }
 static void launch_main41(dim3 g, dim3 blk, hipStream_t s, const alg::AttnP& p) {
   switch (attn_pp()) {
@@ -1664,6 +1830,7 @@ static void launch_main41(dim3 g, dim3 blk, hipStream_t s, const alg::AttnP& p) 
     case 2: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<43, 8>), g, blk, 0, s, p); break;
     case 3: hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel<4>, dim3(g.x * 2), dim3(256), 0, s, p); break;   // two 128-query workgroups per unit
     case 4: hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel<8>, g, dim3(512), 0, s, p); break;             // experiment: one 8-wave workgroup per unit
+    case 5: hipLaunchKernelGGL(alg::flash_attn_d64_pipe64_kernel, g, dim3(256), 0, s, p); break;                // 64 queries per wave, one 4-wave workgroup per unit
     default: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<41, 8>), g, blk, 0, s, p); break;
   }
 }

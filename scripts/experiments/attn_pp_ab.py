@@ -50,7 +50,7 @@ for small in (64, 100, 256, 640, 1000, 4097, S):
     for pp in PPS:
         for rep in range(2):
             got = run(pp, small)
-            if pp in (3, 4, 64):   # row sums of unrounded probabilities inside the statement: close, not bit-equal
+            if pp in (3, 4, 5, 64):   # row sums of unrounded probabilities inside the statement: close, not bit-equal
                 err = (got.float() - ref.float()).abs().max().item()
                 print('pp', pp, 'S', small, 'max abs diff vs straight', err, flush=True)
                 if not (err < 2e-2):
