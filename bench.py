@@ -473,10 +473,16 @@ class _WanBase(Workload):
         total = sum(per_fwd.values()) + 4.0 * S * (512 + 257) * D
         extra["whole_step_tflops"] = total * forwards_local * L / elapsed / 1e12
         a = extra.get("attn_self_tflops", 0.0)
-        return dict(bound="mfma", kernel=self.attn_kernel, achieved=a, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=a / MFMA_PEAK_TFLOPS, traffic=None, launches=len(ms.get("attn_self", [])),
-                    mean_launch_ms=(sum(ms["attn_self"]) / len(ms["attn_self"])) if ms.get("attn_self") else None,
-                    extra=extra)
+        roofline = dict(bound="mfma", kernel=self.attn_kernel, achieved=a, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=a / MFMA_PEAK_TFLOPS, traffic=None, launches=len(ms.get("attn_self", [])),
+                        mean_launch_ms=(sum(ms["attn_self"]) / len(ms["attn_self"])) if ms.get("attn_self") else None,
+                        extra=extra)
+        # the committed PMC pass profiles the 2-sample Wan-480p launch (scripts/kbench.py --only attn128): that IS the C3 launch
+        tr = pmc_traffic(self.attn_kernel) if self.S == 32760 else None
+        if tr is not None:
+            roofline["traffic"] = tr["bytes_per_launch"]
+            roofline["traffic_detail"] = tr
+        return roofline
 
     def config(self, forwards):
         return {"workload": self.describe, "layers": self.layers, "tokens": self.S, "dit_sample_forwards": forwards}
