@@ -1825,11 +1825,14 @@ static int attn_pp() {
   return (v >= 0 && v <= 5) ? v : 4;
 }
 static void launch_main41(dim3 g, dim3 blk, hipStream_t s, const alg::AttnP& p) {
-  switch (attn_pp()) {
+  int pp = attn_pp();
+  // the pipelined statements address K / V^T / Q with 31-bit byte offsets from the (batch, head) panel bases
+  if (pp >= 3 && ((int64_t)(p.S + 4 * alg::KVB) * p.q_rs * 2 >= (1ll << 31) || (int64_t)65 * p.vt_rs * 2 >= (1ll << 31))) pp = 0;
+  switch (pp) {
     case 1: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<42, 8>), g, blk, 0, s, p); break;
     case 2: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<43, 8>), g, blk, 0, s, p); break;
     case 3: hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel<4>, dim3(g.x * 2), dim3(256), 0, s, p); break;   // two 128-query workgroups per unit
-    case 4: hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel<8>, g, dim3(512), 0, s, p); break;             // experiment: one 8-wave workgroup per unit
+    case 4: hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel<8>, g, dim3(512), 0, s, p); break;             // the default: one 8-wave workgroup per unit
     case 5: hipLaunchKernelGGL(alg::flash_attn_d64_pipe64_kernel, g, dim3(256), 0, s, p); break;                // 64 queries per wave, one 4-wave workgroup per unit
     default: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<41, 8>), g, blk, 0, s, p); break;
   }
