@@ -21,7 +21,7 @@ ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
 GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS, GEMM_GATE_F32, GEMM_GATE_SEG_STRIDE = 1, 4, 8, 16
 
 EXPORTS = (
-    "alg_version", "alg_last_error", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16",
+    "alg_version", "alg_last_error", "alg_reload_env", "alg_build_experiments", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16",
     "alg_flash_attn_d64", "alg_layernorm_modulate", "alg_qk_norm_rope", "alg_patchify", "alg_unpatchify",
     "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128", "alg_layernorm_mod_f32", "alg_layernorm_mod_f32_fp8", "alg_rmsnorm_rope",
     "alg_wan_modulation", "alg_patchify3d", "alg_unpatchify3d", "alg_timestep_embedding_f32", "alg_linear_f32",
@@ -88,6 +88,9 @@ def load_library():
     lib = ctypes.CDLL(LIB_PATH)
     lib.alg_version.restype = c_int
     lib.alg_last_error.restype = c_char_p
+    lib.alg_reload_env.restype = None
+    lib.alg_reload_env.argtypes = []
+    lib.alg_build_experiments.argtypes = []
     lib.alg_down_up.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_int64, c_void_p]
     lib.alg_gaussian_blur.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int64,
@@ -160,10 +163,20 @@ def load_library():
     lib.alg_timestep_embedding.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("alg_version", "alg_last_error"):
+        if name not in ("alg_version", "alg_last_error", "alg_reload_env"):
             fn.restype = c_int64 if name in _RET_I64 else c_int
     _lib = lib
     return lib
+
+
+def reload_env():
+    """The library reads its ALG_* options once, at load (include/alg_hip.h); call this after changing one in os.environ."""
+    load_library().alg_reload_env()
+
+
+def experiments_build():
+    """True for a `make EXPERIMENTS=1` library (opt-in kernels and timing-only ablations compiled in)."""
+    return bool(load_library().alg_build_experiments())
 
 
 def _check(rc, what):

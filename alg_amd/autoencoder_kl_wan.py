@@ -74,9 +74,14 @@ class _Act:
 
 
 class AutoencoderKLWan:
-    def __init__(self, config: Optional[AutoencoderKLWanConfig] = None, device="cuda", dtype=BF):
+    def __init__(self, config: Optional[AutoencoderKLWanConfig] = None, device="cuda", dtype=BF,
+                 posterior_dtype=torch.float32):
         self.config = config or AutoencoderKLWanConfig()
         c = self.config
+        # The reference loads this VAE in float32 (run:51-55), so `latent_dist.sample(generator)` of the pixel-space ALG
+        # branch (wan:526) draws float32 noise; torch's generator stream depends on the dtype, so the posterior keeps the
+        # reference's dtype although the convolutions compute in bf16.
+        self.posterior_dtype = posterior_dtype
         if dtype != BF:
             raise ValueError("the HIP VAE computes in bfloat16")
         if c.attn_scales:
@@ -487,7 +492,7 @@ class AutoencoderKLWan:
         B, _, T, H, W = x.shape
         if (T - 1) % 4 or H % 8 or W % 8:
             raise ValueError("encode() takes 4k + 1 frames with H, W multiples of 8 (got %d x %d x %d)" % (T, H, W))
-        mom = torch.stack([self._encode_one(x[b].to(BF)) for b in range(B)])
+        mom = torch.stack([self._encode_one(x[b].to(BF)) for b in range(B)]).to(self.posterior_dtype)
         dist = DiagonalGaussianDistribution(mom)
         return AutoencoderKLOutput(latent_dist=dist) if return_dict else (dist,)
 

@@ -680,705 +680,6 @@ __global__ __launch_bounds__(NW * 64, (VARIANT == 2 ? 2 : 4)) void flash_attn_d6
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Variant 3: same tiling as variant 1, with the per-score VALU work cut down.  Measured on variants 1/2
-// (rocprofv3 PMC): a KV tile costs a wave ~150 VALU instructions against 16 MFMAs, and MFMA issue shares the SIMD's
-// VALU issue slot, so at d = 64 the softmax -- not the matrix pipe -- bounds the kernel.  Changes:
-//   * Q is pre-multiplied by scale*log2(e) once per workgroup and the MFMA accumulator chain STARTS from -m (the
-//     running max, replicated over the 16 accumulator registers, which all belong to the lane's query): the matrix
-//     pipe hands back s*c - m*c directly, so the common case is p = exp2(acc) with no per-score fma;
-//   * row sums accumulate as float2 (v_pk_add_f32): 16 adds instead of 32;
-//   * the half-wave max exchange is a v_permlane32_swap (VALU) instead of an LDS bpermute round trip;
-//   * per-tile DMA addresses advance by a constant stride; the row clamp only exists on the last tile.
-// The max / rescale bookkeeping is exact (same m, l, O as variant 1 up to the rounding of q*c to bf16).
-// ---------------------------------------------------------------------------------------------------------------
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-
-// MSEED = false: the accumulator chain is seeded with a register vector holding -m (costs 16 v_mov_b64 per tile because
-//                 hipcc ties the MFMA's C and D operands);
-// MSEED = true : -m enters through one extra MFMA k-step per sub-tile instead: A = ones in k-slots 0..2, B = the three
-//                 bf16 pieces (hi, mid, lo) of -m, which reproduce the fp32 value exactly; the chain starts from the
-//                 inline constant 0, so the per-tile VALU copies disappear at the price of 18 instead of 16 MFMAs.
-template <bool MSEED>
-__global__ __launch_bounds__(ATT_THREADS, 4) void flash_attn_d64_lean_kernel(const AttnP p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE];
-  char* const k_ring = smem;
-  char* const v_ring = smem + 2 * ATT_TILE;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, h2 = lane >> 5;
-
-  const int nbh = p.batch * p.heads;
-  int bh, qb;
-  {
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int slot = idx / p.q_blocks;
-    qb = idx - slot * p.q_blocks;
-    bh = slot * 8 + xcd;
-    if (bh >= nbh) return;
-  }
-  const int b = bh / p.heads, h = bh - b * p.heads;
-  const int S = p.S;
-  const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 64;
-  const bf16_t* K = p.k + (int64_t)b * p.q_bs + h * 64;
-  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
-
-  // Q^T fragments, pre-scaled by c = scale * log2(e) (one extra bf16 rounding of q*c, see header)
-  const int q_row = qb * QB + wave * 32 + l31;
-  const float c = p.scale_log2;
-  bf16x8 qf[4];
-  {
-    const bf16_t* qp = Q + (int64_t)min(q_row, S - 1) * p.q_rs + h2 * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      union { bf16x8 v; uint32_t u[4]; } raw, sc;
-      raw.v = *(const bf16x8*)(qp + ks * 16);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        sc.u[j] = pack_bf2(__uint_as_float(raw.u[j] << 16) * c, __uint_as_float(raw.u[j] & 0xffff0000u) * c);
-      qf[ks] = sc.v;
-    }
-  }
-
-  const int srow = tid >> 3;
-  const int sslot = (tid & 7) ^ ((tid >> 4) & 7);
-  const bf16_t* vt_src = VT + (int64_t)srow * p.vt_rs + sslot * 8;
-  const bf16_t* k_src = K + (int64_t)min(srow, S - 1) * p.q_rs + sslot * 8;   // tile 0
-  const int64_t k_step = (int64_t)KVB * p.q_rs;
-  const int n_tiles = (S + KVB - 1) / KVB;
-  const bool ragged = (S & (KVB - 1)) != 0;
-  auto stage = [&](int slot, int t) {  // tile t: K rows [64 t, 64 t + 64), V^T columns likewise
-    const bf16_t* ks = k_src + t * k_step;
-    if (ragged && t == n_tiles - 1) ks = K + (int64_t)min(t * KVB + srow, S - 1) * p.q_rs + sslot * 8;
-    __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + slot * ATT_TILE + wave * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(vt_src + t * KVB), (lptr_t)(v_ring + slot * ATT_TILE + wave * 1024), 16,
-                                     0, 0);
-  };
-
-  Frag f;
-  f.row_off = l31 * 128;
-  f.sw = (l31 >> 1) & 7;
-  f.h2 = h2;
-
-  f32x16 o_acc[2], negm;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    o_acc[0][e] = 0.0f;
-    o_acc[1][e] = 0.0f;
-    negm[e] = 0.0f;  // first tile runs against m = 0 and then adopts its own max
-  }
-  float m_run = 0.0f;  // running max in scaled (log2) units
-  float l_run = 0.0f;
-  // MSEED operands: ones in k-slots 0..2 of the lower half-wave (k = 8 h2 + j), and -m split into three bf16 pieces
-  bf16x8 ones_f, negm_f;
-  {
-    union { bf16x8 v; uint32_t u[4]; } a;
-    a.u[0] = h2 ? 0u : 0x3f803f80u;  // (1.0, 1.0)
-    a.u[1] = h2 ? 0u : 0x00003f80u;  // (1.0, 0)
-    a.u[2] = 0u;
-    a.u[3] = 0u;
-    ones_f = a.v;
-    a.u[0] = a.u[1] = 0u;
-    negm_f = a.v;
-  }
-
-  stage(0, 0);
-  for (int t = 0; t < n_tiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < n_tiles) stage((t + 1) & 1, t + 1);
-    const char* Ks = k_ring + (t & 1) * ATT_TILE;
-    const char* Vs = v_ring + (t & 1) * ATT_TILE;
-
-    // s[sub] = K[sub] (c Q)^T - m   (accumulator chain seeded with -m)
-    f32x16 s[2];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      bf16x8 kf = *(const bf16x8*)(Ks + f.row_off + sub * 4096 + ((h2 ^ f.sw) * 16));
-      if (MSEED) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[sub][e] = 0.0f;
-        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_f, negm_f, s[sub], 0, 0, 0);
-        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], s[sub], 0, 0, 0);
-      } else {
-        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], negm, 0, 0, 0);
-      }
-#pragma unroll
-      for (int ks = 1; ks < 4; ++ks) {
-        kf = *(const bf16x8*)(Ks + f.row_off + sub * 4096 + (((2 * ks + h2) ^ f.sw) * 16));
-        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sub], 0, 0, 0);
-      }
-    }
-    if (ragged && t == n_tiles - 1) mask_tail(s, t * KVB, S, h2);
-
-    float mt = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-    for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
-    {
-      // other half-wave's max: after the swap r[0] = mt[lane & 31], r[1] = mt[32 + (lane & 31)] in every lane
-      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
-      mt = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    }
-    // mt is the tile max RELATIVE to the running max: growth iff mt > 0 (always adopt it on the first tile)
-    float d = 0.0f;
-    const bool first = t == 0;
-    if (first || __any(mt > 0.0f)) {
-      d = first ? mt : fmaxf(mt, 0.0f);
-      const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);   // first tile: O = l = 0, nothing to rescale
-      m_run += d;
-      l_run *= alpha;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        o_acc[0][e] *= alpha;
-        o_acc[1][e] *= alpha;
-        if (!MSEED) negm[e] = -m_run;
-      }
-      if (MSEED) {
-        // -m = hi + mid + lo exactly (3 x 8 mantissa bits); only the lower half-wave's k-slots are live
-        const float nm = -m_run;
-        const float hi = rbf(nm), r1 = nm - hi;
-        const float mid = rbf(r1), lo = r1 - mid;
-        union { bf16x8 v; uint32_t u[4]; } a;
-        a.u[0] = h2 ? 0u : pack_bf2(hi, mid);
-        a.u[1] = h2 ? 0u : (pack_bf2(lo, 0.0f) & 0xffffu);
-        a.u[2] = 0u;
-        a.u[3] = 0u;
-        negm_f = a.v;
-      }
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[sub][e] -= d;
-    }
-    f32x2v psum2 = {0.0f, 0.0f};
-    bf16x8 pf[4];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        union { bf16x8 v; uint32_t u[4]; } pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x2v pp;
-          pp[0] = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j]);
-          pp[1] = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j + 1]);
-          pk.u[j] = pack_bf2(pp[0], pp[1]);
-          {  // row sum of the rounded pair in one v_dot2c_f32_bf16 (see variant 32)
-            typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
-            psum2[0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk.u[j]),
-                                                      __builtin_bit_cast(bf2v, 0x3f803f80u), psum2[0], false);
-          }
-        }
-        pf[sub * 2 + g] = pk.v;
-      }
-    l_run += psum2[0] + psum2[1];
-    pv_tile(Vs, pf, f, o_acc);
-  }
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  if (q_row < S) {
-    bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = dt * 32 + 8 * g + 4 * h2;
-        uint2 v;
-        v.x = pack_bf2(o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv);
-        v.y = pack_bf2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
-        *(uint2*)(op + d) = v;
-      }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Variant 6: 64 queries per wave (two independent 32-query groups that share every K / V^T fragment read).
-// Ablations on the GEMM (same LDS-DMA + ds_read_b128 + MFMA structure) showed that LDS traffic does not hide behind
-// the matrix pipe: at 32 queries per wave this kernel needs 16 KiB of fragment reads per 16 MFMAs -- 256 B/clk/CU at
-// full MFMA rate, the LDS peak.  Sharing each fragment between two query groups halves that (and halves the DMA per
-// MFMA: a workgroup now covers NW*64 queries).  The two groups are independent instruction streams inside one wave, so
-// one group's MFMAs run under the other group's softmax.
-// ---------------------------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const AttnP p) {
-  constexpr int ROUNDS = 8 / NW;
-  __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE];
-  char* const k_ring = smem;
-  char* const v_ring = smem + 2 * ATT_TILE;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, h2 = lane >> 5;
-
-  const int nbh = p.batch * p.heads;
-  int bh, qb;
-  {
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int slot = idx / p.q_blocks;
-    qb = idx - slot * p.q_blocks;
-    bh = slot * 8 + xcd;
-    if (bh >= nbh) return;
-  }
-  const int b = bh / p.heads, h = bh - b * p.heads;
-  const int S = p.S;
-  const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 64;
-  const bf16_t* K = p.k + (int64_t)b * p.q_bs + h * 64;
-  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
-
-  int q_row[2];
-  bf16x8 qf[2][4];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    q_row[g] = qb * (NW * 64) + wave * 64 + g * 32 + l31;
-    const bf16_t* qp = Q + (int64_t)min(q_row[g], S - 1) * p.q_rs + h2 * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[g][ks] = *(const bf16x8*)(qp + ks * 16);
-  }
-
-  const int srow = tid >> 3;
-  const int sslot = (tid & 7) ^ ((tid >> 4) & 7);
-  const bf16_t* vt_src = VT + (int64_t)srow * p.vt_rs + sslot * 8;
-  auto stage = [&](int slot, int kv0) {
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) {
-      const bf16_t* ks = K + (int64_t)min(kv0 + srow + i * NW * 8, S - 1) * p.q_rs + sslot * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + slot * ATT_TILE + (i * NW + wave) * 1024), 16, 0,
-                                       0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(vt_src + (int64_t)i * NW * 8 * p.vt_rs + kv0),
-                                       (lptr_t)(v_ring + slot * ATT_TILE + (i * NW + wave) * 1024), 16, 0, 0);
-    }
-  };
-
-  const int row_off = l31 * 128, sw = (l31 >> 1) & 7;
-  f32x16 o_acc[2][2];
-#pragma unroll
-  for (int g = 0; g < 2; ++g)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o_acc[g][i][e] = 0.0f;
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
-  const float c = p.scale_log2;
-  const int n_tiles = (S + KVB - 1) / KVB;
-  const bool ragged = (S & (KVB - 1)) != 0;
-
-  stage(0, 0);
-  for (int t = 0; t < n_tiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < n_tiles) stage((t + 1) & 1, (t + 1) * KVB);
-    const char* Ks = k_ring + (t & 1) * ATT_TILE;
-    const char* Vs = v_ring + (t & 1) * ATT_TILE;
-
-    // S^T for both query groups from ONE read of each K fragment
-    f32x16 s[2][2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[g][sub][e] = 0.0f;
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(Ks + row_off + sub * 4096 + (((2 * ks + h2) ^ sw) * 16));
-        s[0][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], s[0][sub], 0, 0, 0);
-        s[1][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], s[1][sub], 0, 0, 0);
-      }
-    bf16x8 pf[2][4];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      if (ragged && t == n_tiles - 1) mask_tail(s[g], t * KVB, S, h2);
-      softmax_tile_lazy(s[g], c, m_run[g], l_run[g], o_acc[g], pf[g]);
-    }
-    // O^T for both groups from ONE read of each V^T fragment
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const bf16x8 vf = *(const bf16x8*)(Vs + row_off + dt * 4096 + (((2 * kk + h2) ^ sw) * 16));
-        o_acc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0][kk], o_acc[0][dt], 0, 0, 0);
-        o_acc[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1][kk], o_acc[1][dt], 0, 0, 0);
-      }
-  }
-
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const float l_tot = l_run[g] + __shfl_xor(l_run[g], 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (q_row[g] < S) {
-      bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row[g] * p.o_rs + h * 64;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-          const int d = dt * 32 + 8 * gg + 4 * h2;
-          uint2 v;
-          v.x = pack_bf2(o_acc[g][dt][4 * gg] * inv, o_acc[g][dt][4 * gg + 1] * inv);
-          v.y = pack_bf2(o_acc[g][dt][4 * gg + 2] * inv, o_acc[g][dt][4 * gg + 3] * inv);
-          *(uint2*)(op + d) = v;
-        }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Variant 8 / 9: variant 1 with TWO 64-row KV tiles per ring stage (one workgroup barrier per 128 kv instead of per
-// 64; 64 KiB of LDS per workgroup, still two workgroups per CU) and, for 9, s_setprio(1) around the MFMA clusters.
-// ---------------------------------------------------------------------------------------------------------------
-template <bool PRIO>
-__global__ __launch_bounds__(512, 4) void flash_attn_d64_kv128_kernel(const AttnP p) {
-  constexpr int STAGE = 4 * ATT_TILE;  // K0 K1 V0 V1
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, h2 = lane >> 5;
-  const int nbh = p.batch * p.heads;
-  int bh, qb;
-  {
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-    const int slot = idx / p.q_blocks;
-    qb = idx - slot * p.q_blocks;
-    bh = slot * 8 + xcd;
-    if (bh >= nbh) return;
-  }
-  const int b = bh / p.heads, h = bh - b * p.heads, S = p.S;
-  const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 64;
-  const bf16_t* K = p.k + (int64_t)b * p.q_bs + h * 64;
-  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
-  const int q_row = qb * 256 + wave * 32 + l31;
-  bf16x8 qf[4];
-  {
-    const bf16_t* qp = Q + (int64_t)min(q_row, S - 1) * p.q_rs + h2 * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-  }
-  const int srow = tid >> 3, sslot = (tid & 7) ^ ((tid >> 4) & 7);
-  const bf16_t* v_src = VT + (int64_t)srow * p.vt_rs + sslot * 8;
-  const int n_tiles = (S + KVB - 1) / KVB;       // 64-row tiles
-  const int n_stages = (n_tiles + 1) / 2;
-  const bool ragged = (S & (KVB - 1)) != 0;
-  // stage st holds tiles 2 st and 2 st + 1 (the second may lie entirely beyond S: its K rows clamp to S-1, its V^T
-  // columns are the zero pad -- vt rows cover S rounded up to 128 -- and its scores are masked)
-  auto stage = [&](int buf, int st) {
-    char* base = smem + buf * STAGE;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int kv0 = (2 * st + j) * KVB;
-      const bf16_t* ks = K + (int64_t)min(kv0 + srow, S - 1) * p.q_rs + sslot * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(base + j * ATT_TILE + wave * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(v_src + kv0), (lptr_t)(base + (2 + j) * ATT_TILE + wave * 1024), 16, 0,
-                                       0);
-    }
-  };
-  Frag f;
-  f.row_off = l31 * 128;
-  f.sw = (l31 >> 1) & 7;
-  f.h2 = h2;
-  f32x16 o_acc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o_acc[i][e] = 0.0f;
-  float m_run = -INFINITY, l_run = 0.0f;
-  const float c = p.scale_log2;
-  stage(0, 0);
-  for (int st = 0; st < n_stages; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (st + 1 < n_stages) stage((st + 1) & 1, st + 1);
-    const char* base = smem + (st & 1) * STAGE;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int t = 2 * st + j;
-      if (t < n_tiles) {
-        f32x16 s[2];
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-        qk_tile(base + j * ATT_TILE, qf, f, s);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (ragged && t == n_tiles - 1) mask_tail(s, t * KVB, S, h2);
-        bf16x8 pf[4];
-        softmax_tile_lazy(s, c, m_run, l_run, o_acc, pf);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-        pv_tile(base + (2 + j) * ATT_TILE, pf, f, o_acc);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-      }
-    }
-  }
-  const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
-  if (q_row < S) {
-    bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 v;
-        v.x = pack_bf2(o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv);
-        v.y = pack_bf2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
-        *(uint2*)(op + dt * 32 + 8 * g + 4 * h2) = v;
-      }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Variant 15/16 "duo": two 32-query streams per wave, staggered so one stream's MFMAs issue BETWEEN the other
-// stream's softmax instructions.  Measured on the box (scripts/micro/*.hip): a wave issues in order, so a cluster of
-// 8 MFMAs holds the wave for 8 x 32 cycles and the VALU work behind it cannot start; across waves the SIMD overlaps
-// an MFMA phase with a VALU phase only partially (4 waves alternating 16 MFMA / 64 v_exp: 61 % matrix-pipe busy), while
-// one wave that interleaves them finely (1 MFMA : 2 v_exp, or 1 : 7 v_fma) keeps the pipe 86-98 % busy.  Per tile:
-//     R1  S_A = K Q_A^T                          (8 MFMA)
-//     R2  S_B = K Q_B^T   ||  softmax(S_A) -> P_A (8 MFMA interleaved with ~125 VALU, sched_group_barrier)
-//     R3  O_A += V^T P_A  ||  softmax(S_B) -> P_B
-//     R4  O_B += V^T P_B
-// Both streams share every K / V^T fragment read (half the LDS traffic per MFMA) and the workgroup stages K/V once
-// per NW*64 queries.  ~230 VGPRs -> 2 waves per SIMD.  The rescale is unconditional (a branch would split the
-// scheduling region); the ragged tail tile runs a masked, non-interleaved copy.
-// ---------------------------------------------------------------------------------------------------------------
-#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-
-template <int NW, bool LAZY_ = false, int SG = 10>
-__global__ __launch_bounds__(NW * 64, 2) void flash_attn_d64_duo_kernel(const AttnP p) {
-  constexpr bool LAZY = LAZY_;  // lazy running max + dot2 row sums (see softmax_tile_lazy): the common path has no branch
-                                // inside a scheduling region; the exact-max fix-up sits between the regions
-  constexpr int ROUNDS = 8 / NW;
-  __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE];
-  char* const k_ring = smem;
-  char* const v_ring = smem + 2 * ATT_TILE;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, h2 = lane >> 5;
-
-  const int nbh = p.batch * p.heads;
-  int bh, qb;
-  {
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int slot = idx / p.q_blocks;
-    qb = idx - slot * p.q_blocks;
-    bh = slot * 8 + xcd;
-    if (bh >= nbh) return;
-  }
-  const int b = bh / p.heads, h = bh - b * p.heads;
-  const int S = p.S;
-  const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 64;
-  const bf16_t* K = p.k + (int64_t)b * p.q_bs + h * 64;
-  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
-
-  int q_row[2];
-  bf16x8 qf[2][4];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    q_row[g] = qb * (NW * 64) + wave * 64 + g * 32 + l31;
-    const bf16_t* qp = Q + (int64_t)min(q_row[g], S - 1) * p.q_rs + h2 * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[g][ks] = *(const bf16x8*)(qp + ks * 16);
-  }
-
-  const int srow = tid >> 3;
-  const int sslot = (tid & 7) ^ ((tid >> 4) & 7);
-  const bf16_t* vt_src = VT + (int64_t)srow * p.vt_rs + sslot * 8;
-  auto stage = [&](int slot, int kv0) {
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) {
-      const bf16_t* ks = K + (int64_t)min(kv0 + srow + i * NW * 8, S - 1) * p.q_rs + sslot * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + slot * ATT_TILE + (i * NW + wave) * 1024), 16, 0,
-                                       0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(vt_src + (int64_t)i * NW * 8 * p.vt_rs + kv0),
-                                       (lptr_t)(v_ring + slot * ATT_TILE + (i * NW + wave) * 1024), 16, 0, 0);
-    }
-  };
-
-  const int row_off = l31 * 128, sw = (l31 >> 1) & 7;
-  f32x16 o_acc[2][2];
-#pragma unroll
-  for (int g = 0; g < 2; ++g)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o_acc[g][i][e] = 0.0f;
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
-  const float c = p.scale_log2;
-  const int n_tiles = (S + KVB - 1) / KVB;
-  const bool ragged = (S & (KVB - 1)) != 0;
-
-  // softmax of one stream's tile, branch-free: always rescales (alpha == 1 when the max did not grow)
-  auto softmax = [&](f32x16 (&s)[2], float& m, float& l, f32x16 (&o)[2], bf16x8 (&pf)[4]) {
-    float mt = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-    for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
-    {
-      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
-      mt = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    }
-    const float m_new = fmaxf(m, mt);
-    const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
-    m = m_new;
-    l *= alpha;
-    o[0] *= alpha;
-    o[1] *= alpha;
-    const float mc = m_new * c;
-    const f32x2p c2 = {c, c}, mc2 = {mc, mc};
-    f32x2p ps2 = {0.0f, 0.0f};
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        union { bf16x8 v; uint32_t u[4]; } pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x2p sv = {s[sub][8 * g + 2 * j], s[sub][8 * g + 2 * j + 1]};
-          const f32x2p x = __builtin_elementwise_fma(sv, c2, -mc2);
-          const f32x2p pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-          ps2 += pv;
-          pk.u[j] = pack_bf2(pv.x, pv.y);
-        }
-        pf[sub * 2 + g] = pk.v;
-      }
-    l += ps2.x + ps2.y;
-  };
-  // LAZY: probabilities against the current m (straight-line: 32 fma, 32 exp, 16 pack, 16 dot2), the row sum is returned
-  auto soft_fast = [&](const f32x16 (&s)[2], float m, bf16x8 (&pf)[4]) -> float {
-    typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
-    const float mc = m * c;
-    float psum = 0.0f;
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        union { bf16x8 v; uint32_t u[4]; } pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float p0 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j] * c - mc);
-          const float p1 = __builtin_amdgcn_exp2f(s[sub][8 * g + 2 * j + 1] * c - mc);
-          pk.u[j] = pack_bf2(p0, p1);
-          psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk.u[j]), __builtin_bit_cast(bf2v, 0x3f803f80u),
-                                                 psum, false);
-        }
-        pf[sub * 2 + g] = pk.v;
-      }
-    return psum;
-  };
-  // LAZY fix-up between two scheduling regions: exact tile max, grow m, rescale, recompute (rare)
-  auto soft_fix = [&](const f32x16 (&s)[2], float& psum, float& m, float& l, f32x16 (&o)[2], bf16x8 (&pf)[4]) {
-    if (__any(!(psum < 1.0995116e12f))) {
-      float mt = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-      for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = fmaxf(m, mt);
-      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
-      m = m_new;
-      l *= alpha;
-      o[0] *= alpha;
-      o[1] *= alpha;
-      psum = soft_fast(s, m, pf);
-    }
-    l += psum;
-  };
-  auto qk = [&](const bf16x8 (&kf)[8], const bf16x8 (&q)[4], f32x16 (&s)[2]) {
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[sub][e] = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub * 4 + ks], q[ks], s[sub], 0, 0, 0);
-  };
-  auto pv = [&](const bf16x8 (&vf)[8], const bf16x8 (&pf)[4], f32x16 (&o)[2]) {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt * 4 + kk], pf[kk], o[dt], 0, 0, 0);
-  };
-
-  stage(0, 0);
-  auto tile = [&](int t, auto masked) {
-    constexpr bool MASK = decltype(masked)::value;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < n_tiles) stage((t + 1) & 1, (t + 1) * KVB);
-    const char* Ks = k_ring + (t & 1) * ATT_TILE + row_off;
-    const char* Vs = v_ring + (t & 1) * ATT_TILE + row_off;
-    bf16x8 kf[8], vf[8], pfa[4], pfb[4];
-    f32x16 sa[2], sb[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) kf[i] = *(const bf16x8*)(Ks + (i >> 2) * 4096 + (((2 * (i & 3) + h2) ^ sw) * 16));
-    __builtin_amdgcn_sched_barrier(0);
-    // R1
-    qk(kf, qf[0], sa);
-    if (MASK) mask_tail(sa, t * KVB, S, h2);
-    __builtin_amdgcn_sched_barrier(0);
-    // R2: QK of stream B between the softmax instructions of stream A; the V^T fragments follow the last K use
-    qk(kf, qf[1], sb);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) vf[i] = *(const bf16x8*)(Vs + (i >> 2) * 4096 + (((2 * (i & 3) + h2) ^ sw) * 16));
-    float psa = 0.0f, psb = 0.0f;
-    if (LAZY)
-      psa = soft_fast(sa, m_run[0], pfa);
-    else
-      softmax(sa, m_run[0], l_run[0], o_acc[0], pfa);
-    if (!MASK) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        SGB(0x008, 1);               // 1 MFMA
-        SGB(0x402, LAZY ? SG : 14);  // VALU / transcendental
-      }
-      SGB(0x100, 8);                 // the 8 V^T fragment reads
-      SGB(0x402, 40);                // the rest of the softmax
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (LAZY) soft_fix(sa, psa, m_run[0], l_run[0], o_acc[0], pfa);
-    if (MASK) mask_tail(sb, t * KVB, S, h2);
-    // R3: PV of stream A between the softmax instructions of stream B
-    pv(vf, pfa, o_acc[0]);
-    if (LAZY)
-      psb = soft_fast(sb, m_run[1], pfb);
-    else
-      softmax(sb, m_run[1], l_run[1], o_acc[1], pfb);
-    if (!MASK) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        SGB(0x008, 1);
-        SGB(0x402, LAZY ? SG : 14);
-      }
-      SGB(0x402, 40);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (LAZY) soft_fix(sb, psb, m_run[1], l_run[1], o_acc[1], pfb);
-    // R4
-    pv(vf, pfb, o_acc[1]);
-  };
-  const int n_loop = ragged ? n_tiles - 1 : n_tiles;
-  for (int t = 0; t < n_loop; ++t) tile(t, BoolC<false>{});
-  if (ragged) tile(n_tiles - 1, BoolC<true>{});
-
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const float l_tot = l_run[g] + __shfl_xor(l_run[g], 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (q_row[g] < S) {
-      bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row[g] * p.o_rs + h * 64;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-          const int d = dt * 32 + 8 * gg + 4 * h2;
-          uint2 v;
-          v.x = pack_bf2(o_acc[g][dt][4 * gg] * inv, o_acc[g][dt][4 * gg + 1] * inv);
-          v.y = pack_bf2(o_acc[g][dt][4 * gg + 2] * inv, o_acc[g][dt][4 * gg + 3] * inv);
-          *(uint2*)(op + d) = v;
-        }
-    }
-  }
-}
-
 // Merge of the split-KV tail: O = sum_c 2^((m_c - M) c) O_c / sum_c 2^((m_c - M) c) l_c.  One thread = 4 output values.
 __global__ __launch_bounds__(256) void flash_attn_d64_merge_kernel(const AttnP p) {
   constexpr int QBR = 256;  // query rows per unit (8 waves x 32)
@@ -1608,170 +909,9 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_pipe_kernel(const Attn
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Pipelined form with 64 QUERIES PER WAVE (ALG_ATTN_PP=5; attn_pipe64_loop.inc, scripts/gen_attn_pipe64.py): four waves = one
-// 256-query unit per workgroup, one wave per SIMD; every K / V^T fragment read from LDS feeds two MFMAs (one per 32-query half),
-// i.e. half the fragment traffic per MFMA of flash_attn_d64_pipe_kernel.  Same frame, protocol and bail-out rules; the wave
-// carries two independent softmax states (one per half), the statement needs both offsets at zero.
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void flash_attn_d64_pipe64_kernel(const AttnP p) {
-  constexpr int NW = 4;
-  __shared__ __attribute__((aligned(16))) char smem[8 * ATT_TILE];
-  char* const k_ring = smem;
-  char* const v_ring = smem + 4 * ATT_TILE;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int nbh = p.batch * p.heads;
-  int bh, qb;
-  {
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int unit = bid >> 3;
-    const int slot = unit / p.q_blocks;
-    qb = unit - slot * p.q_blocks;
-    bh = slot * 8 + xcd;
-    if (bh >= nbh) return;
-  }
-  const int b = bh / p.heads, h = bh - b * p.heads;
-  const int S = p.S;
-  const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 64;
-  const bf16_t* K = p.k + (int64_t)b * p.q_bs + h * 64;
-  const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
-  const int T = (S + KVB - 1) / KVB;
-  const bool ragged = (S & (KVB - 1)) != 0;
-  f32x16 oa[2][2];
-#pragma unroll
-  for (int i = 0; i < 64; ++i) oa[i >> 5][(i >> 4) & 1][i & 15] = 0.0f;
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
-
-  struct LaneCtx {
-    int lane, l31, h2, tid, srow, sslot, q_row;   // q_row: of half 0; half 1 is 32 rows further
-    Frag f;
-  };
-  auto make_ctx = [&](int lane) -> LaneCtx {
-    LaneCtx c;
-    c.lane = lane, c.l31 = lane & 31, c.h2 = lane >> 5, c.tid = wave * 64 + lane;
-    c.srow = c.tid >> 3, c.sslot = (c.tid & 7) ^ ((c.tid >> 4) & 7);
-    c.q_row = qb * 256 + wave * 64 + c.l31;
-    c.f.row_off = c.l31 * 128, c.f.sw = (c.l31 >> 1) & 7, c.f.h2 = c.h2;
-    return c;
-  };
-  auto fresh_lane = [&]() -> int {
-    int z = 0;
-    asm volatile("" : "+s"(z));
-    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
-  };
-  auto stage_k = [&](const LaneCtx& c, int t) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bf16_t* ks = K + (int64_t)min(t * KVB + c.srow + 32 * i, S - 1) * p.q_rs + c.sslot * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + (t & 3) * ATT_TILE + (i * NW + wave) * 1024), 16, 0, 0);
-    }
-  };
-  auto stage_v = [&](const LaneCtx& c, int t) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(VT + (int64_t)(c.srow + 32 * i) * p.vt_rs + c.sslot * 8 + min(t, T - 1) * KVB),
-                                       (lptr_t)(v_ring + (t & 3) * ATT_TILE + (i * NW + wave) * 1024), 16, 0, 0);
-  };
-  auto straight = [&](const LaneCtx& c, int t, int t_end, bool top_done) {
-    for (; t < t_end; ++t) {
-      if (!top_done) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __syncthreads();
-        stage_k(c, t + 3);
-        stage_v(c, t + 2);
-      }
-      top_done = false;
-#pragma unroll
-      for (int qh = 0; qh < 2; ++qh) {
-        bf16x8 qf[4];
-        const bf16_t* qp = Q + (int64_t)min(c.q_row + 32 * qh, S - 1) * p.q_rs + c.h2 * 8;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-        f32x16 s[2];
-        qk_tile(k_ring + (t & 3) * ATT_TILE, qf, c.f, s);
-        if (ragged && t == T - 1) mask_tail(s, t * KVB, S, c.h2);
-        bf16x8 pf[4];
-        softmax_tile_zero(s, m_run[qh], l_run[qh], oa[qh], pf);
-        pv_tile(v_ring + (t & 3) * ATT_TILE, pf, c.f, oa[qh]);
-      }
-    }
-  };
-
-  const int tend = ragged ? T - 4 : T - 3;
-  int t = 1;
-  bool top_done = false;
-  {
-    const LaneCtx c = make_ctx(fresh_lane());
-    stage_k(c, 0);
-    stage_k(c, 1);
-    stage_v(c, 0);
-    stage_v(c, 0);       // (filler: four DMAs per batch)
-    stage_k(c, 2);
-    stage_v(c, 1);
-    straight(c, 0, 1, false);
-  }
-  if (1 + 4 <= tend && __all(m_run[0] == 0.0f && m_run[1] == 0.0f)) {
-    const LaneCtx c = make_ctx(fresh_lane());
-    auto sreg = [](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
-    auto uniform64 = [](const void* ptr) -> uint64_t {
-      const uint64_t v = (uint64_t)(uintptr_t)ptr;
-      return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    };
-    const uint32_t kl = (uint32_t)(uintptr_t)(lptr_t)k_ring, vl = (uint32_t)(uintptr_t)(lptr_t)v_ring;
-    const int fl0 = c.f.row_off + (((0 + c.h2) ^ c.f.sw) * 16), fl1 = c.f.row_off + (((2 + c.h2) ^ c.f.sw) * 16);
-    const int fl2 = c.f.row_off + (((4 + c.h2) ^ c.f.sw) * 16), fl3 = c.f.row_off + (((6 + c.h2) ^ c.f.sw) * 16);
-    const int lk0 = kl + fl0, lk1 = kl + fl1, lk2 = kl + fl2, lk3 = kl + fl3;
-    const int lv0 = vl + fl0, lv1 = vl + fl1, lv2 = vl + fl2, lv3 = vl + fl3;
-    int kvo0 = (int)(((int64_t)((t + 3) * KVB + c.srow) * p.q_rs + c.sslot * 8) * 2);
-    int kvo1 = (int)(((int64_t)((t + 3) * KVB + c.srow + 32) * p.q_rs + c.sslot * 8) * 2);
-    int vvo0 = (int)(((int64_t)c.srow * p.vt_rs + c.sslot * 8 + (t + 2) * KVB) * 2);
-    int vvo1 = (int)(((int64_t)(c.srow + 32) * p.vt_rs + c.sslot * 8 + (t + 2) * KVB) * 2);
-    const int qvo0 = (int)(((int64_t)min(c.q_row, S - 1) * p.q_rs + c.h2 * 8) * 2);
-    const int qvo1 = (int)(((int64_t)min(c.q_row + 32, S - 1) * p.q_rs + c.h2 * 8) * 2);
-    const uint64_t kb = uniform64(K), vb = uniform64(VT), qbs = uniform64(Q);
-    const int kstep = sreg((int)(KVB * p.q_rs * 2)), tend_s = sreg(tend);
-    const int wk = sreg((int)kl + wave * 1024), wv = sreg((int)vl + wave * 1024);
-    int ts = sreg(t), code;
-    float o[64];
-#pragma unroll
-    for (int i = 0; i < 64; ++i) o[i] = oa[i >> 5][(i >> 4) & 1][i & 15];
-    asm volatile(ALG_ATTN_PIPE64_LOOP_ASM
-                 : ALG_ATTN_PIPE64_O_OPERANDS(o), [l0] "+v"(l_run[0]), [l1] "+v"(l_run[1]), [t] "+s"(ts), [code] "=&s"(code),
-                   [kvo0] "+v"(kvo0), [kvo1] "+v"(kvo1), [vvo0] "+v"(vvo0), [vvo1] "+v"(vvo1)
-                 : [lk0] "v"(lk0), [lk1] "v"(lk1), [lk2] "v"(lk2), [lk3] "v"(lk3), [lv0] "v"(lv0), [lv1] "v"(lv1),
-                   [lv2] "v"(lv2), [lv3] "v"(lv3), [qvo0] "v"(qvo0), [qvo1] "v"(qvo1), [kb] "s"(kb), [vb] "s"(vb), [qb] "s"(qbs),
-                   [kstep] "s"(kstep), [tend] "s"(tend_s), [wk] "s"(wk), [wv] "s"(wv)
-                 : "memory", "vcc", "scc", ALG_ATTN_PIPE64_CLOBBERS);
-#pragma unroll
-    for (int i = 0; i < 64; ++i) oa[i >> 5][(i >> 4) & 1][i & 15] = o[i];
-    t = ts;
-    top_done = code != 0;
-  }
-  LaneCtx c = make_ctx(fresh_lane());
-  straight(c, t, T, top_done);
-
-#pragma unroll
-  for (int qh = 0; qh < 2; ++qh) {
-    const float l_tot = l_run[qh] + __shfl_xor(l_run[qh], 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int q_row = c.q_row + 32 * qh;
-    if (q_row < S) {
-      bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + h * 64;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = dt * 32 + 8 * g + 4 * c.h2;
-          uint2 v;
-          v.x = pack_bf2(oa[qh][dt][4 * g] * inv, oa[qh][dt][4 * g + 1] * inv);
-          v.y = pack_bf2(oa[qh][dt][4 * g + 2] * inv, oa[qh][dt][4 * g + 3] * inv);
-          *(uint2*)(op + d) = v;
-        }
-    }
-  }
-}
+#ifdef ALG_EXPERIMENTS
+#include "attention_experiments.inc"
+#endif
 
 // Workgroup-count quantisation (measured, scripts/attn_tail_probe.py): every XCD runs 64 workgroups at a time (32 CUs x
 // 2), a workgroup takes ~0.64 ms at S = 17,776, and a 2-sample C2 launch is 840 units per XCD = 13.125 rounds: the

@@ -1,5 +1,6 @@
 // Error plumbing and version for the C ABI (include/alg_hip.h).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -24,7 +25,73 @@ int check_launch(const char* what) {
   return ALG_OK;
 }
 
+// ---- run-time options: one table, read from the environment at load (and on alg_reload_env) ----------------------------
+struct OptDef {
+  const char* name;
+  int def;
+  int n_ok;        // number of accepted values (0: any integer)
+  int ok[4];
+};
+static const OptDef g_defs[OPT_COUNT] = {
+    {"ALG_ATTN_SPLIT_TAIL", 1, 2, {0, 1}},
+#ifdef ALG_EXPERIMENTS
+    {"ALG_ATTN_PP", 4, 0, {}},
+    {"ALG_ATTN_VARIANT", 33, 0, {}},
+#else
+    {"ALG_ATTN_PP", 4, 2, {0, 4}},
+    {"ALG_ATTN_VARIANT", 33, 2, {1, 33}},
+#endif
+    {"ALG_ATTN128_PIPE", 1, 2, {0, 1}},
+#ifdef ALG_EXPERIMENTS
+    {"ALG_GEMM_PIPE", 9, 0, {}},
+#else
+    {"ALG_GEMM_PIPE", 9, 2, {6, 9}},
+#endif
+    {"ALG_LOWPASS_PATH", 0, 0, {}},
+#ifdef ALG_EXPERIMENTS
+    {"ALG_ATTN_PRIO", 0, 2, {0, 1}},
+    {"ALG_ATTN64_Q64", 0, 2, {0, 1}},
+    {"ALG_ATTN128_Q64", 0, 2, {0, 1}},
+    {"ALG_GEMM_PERSIST", 1, 2, {0, 1}},
+    {"ALG_GEMM_GROUP_M", 0, 0, {}},
+    {"ALG_GEMM_ABLATE", 0, 0, {}},
+    {"ALG_LOWPASS_V3_WGS", 0, 0, {}},
+    {"ALG_LOWPASS_V3_THREADS", 0, 0, {}},
+#endif
+};
+static std::atomic<int> g_opt[OPT_COUNT];
+
+static void load_options() {
+  for (int i = 0; i < OPT_COUNT; ++i) {
+    const OptDef& d = g_defs[i];
+    int v = d.def;
+    const char* e = getenv(d.name);
+    if (e && *e) {
+      const int x = atoi(e);
+      bool ok = d.n_ok == 0;
+      for (int j = 0; j < d.n_ok; ++j) ok |= d.ok[j] == x;
+      if (ok) v = x;     // a value this build does not know leaves the default in place
+    }
+    g_opt[i].store(v, std::memory_order_relaxed);
+  }
+}
+namespace {
+struct OptInit {
+  OptInit() { load_options(); }
+} g_opt_init;
+}  // namespace
+
+int opt(Opt o) { return g_opt[o].load(std::memory_order_relaxed); }
+
 }  // namespace alg
 
+extern "C" void alg_reload_env(void) { alg::load_options(); }
+extern "C" int alg_build_experiments(void) {
+#ifdef ALG_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 extern "C" int alg_version(void) { return ALG_VERSION; }
 extern "C" const char* alg_last_error(void) { return alg::g_err; }

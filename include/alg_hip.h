@@ -38,6 +38,15 @@ extern "C" {
 int alg_version(void);
 const char* alg_last_error(void);
 
+/* Run-time options.  The library reads its ALG_* environment variables ONCE, when it is loaded; no launch path calls getenv.
+ * A host that changes one of them afterwards calls alg_reload_env() (host-only, no GPU work; not to be called while another
+ * thread is inside the library).  The default build knows six, each selecting between bit-identical or documented-equivalent
+ * schedules (README.md "Run-time options"): ALG_ATTN_SPLIT_TAIL, ALG_ATTN_PP, ALG_ATTN_VARIANT, ALG_ATTN128_PIPE,
+ * ALG_GEMM_PIPE, ALG_LOWPASS_PATH.  Timing-only ablations and opt-in experimental kernels exist only in a
+ * `make EXPERIMENTS=1` build, for which alg_build_experiments() returns 1. */
+void alg_reload_env(void);
+int alg_build_experiments(void);
+
 /* ------------------------------------------------------------------------------------------------
  * Low-pass filters on [planes, H, W] contiguous planes (a 4-D/5-D tensor viewed per (H, W) plane,
  * lp:31-37).  Planes resident in LDS: one workgroup per plane for small calls, a persistent grid of

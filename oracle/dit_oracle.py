@@ -213,7 +213,7 @@ def apply_rotary(x, cos, sin):
 
 def timestep_sinusoid(timesteps, dim, flip_sin_to_cos=True, freq_shift=0, max_period=10000):
     half = dim // 2
-    exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32)
+    exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32, device=timesteps.device)
     exponent = exponent / (half - freq_shift)
     emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
     emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)

@@ -1,6 +1,7 @@
 """CPU restatement of the CogVideoX ALG denoising loop
 (pipeline_cogvideox_image2video_lowpass.py:1000-1140) and of prepare_lp's latent branch
-(cog:682-703), with the DiT and the scheduler injected as callables.
+(cog:682-703) and pixel branch (cog:628-680; Wan: wan:493-540), with the DiT, the scheduler and
+the VAE encoder injected as callables.
 
 TEST INFRASTRUCTURE -- never imported by ``alg_amd``.
 """
@@ -70,16 +71,86 @@ def prepare_lp_latent(image_latents, filter_type, sigma, ksize, factor):
     return out.permute(0, 2, 1, 3, 4).contiguous().to(image_latents.dtype)
 
 
+def posterior_sample(moments, generator, noise_dtype=None):
+    """diffusers DiagonalGaussianDistribution(moments).sample(generator): mean / logvar = chunk(2, dim=1), logvar clamped to
+    [-30, 20], std = exp(0.5 logvar), noise = randn_tensor(mean.shape, generator, dtype=moments.dtype), mean + std * noise.
+    ``noise_dtype`` is the dtype the REFERENCE's VAE runs in (cog: the pipeline dtype, bf16 under run.py:65-69; wan: float32,
+    run:51-55): torch's CPU generator gives a different stream per dtype (bf16 randn is not fp32 randn rounded), so an fp32
+    oracle run that is to see the product's noise draws it in that dtype and widens it."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+    noise = torch.randn(mean.shape, generator=generator, dtype=noise_dtype or moments.dtype).to(moments.dtype)
+    return mean + std * noise
+
+
+def cog_encode_image(image, vae_moments, generator, scaling_factor=0.7, invert_scale_latents=False, noise_dtype=None):
+    """cog:388-400 (prepare_latents): image [B, 3, H, W] -> unsqueeze(2) -> vae.encode -> latent_dist.sample(generator) ->
+    x scaling_factor (or its inverse) -> [B, 1, C, h, w] (the frame the zero padding of cog:402-411 follows)."""
+    z = posterior_sample(vae_moments(image.unsqueeze(2)), generator, noise_dtype)
+    z = scaling_factor * z if not invert_scale_latents else 1 / scaling_factor * z
+    return z.permute(0, 2, 1, 3, 4)
+
+
+def prepare_lp_pixel_cog(image_tensor, vae_moments, generator, num_frames, filter_type, sigma, ksize, factor, out_dtype,
+                         scaling_factor=0.7, invert_scale_latents=False, temporal_ratio=4, patch_size_t=None,
+                         noise_dtype=None):
+    """cog:628-680, the `lp_filter_in_latent=False` branch, statement by statement: filter the RGB image [B, 3, H, W]
+    (cog:632-638) -> unsqueeze(2) (cog:642) -> vae.encode(...).latent_dist.sample(generator) (cog:645: FRESH posterior noise
+    on every call, i.e. every step) -> x scaling factor (cog:647-650) -> permute to [B, 1, C, h, w] (cog:652) -> zero frames up
+    to (num_frames - 1) // 4 + 1 (cog:655-671) -> CogVideoX-1.5 leading-frame repeat (cog:673-680) -> cast (cog:701).
+    ``vae_moments(x[B,3,1,H,W]) -> [B, 2C, 1, h, w]`` is the VAE oracle's encoder."""
+    img = apply_low_pass_filter_torch(image_tensor, filter_type, sigma, ksize, factor)
+    enc = cog_encode_image(img, vae_moments, generator, scaling_factor, invert_scale_latents, noise_dtype)
+    padded = (num_frames - 1) // temporal_ratio + 1
+    if padded > enc.shape[1]:
+        b, f, c, h, w = enc.shape
+        enc = torch.cat([enc, torch.zeros((b, padded - f, c, h, w), dtype=enc.dtype)], dim=1)
+    else:
+        enc = enc[:, :padded]
+    if patch_size_t is not None and enc.size(1) % patch_size_t:
+        n = min(patch_size_t - enc.size(1) % patch_size_t, enc.shape[1])
+        enc = torch.cat([enc[:, :n], enc], dim=1)
+    return enc.to(out_dtype)
+
+
+def wan_condition(latent, num_frames, temporal_ratio=4):
+    """wan:439-449 / wan:527-538: [mask4 | normalised latent16] -- ones for the first pixel frame, repeated 4 times, folded
+    in groups of 4 pixel frames into channels."""
+    b, _, _, h, w = latent.shape
+    mask = torch.ones(b, 1, num_frames, h, w)
+    mask[:, :, list(range(1, num_frames))] = 0
+    first = torch.repeat_interleave(mask[:, :, 0:1], dim=2, repeats=temporal_ratio)
+    mask = torch.concat([first, mask[:, :, 1:, :]], dim=2)
+    mask = mask.view(b, -1, temporal_ratio, h, w).transpose(1, 2)
+    return torch.concat([mask.to(latent.dtype), latent], dim=1)
+
+
+def prepare_lp_pixel_wan(image_tensor, vae_moments, generator, num_frames, filter_type, sigma, ksize, factor, out_dtype,
+                         latents_mean, latents_std, temporal_ratio=4, noise_dtype=None):
+    """wan:493-540, the `lp_filter_in_latent=False` branch: filter the RGB image (wan:495-501) -> [image_lp, zeros x
+    (num_frames - 1)] (wan:509-518) -> vae.encode(...).latent_dist.SAMPLE(generator) (wan:526 -- not the mode the unfiltered
+    condition uses at wan:430) -> (z - mean) * (1 / std) (wan:519-527) -> mask channels in front (wan:529-540) -> cast."""
+    img = apply_low_pass_filter_torch(image_tensor, filter_type, sigma, ksize, factor)
+    x = img.unsqueeze(2)
+    video = torch.cat([x, x.new_zeros(x.shape[0], x.shape[1], num_frames - 1, x.shape[3], x.shape[4])], dim=2)
+    z = posterior_sample(vae_moments(video), generator, noise_dtype)
+    mean = torch.tensor(latents_mean).view(1, -1, 1, 1, 1).to(img.dtype)
+    inv_std = 1.0 / torch.tensor(latents_std).view(1, -1, 1, 1, 1).to(img.dtype)
+    return wan_condition((z - mean) * inv_std, num_frames, temporal_ratio).to(out_dtype)
+
+
 def alg_denoise_loop(transformer, scheduler, latents, image_latents, prompt_embeds, negative_prompt_embeds,
                      num_inference_steps, guidance_scale=6.0, use_low_pass_guidance=True, lp_filter_type="down_up",
                      lp_blur_sigma=15.0, lp_blur_kernel_size=0.02734375, lp_resize_factor=0.25,
                      lp_strength_schedule_type="interval", schedule_blur_kernel_size=False,
                      schedule_interval_start_time=0.0, schedule_interval_end_time=0.05,
                      schedule_linear_start_weight=1.0, schedule_linear_end_weight=0.0, schedule_linear_end_time=0.5,
-                     schedule_exp_decay_rate=10.0, image_rotary_emb=None, trace=None, generator=None):
+                     schedule_exp_decay_rate=10.0, image_rotary_emb=None, trace=None, generator=None, prepare_lp=None):
     """Returns final latents [B,F,C,H,W].  ``transformer(hidden_states, encoder_hidden_states, timestep,
     image_rotary_emb)`` -> noise prediction.  ``trace`` (list) receives per-step
-    (strength, two_pass, n_forward) for branch-table tests."""
+    (strength, two_pass, n_forward) for branch-table tests.  ``prepare_lp(filter_type, sigma, ksize, factor)`` replaces the
+    latent-space filter by the pixel branch (cog:1043-1057 calls prepare_lp on EVERY ALG step, so a pixel-branch callable
+    consumes its generator once per step)."""
     do_cfg = guidance_scale > 1.0
     dtype = prompt_embeds.dtype
     if do_cfg and use_low_pass_guidance:  # cog:948-951
@@ -102,7 +173,10 @@ def alg_denoise_loop(transformer, scheduler, latents, image_latents, prompt_embe
             two_pass = lp_oracle.two_pass_flag(s, lp_strength_schedule_type, use_low_pass_guidance)
             sigma, ksize, factor = lp_oracle.modulated_params(s, lp_blur_sigma, lp_blur_kernel_size,
                                                               lp_resize_factor, schedule_blur_kernel_size)
-            lp_lat = prepare_lp_latent(image_latents, lp_filter_type, sigma, ksize, factor)
+            if prepare_lp is None:
+                lp_lat = prepare_lp_latent(image_latents, lp_filter_type, sigma, ksize, factor)
+            else:
+                lp_lat = prepare_lp(lp_filter_type, sigma, ksize, factor)
             n = 2 if two_pass else 3
             x = scheduler.scale_model_input(torch.cat([latents] * n), t)
             cond = [lp_lat, lp_lat] if two_pass else [image_latents, lp_lat, lp_lat]  # cog:1068-1070
@@ -157,19 +231,23 @@ def _schedule(i, n, kw):
 
 def wan_denoise_loop(transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds, image_embeds,
                      num_inference_steps, guidance_scale=5.0, use_low_pass_guidance=True, transformer_dtype=torch.bfloat16,
-                     patch_t=1, trace=None, **kw):
+                     patch_t=1, trace=None, prepare_lp=None, **kw):
     """wan:815-927.  latents fp32 [B,16,F,h,w]; condition fp32 [B,20,F,h,w].  ``transformer(x, timestep, ehs,
-    ehs_image)`` -> prediction in transformer_dtype.  ``scheduler``: oracle.sched_oracle.UniPCOracle."""
+    ehs_image)`` -> prediction in transformer_dtype.  ``scheduler``: oracle.sched_oracle.UniPCOracle.
+    ``prepare_lp(filter_type, sigma, ksize, factor)``: the pixel branch (wan:493-540), called on every ALG step (wan:869-880)."""
     scheduler.set_timesteps(num_inference_steps)
     do_cfg = guidance_scale > 1
     for i, t in enumerate(scheduler.timesteps):
         s = None
         if do_cfg and use_low_pass_guidance:
             s, sigma, ksize, factor = _schedule(i, num_inference_steps, kw)
-            lp = apply_low_pass_filter_torch(condition, kw.get("lp_filter_type", "none"), sigma, ksize, factor)
-            rem = lp.size(1) % patch_t                        # wan:549-556 (dim 1 is the channel dim here)
-            if rem != 0:
-                lp = torch.cat([lp[:, :min(patch_t - rem, lp.shape[1])], lp], dim=1)
+            if prepare_lp is not None:
+                lp = prepare_lp(kw.get("lp_filter_type", "none"), sigma, ksize, factor)
+            else:
+                lp = apply_low_pass_filter_torch(condition, kw.get("lp_filter_type", "none"), sigma, ksize, factor)
+                rem = lp.size(1) % patch_t                        # wan:549-556 (dim 1 is the channel dim here)
+                if rem != 0:
+                    lp = torch.cat([lp[:, :min(patch_t - rem, lp.shape[1])], lp], dim=1)
             lp = lp.to(condition.dtype)
             if s == 0.0:
                 x = torch.cat([torch.cat([latents] * 2), torch.cat([condition, condition], dim=0)], dim=1)

@@ -285,3 +285,36 @@ def test_prescaled_attention_path_agrees_in_a_full_width_forward(device, monkeyp
     b = model.forward_assembled(lat, [c0, c0], torch.cat([ne, pe]), ts, rope).float()
     rel = ((a - b).norm() / b.norm()).item()
     assert bool(torch.isfinite(a).all()) and 0 < rel < 5e-3, rel
+
+
+def test_c2_forward_at_its_real_shape_two_layers_vs_fp32_oracle(device):
+    """VERDICT r3 missing 2: the HEADLINE configuration's forward at its real shape -- 48 heads x 64, 17,550 video + 226 text =
+    17,776 tokens, N = 2 (a CFG step), 2 of the 42 layers -- HIP against `oracle/dit_oracle.dit_forward` in fp32 on the host
+    (the mathematical reference, ~2 x 2 x 7.9e12 FLOP).  The floor is the reference's OWN execution mode at this shape: the same
+    oracle function with bf16 weights / activations run by torch's eager ops on the device (what `run.py:65-69` executes on a
+    GPU).  Bounds: tests/_parity.py -- global relative L2 <= 1.5 x floor, every token <= 4 x the floor's p99.9 token error,
+    worst element <= 2 x the floor's worst element."""
+    from _parity import check_floor
+    from oracle import dit_oracle
+    kw = dict(num_attention_heads=48, attention_head_dim=64, in_channels=32, out_channels=16, num_layers=2,
+              time_embed_dim=512, text_embed_dim=4096, max_text_seq_length=226, sample_width=90, sample_height=60,
+              sample_frames=49, patch_size=2)
+    ocfg = dit_oracle.DiTConfig(**kw)
+    wbf = {k: v.to(BF) for k, v in dit_oracle.init_weights(ocfg, seed=21, std=0.02, randomize_affine=True).items()}
+    w32 = {k: v.float() for k, v in wbf.items()}
+    model = CogVideoXTransformer3DModel(CogVideoXTransformerConfig(**kw), wbf, device=device)
+    g = torch.Generator().manual_seed(8)
+    hs = torch.randn(2, 13, 32, 60, 90, generator=g).to(BF)
+    hs[:, 1:, 16:] = 0                                       # the conditioning half: frame 0 real, frames 1..12 zero (cog:402-411)
+    ehs = torch.randn(2, 226, 4096, generator=g).to(BF)
+    ts = torch.tensor([999, 999])
+    rope = dit_oracle.rope_tables(ocfg, 480, 720, 13)
+    assert rope[0].shape == (17550, 64)
+    out = model(hs.to(device), ehs.to(device), ts, image_rotary_emb=rope, return_dict=False)[0]
+    assert out.shape == (2, 13, 16, 60, 90)
+    wdev = {k: v.to(device) for k, v in wbf.items()}
+    eager = dit_oracle.dit_forward(ocfg, wdev, hs.to(device), ehs.to(device), ts.to(device),
+                                   tuple(t.to(device) for t in rope)).cpu()
+    del wdev
+    ref = dit_oracle.dit_forward(ocfg, w32, hs.float(), ehs.float(), ts, rope)
+    check_floor("cog_forward_c2_real_shape_2layers_17776tokens", out, ref, eager, channel_dim=2)

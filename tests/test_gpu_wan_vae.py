@@ -86,7 +86,9 @@ def test_encode_whole_video_vs_chunked_oracle(base_dim, T, H, W):
     check_floor("wan_vae_encode_dim%d_T%d" % (base_dim, T), mom, ref, eager)
     assert torch.equal(dist.mode(), mom[:, :4])
     s1 = dist.sample(generator=torch.Generator().manual_seed(1))
-    noise = torch.randn(dist.mean.shape, generator=torch.Generator().manual_seed(1), dtype=BF)
+    # the posterior lives in float32 like the reference's float32 Wan VAE (run:51-55): the draw is the float32 stream
+    assert mom.dtype == torch.float32 and s1.dtype == torch.float32
+    noise = torch.randn(dist.mean.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float32)
     assert torch.equal(s1.cpu(), (dist.mean.cpu() + dist.std.cpu() * noise))
 
 

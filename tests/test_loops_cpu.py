@@ -229,3 +229,47 @@ def test_wan_prompt_encoding_trims_and_zero_pads():
     assert bool((ne[:, :1] > 100).all()) and bool((ne[:, 1:] == 0).all())          # '' -> just the end-of-sequence token
     with pytest.raises(ValueError, match="batch size"):
         pipe.encode_prompt(["a", "b"], ["x"], True, 1, None, None, 12, torch.device("cpu"))
+
+
+def test_pixel_branch_oracle_structure():
+    """oracle/loop_oracle.py's restatement of the pixel-space ALG branch (cog:628-680, wan:493-540), host-side facts only: one
+    posterior draw per call in the VAE's dtype stream, zero frames / mask channels where the reference puts them, the identity
+    filter still re-encodes, and the Wan mask equals the product's condition builder."""
+    from alg_amd.pipeline_wan_image2video_lowpass import build_wan_condition
+    calls = []
+
+    def moments(x):                                   # stand-in encoder: 8x spatial mean pool -> 2 x 16 moment planes
+        calls.append(tuple(x.shape))
+        b, _, t, h, w = x.shape
+        t_lat = 1 + (t - 1) // 4
+        m = torch.nn.functional.avg_pool2d(x[:, :, 0], 8).mean(1, keepdim=True)          # [B, 1, h/8, w/8]
+        return m[:, :, None].expand(b, 32, t_lat, h // 8, w // 8).contiguous() * 0.5
+
+    img = torch.rand(1, 3, 32, 48, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    g = torch.Generator().manual_seed(1)
+    a = loop_oracle.prepare_lp_pixel_cog(img, moments, g, 9, "down_up", 0.0, 0, 0.25, torch.float32)
+    assert a.shape == (1, 3, 16, 4, 6) and bool((a[:, 1:] == 0).all()) and calls[-1] == (1, 3, 1, 32, 48)
+    b = loop_oracle.prepare_lp_pixel_cog(img, moments, g, 9, "down_up", 0.0, 0, 0.25, torch.float32)
+    assert not torch.equal(a, b)                                                          # fresh noise on every call (cog:645)
+    g2 = torch.Generator().manual_seed(1)
+    a2 = loop_oracle.prepare_lp_pixel_cog(img, moments, g2, 9, "down_up", 0.0, 0, 0.25, torch.float32)
+    assert torch.equal(a, a2)
+    # the draw follows the VAE's dtype: bf16 noise is NOT fp32 noise rounded (torch CPU generator), hence `noise_dtype`
+    n_bf = loop_oracle.posterior_sample(torch.zeros(1, 32, 1, 4, 6), torch.Generator().manual_seed(3), torch.bfloat16)
+    n_32 = loop_oracle.posterior_sample(torch.zeros(1, 32, 1, 4, 6), torch.Generator().manual_seed(3))
+    assert torch.equal(n_bf, torch.randn(1, 16, 1, 4, 6, generator=torch.Generator().manual_seed(3), dtype=torch.bfloat16).float())
+    assert not torch.equal(n_bf, n_32.bfloat16().float())
+    # CogVideoX 1.5: 3 latent frames, patch_size_t 2 -> the leading frame repeated in front (cog:673-680)
+    c = loop_oracle.prepare_lp_pixel_cog(img, moments, torch.Generator().manual_seed(1), 9, "none", 0.0, 0, 1.0,
+                                         torch.float32, patch_size_t=2)
+    assert c.shape == (1, 4, 16, 4, 6) and torch.equal(c[:, 0], c[:, 1]) and bool((c[:, 2:] == 0).all())
+    # Wan: [mask4 | (z - mean) / std], the condition video is [image_lp, zeros x (F - 1)], sampled (not the mode)
+    mean, std = [0.1] * 16, [2.0] * 16
+    w = loop_oracle.prepare_lp_pixel_wan(img, moments, torch.Generator().manual_seed(2), 9, "gaussian_blur", 2.0, 5, 1.0,
+                                         torch.float32, mean, std)
+    assert w.shape == (1, 20, 3, 4, 6) and calls[-1] == (1, 3, 9, 32, 48)
+    assert bool((w[:, :4, 0] == 1).all()) and bool((w[:, :4, 1:] == 0).all())
+    assert torch.equal(w, build_wan_condition(w[:, 4:], 9))
+    mode = (torch.chunk(moments(torch.cat([loop_oracle.apply_low_pass_filter_torch(img, "gaussian_blur", 2.0, 5, 1.0)[:, :, None],
+                                           torch.zeros(1, 3, 8, 32, 48)], 2)), 2, 1)[0] - 0.1) * 0.5
+    assert not torch.equal(w[:, 4:], mode)
