@@ -62,18 +62,19 @@ class VaeGeom(Structure):
 _lib = None
 
 
-def build_library(verbose=False):
-    """Compile libalg_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+def build_library(verbose=False, experiments=False):
+    """Compile libalg_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).  ``experiments=True`` builds the
+    EXPERIMENTS flavour next to it (alg_amd/libalg_hip_exp.so: shelved kernels + timing-only ablations, csrc/Makefile)."""
     import subprocess
 
     src = os.path.join(_HERE, "csrc")
-    r = subprocess.run(["make", "-C", src, "-j8"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", src, "-j8"] + (["EXPERIMENTS=1"] if experiments else []), capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout[-4000:])
         print(r.stderr[-4000:])
     if r.returncode != 0:
         raise AlgHipError("building libalg_hip.so failed (see output above)")
-    return LIB_PATH
+    return os.path.join(_HERE, "libalg_hip_exp.so") if experiments else LIB_PATH
 
 
 def load_library():

@@ -276,19 +276,19 @@ int flash_attn_d128_pipe(const void* q, const void* k, const void* vt, void* o, 
                          int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t vt_bs, int64_t vt_rs, int64_t o_bs,
                          int64_t o_rs, float scale, hipStream_t stream) {
   using namespace a128p;
-  const char* env = getenv("ALG_ATTN128_PIPE");
-  if ((env && env[0] == '0') || (Skv + KVB - 1) / KVB < MIN_TILES) return 1;   // default since round 3; ALG_ATTN128_PIPE=0: attention128.hip
+  if (!opt(OPT_ATTN128_PIPE) || (Skv + KVB - 1) / KVB < MIN_TILES) return 1;   // default since round 3; ALG_ATTN128_PIPE=0: attention128.hip
   // 31-bit BYTE offsets inside one (batch, head) for the DMA's lane offsets; V^T rows cover whole 64-key tiles
   if ((int64_t)(Skv + 64) * k_rs * 2 >= (1ll << 31) || (int64_t)129 * vt_rs * 2 >= (1ll << 31) ||
       (int64_t)Sq * q_rs * 2 >= (1ll << 31))
     return 1;
   if (vt_rs < (int64_t)((Skv + KVB - 1) / KVB) * KVB) return 1;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  const int dev_slot = current_device_slot();
+  if (!device_done(attr_set, dev_slot)) {
     if (hipFuncSetAttribute((const void*)flash_attn_d128_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
         hipSuccess)
       return 1;
-    attr_set = true;
+    device_mark(attr_set, dev_slot);
   }
   P p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;

@@ -1020,18 +1020,18 @@ int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, i
   // tokens of the first wave of workgroups, and never with attention128.hip's 32-query kernel in its place
   // (profiles/r2_attention128_q64_flake.txt: what was tried, what moved the rate).  Until that is understood the
   // product default is the kernel that has never produced a mismatch.
-  const char* env = getenv("ALG_ATTN128_Q64");
-  const int enabled = env ? atoi(env) : 0;
+  const int enabled = opt(OPT_ATTN128_Q64);
   if (!enabled || (Skv + KVB - 1) / KVB < MIN_TILES) return 1;
   // 31-bit BYTE offsets inside one (batch, head) for the DMA's lane offsets; V^T rows cover whole 64-key tiles
   if ((int64_t)(Skv + 64) * k_rs * 2 >= (1ll << 31) || (int64_t)129 * vt_rs * 2 >= (1ll << 31)) return 1;
   if (vt_rs < (int64_t)((Skv + KVB - 1) / KVB) * KVB) return 1;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  const int dev_slot = current_device_slot();
+  if (!device_done(attr_set, dev_slot)) {
     for (const void* fn : {(const void*)flash_attn_d128_q64_kernel<1>, (const void*)flash_attn_d128_q64_kernel<2>,
                            (const void*)flash_attn_d128_q64_kernel<3>, (const void*)flash_attn_d128_q64_kernel<4>})
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return 1;
-    attr_set = true;
+    device_mark(attr_set, dev_slot);
   }
   P p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;

@@ -689,16 +689,16 @@ int flash_attn_d64_q64(const void* q, const void* k, const void* vt, void* o, in
   // / pack / dot2 against the 28 an MFMA leaves free, before the fragment read, the waits and the DMA -- one in-order wave per
   // SIMD cannot keep the matrix pipe fed, while four waves per SIMD of the 32-query kernel overlap freely.  Kept, tested and
   // bit-compatible, as the A/B reference for that statement.
-  const char* env = getenv("ALG_ATTN64_Q64");
-  if (!(env && atoi(env) == 1) || (S + KVB - 1) / KVB < MIN_TILES || blocks == 0) return 1;
+  if (opt(OPT_ATTN64_Q64) != 1 || (S + KVB - 1) / KVB < MIN_TILES || blocks == 0) return 1;
   if (q_blocks != (S + NW * QW - 1) / (NW * QW)) return 1;
   if ((int64_t)(S + 64) * q_rs * 2 >= (1ll << 31) || (int64_t)65 * vt_rs * 2 >= (1ll << 31)) return 1;   // 31-bit byte offsets
   if (vt_rs < (int64_t)((S + KVB - 1) / KVB) * KVB) return 1;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  const int dev_slot = current_device_slot();
+  if (!device_done(attr_set, dev_slot)) {
     if (hipFuncSetAttribute((const void*)flash_attn_d64_q64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return 1;
-    attr_set = true;
+    device_mark(attr_set, dev_slot);
   }
   P p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;

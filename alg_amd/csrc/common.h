@@ -40,6 +40,23 @@ enum Opt {
 };
 int opt(Opt o);
 
+// One-time opt-in to more than 64 KiB of dynamic LDS, remembered PER DEVICE (hipFuncSetAttribute is a per-device property: a
+// process that drives several GPUs must set it on each).  Racing first calls both set it -- idempotent.
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+};
+inline int current_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;   // unknown: never cached, set on every call
+  return dev;
+}
+inline bool device_done(const PerDeviceOnce& o, int slot) {
+  return slot >= 0 && ((o.mask.load(std::memory_order_acquire) >> slot) & 1ull);
+}
+inline void device_mark(PerDeviceOnce& o, int slot) {
+  if (slot >= 0) o.mask.fetch_or(1ull << slot, std::memory_order_release);
+}
+
 typedef unsigned short bf16_t;  // raw bf16 bits
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;

@@ -3,8 +3,9 @@
 
 namespace alg {
 int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s) {
-  static std::atomic<bool> attr_set{false};  // idempotent one-time setup; racing first calls both succeed
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;  // idempotent one-time setup per device; racing first calls both succeed
+  const int dev_slot = current_device_slot();
+  if (!device_done(attr_set, dev_slot)) {
     const void* fns[2] = {(const void*)gemm_bf16_kernel<ALG_ACT_NONE, true, 6, 4, false, true>,
                           (const void*)gemm_bf16_kernel<ALG_ACT_NONE, false, 6, 4, false, true>};
     for (const void* fn : fns) {
@@ -14,7 +15,7 @@ int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_
         return ALG_ELAUNCH;
       }
     }
-    attr_set = true;
+    device_mark(attr_set, dev_slot);
   }
   const dim3 grid(gemm_grid(nwg)), block(512);
   const int gm = gemm_group_m(6);

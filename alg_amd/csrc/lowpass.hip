@@ -294,15 +294,10 @@ int gaussian_v3(const void* in, void* out, int64_t planes, int H, int W, int ksi
 int down_up_v3(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
                const void* tables, hipStream_t s);
 
-static bool force_v1() {  // debug knob: the one-plane-per-workgroup kernels of this file (bit-identity tests)
-  const char* e = getenv("ALG_LOWPASS_V1");
-  return e && e[0] == '1';
-}
-
-static bool force_global() {  // debug knob: run LDS-sized planes through the global-memory passes (parity tests)
-  const char* e = getenv("ALG_LOWPASS_FORCE_GLOBAL");
-  return e && e[0] == '1';
-}
+// ALG_LOWPASS_PATH (all paths bit-identical; the tests walk them): 1 = the one-plane-per-workgroup kernels of this file,
+// 4 = LDS-sized planes through the global-memory passes of lowpass_big.hip (2 / 3: see lowpass_v3.hip)
+static bool force_v1() { return opt(OPT_LOWPASS_PATH) == 1; }
+static bool force_global() { return opt(OPT_LOWPASS_PATH) == 4; }
 
 template <typename K>
 static int set_lds_limit(K kernel, size_t bytes) {

@@ -491,15 +491,16 @@ static int num_cus() {
 
 // planes a launch must have for these kernels to be used (fewer: the plane-per-workgroup kernels of lowpass.hip put up to
 // 1024 threads on a plane and have the lower latency; measured cross-over well below one plane per CU)
-static int64_t min_planes() {
-  const char* e = getenv("ALG_LOWPASS_V3_MIN_PLANES");
-  return e ? atoll(e) : num_cus() / 2;
-}
+static int64_t min_planes() { return opt(OPT_LOWPASS_PATH) == 3 ? 1 : num_cus() / 2; }   // ALG_LOWPASS_PATH=3: at any plane count
+static bool v3_off() { return opt(OPT_LOWPASS_PATH) == 2; }                               // ALG_LOWPASS_PATH=2: lowpass_v2.hip
 
-static int wgs_cap() {   // tuning knob: resident workgroups per CU the persistent grid is sized for
-  const char* e = getenv("ALG_LOWPASS_V3_WGS");
-  const int v = e ? atoi(e) : 0;
+static int wgs_cap() {   // EXPERIMENTS tuning knob: resident workgroups per CU the persistent grid is sized for
+#ifdef ALG_EXPERIMENTS
+  const int v = opt(OPT_LOWPASS_V3_WGS);
   return v > 0 ? v : 1 << 20;
+#else
+  return 1 << 20;
+#endif
 }
 
 // Workgroups of `kernel` a CU really holds (registers AND LDS): the persistent grid must not be larger than that, or the
@@ -516,9 +517,12 @@ static int resident_wgs(K kernel, int nt, size_t lds) {
 }
 
 static int threads_override() {
-  const char* e = getenv("ALG_LOWPASS_V3_THREADS");
-  const int v = e ? atoi(e) : 0;
+#ifdef ALG_EXPERIMENTS
+  const int v = opt(OPT_LOWPASS_V3_THREADS);
   return (v == 256 || v == 512 || v == 1024) ? v : 0;
+#else
+  return 0;
+#endif
 }
 
 // per kernel instantiation: raise the LDS limit when needed and ask the runtime how many workgroups a CU holds; both are
@@ -614,8 +618,7 @@ static int dispatch_d(const void* in, void* out, const uint32_t* blob, const DAr
 // Returns ALG_OK when the launch was made, 1 when this shape is not covered (the caller goes on to lowpass_v2.hip).
 int gaussian_v3(const void* in, void* out, int64_t planes, int H, int W, int ksize, float sigma, int dtype, hipStream_t s) {
   using namespace v3;
-  const char* off = getenv("ALG_LOWPASS_V3");
-  if (off && off[0] == '0') return 1;
+  if (v3_off()) return 1;
   const int pad = ksize / 2, p4 = (pad + 3) & ~3;
   if ((W & 1) || ((H * W) & 3) || ksize < 3 || ksize > 19 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return 1;
   if (pad + 1 >= H || pad + 1 >= W) return 1;                 // the mirrored rows / columns must be distinct from the edge
@@ -643,8 +646,7 @@ int gaussian_v3(const void* in, void* out, int64_t planes, int H, int W, int ksi
 int down_up_v3(const void* in, void* out, int64_t planes, int H, int W, int h1, int w1, int dtype, int round_mid,
                const void* tables, hipStream_t s) {
   using namespace v3;
-  const char* off = getenv("ALG_LOWPASS_V3");
-  if (off && off[0] == '0') return 1;
+  if (v3_off()) return 1;
   const int n = H * W;
   if ((W & 1) || (n & 3) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return 1;
   if (planes < min_planes()) return 1;

@@ -219,8 +219,9 @@ extern "C" int alg_attn_bias(const void* q, const void* k, const void* v, void* 
     set_error("alg_attn_bias: null pointer");
     return ALG_EINVAL;
   }
-  static std::atomic<bool> attr_set{false};  // idempotent one-time setup; racing first calls both succeed
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;  // idempotent one-time setup per device; racing first calls both succeed
+  const int dev_slot = current_device_slot();
+  if (!device_done(attr_set, dev_slot)) {
     for (const void* fn : {(const void*)t5::attn_bias_kernel<64>, (const void*)t5::attn_bias_kernel<80>}) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) {
@@ -228,7 +229,7 @@ extern "C" int alg_attn_bias(const void* q, const void* k, const void* v, void* 
         return ALG_ELAUNCH;
       }
     }
-    attr_set = true;
+    device_mark(attr_set, dev_slot);
   }
   const int rows_per_wg = 32;
   const dim3 grid((L + rows_per_wg - 1) / rows_per_wg, batch * heads);

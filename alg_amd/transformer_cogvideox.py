@@ -25,7 +25,6 @@ HBM layout (all bf16, allocated once per batch size N and reused every step):
 from __future__ import annotations
 
 import math
-import os
 from dataclasses import dataclass, asdict
 from typing import Optional
 
@@ -89,6 +88,9 @@ class CogVideoXTransformer3DModel:
         if D % 512:
             raise _lib.AlgHipError("inner_dim must be a multiple of 512 (LayerNorm kernel tiling)")
         _lib.load_library()
+        # True (default): the softmax scale * log2(e) rides in Q's last rounding and the attention takes log2-unit scores
+        # (alg_qk_norm_rope_scaled + ALG_ATTN_Q_PRESCALED); False keeps the per-score multiply (A/B and parity tests)
+        self.attn_prescale = True
         dev = self.device
         w = weights
         p = cfg.patch_size
@@ -313,7 +315,7 @@ class CogVideoXTransformer3DModel:
 
         # 3. transformer blocks
         scale = 1.0 / math.sqrt(cfg.attention_head_dim)
-        prescale = os.environ.get("ALG_ATTN_PRESCALE", "1") != "0"
+        prescale = self.attn_prescale
         q_scale = scale * 1.4426950408889634 if prescale else 1.0
         F4 = cfg.ff_inner_mult * D
         for li, L in enumerate(self.layers):
@@ -324,7 +326,7 @@ class CogVideoXTransformer3DModel:
             TM("gemm_qk", G, y, L["wqk"], qk, S, 2 * D, D, D, D, 2 * D, bias=L["bqk"], batch=N, strideA=S * D, strideC=S * 2 * D)
             TM("gemm_vt", G, L["wv"], y, vt, D, S, D, D, D, S_pad, bias=L["bv"], batch=N, strideB=S * D, strideC=D * S_pad,
               flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
-            # the softmax scale * log2(e) rides in Q's last rounding (ALG_ATTN_PRESCALE=0: scaled per score in the attention)
+            # the softmax scale * log2(e) rides in Q's last rounding (attn_prescale = False: scaled per score in the attention)
             TM("qk_norm_rope", _lib.qk_norm_rope_, qk, L["norm_q_w"], L["norm_q_b"], L["norm_k_w"], L["norm_k_b"], cos, sin, N, S, Hn, T,
                                cfg.qk_norm_eps, q_scale=q_scale)
             TM("attn", _lib.flash_attn_d64, qk, qk, vt, att, N, Hn, S, S * 2 * D, 2 * D, D * S_pad, S_pad, S * D, D, scale,

@@ -140,6 +140,7 @@ class WanTransformer3DModel:
         quantised once to OCP e4m3 with one scale per output channel, activations per token right before each GEMM
         (alg_quantize_fp8_rows); norms, attention, embedders and the residual stream stay bf16 / fp32."""
         self.fp8 = bool(fp8)
+        self.fuse_quant = True   # fp8: the modulated LayerNorm writes the e4m3 tokens + row scales itself (bit-identical to the quantiser pass)
         if config.qk_norm != "rms_norm_across_heads" or config.attention_head_dim != 128:
             raise NotImplementedError("the Wan DiT path is built for rms_norm_across_heads and head_dim 128")
         if tuple(config.patch_size)[0] != 1:
@@ -379,7 +380,7 @@ class WanTransformer3DModel:
 
         # fp8 blocks: the norms write the e4m3 tokens + row scales straight into the GEMM operand workspace (the bytes
         # alg_quantize_fp8_rows would make of the bf16 norm output); ws.y is not touched
-        fuse_q = self.fp8 and D % 512 == 0 and os.environ.get("ALG_WAN_FUSE_QUANT", "1") != "0"
+        fuse_q = self.fp8 and D % 512 == 0 and self.fuse_quant
 
         def ln_mod(wgt, bia, sc, sh, bs, **kw):
             if fuse_q:

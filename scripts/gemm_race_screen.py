@@ -18,7 +18,8 @@ g = torch.Generator(device=dev).manual_seed(0)
 
 
 def run(pipe, a, w, bias, M, N, K):
-    os.environ["ALG_GEMM_PIPE"] = str(pipe)
+    os.environ["ALG_GEMM_PIPE"] = str(pipe)     # 0 exists in the EXPERIMENTS build only (ALG_HIP_LIB=alg_amd/libalg_hip_exp.so)
+    _lib.reload_env()                           # the library reads its options once, at load
     c = torch.empty(M, N, dtype=BF, device=dev)
     _lib.gemm(a, w, c, M, N, K, K, K, N, bias=bias, act=_lib.ACT_GELU_TANH)
     return c

@@ -13,6 +13,49 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _alg_env_follows_monkeypatch(monkeypatch):
+    """libalg_hip.so reads its ALG_* options once, at load (include/alg_hip.h: alg_reload_env).  Tests flip them through
+    `monkeypatch.setenv / delenv`; this hook makes the library follow -- and re-reads once more after monkeypatch has restored
+    the environment, so that no test leaks an option into the next."""
+    from alg_amd import _lib
+
+    def reload():
+        if _lib._lib is not None or os.path.exists(_lib.LIB_PATH):
+            _lib.reload_env()
+
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+    touched = []
+
+    def setenv_(name, value, *a, **k):
+        setenv(name, value, *a, **k)
+        if name.startswith("ALG_"):
+            touched.append(name)
+            reload()
+
+    def delenv_(name, *a, **k):
+        delenv(name, *a, **k)
+        if name.startswith("ALG_"):
+            touched.append(name)
+            reload()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv_, delenv_
+    yield
+    if touched:
+        monkeypatch.undo()
+        reload()
+
+
+@pytest.fixture(scope="session")
+def experiments():
+    """Skip unless the loaded library is the `make EXPERIMENTS=1` build (ALG_HIP_LIB=alg_amd/libalg_hip_exp.so): opt-in
+    kernels, shelved schedules and the timing-only ablations do not exist in the default library."""
+    from alg_amd import _lib
+    if not _lib.experiments_build():
+        pytest.skip("needs the EXPERIMENTS build: ALG_HIP_LIB=alg_amd/libalg_hip_exp.so")
+    return True
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

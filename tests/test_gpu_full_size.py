@@ -269,7 +269,7 @@ def test_default_attention_agrees_with_the_exact_max_variant_in_a_full_width_for
 
 def test_prescaled_attention_path_agrees_in_a_full_width_forward(device, monkeypatch):
     """The transformer folds the softmax scale into Q (alg_qk_norm_rope_scaled + ALG_ATTN_Q_PRESCALED, default);
-    ALG_ATTN_PRESCALE=0 keeps the per-score multiply: same forward to bf16 rounding at the full C2 size (split-KV tail
+    `model.attn_prescale = False` keeps the per-score multiply: same forward to bf16 rounding at the full C2 size (split-KV tail
     included on both paths)."""
     cfg = CogVideoXTransformerConfig(num_layers=2)
     model = CogVideoXTransformer3DModel.from_synthetic(cfg, seed=13, device=device)
@@ -281,7 +281,7 @@ def test_prescaled_attention_path_agrees_in_a_full_width_forward(device, monkeyp
     rope = rotary_tables(64, get_resize_crop_region_for_grid((30, 45), 45, 30), (30, 45), 13)
     ts = torch.full((2,), 500.0)
     a = model.forward_assembled(lat, [c0, c0], torch.cat([ne, pe]), ts, rope).float()
-    monkeypatch.setenv("ALG_ATTN_PRESCALE", "0")
+    model.attn_prescale = False
     b = model.forward_assembled(lat, [c0, c0], torch.cat([ne, pe]), ts, rope).float()
     rel = ((a - b).norm() / b.norm()).item()
     assert bool(torch.isfinite(a).all()) and 0 < rel < 5e-3, rel

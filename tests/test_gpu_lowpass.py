@@ -35,7 +35,7 @@ def test_register_blocked_kernels_against_golden_vectors_and_oracle(device, gold
     """lowpass_v3.hip takes calls of 128 planes and more; here the plane threshold is dropped to 1 so that the
     reference-generated golden vectors (small plane counts) and the oracle cases run through it directly, not only through
     its bit-identity with the plane-per-workgroup kernels."""
-    monkeypatch.setenv("ALG_LOWPASS_V3_MIN_PLANES", "1")
+    monkeypatch.setenv("ALG_LOWPASS_PATH", "3")      # lowpass_v3.hip at any plane count
     with open(os.path.join(golden_dir, "lp_misc.json")) as f:
         meta = json.load(f)["down_up_meta"]
     vec = np.load(os.path.join(golden_dir, "down_up_vectors.npz"))
@@ -215,14 +215,14 @@ def test_gaussian_more_than_255_taps(device):
 
 
 def test_global_memory_path_is_bit_identical_to_the_lds_path(device, monkeypatch):
-    """ALG_LOWPASS_FORCE_GLOBAL=1 (debug knob) sends LDS-sized planes through lowpass_big.hip: same bits."""
+    """ALG_LOWPASS_PATH=4 sends LDS-sized planes through lowpass_big.hip: same bits."""
     g = torch.Generator().manual_seed(31)
     for dt in (torch.float32, torch.bfloat16):
         x = torch.randn(1, 16, 3, 60, 90, generator=g).to(dt).to(device)
-        monkeypatch.delenv("ALG_LOWPASS_FORCE_GLOBAL", raising=False)
+        monkeypatch.delenv("ALG_LOWPASS_PATH", raising=False)
         a = lp_utils.apply_low_pass_filter(x, "down_up", 0.0, 0, 0.25)
         b = lp_utils.apply_low_pass_filter(x, "gaussian_blur", 3.0, 9, 1.0)
-        monkeypatch.setenv("ALG_LOWPASS_FORCE_GLOBAL", "1")
+        monkeypatch.setenv("ALG_LOWPASS_PATH", "4")
         assert torch.equal(lp_utils.apply_low_pass_filter(x, "down_up", 0.0, 0, 0.25), a)
         assert torch.equal(lp_utils.apply_low_pass_filter(x, "gaussian_blur", 3.0, 9, 1.0), b)
 
@@ -266,9 +266,9 @@ def test_bandwidth_shaped_kernels_are_bit_identical_to_the_plane_per_workgroup_k
     call = (lambda: lp_utils.apply_low_pass_filter(x, "down_up", 0.0, 0, arg)) if kind == "down_up" else \
         (lambda: lp_utils.apply_low_pass_filter(x, "gaussian_blur", arg[1], arg[0], 1.0))
     new = call()
-    monkeypatch.setenv("ALG_LOWPASS_V1", "1")
+    monkeypatch.setenv("ALG_LOWPASS_PATH", "1")
     old = call()
-    monkeypatch.delenv("ALG_LOWPASS_V1")
+    monkeypatch.delenv("ALG_LOWPASS_PATH")
     assert new.dtype == dtype and new.shape == x.shape
     assert torch.equal(new, old)
     assert torch.equal(call(), new)                      # deterministic, table cache warm

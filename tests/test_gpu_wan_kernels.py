@@ -51,7 +51,7 @@ def test_flash_attn_d128_matches_sdpa(B, H, Sq, Skv):
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 1024), (2, 3, 257, 1000), (1, 1, 256, 513), (1, 2, 1300, 2050),
                                           (1, 1, 64, 544), (1, 2, 520, 575), (1, 1, 300, 640), (1, 2, 100, 700),
                                           (1, 1, 200, 832)])
-def test_flash_attn_d128_q64_kernel(B, H, Sq, Skv, monkeypatch):
+def test_flash_attn_d128_q64_kernel(B, H, Sq, Skv, monkeypatch, experiments):
     """The long self-attention form (attention128_q64.hip: 64 queries per wave, software-pipelined 32-key half-tiles, taken for
     >= 8 KV tiles): against fp32 SDPA and against the 32-query kernel (ALG_ATTN128_Q64=0) on the same tensors.  Ragged key
     counts: a last tile whose second half is partly (1000, 2050), entirely (513, 544: 1 / 32 keys) masked, or exactly half
