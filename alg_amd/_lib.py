@@ -215,14 +215,42 @@ def _ptr(t):
 # The library never allocates (include/alg_hip.h): scratch space and the down_up tap tables are torch tensors owned here.
 # Tables depend on the shape only, so they are built once per (device, stream, shape) and kept in a small LRU; a scratch
 # buffer is kept per (device, stream, tag) and only ever grows -- launches on one stream are ordered, so the calls that
-# share it never overlap.  Both survive a hipGraph capture: a replay reads / writes the very buffers the capture saw.
+# share it never overlap.
+#
+# hipGraph capture: a captured launch holds the RAW pointer of the table / scratch buffer it was handed, so
+#   * a buffer that was handed out while the stream was capturing is PINNED: it leaves the caches like any other (LRU eviction,
+#     a larger scratch request) but is never freed -- a replay may dereference it at any later time (release_captured_buffers()
+#     is the explicit way out once the graphs are gone);
+#   * a table first BUILT inside a capture is filled by the replay, not now: it is pinned for the graph and NOT put into the
+#     eager cache, where a later eager call would read it before any replay has run.
 _TABLES = OrderedDict()
 _TABLES_MAX = 64
 _SCRATCH = {}
+_PINNED = {}          # id(tensor) -> tensor
 
 
 def _stream_key(t):
     return (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def _pin(t):
+    _PINNED[id(t)] = t
+    return t
+
+
+def release_captured_buffers():
+    """Drop the buffers pinned for hipGraph captures.  Only call this when every graph captured so far has been destroyed."""
+    _PINNED.clear()
+
+
+def clear_caches():
+    """Drop the table / scratch caches (a long-running host that has retired a stream); pinned buffers stay."""
+    _TABLES.clear()
+    _SCRATCH.clear()
 
 
 def lowpass_tables(x, h1, w1):
@@ -230,15 +258,18 @@ def lowpass_tables(x, h1, w1):
     lib = load_library()
     H, W = x.shape[-2:]
     key = _stream_key(x) + (H, W, h1, w1)
+    cap = _capturing()
     t = _TABLES.get(key)
     if t is not None:
         _TABLES.move_to_end(key)
-        return t
+        return _pin(t) if cap else t
     n = int(lib.alg_lowpass_tables_bytes(H, W, h1, w1))
     if n <= 0:
         return None
     t = torch.empty(n, dtype=torch.uint8, device=x.device)
     _check(lib.alg_lowpass_tables_build(_ptr(t), n, H, W, h1, w1, _stream()), "alg_lowpass_tables_build")
+    if cap:
+        return _pin(t)          # built by the graph's own replay: lives with the graph, invisible to eager calls
     _TABLES[key] = t
     while len(_TABLES) > _TABLES_MAX:
         _TABLES.popitem(last=False)
@@ -253,8 +284,8 @@ def scratch(ref, nbytes, tag):
     t = _SCRATCH.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=ref.device)
-        _SCRATCH[key] = t
-    return t
+        _SCRATCH[key] = t       # a superseded buffer that a capture saw stays alive in _PINNED
+    return _pin(t) if _capturing() else t
 
 
 def down_up(x, h1, w1, round_intermediate=True):

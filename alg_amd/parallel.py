@@ -20,6 +20,48 @@ DIST_TIMEOUT_S = 6 * 3600
 SMALL_TENSOR_BYTES = 1 << 20
 
 
+# what the one-time weight broadcast cost (bench.py reports it next to an N > 1 line): seconds are host wall time around each
+# bucket's collective with the device drained on both sides -- start-up only, never on the data path
+BCAST_STATS = {"seconds": 0.0, "bytes": 0, "collectives": 0}
+
+
+def _timed_broadcast(flat, src):
+    import time
+    cuda = flat.is_cuda
+    if cuda:
+        torch.cuda.synchronize(flat.device)
+    t0 = time.perf_counter()
+    dist.broadcast(flat, src=src)
+    if cuda:
+        torch.cuda.synchronize(flat.device)
+    BCAST_STATS["seconds"] += time.perf_counter() - t0
+    BCAST_STATS["bytes"] += flat.numel() * flat.element_size()
+    BCAST_STATS["collectives"] += 1
+
+
+def ranks_seen(device=None):
+    """One record per rank -- host, device index, name and the GPU's identity (UUID / PCI bus id as the runtime reports them)
+    -- all-gathered, so a multi-GPU bench line can PROVE that N ranks sat on N distinct GPUs (`distinct_gpus`)."""
+    import socket
+    rec = {"rank": dist.get_rank() if dist.is_initialized() else 0, "host": socket.gethostname(), "pid": os.getpid()}
+    if device is not None and torch.device(device).type == "cuda" and torch.cuda.is_available():
+        idx = torch.device(device).index
+        idx = torch.cuda.current_device() if idx is None else idx
+        prop = torch.cuda.get_device_properties(idx)
+        rec.update(device=idx, name=prop.name, uuid=str(getattr(prop, "uuid", "")),
+                   pci="%s:%s:%s" % (getattr(prop, "pci_domain_id", "?"), getattr(prop, "pci_bus_id", "?"),
+                                      getattr(prop, "pci_device_id", "?")))
+    else:
+        rec.update(device=None, name="cpu", uuid="", pci="")
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        recs = [None] * dist.get_world_size()
+        dist.all_gather_object(recs, rec)
+    else:
+        recs = [rec]
+    ids = {(r["host"], r["uuid"] or r["pci"] or r["pid"]) for r in recs}
+    return {"ranks": recs, "distinct_gpus": len(ids)}
+
+
 def env_world():
     """(rank, local_rank, world) of the torchrun environment.  ALG_DIST_ONE_GPU=1 (test hook: exercising the multi-process
     launch path on a one-GPU box, together with ALG_DIST_BACKEND=gloo) maps every local rank to device 0."""
@@ -72,7 +114,7 @@ def broadcast_state_dict(make_state_dict, shapes, device, src=0, dtype=torch.bfl
                 k = _numel(shapes[n])
                 flat[off:off + k].copy_(sd[n].to(device=device, dtype=dtype).reshape(-1))
                 off += k
-        dist.broadcast(flat, src=src)
+        _timed_broadcast(flat, src)
         off = 0
         for n in group:
             k = _numel(shapes[n])
@@ -125,7 +167,7 @@ def broadcast_loaded_state_dict(sd, device, src=0, bucket_bytes=1 << 30):
                     nb = _numel(shape) * esize
                     flat[off:off + nb].copy_(sd[k].to(device).contiguous().reshape(-1).view(torch.uint8))
                     off += -(-nb // 16) * 16
-            dist.broadcast(flat, src=src)
+            _timed_broadcast(flat, src)
             off = 0
             for k, shape in group:
                 nb = _numel(shape) * esize

@@ -102,6 +102,8 @@ def read_shards(root, device=None):
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and \
         os.environ.get("ALG_BROADCAST_WEIGHTS", "1") != "0"
     if not multi:
+        if not shards:
+            raise FileNotFoundError("no *.safetensors under %s" % root)
         sd = {}
         for shard in shards:
             sd.update(load_file(shard))

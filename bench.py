@@ -630,6 +630,59 @@ def private_loop_crosscheck(wl, k_steps):
     return (time.perf_counter() - t0) / k_steps * 1e3
 
 
+def timed_region(wl, warmup, steps, parallel):
+    """W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; HIP-event brackets of the
+    kernel families live only inside the timed region.  Returns (elapsed seconds = max over ranks, sample-forwards of this
+    rank, per-family event times in ms)."""
+    run_steps(wl, max(warmup, wl.min_warmup))
+    kinds = {}  # kernel family -> list of event pairs
+    wl.instrument(kinds)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    forwards = run_steps(wl, steps)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    wl.instrument(None)
+    elapsed = parallel.max_over_ranks(elapsed, wl.dev)
+    return elapsed, forwards, {k: event_ms(v) for k, v in kinds.items()}
+
+
+def other_workloads(args, dev, parallel):
+    """BASELINE configs 3 / 4 / 5 on the driver's clock.  After the C2 region (its weights freed), each of
+    the other workloads is built at FULL depth and timed for 2 steps after 1 warm-up step through its pipeline's __call__ --
+    the same code path and the same value formula as `bench.py --workload cX --steps 2 --warmup 1` (loop iterations 0-1, i.e.
+    the 3-pass ALG steps of c3 / c5 and the single-pass branch of c4: the conservative end of each schedule)."""
+    import gc
+    res = {}
+    for name in ("c3", "c4", "c5"):
+        t_build = time.perf_counter()
+        try:
+            wl = WORKLOADS[name](args, dev, 0, 1, None)
+            wl.build()
+            torch.cuda.synchronize()
+            t_build = time.perf_counter() - t_build
+            elapsed, forwards, ms = timed_region(wl, 1, 2, parallel)
+            rl = wl.roofline(ms, forwards, elapsed)
+            res[name] = {
+                "metric": wl.metric, "frames_per_s": wl.frames * 2 / wl.steps_per_video / elapsed, "ms_per_step": elapsed / 2 * 1e3,
+                "steps": 2, "warmup": 1, "dit_sample_forwards": forwards, "layers": wl.layers, "tokens": wl.config(forwards)["tokens"],
+                "dtype": wl.dtype, "attn_kernel": rl["kernel"], "attn_tflops": rl["achieved"], "attn_frac": rl["frac"],
+                "whole_step_tflops": rl["extra"].get("whole_step_tflops"), "time_share": rl["extra"].get("time_share"),
+                "gemm_tflops": {k: round(v, 1) for k, v in rl["extra"].items() if k.startswith("gemm_") and k.endswith("_tflops")},
+                "finite": bool(torch.isfinite(wl.last_out.float()).all().item()), "build_seconds": round(t_build, 1),
+                "peak_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+            }
+        except Exception as e:   # an auxiliary workload must never take the headline line down
+            res[name] = {"error": repr(e)}
+        wl = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+    return res
+
+
 def self_launch(args):
     """`python bench.py --gpus N` run plainly: become the launcher of N ranks (one per GPU) on this node."""
     with socket.socket() as s:
@@ -658,6 +711,8 @@ def main():
                     help="opt-in: cond/uncond CFG passes of one video on a pair of GPUs (latency mode, one all-gather per step)")
     ap.add_argument("--cross-check", action="store_true", help="c2: also time round 1's bench-private loop")
     ap.add_argument("--filters-only", action="store_true", help="debug: only the low-pass kernel micro-benchmark")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="c2 at 1 GPU: skip the c3 / c4 / c5 legs (2 timed full-depth steps each, ~3 min) that ride behind the headline")
     args = ap.parse_args()
     if args.filters_only:
         print(json.dumps(filter_microbench(torch.device("cuda:0"))))
@@ -687,24 +742,14 @@ def main():
         split = parallel.CFGPairSplit.from_world()
 
     wl = WORKLOADS[args.workload](args, dev, rank, world, split)
+    t_b0 = time.perf_counter()
     wl.build()
-    run_steps(wl, max(args.warmup, wl.min_warmup))
-
-    kinds = {}  # kernel family -> list of event pairs
-    wl.instrument(kinds)
-    parallel.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    forwards = run_steps(wl, args.steps)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    elapsed = time.perf_counter() - t0
-    wl.instrument(None)
-    elapsed = parallel.max_over_ranks(elapsed, dev)
+    build_seconds = time.perf_counter() - t_b0
+    elapsed, forwards, ms = timed_region(wl, args.warmup, args.steps, parallel)
 
     n_videos_parallel = world // 2 if split else world
     value = wl.frames * args.steps / wl.steps_per_video * n_videos_parallel / elapsed
-    ms = {k: event_ms(v) for k, v in kinds.items()}
     roofline = wl.roofline(ms, forwards, elapsed)
 
     cfgd = wl.config(forwards)
@@ -717,6 +762,15 @@ def main():
         "dtype": wl.dtype, "data": wl.data, "config": cfgd, "seconds": elapsed,
         "finite": bool(torch.isfinite(wl.last_out.float()).all().item()), "roofline": roofline,
     }
+    if world > 1:
+        # proof that N ranks sat on N distinct GPUs, and what the ONE collective of the data-parallel path cost (start-up only)
+        seen = parallel.ranks_seen(dev)
+        out["ranks_seen"] = seen["ranks"]
+        out["distinct_gpus"] = seen["distinct_gpus"]
+        out["bcast_seconds"] = parallel.max_over_ranks(parallel.BCAST_STATS["seconds"], dev)
+        out["bcast_gbytes"] = parallel.BCAST_STATS["bytes"] / 1e9
+        out["bcast_collectives"] = parallel.BCAST_STATS["collectives"]
+    out["build_seconds"] = build_seconds
     if args.layers:
         out["INVALID"] = "debug run with %d layers" % args.layers
     if rank == 0 and world == 1 and args.workload == "c2":
@@ -725,6 +779,12 @@ def main():
         out["roofline"]["extra"]["filters"] = filter_microbench(dev)
         out["roofline"]["extra"]["vae_decode"] = vae_decode_microbench(dev, wl.latents0,
                                                                        elapsed / args.steps * wl.steps_per_video)
+    if rank == 0 and world == 1 and args.workload == "c2" and not args.no_other_workloads and not args.layers:
+        import gc
+        wl.model = wl.pipe = wl.sched = wl.last_out = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["roofline"]["extra"]["workloads"] = other_workloads(args, dev, parallel)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(with_c1=not args.no_c1, c1_budget=args.c1_budget)
     if rank == 0:

@@ -77,3 +77,44 @@ def test_filters_on_pixel_sized_planes_run_in_caller_workspace_under_capture(dev
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(got_d, want_d) and torch.equal(got_g, want_g)
+
+
+def test_buffers_a_capture_saw_outlive_the_caches_and_cold_tables_stay_out_of_them(device):
+    """(1) a tap table first built INSIDE a capture is filled by the replay, not at capture time -- it must not
+    reach the eager cache; (2) a table / scratch buffer a capture was handed stays alive when the caches evict or outgrow it:
+    the graph holds its raw pointer."""
+    g = torch.Generator(device=device).manual_seed(4)
+    x = torch.randn(4, 3, 44, 52, generator=g, device=device)              # a plane shape nothing else in the suite uses
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    n_tables, n_pinned = len(_lib._TABLES), len(_lib._PINNED)
+    with torch.cuda.graph(graph, stream=side):                             # NO warm-up: the table build is captured
+        got = _lib.down_up(x, 11, 13)
+    assert len(_lib._TABLES) == n_tables and len(_lib._PINNED) > n_pinned  # pinned for the graph, not cached
+    with torch.cuda.stream(side):
+        eager = _lib.down_up(x, 11, 13)                                    # builds its own table: no half-built hit
+    torch.cuda.synchronize()
+    want = _lib.down_up(x, 11, 13)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(eager, want) and torch.equal(got, want)
+    # (2) warm-up, capture, then evict everything and outgrow the scratch: the replay must still be right
+    big = torch.randn(3, 480, 720, generator=g, device=device)
+    with torch.cuda.stream(side):
+        _lib.down_up(big, 120, 180)
+    torch.cuda.synchronize()
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2, stream=side):
+        got2 = _lib.down_up(big, 120, 180)
+        got3 = _lib.down_up(x, 11, 13)
+    want2 = _lib.down_up(big, 120, 180)
+    _lib.clear_caches()
+    with torch.cuda.stream(side):
+        _lib.down_up(torch.randn(6, 600, 800, generator=g, device=device), 150, 200)   # a larger scratch on the same stream
+        junk = [torch.randn(1 << 20, device=device) for _ in range(8)]                  # reuse whatever the allocator freed
+    torch.cuda.synchronize()
+    graph2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got2, want2) and torch.equal(got3, want)
+    del junk

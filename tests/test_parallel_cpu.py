@@ -278,5 +278,67 @@ def test_loaded_state_dict_broadcast_status_small_tensors_and_empty_buckets(fail
     assert res == [(0, "raised" if fail else "ok", True), (1, "raised" if fail else "ok", True)]
 
 
+def _world8_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_distributed(backend="gloo")
+    res = {"rank": rank}
+    # (1) rank 0 fails to read its shards: EVERY one of the eight ranks raises, nobody is left inside a broadcast
+    try:
+        parallel.broadcast_loaded_state_dict(FileNotFoundError("shard missing") if rank == 0 else None, "cpu")
+        res["load_failure"] = "no error"
+    except RuntimeError as e:
+        res["load_failure"] = "shard missing" in str(e)
+    # (2) the weight broadcast proper, several buckets, and its statistics
+    g = torch.Generator().manual_seed(9)
+    full = {"w": torch.randn(300, 200, generator=g).to(torch.bfloat16), "b": torch.randn(77, generator=g)}
+    got = parallel.broadcast_loaded_state_dict(full if rank == 0 else None, "cpu", bucket_bytes=1 << 14)
+    res["bcast_ok"] = all(torch.equal(got[k], full[k]) for k in full)
+    res["bcast_stats"] = (parallel.BCAST_STATS["collectives"] >= 2, parallel.BCAST_STATS["bytes"] >= 300 * 200 * 2 + 77 * 4,
+                          parallel.BCAST_STATS["seconds"] > 0)
+    # (3) 11 jobs on 8 ranks (jobs % world != 0): v -> rank v mod world, every job exactly once, ranks 3.. take one job only
+    res["jobs"] = parallel.shard_videos(11, rank, world)
+    # (4) four CFG pairs (BASELINE config 5: 2 GPUs x 4 videos): pair groups (0,1) (2,3) (4,5) (6,7), each merging ITS video
+    split = parallel.CFGPairSplit.from_world()
+    ok = True
+    for n_pass in (2, 3):
+        gg = torch.Generator().manual_seed(100 * (rank // 2) + n_pass)           # one prediction per PAIR (= per video)
+        pred = torch.randn(n_pass, 4, 6, generator=gg).to(torch.bfloat16)
+        mine = split.my_passes(n_pass)
+        merged = split.merge(torch.cat([pred[p:p + 1] for p in mine]), n_pass, 1)
+        ok = ok and torch.equal(merged, pred)
+    res["cfg_pairs"] = (split.pair_rank, ok)
+    # (5) who is here: eight distinct processes report in (on a GPU node: eight distinct device UUIDs)
+    seen = parallel.ranks_seen("cpu")
+    res["seen"] = (len(seen["ranks"]), seen["distinct_gpus"], sorted(r["rank"] for r in seen["ranks"]))
+    res["tmax"] = parallel.max_over_ranks(float(rank), "cpu")
+    parallel.barrier()
+    out.put(res)
+    dist.destroy_process_group()
+
+
+def test_world_size_8_pairs_ragged_jobs_and_load_failure():
+    """the N = 8 layout of the node the metric is quoted on, on gloo: a failed checkpoint read on rank 0 reaches
+    all eight ranks as an exception; the bucketed broadcast delivers identical bits and counts its bytes / seconds; 11 jobs over
+    8 ranks are each run exactly once; the four CFG pairs exchange within their own pair only; ranks_seen lists all eight."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in procs), key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r["load_failure"] for r in res] == [True] * 8
+    assert all(r["bcast_ok"] and r["bcast_stats"] == (True, True, True) for r in res)
+    jobs = [v for r in res for v in r["jobs"]]
+    assert sorted(jobs) == list(range(11)) and [len(r["jobs"]) for r in res] == [2, 2, 2, 1, 1, 1, 1, 1]
+    assert [r["cfg_pairs"] for r in res] == [(i % 2, True) for i in range(8)]
+    assert all(r["seen"] == (8, 8, list(range(8))) for r in res)
+    assert all(r["tmax"] == 7.0 for r in res)
+
+
 def test_process_group_timeout_outlasts_a_video():
     assert parallel.DIST_TIMEOUT_S >= 3600      # C4 / C5: 9-13 minutes per video; ranks with fewer jobs wait in the barrier
