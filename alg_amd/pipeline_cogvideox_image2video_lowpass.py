@@ -541,6 +541,8 @@ class CogVideoXImageToVideoPipeline:
         old_pred_original_sample = None  # cog:998
 
         B = latents.shape[0]
+        # every timestep of the schedule on the device ONCE: a step takes a view of it (no host tensor + H2D copy per step)
+        ts_dev = torch.as_tensor([int(t_) for t_ in timesteps], dtype=torch.float32).to(device)
         for i, t in enumerate(timesteps):
             if self._interrupt:
                 continue
@@ -587,7 +589,7 @@ class CogVideoXImageToVideoPipeline:
             n_pass = len(cond_groups)
             conds = [g[b:b + 1] for g in cond_groups for b in range(B)]
             lat_in = latents if B == 1 else torch.cat([latents] * n_pass, dim=0)
-            ts = torch.full((n_pass * B,), int(t), dtype=torch.float32)
+            ts = ts_dev[i:i + 1].expand(n_pass * B)
             if cfg_split is not None and n_pass > 1:
                 # alg_amd.parallel.CFGPairSplit: this rank evaluates its share of the CFG passes, one all-gather merges
                 # the predictions; combine + step below run identically on both ranks of the pair

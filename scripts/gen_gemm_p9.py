@@ -117,7 +117,10 @@ def addr_math():
 
 RES_COPIES = 8        # residual variant: the first eight steady-state k-tiles each fetch four of the 32 residual quads
 RES_GAPS = (3, 7, 11, 15)
-RS = MA               # running scalar byte offset of the residual row block (MA / MB are only used by the BUF experiment)
+RV = "v162"           # running PER-LANE byte offset of the residual row block (tile origin + lane part, advanced 16 rows per
+                      # copy).  Everything sits in the VECTOR offset and the scalar offset is 0: the buffer bounds check covers
+                      # voffset + the immediate only (soffset is outside it), so this is what makes rows past M read as 0 instead
+                      # of reading up to 255 rows beyond R
 
 
 def res_loads(c):
@@ -127,7 +130,7 @@ def res_loads(c):
     out = []
     for nt in range(4):
         it = ((mt * 4 + nt) << 1) | half
-        out.append("buffer_load_dwordx4 %%[r%d], %%[rvoff], %%[rs], %s offen offset:%d" % (it, RS, nt * 64))
+        out.append("buffer_load_dwordx4 %%[r%d], %s, %%[rs], 0 offen offset:%d" % (it, RV, nt * 64))
     return out
 
 
@@ -171,7 +174,7 @@ def ktile(dma_on, barrier_on, res_copy=None):
     if res_copy is not None:
         for g, ins in zip(RES_GAPS, res_loads(res_copy)):
             posts[g].append(ins)
-        posts[RES_GAPS[-1]].append("s_add_u32 %s, %s, %%[ldr16]" % (RS, RS))
+        posts[RES_GAPS[-1]].append("v_add_u32 %s, %%[ldr16], %s" % (RV, RV))
     body = list(pre)
     for j in range(64):
         ks, q = j >> 4, j & 15
@@ -257,7 +260,7 @@ def _emit(res):
         # front of it -- every CU asks for its 128 KiB in the same microsecond (32 MB per round of tiles) and the burst is on
         # the critical path either way (vmcnt retires in order: a counted wait covers everything older).  Short K: whatever
         # the loop did not get to is fetched by the catch-up chain (labels 1xx) in front of the last two k-tiles.
-        lines += ["s_mov_b32 %s, %%[rsoff]" % RS]
+        lines += ["v_mov_b32 %s, %%[rvoff]" % RV]
         lines += ["s_mov_b32 %s, %%[nloop]" % CNT, "s_cmp_eq_u32 %s, 0" % CNT, "s_cbranch_scc1 100f"]
         for c in range(RES_COPIES):
             lines += ktile(True, True, res_copy=c)
@@ -266,7 +269,7 @@ def _emit(res):
         lines += ktile(True, True)
         lines += ["s_sub_u32 %s, %s, 1" % (CNT, CNT), "s_cmp_lg_u32 %s, 0" % CNT, "s_cbranch_scc1 1b", "s_branch 2f"]
         for c in range(RES_COPIES):
-            lines += ["%d:" % (100 + c)] + res_loads(c) + ["s_add_u32 %s, %s, %%[ldr16]" % (RS, RS)]
+            lines += ["%d:" % (100 + c)] + res_loads(c) + ["v_add_u32 %s, %%[ldr16], %s" % (RV, RV)]
         lines += ["%d:" % (100 + RES_COPIES), "2:"]
     lines += ktile(False, True)     # last but one: nothing left to stage, the wait drains
     lines += ktile(False, False)    # last

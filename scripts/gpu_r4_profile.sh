@@ -1,0 +1,44 @@
+#!/bin/bash
+# Round-4 evidence run.  usage: bash scripts/gpu_r4_profile.sh [gemmtests] [bench] [prof] [pmc] [workloads]
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
+TAG=${TAG:-r4}
+for w in ${@:-gemmtests bench prof}; do
+  case $w in
+    gemmtests)
+      cd $R
+      timeout 900 python -m pytest tests/test_gpu_dit_kernels.py tests/test_gpu_fp8.py tests/test_gpu_full_size.py -q --no-header -p no:cacheprovider -k "gemm or schedule9 or race or forward" 2>&1 | tail -5 > $O/${TAG}_gemm_tests.log
+      ALG_HIP_LIB=$R/alg_amd/libalg_hip_exp.so timeout 900 python -m pytest tests/test_gpu_dit_kernels.py -q --no-header -p no:cacheprovider -k "gemm or schedule9 or race" 2>&1 | tail -5 >> $O/${TAG}_gemm_tests.log
+      cat $O/${TAG}_gemm_tests.log ;;
+    bench)
+      cd $R
+      timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_driver_steps20.json 2> $O/${TAG}_bench.err; echo "bench exit $?"
+      tail -c 1500 $O/${TAG}_bench_driver_steps20.json; tail -3 $O/${TAG}_bench.err ;;
+    prof)
+      cd /tmp
+      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profd4 -o $TAG -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-other-workloads > $O/${TAG}_bench_default_under_rocprof.json 2> $O/profd4.err
+      echo "prof exit $?"
+      find $O/profd4 -name "*kernel_trace*" -delete
+      cp $(find $O/profd4 -name "*kernel_stats*" | head -1) $O/${TAG}_bench_default_kernel_stats.csv
+      rm -rf $O/profd4
+      head -12 $O/${TAG}_bench_default_kernel_stats.csv | cut -c1-160 ;;
+    pmc)
+      cd /tmp
+      P=$O/pmc_r4; rm -rf $P; mkdir -p $P
+      i=0
+      for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_BUSY_CYCLES" \
+                  "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
+                  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE"; do
+        i=$((i+1))
+        timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $P/kb_p$i -o p -- python $R/scripts/kbench.py --only attn_prescaled,gemm_qk,gemm_vt,gemm_out,gemm_ff1,gemm_ff2 --iters 2 > /dev/null 2> $P/kb_p$i.err
+      done
+      python $R/scripts/pmc_summary.py $P > $O/${TAG}_pmc_summary.txt 2>&1
+      rm -rf $P
+      grep -c mean $O/${TAG}_pmc_summary.txt ;;
+    workloads)
+      cd $R
+      for wl in c3 c4 c5; do
+        timeout 900 python bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_workload_$wl.json 2>> $O/${TAG}_bench.err; echo "$wl exit $?"
+      done ;;
+  esac
+done
