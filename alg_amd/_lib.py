@@ -21,7 +21,7 @@ ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
 GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS, GEMM_GATE_F32, GEMM_GATE_SEG_STRIDE = 1, 4, 8, 16
 
 EXPORTS = (
-    "alg_version", "alg_last_error", "alg_reload_env", "alg_build_experiments", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16",
+    "alg_version", "alg_last_error", "alg_reload_env", "alg_build_experiments", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16", "alg_gemm_bf16_pair",
     "alg_flash_attn_d64", "alg_layernorm_modulate", "alg_qk_norm_rope", "alg_patchify", "alg_unpatchify",
     "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128", "alg_layernorm_mod_f32", "alg_layernorm_mod_f32_fp8", "alg_rmsnorm_rope",
     "alg_wan_modulation", "alg_patchify3d", "alg_unpatchify3d", "alg_timestep_embedding_f32", "alg_linear_f32",
@@ -147,6 +147,7 @@ def load_library():
     lib.alg_gelu_erf.argtypes = [c_void_p, c_int64, c_void_p]
     lib.alg_unipc_update.argtypes = [c_void_p] * 5 + [c_int64] + [c_float] * 6 + [c_void_p]
     lib.alg_gemm_bf16.argtypes = [POINTER(GemmArgs), c_void_p]
+    lib.alg_gemm_bf16_pair.argtypes = [POINTER(GemmArgs), POINTER(GemmArgs), c_void_p]
     lib.alg_flash_attn_d64.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
                                        c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]
     lib.alg_layernorm_modulate.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
@@ -649,13 +650,11 @@ def unipc_update(x, m0, m1, m_new, r, c, k, rk=1.0, rho0=0.0, rho_new=0.0):
     return out
 
 
-def gemm(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=None, batch=1, strideA=0, strideB=0,
-         strideC=0, strideR=0, strideGate=0, seg_split=0, act=ACT_NONE, flags=0, a_off=0, b_off=0, c_off=0, r_off=0,
-         gate_off=0, gate_seg_stride=None, bias_off=0, perm_col0=0, a_scale=None, b_scale=None, strideAScale=0,
-         strideBScale=0, a_scale_off=0, b_scale_off=0):
-    """Raw pointer-level GEMM: C = R + gate * act(A @ B^T + bias); offsets in elements.  With a_scale / b_scale (float32
-    row scales) A and B are OCP e4m3 bytes and the call goes to alg_gemm_fp8."""
-    lib = load_library()
+def gemm_args(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=None, batch=1, strideA=0, strideB=0,
+              strideC=0, strideR=0, strideGate=0, seg_split=0, act=ACT_NONE, flags=0, a_off=0, b_off=0, c_off=0, r_off=0,
+              gate_off=0, gate_seg_stride=None, bias_off=0, perm_col0=0, a_scale=None, b_scale=None, strideAScale=0,
+              strideBScale=0, a_scale_off=0, b_scale_off=0):
+    """The alg_gemm_args struct of one call (offsets in elements)."""
     args = GemmArgs()
     fp8 = a_scale is not None
     args.A = A.data_ptr() + A.element_size() * a_off
@@ -676,10 +675,29 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=None, b
     args.M, args.N, args.K, args.batch = M, N, K, batch
     args.seg_split, args.act, args.flags = seg_split, act, flags
     args.perm_col0 = perm_col0
+    return args, fp8
+
+
+def gemm(*a, **kw):
+    """Raw pointer-level GEMM: C = R + gate * act(A @ B^T + bias); offsets in elements.  With a_scale / b_scale (float32
+    row scales) A and B are OCP e4m3 bytes and the call goes to alg_gemm_fp8."""
+    lib = load_library()
+    args, fp8 = gemm_args(*a, **kw)
     if fp8:
         _check(lib.alg_gemm_fp8(ctypes.byref(args), _stream()), "alg_gemm_fp8")
     else:
         _check(lib.alg_gemm_bf16(ctypes.byref(args), _stream()), "alg_gemm_bf16")
+
+
+def gemm_pair(first, second):
+    """Two independent plain bf16 GEMMs -- each a (args, kwargs) pair of `gemm` -- as one persistent launch
+    (alg_gemm_bf16_pair); bit-identical to the two separate calls."""
+    lib = load_library()
+    a, fa = gemm_args(*first[0], **first[1])
+    b, fb = gemm_args(*second[0], **second[1])
+    if fa or fb:
+        raise AlgHipError("gemm_pair takes bf16 problems")
+    _check(lib.alg_gemm_bf16_pair(ctypes.byref(a), ctypes.byref(b), _stream()), "alg_gemm_bf16_pair")
 
 
 def quantize_fp8_rows(x, q, scale, rows, K, x_rstride=None, x_off=0, q_off=0, scale_off=0):

@@ -13,6 +13,8 @@ int launch_gemm_p8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg
 #endif
 int launch_gemm_p6(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p9(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
+int launch_gemm_p9_pair(const alg_gemm_args* a, int m_tiles_a, int n_tiles_a, const alg_gemm_args* b, int m_tiles_b, int n_tiles_b,
+                        hipStream_t s);
 int launch_gemm_p6_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 // ALG_GEMM_PIPE: 9 (default: 4 waves, asm main loop; round 3: faster than the 8-wave ping-pong on all five C2 shapes) | 6 (the
@@ -23,7 +25,7 @@ static int gemm_pipe() { return opt(OPT_GEMM_PIPE); }
 
 using namespace alg;
 
-static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
+static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8, bool validate_only = false) {
   if (!a || !a->A || !a->B || !a->C) {
     set_error("alg_gemm_bf16: null argument");
     return ALG_EINVAL;
@@ -87,6 +89,7 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
       return ALG_EINVAL;
     }
   }
+  if (validate_only) return ALG_OK;
   if ((int64_t)a->M * a->ldc >= (1ll << 31) || (a->R && (int64_t)a->M * a->ldr >= (1ll << 31))) {
     // Every argument check above has run on the WHOLE call, so a slab can only fail at launch (no error after
     // earlier slabs have already written C, which may alias R).  Per-row operands are A, C, R, a per-row bias, a_scale and
@@ -140,6 +143,34 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8) {
 }
 
 extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) { return gemm_entry(a, stream, false); }
+
+// Two independent plain GEMMs in one persistent launch when schedule 9 can take both (no residual / activation / convolution,
+// K >= 128, 32-bit offsets, no slab split); otherwise -- and always with ALG_GEMM_PIPE=6 -- simply one launch after the other.
+// Either way every output element is computed exactly as alg_gemm_bf16 would compute it (bit-identical).
+static bool pair_eligible(const alg_gemm_args* a) {
+  return a && a->A && a->B && a->C && !a->R && !a->gate && a->act == ALG_ACT_NONE && !a->conv_wp && a->M > 0 && a->N > 0 &&
+         a->batch > 0 && a->K >= 128 && a->K % 64 == 0 && 256 * a->lda * 2 + (int64_t)a->K * 2 < (1ll << 32) &&
+         256 * a->ldb * 2 + (int64_t)a->K * 2 < (1ll << 32) && (int64_t)a->M * a->ldc < (1ll << 31) &&
+         !(a->lda % 8 || a->ldb % 8 || a->strideA % 8 || a->strideB % 8 || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15)) &&
+         ((a->N & 3) != 0 || !((a->ldc & 3) || (a->strideC & 3) || ((uintptr_t)a->C & 7) ||
+                               (a->bias && !(a->flags & ALG_GEMM_BIAS_PER_ROW) && ((uintptr_t)a->bias & 7))));
+}
+
+extern "C" int alg_gemm_bf16_pair(const alg_gemm_args* a, const alg_gemm_args* b, void* stream) {
+  // every argument check of alg_gemm_bf16 runs on BOTH calls before anything is launched
+  int rc = gemm_entry(a, stream, false, true);
+  if (rc == ALG_OK) rc = gemm_entry(b, stream, false, true);
+  if (rc != ALG_OK) return rc;
+  if (gemm_pipe() == 9 && pair_eligible(a) && pair_eligible(b)) {
+    const int64_t ta = (int64_t)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN) * a->batch;
+    const int64_t tb = (int64_t)((b->M + BM - 1) / BM) * ((b->N + BN - 1) / BN) * b->batch;
+    if (ta + tb <= 0x7fffffff)
+      return launch_gemm_p9_pair(a, (a->M + BM - 1) / BM, (a->N + BN - 1) / BN, b, (b->M + BM - 1) / BM, (b->N + BN - 1) / BN,
+                                 (hipStream_t)stream);
+  }
+  rc = gemm_entry(a, stream, false);
+  return rc != ALG_OK ? rc : gemm_entry(b, stream, false);
+}
 
 extern "C" int alg_gemm_fp8(const alg_gemm_args* a, void* stream) { return gemm_entry(a, stream, true); }
 

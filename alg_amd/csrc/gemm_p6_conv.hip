@@ -21,10 +21,10 @@ int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_
   const int gm = gemm_group_m(6);
   if (a->R)
     hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, true, 6, 4, false, true>), grid, block, GEMM_LDS, s, *a, m_tiles,
-                       n_tiles, gm);
+                       n_tiles, gm, GemmNoPair{});
   else
     hipLaunchKernelGGL((gemm_bf16_kernel<ALG_ACT_NONE, false, 6, 4, false, true>), grid, block, GEMM_LDS, s, *a, m_tiles,
-                       n_tiles, gm);
+                       n_tiles, gm, GemmNoPair{});
   return check_launch("alg_conv_cl_bf16");
 }
 }  // namespace alg

@@ -91,6 +91,9 @@ class CogVideoXTransformer3DModel:
         # True (default): the softmax scale * log2(e) rides in Q's last rounding and the attention takes log2-unit scores
         # (alg_qk_norm_rope_scaled + ALG_ATTN_Q_PRESCALED); False keeps the per-score multiply (A/B and parity tests)
         self.attn_prescale = True
+        # True (default): the Q|K projection and the transposed V projection of a block go out as one alg_gemm_bf16_pair
+        # launch (bit-identical to the two launches; False keeps them apart: A/B runs, tests)
+        self.pair_qkv = True
         dev = self.device
         w = weights
         p = cfg.patch_size
@@ -323,9 +326,14 @@ class CogVideoXTransformer3DModel:
             m2 = m1 + 6 * D           # norm2
             TM("ln_mod", _lib.layernorm_modulate, x, y, L["norm1_w"], L["norm1_b"], mod, mod, self.mod_cols, N, S, D,
                T, cfg.norm_eps, scale_off=m1 + 2 * D, shift_off=m1)
-            TM("gemm_qk", G, y, L["wqk"], qk, S, 2 * D, D, D, D, 2 * D, bias=L["bqk"], batch=N, strideA=S * D, strideC=S * 2 * D)
-            TM("gemm_vt", G, L["wv"], y, vt, D, S, D, D, D, S_pad, bias=L["bv"], batch=N, strideB=S * D, strideC=D * S_pad,
-              flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
+            qk_call = ((y, L["wqk"], qk, S, 2 * D, D, D, D, 2 * D), dict(bias=L["bqk"], batch=N, strideA=S * D, strideC=S * 2 * D))
+            vt_call = ((L["wv"], y, vt, D, S, D, D, D, S_pad), dict(bias=L["bv"], batch=N, strideB=S * D, strideC=D * S_pad,
+                                                                   flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS))
+            if self.pair_qkv:   # both projections read y: ONE persistent launch, the two partial last rounds become one
+                TM("gemm_qkv", _lib.gemm_pair, qk_call, vt_call)
+            else:
+                TM("gemm_qk", G, *qk_call[0], **qk_call[1])
+                TM("gemm_vt", G, *vt_call[0], **vt_call[1])
             # the softmax scale * log2(e) rides in Q's last rounding (attn_prescale = False: scaled per score in the attention)
             TM("qk_norm_rope", _lib.qk_norm_rope_, qk, L["norm_q_w"], L["norm_q_b"], L["norm_k_w"], L["norm_k_b"], cos, sin, N, S, Hn, T,
                                cfg.qk_norm_eps, q_scale=q_scale)

@@ -140,6 +140,7 @@ class WanTransformer3DModel:
         quantised once to OCP e4m3 with one scale per output channel, activations per token right before each GEMM
         (alg_quantize_fp8_rows); norms, attention, embedders and the residual stream stay bf16 / fp32."""
         self.fp8 = bool(fp8)
+        self.pair_qkv = True     # bf16: Q|K and V^T projections of a block as one alg_gemm_bf16_pair launch (bit-identical)
         self.fuse_quant = True   # fp8: the modulated LayerNorm writes the e4m3 tokens + row scales itself (bit-identical to the quantiser pass)
         if config.qk_norm != "rms_norm_across_heads" or config.attention_head_dim != 128:
             raise NotImplementedError("the Wan DiT path is built for rms_norm_across_heads and head_dim 128")
@@ -391,14 +392,17 @@ class WanTransformer3DModel:
             m0 = li * N * 6 * D  # element offset of this block's [N, 6, D] modulation: shift, scale, gate, c_shift, c_scale, c_gate
             # ---- self-attention ----
             ln_mod(None, None, ws.mod, ws.mod, mod_bs, scale_off=m0 + D, shift_off=m0)
-            lin("gemm_qk", ws.y, L.wqk, ws.qk, N * S, 2 * D, D, D, 2 * D, requant=not fuse_q, bias=L.bqk)
-            if self.fp8:   # V^T: the weight is the A operand, the (already quantised) tokens are B
-                T("gemm_vt", G, L.wv[0], ws.q8, ws.vt, D, S, D, D, D, S_pad, bias=L.bv, batch=N, strideB=S * D,
-                  strideC=D * S_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS, a_scale=L.wv[1],
-                  b_scale=ws.q8s, strideBScale=S)
+            vt_kw = dict(bias=L.bv, batch=N, strideB=S * D, strideC=D * S_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
+            if self.fp8:
+                lin("gemm_qk", ws.y, L.wqk, ws.qk, N * S, 2 * D, D, D, 2 * D, requant=not fuse_q, bias=L.bqk)
+                # V^T: the weight is the A operand, the (already quantised) tokens are B
+                T("gemm_vt", G, L.wv[0], ws.q8, ws.vt, D, S, D, D, D, S_pad, a_scale=L.wv[1], b_scale=ws.q8s, strideBScale=S, **vt_kw)
+            elif self.pair_qkv:   # both projections read y: one persistent launch (alg_gemm_bf16_pair), bit-identical
+                T("gemm_qkv", _lib.gemm_pair, ((ws.y, L.wqk, ws.qk, N * S, 2 * D, D, D, D, 2 * D), dict(bias=L.bqk)),
+                  ((L.wv, ws.y, ws.vt, D, S, D, D, D, S_pad), vt_kw))
             else:
-                T("gemm_vt", G, L.wv, ws.y, ws.vt, D, S, D, D, D, S_pad, bias=L.bv, batch=N, strideB=S * D,
-                  strideC=D * S_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
+                lin("gemm_qk", ws.y, L.wqk, ws.qk, N * S, 2 * D, D, D, 2 * D, bias=L.bqk)
+                T("gemm_vt", G, L.wv, ws.y, ws.vt, D, S, D, D, D, S_pad, **vt_kw)
             T("rms_rope", _lib.rmsnorm_rope_, ws.qk, L.nq, cos, sin, 2 * D, N, S, D, cfg.eps)
             T("rms_rope", _lib.rmsnorm_rope_, ws.qk, L.nk, cos, sin, 2 * D, N, S, D, cfg.eps, x_off=D)
             T("attn_self", _lib.flash_attn_d128, ws.qk, ws.qk, ws.vt, ws.att, N, heads, S, S, S * 2 * D, 2 * D,

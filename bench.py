@@ -370,6 +370,8 @@ class C2(Workload):
         attn_time_total = sum(ms.get("attn", [])) / 1e3
         gemm_flops = dict(gemm_qk=2.0 * S * D * 2 * D, gemm_vt=2.0 * S * D * D, gemm_out=2.0 * S * D * D,
                           gemm_ff1=2.0 * S * D * 4 * D, gemm_ff2=2.0 * S * D * 4 * D)
+        if "gemm_qkv" in ms:   # the Q|K and V^T projections as ONE alg_gemm_bf16_pair launch (the default since round 4)
+            gemm_flops["gemm_qkv"] = gemm_flops.pop("gemm_qk") + gemm_flops.pop("gemm_vt")
         extra = {}
         for k, f in gemm_flops.items():
             tt = sum(ms.get(k, [])) / 1e3
@@ -414,6 +416,9 @@ class C2(Workload):
                                         gemm_ff1=(S, 4 * D, 2), gemm_ff2=(S, D, 2)).items():
             t = tiles(m, n, batch)
             tail[name] = {"tiles": t, "rounds_of_work": round(t / cus, 3), "rounds_paid": -(-t // cus)}
+        if "gemm_qkv" in ms:
+            t = tail.pop("gemm_qk")["tiles"] + tail.pop("gemm_vt")["tiles"]
+            tail["gemm_qkv"] = {"tiles": t, "rounds_of_work": round(t / cus, 3), "rounds_paid": -(-t // cus)}
         extra["gemm_tile_rounds"] = tail
         return roofline
 
@@ -464,6 +469,8 @@ class _WanBase(Workload):
         per_fwd = {"gemm_qk": 2.0 * S * D * 2 * D, "gemm_vt": 2.0 * S * D * D, "gemm_out": 2.0 * S * D * D,
                    "gemm_cq": 2.0 * S * D * D, "gemm_cout": 2.0 * S * D * D, "gemm_ff1": 2.0 * S * D * Ff,
                    "gemm_ff2": 2.0 * S * D * Ff, "attn_self": 4.0 * S * S * D}
+        if "gemm_qkv" in ms:   # bf16: Q|K and V^T projections as one alg_gemm_bf16_pair launch
+            per_fwd["gemm_qkv"] = per_fwd.pop("gemm_qk") + per_fwd.pop("gemm_vt")
         extra = {}
         for k, f in per_fwd.items():
             tt = sum(ms.get(k, [])) / 1e3
@@ -711,6 +718,8 @@ def main():
                     help="opt-in: cond/uncond CFG passes of one video on a pair of GPUs (latency mode, one all-gather per step)")
     ap.add_argument("--cross-check", action="store_true", help="c2: also time round 1's bench-private loop")
     ap.add_argument("--filters-only", action="store_true", help="debug: only the low-pass kernel micro-benchmark")
+    ap.add_argument("--set", action="append", default=[], metavar="ATTR=VALUE",
+                    help="A/B runs: set an attribute of the transformer (e.g. pair_qkv=0, attn_prescale=0) before the warm-up")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="c2 at 1 GPU: skip the c3 / c4 / c5 legs (2 timed full-depth steps each, ~3 min) that ride behind the headline")
     args = ap.parse_args()
@@ -746,6 +755,11 @@ def main():
     wl.build()
     torch.cuda.synchronize()
     build_seconds = time.perf_counter() - t_b0
+    for kv in args.set:
+        k, v_ = kv.split("=", 1)
+        if not hasattr(wl.model, k):
+            raise SystemExit("--set: the transformer has no attribute %r" % k)
+        setattr(wl.model, k, type(getattr(wl.model, k))(int(v_)) if v_.lstrip("-").isdigit() else v_)
     elapsed, forwards, ms = timed_region(wl, args.warmup, args.steps, parallel)
 
     n_videos_parallel = world // 2 if split else world
@@ -771,6 +785,8 @@ def main():
         out["bcast_gbytes"] = parallel.BCAST_STATS["bytes"] / 1e9
         out["bcast_collectives"] = parallel.BCAST_STATS["collectives"]
     out["build_seconds"] = build_seconds
+    if args.set:
+        out["config"]["overrides"] = args.set
     if args.layers:
         out["INVALID"] = "debug run with %d layers" % args.layers
     if rank == 0 and world == 1 and args.workload == "c2":

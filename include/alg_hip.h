@@ -168,6 +168,13 @@ typedef struct alg_gemm_args {
  * A and B 16-byte aligned.  M and N are arbitrary (edge tiles clamp loads and guard stores). */
 int alg_gemm_bf16(const alg_gemm_args* args, void* stream);
 
+/* Two independent alg_gemm_bf16 calls as ONE persistent launch when both are plain (no residual, gate, activation or
+ * convolution addressing; the Q|K and V^T projections of a DiT block, cog:1082-1090, read the same activations): the tiles of
+ * `b` follow the tiles of `a` in the tile list, so the two launches' partial last rounds become one.  Every output element is
+ * computed exactly as by the two separate calls (bit-identical); calls the pair form cannot take run one after the other.
+ * C of one problem must not alias an operand of the other. */
+int alg_gemm_bf16_pair(const alg_gemm_args* a, const alg_gemm_args* b, void* stream);
+
 /* BASELINE config 5 (fp8 weights on the CDNA4 fp8 MFMA): same contract and epilogues with A and B holding OCP e4m3 bytes
  * (lda / ldb / strides in elements = bytes) and per-row float32 scales: C = epilogue(a_scale[m] * b_scale[n] * (A @ B^T)).
  * K % 128 == 0.  Operands come from alg_quantize_fp8_rows (activations: per token, weights: per output channel). */

@@ -73,6 +73,11 @@ def main():
                     2.0 * N * S * D * 2 * D, "flop"),
         "gemm_vt": (lambda: G(wv, y, vt, D, S, D, D, D, S_pad, bias=bv, batch=N, strideB=S * D, strideC=D * S_pad,
                               flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS), 2.0 * N * S * D * D, "flop"),
+        "gemm_qkv": (lambda: _lib.gemm_pair(
+            ((y, wqk, qk, S, 2 * D, D, D, D, 2 * D), dict(bias=bqk, batch=N, strideA=S * D, strideC=S * 2 * D)),
+            ((wv, y, vt, D, S, D, D, D, S_pad), dict(bias=bv, batch=N, strideB=S * D, strideC=D * S_pad,
+                                                    flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS))),
+            2.0 * N * S * D * 3 * D, "flop"),
         "gemm_out": (lambda: G(att, wo, x, S, D, D, D, D, D, bias=bo, R=x, ldr=D, gate=mod, gate_off=4 * D,
                                strideGate=12 * D, seg_split=T, batch=N, strideA=S * D, strideC=S * D, strideR=S * D),
                      2.0 * N * S * D * D, "flop"),

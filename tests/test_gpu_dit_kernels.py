@@ -370,6 +370,54 @@ def test_pingpong_gemm_race_screen(monkeypatch):
             assert torch.equal(outs["8"], outs["0"]), (M, N, K)
 
 
+@pytest.mark.parametrize("S,D,N", [(17776, 3072, 2), (300, 512, 3), (1000, 256, 1), (257, 128, 2)])
+def test_gemm_pair_is_bit_identical_to_the_two_launches(monkeypatch, S, D, N):
+    """alg_gemm_bf16_pair: a block's Q|K projection and its transposed, permuted V projection (different operand roles, the
+    same activations) as ONE persistent launch -- every tile computed as by its own launch, so the bits are those of the two
+    separate calls, at the C2 shape and at shapes with edge tiles in both problems; under ALG_GEMM_PIPE=6 and for calls the pair
+    form cannot take (K = 64; a residual) it is the two launches one after the other; bad arguments are rejected before any
+    launch."""
+    g = torch.Generator(device="cuda").manual_seed(S + D)
+    rn = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g, device="cuda") * sc).to(BF)
+    S_pad = (S + 63) // 64 * 64
+    y, wqk, bqk, wv, bv = rn(N, S, D), rn(2 * D, D, sc=0.05), rn(2 * D), rn(D, D, sc=0.05), rn(D)
+
+    def calls(qk, vt, K=D):
+        return (((y, wqk, qk, S, 2 * D, K, D, D, 2 * D), dict(bias=bqk, batch=N, strideA=S * D, strideC=S * 2 * D)),
+                ((wv, y, vt, D, S, K, D, D, S_pad), dict(bias=bv, batch=N, strideB=S * D, strideC=D * S_pad,
+                                                        flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)))
+
+    def separate(K=D):
+        qk, vt = torch.full((N, S, 2 * D), 7.0, dtype=BF, device="cuda"), torch.zeros(N, D, S_pad, dtype=BF, device="cuda")
+        for a, kw in calls(qk, vt, K):
+            _lib.gemm(*a, **kw)
+        return qk, vt
+
+    def paired(K=D):
+        qk, vt = torch.full((N, S, 2 * D), 7.0, dtype=BF, device="cuda"), torch.zeros(N, D, S_pad, dtype=BF, device="cuda")
+        _lib.gemm_pair(*calls(qk, vt, K))
+        return qk, vt
+
+    want = separate()
+    for _ in range(3):
+        got = paired()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert torch.count_nonzero(got[1][:, :, (S + 15) // 16 * 16:]) == 0   # pad columns of V^T (beyond S's 16-column permutation block) stay zero
+    if D >= 128:                                                           # K = 64: schedule 9 cannot take it -> two launches
+        w64, g64 = separate(64), paired(64)
+        assert torch.equal(g64[0], w64[0]) and torch.equal(g64[1], w64[1])
+    monkeypatch.setenv("ALG_GEMM_PIPE", "6")
+    got = paired()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    monkeypatch.delenv("ALG_GEMM_PIPE")
+    qk = torch.zeros(N, S, 2 * D, dtype=BF, device="cuda")
+    bad = (((y, wqk, qk, S, 2 * D, D - 8, D, D, 2 * D), dict(batch=N, strideA=S * D, strideC=S * 2 * D)), calls(qk, qk)[0])
+    with pytest.raises(_lib.AlgHipError):                                   # K % 64 != 0 in the FIRST problem: nothing launched
+        _lib.gemm_pair(bad[0], bad[1])
+    with pytest.raises(_lib.AlgHipError):                                   # ... or in the second
+        _lib.gemm_pair(bad[1], bad[0])
+
+
 @pytest.mark.parametrize("form", ["plain", "gelu", "vt", "res", "res_gate_seg", "res_gate_f32", "res_gate_f32_straddle"])
 def test_schedule9_equals_the_drain_and_barrier_schedule_bit_for_bit(monkeypatch, form):
     """Schedule 9 (hand-written asm K loop, accumulators in AGPRs, residual quads fetched INSIDE the loop over its first eight

@@ -318,3 +318,25 @@ def test_c2_forward_at_its_real_shape_two_layers_vs_fp32_oracle(device):
     del wdev
     ref = dit_oracle.dit_forward(ocfg, w32, hs.float(), ehs.float(), ts, rope)
     check_floor("cog_forward_c2_real_shape_2layers_17776tokens", out, ref, eager, channel_dim=2)
+
+
+def test_paired_qkv_launch_leaves_the_forward_bit_identical(device):
+    """`pair_qkv` (default): the Q|K and V^T projections of every block as one alg_gemm_bf16_pair launch.  A tile is computed
+    exactly as by its own launch, so the full-width 2-layer C2 forward must not change by a bit (N = 2 and N = 3)."""
+    cfg = CogVideoXTransformerConfig(num_layers=2)
+    model = CogVideoXTransformer3DModel.from_synthetic(cfg, seed=17, device=device)
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(1, 13, 16, 60, 90, generator=g).to(device, BF)
+    c0 = torch.zeros(1, 13, 16, 60, 90, dtype=BF, device=device)
+    c0[:, 0] = (torch.randn(1, 16, 60, 90, generator=g) * 0.7).to(device, BF)
+    pe, ne = (torch.randn(1, 226, 4096, generator=g).to(device, BF) for _ in range(2))
+    rope = rotary_tables(64, get_resize_crop_region_for_grid((30, 45), 45, 30), (30, 45), 13)
+    for n in (2, 3):
+        ehs = torch.cat([ne] * (n - 1) + [pe])
+        ts = torch.full((n,), 700.0)
+        assert model.pair_qkv
+        a = model.forward_assembled(lat, [c0] * n, ehs, ts, rope)
+        model.pair_qkv = False
+        b = model.forward_assembled(lat, [c0] * n, ehs, ts, rope)
+        model.pair_qkv = True
+        assert bool(torch.isfinite(a.float()).all()) and torch.equal(a, b)
