@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Does the 64-queries-per-wave d = 128 attention (attention128_q64.hip, EXPERIMENTS build) ever compute on STALE inputs?
+
+Earlier stand-alone stress (attn128_q64_coldstart.py, profiles/r2_attention128_q64_flake.txt) re-launched the kernel on the SAME
+tensors: a read that returns the previous contents of an address is invisible there.  In the forward the kernel's inputs are
+REWRITTEN in place right before every launch (rmsnorm_rope on qk, the V^T GEMM) with values that differ from layer to layer.
+This probe does the same in isolation: K data sets rotate through ONE qk / vt allocation -- written by a producer kernel on the
+same stream immediately before the launch -- and every output is compared with that data set's own reference (made once, with the
+default pipelined kernel).  A stale read of Q, K or V^T now lands on another data set's values and shows.
+
+    ALG_HIP_LIB=alg_amd/libalg_hip_exp.so python scripts/experiments/q64_stale_probe.py [iters] [S] [heads] [producer] [arm]
+producer: copy (torch copy_ from the rotating sources) | rope (copy + our rmsnorm_rope in place on q and k, as the Wan block does)
+arm: value of ALG_ATTN128_Q64 (1..4); 0 = the default pipelined kernel as a control
+"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from alg_amd import _lib  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+Hh = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+producer = sys.argv[4] if len(sys.argv) > 4 else "copy"
+arm = sys.argv[5] if len(sys.argv) > 5 else "1"
+SETS = 4
+dev, BF = torch.device("cuda:0"), torch.bfloat16
+N, D = 1, Hh * 128
+S_pad = (S + 63) // 64 * 64
+g = torch.Generator(device=dev).manual_seed(3)
+src_qk = [torch.randn(N, S, 2 * D, generator=g, device=dev).to(BF) for _ in range(SETS)]
+src_vt = [torch.zeros(N, D, S_pad, dtype=BF, device=dev) for _ in range(SETS)]
+for t in src_vt:
+    t[:, :, :S] = torch.randn(N, D, S, generator=g, device=dev).to(BF)
+qk = torch.empty(N, S, 2 * D, dtype=BF, device=dev)
+vt = torch.empty(N, D, S_pad, dtype=BF, device=dev)
+o = torch.empty(N, S, D, dtype=BF, device=dev)
+wq, wk = torch.ones(D, dtype=BF, device=dev), torch.ones(D, dtype=BF, device=dev)
+cos = torch.rand(S, 64, device=dev)          # (the rope table layout does not matter here: any deterministic in-place rewrite does)
+sin = torch.rand(S, 64, device=dev)
+
+
+def produce(i):
+    qk.copy_(src_qk[i])
+    vt.copy_(src_vt[i])
+    if producer == "rope":
+        _lib.rmsnorm_rope_(qk, wq, cos, sin, 2 * D, N, S, D, 1e-6)
+        _lib.rmsnorm_rope_(qk, wk, cos, sin, 2 * D, N, S, D, 1e-6, x_off=D)
+
+
+def attend():
+    _lib.flash_attn_d128(qk, qk, vt, o, N, Hh, S, S, S * 2 * D, 2 * D, S * 2 * D, 2 * D, D * S_pad, S_pad, S * D, D, 128 ** -0.5,
+                         k_off=D)
+
+
+def select(a):
+    os.environ["ALG_ATTN128_Q64"] = a
+    _lib.reload_env()
+
+
+refs = []
+select("0")
+for i in range(SETS):
+    produce(i)
+    attend()
+    torch.cuda.synchronize()
+    refs.append(o.clone())
+select(arm)
+# the arm's own reference per set (the q64 kernel is not bit-equal to the pipelined one): first pass, checked against the control
+arm_refs = []
+for i in range(SETS):
+    produce(i)
+    attend()
+    torch.cuda.synchronize()
+    arm_refs.append(o.clone())
+    d = (o.float() - refs[i].float()).abs().max().item()
+    assert d < 3e-2, ("arm differs from the control kernel", i, d)
+bad = []
+order = torch.randint(0, SETS, (iters,), generator=torch.Generator().manual_seed(7)).tolist()
+outs = torch.empty(8, N, S, D, dtype=BF, device=dev)    # results are checked in batches of 8: no host sync between launches
+for base in range(0, iters, 8):
+    chunk = order[base:base + 8]
+    for j, i in enumerate(chunk):
+        produce(i)
+        attend()
+        outs[j].copy_(o)
+    for j, i in enumerate(chunk):
+        if not torch.equal(outs[j], arm_refs[i]):
+            dd = (outs[j].float() - arm_refs[i].float()).abs()
+            rows = (dd.sum(dim=-1).sum(dim=0) > 0).nonzero().flatten()
+            heads = sorted(set(((dd.sum(dim=1).sum(dim=0) > 0).nonzero().flatten() // 128).tolist()))
+            # which other data set do the wrong rows look like?
+            like = [round((outs[j].float() - arm_refs[k].float())[:, rows].abs().max().item(), 4) for k in range(SETS)]
+            bad.append(dict(iter=base + j, set=i, prev_set=order[base + j - 1] if base + j else None, n=int((dd > 0).sum()),
+                            max=round(float(dd.max()), 4), rows=(int(rows.min()), int(rows.max()), int(rows.numel())),
+                            heads=heads[:8], like=like))
+print(json.dumps(dict(arm=arm, producer=producer, iters=iters, S=S, heads=Hh, bad=len(bad), first=bad[:5],
+                      experiments=_lib.experiments_build())))
