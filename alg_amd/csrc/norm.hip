@@ -90,6 +90,101 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// The same arithmetic, RPW consecutive rows per wave (round 4).  ln_mod_kernel re-reads the four parameter rows (weight, bias,
+// scale, shift: 4 x 2 D bytes) for every token row -- 30 KB through the vector L1 per 12 KB of HBM traffic at D = 3072, and the
+// loads sit behind the statistics.  Here a wave keeps the parameters of its 8 ITERS columns packed in registers across its rows
+// (rbf(1 + scale) formed once: the value the per-row form rounds every time), reloads scale / shift only when the (batch item,
+// segment) of the next row changes, and has the NEXT row's 16-byte loads in flight while it works on the current one.
+// Bit-identical to ln_mod_kernel (same operations in the same order per element).
+template <int ITERS, int RPW>
+__global__ __launch_bounds__(256) void ln_mod_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                          const bf16_t* __restrict__ w, const bf16_t* __restrict__ bs,
+                                                          const bf16_t* __restrict__ scale,
+                                                          const bf16_t* __restrict__ shift, int64_t mod_bs, int64_t x_bs,
+                                                          int64_t y_bs, int64_t total_rows, int rows, int seg_split,
+                                                          int64_t seg_stride, float eps) {
+  constexpr int D = ITERS * 512;
+  const int lane = threadIdx.x & 63;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= total_rows) return;
+  const int64_t row_end = row0 + RPW < total_rows ? row0 + RPW : total_rows;
+  uint4 wp[ITERS], bp[ITERS], s1p[ITERS], shp[ITERS];
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    wp[i] = *(const uint4*)(w + i * 512 + lane * 8);
+    bp[i] = *(const uint4*)(bs + i * 512 + lane * 8);
+  }
+  auto src = [&](int64_t row) -> const bf16_t* {
+    const int bidx = (int)(row / rows);
+    return x + (int64_t)bidx * x_bs + (int64_t)(row - (int64_t)bidx * rows) * D + lane * 8;
+  };
+  uint4 nxt[ITERS];
+  {
+    const bf16_t* xr = src(row0);
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) nxt[i] = *(const uint4*)(xr + i * 512);
+  }
+  int cur_key = -1;
+  for (int64_t row = row0; row < row_end; ++row) {
+    float v[ITERS][8];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      unpack8(nxt[i], v[i]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[i][k];
+    }
+    if (row + 1 < row_end) {
+      const bf16_t* xr = src(row + 1);
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) nxt[i] = *(const uint4*)(xr + i * 512);
+    }
+    const int bidx = (int)(row / rows);
+    const int r = (int)(row - (int64_t)bidx * rows);
+    const int key = bidx * 2 + (r >= seg_split ? 1 : 0);
+    if (key != cur_key) {   // wave-uniform: the first row of the wave, a new batch item, the text -> video boundary
+      cur_key = key;
+      const int64_t off = (int64_t)bidx * mod_bs + (int64_t)(key & 1) * seg_stride + lane * 8;
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) {
+        float scv[8];
+        unpack8(*(const uint4*)(scale + off + i * 512), scv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) scv[k] = 1.0f + scv[k];
+        s1p[i] = pack8(scv);                                  // = rbf(1 + scale), packed
+        shp[i] = *(const uint4*)(shift + off + i * 512);
+      }
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float d = v[i][k] - mean;
+        q = fmaf(d, d, q);
+      }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+    bf16_t* yr = y + (int64_t)bidx * y_bs + (int64_t)r * D + lane * 8;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      float wv[8], bv[8], s1[8], shv[8], o[8];
+      unpack8(wp[i], wv);
+      unpack8(bp[i], bv);
+      unpack8(s1p[i], s1);
+      unpack8(shp[i], shv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float n = (v[i][k] - mean) * rstd;
+        n = n * wv[k];
+        n = n + bv[k];
+        o[k] = rbf(rbf(rbf(n) * s1[k]) + shv[k]);
+      }
+      *(uint4*)(yr + i * 512) = pack8(o);
+    }
+  }
+}
+
 // In place per-head LayerNorm(64) + RoPE on qk [batch][S][2][heads][64]; 8 lanes per head vector.
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ qk, const bf16_t* __restrict__ wq,
                                                            const bf16_t* __restrict__ bq,
@@ -197,6 +292,20 @@ extern "C" int alg_layernorm_modulate_seg(const void* x, void* y, const void* we
   const int64_t total = (int64_t)batch * rows;
   const unsigned grid = (unsigned)((total + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
+  // many rows with all four parameter rows present (every AdaLN of the CogVideoX / HunyuanVideo blocks): the multi-row form
+  constexpr int RPW = 8;
+  if (weight && bias && scale && D <= 3072 && total >= 4096) {
+    const unsigned g2 = (unsigned)((total + 4 * RPW - 1) / (4 * RPW));
+#define LN_ROWS(I)                                                                                                      \
+  case I:                                                                                                               \
+    hipLaunchKernelGGL((ln_mod_rows_kernel<I, RPW>), dim3(g2), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,            \
+                       (const bf16_t*)weight, (const bf16_t*)bias, (const bf16_t*)scale, (const bf16_t*)shift,          \
+                       mod_bstride, x_bstride, y_bstride, total, rows, seg_split, seg_stride, eps);                     \
+    break;
+    switch (D / 512) { LN_ROWS(1) LN_ROWS(2) LN_ROWS(3) LN_ROWS(4) LN_ROWS(5) LN_ROWS(6) }
+#undef LN_ROWS
+    return check_launch("alg_layernorm_modulate");
+  }
 #define LN_CASE(I)                                                                                                  \
   case I:                                                                                                           \
     hipLaunchKernelGGL(ln_mod_kernel<I>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,                  \

@@ -30,9 +30,26 @@ for w in ${@:-gemmtests bench prof}; do
                   "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
                   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE"; do
         i=$((i+1))
-        timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $P/kb_p$i -o p -- python $R/scripts/kbench.py --only attn_prescaled,gemm_qk,gemm_vt,gemm_out,gemm_ff1,gemm_ff2 --iters 2 > /dev/null 2> $P/kb_p$i.err
+        timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $P/kb_p$i -o p -- python $R/scripts/kbench.py --only attn_prescaled,gemm_qkv,gemm_out,gemm_ff1,gemm_ff2,ln_mod,qk_norm_rope --iters 2 > /dev/null 2> $P/kb_p$i.err
       done
       python $R/scripts/pmc_summary.py $P > $O/${TAG}_pmc_summary.txt 2>&1
+      # calibration of SQ_INSTS_VALU on a kernel whose instruction mix is known exactly (scripts/micro/attn_mix.hip)
+      if [ -x $R/scripts/micro/attn_mix ]; then
+        timeout 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAVES --output-format csv -d $P/mix_p1 -o p -- $R/scripts/micro/attn_mix > $P/mix.out 2> $P/mix.err
+        python - $P/mix_p1 >> $O/${TAG}_pmc_summary.txt <<'PY'
+import csv, glob, sys, os
+from collections import defaultdict
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection*.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        acc[row["Kernel_Name"][:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+print("== calibration: scripts/micro/attn_mix (k<FILL, NT>: per MFMA FILL 0 = nothing, 1 = 2 exp, 5 = 2 exp + cvt_pk, 6 = 5 + 2 v_add, 7 = 6 + ds_read)")
+for k, c in sorted(acc.items()):
+    m = sum(c["SQ_INSTS_MFMA"]) / max(len(c["SQ_INSTS_MFMA"]), 1)
+    if m > 0:
+        print("  %-70s VALU/MFMA %.3f  LDS/MFMA %.3f" % (k, sum(c["SQ_INSTS_VALU"]) / len(c["SQ_INSTS_VALU"]) / m, sum(c["SQ_INSTS_LDS"]) / len(c["SQ_INSTS_LDS"]) / m))
+PY
+      fi
       rm -rf $P
       grep -c mean $O/${TAG}_pmc_summary.txt ;;
     workloads)

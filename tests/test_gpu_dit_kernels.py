@@ -220,6 +220,28 @@ def test_layernorm_modulate(device, D, rows, T):
     assert (y2.float().cpu() - n[:, 2:].float()).abs().max() <= 2e-2
 
 
+@pytest.mark.parametrize("nb,rows,D,T", [(2, 17776, 3072, 226), (3, 3000, 1536, 226), (1, 4100, 512, 0), (2, 2100, 3072, 2099)])
+def test_layernorm_modulate_multi_row_form_is_bit_identical(device, nb, rows, D, T):
+    """From 4,096 rows up alg_layernorm_modulate runs ln_mod_rows_kernel (eight rows per wave, the four parameter rows held in
+    registers, the next row's loads in flight): same operations per element, so the same bits as the one-row-per-wave kernel --
+    which here processes the same tensors in slices of at most 2,048 rows (below the switch).  Row counts that leave a ragged
+    last wave, the text -> video boundary inside a wave, a boundary at 0 and at rows - 1, three batch items."""
+    g = torch.Generator(device=device).manual_seed(rows + D)
+    x = (torch.randn(nb, rows, D, generator=g, device=device) * 1.5 + 0.3).to(BF)
+    w, b = (1 + 0.1 * torch.randn(D, generator=g, device=device)).to(BF), (0.1 * torch.randn(D, generator=g, device=device)).to(BF)
+    mod = (0.3 * torch.randn(nb, 6 * D, generator=g, device=device)).to(BF)
+    y = torch.full((nb, rows, D), 5.0, dtype=BF, device=device)
+    _lib.layernorm_modulate(x, y, w, b, mod, mod, 6 * D, nb, rows, D, T, 1e-5, scale_off=2 * D, shift_off=0)
+    want = torch.full((nb, rows, D), 7.0, dtype=BF, device=device)
+    for bi in range(nb):
+        for a in range(0, rows, 2048):
+            n = min(2048, rows - a)
+            _lib.layernorm_modulate(x, want, w, b, mod, mod, 6 * D, 1, n, D, max(0, min(T - a, n)), 1e-5,
+                                    x_off=(bi * rows + a) * D, y_off=(bi * rows + a) * D, scale_off=bi * 6 * D + 2 * D,
+                                    shift_off=bi * 6 * D)
+    assert torch.equal(y, want)
+
+
 def test_qk_norm_rope(device):
     g = torch.Generator().manual_seed(4)
     nb, S, H, T = 2, 50, 3, 10
