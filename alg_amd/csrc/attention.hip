@@ -31,7 +31,7 @@
 //   32  variant 1 with the row sums taken by v_dot2c_f32_bf16 from the packed P pairs (16 instructions per tile instead
 //       of 32 adds; sums the bf16-rounded probabilities the PV MFMA uses): 925 -> 945 TFLOP/s on the same box
 //   33  (DEFAULT) 32 + lazy running max (softmax_tile_lazy): no tile max in the common path, the exact max / rescale
-//       path runs only when a row sum leaves [0, 2^40): 919 -> 990 TFLOP/s on the same box; the split-KV tail launch is
+//       path runs only when a row sum leaves [0, 2^80): 919 -> 990 TFLOP/s on the same box; the split-KV tail launch is
 //       built on it
 //   39/40  the duo kernels (15/16) with the lazy softmax; the exact-max fix-up sits between the scheduling regions:
 //       828 -> 995 / 1044 TFLOP/s (8 / 4 waves), i.e. on par with 33 (1027 on the same box); the interleave granularity
@@ -192,7 +192,7 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&s)[2], float c, floa
 // Lazy running max (variant 33).  Softmax is invariant to the subtracted offset, and fp32 / bf16 keep their relative
 // precision at any magnitude, so the offset only has to keep exp2 inside the exponent range: the probabilities are formed
 // against the CURRENT m (no tile max: 23 VALU instructions saved per tile) and the exact path -- tile max, grow m, rescale
-// O and l, recompute -- runs only when a tile's row sum leaves [0, 2^40) (inf on the first tile, where m = -inf; NaN if
+// O and l, recompute -- runs only when a tile's row sum leaves [0, 2^80) (inf on the first tile, where m = -inf; NaN if
 // a masked score meets m = -inf).  m is then always a max actually seen, so nothing that matters can underflow.
 template <bool DOT2 = true>
 __device__ __forceinline__ void softmax_tile_lazy(const f32x16 (&s)[2], float c, float& m_run, float& l_run,
@@ -221,7 +221,7 @@ __device__ __forceinline__ void softmax_tile_lazy(const f32x16 (&s)[2], float c,
     return psum;
   };
   float psum = probs(m_run * c);
-  if (__any(!(psum < 1.0995116e12f))) {  // 2^40; also true for inf and NaN
+  if (__any(!(psum < ALG_LAZY_SUM_LIMIT))) {  // 2^80; also true for inf and NaN
     float mt = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
     for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
@@ -273,7 +273,7 @@ __device__ __forceinline__ void softmax_tile_zero(const f32x16 (&s)[2], float& m
     psum = probs(BoolC<false>{}, 0.0f);
   else
     psum = probs(BoolC<true>{}, m_run);
-  if (__any(!(psum < 1.0995116e12f))) {  // 2^40; also inf (first tile: m = -inf) and NaN
+  if (__any(!(psum < ALG_LAZY_SUM_LIMIT))) {  // 2^80; also inf (first tile: m = -inf) and NaN
     float mt = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
     for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256) void flash_attn_d64_merge_kernel(const AttnP p
 // (profiles/r3_attention_d64_mix_microbench.txt).  This kernel is the frame around it: the same workgroup -> (head, q block)
 // map, Q / K / V^T layouts and finish as flash_attn_d64_kernel<41>, a C++ loop that runs tile 0 (where the running offset is
 // established and snapped to zero), the last few tiles (ragged tail) and any tile on which the statement bails out (row sum
-// outside [0, 2^40): the exact max / rescale path), all under the statement's collective protocol:
+// outside [0, 2^80): the exact max / rescale path), all under the statement's collective protocol:
 //     top of iteration t:  s_waitcnt vmcnt(0); s_barrier; DMA K(t+2) -> K slot (t+2) & 3, V^T(t+1) -> V slot (t+1) & 3
 // so that the waves of a workgroup may be inside or outside the statement independently.  The straight form of an iteration
 // reads K(t), V^T(t); the pipelined form K(t+1), V^T(t-1): four-slot rings keep all of them resident.

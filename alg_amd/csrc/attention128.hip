@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
         }
     }
     // ---- online softmax with a LAZY running max (see attention.hip softmax_tile_lazy): probabilities are formed against
-    // the current m; the exact tile max / rescale path runs only when a row sum leaves [0, 2^40) (inf on the first tile) ----
+    // the current m; the exact tile max / rescale path runs only when a row sum leaves [0, 2^80) (inf on the first tile) ----
     typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
     bf16x8 pf[4];
     auto probs = [&](float mc) -> float {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
       return psum;
     };
     float psum = probs(m_run * c);
-    if (__any(!(psum < 1.0995116e12f))) {  // 2^40; also inf / NaN
+    if (__any(!(psum < ALG_LAZY_SUM_LIMIT))) {  // 2^80; also inf / NaN
       float mt = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
       for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);

@@ -5,7 +5,7 @@
 // of the previous tile and one fragment read -- PV(t-1), QK(t+1) and softmax(t) software-pipelined.  This file is the frame:
 // attention128.hip's workgroup -> (head, q block) order, operand layouts, swizzles and lazy running max, a C++ loop for tile 0
 // (where the running max is established), the last tiles (ragged tail) and any tile the statement refuses (row sum outside
-// [0, 2^40): exact max / rescale), under the statement's collective protocol
+// [0, 2^80): exact max / rescale), under the statement's collective protocol
 //     top of iteration t:  s_waitcnt vmcnt(8); s_barrier; DMA K(t+3) -> K slot (t+3) & 3, V^T(t+2) -> V slot (t+2) & 3
 // so the waves of a workgroup may be inside or outside the statement independently.  Four waves x 32 queries per workgroup,
 // one wave per SIMD (the statement names v[64:169] and a[0:127]; O^T travels in 64 operands); K / V^T through two four-slot
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_pipe_kernel(const P p
         return psum;
       };
       float psum = probs(m_run * c);
-      if (__any(!(psum < 1.0995116e12f))) {  // 2^40; also inf / NaN
+      if (__any(!(psum < ALG_LAZY_SUM_LIMIT))) {  // 2^80; also inf / NaN
         float mt = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
         for (int e = 1; e < 16; ++e) mt = fmaxf(fmaxf(mt, s[0][e]), s[1][e]);

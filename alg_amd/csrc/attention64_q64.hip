@@ -476,10 +476,10 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const P p) 
       }
   };
   auto finish_softmax = [&](f32x16 (&s)[2], bf16x8 (&pf)[2][2], float (&psum)[2]) {
-    if (__any(!(psum[0] < 1.0995116e12f) || !(psum[1] < 1.0995116e12f))) {
+    if (__any(!(psum[0] < ALG_LAZY_SUM_LIMIT) || !(psum[1] < ALG_LAZY_SUM_LIMIT))) {
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh)
-        if (__any(!(psum[qh] < 1.0995116e12f))) fixup(qh, s[qh], pf[qh], psum[qh]);
+        if (__any(!(psum[qh] < ALG_LAZY_SUM_LIMIT))) fixup(qh, s[qh], pf[qh], psum[qh]);
     }
     l_run[0] += psum[0];
     l_run[1] += psum[1];

@@ -59,6 +59,15 @@ inline void device_mark(PerDeviceOnce& o, int slot) {
 
 typedef unsigned short bf16_t;  // raw bf16 bits
 
+// Lazy running max of the attention kernels: probabilities are formed against the CURRENT offset and the exact path (tile max,
+// grow the offset, rescale O and l) runs only when a tile's row sum leaves [0, 2^80).  fp32 and bf16 keep their relative
+// precision at any magnitude, so the limit only has to keep everything finite: at most 2^11 tiles of at most 2^80 each per row
+// (l, O <= 2^97 |v|), and 1 / l stays a normal number.  Round 4 raised it from 2^40: with scores ~ N(0, 8^2) log2 units a wave
+// crossed 2^40 somewhere along a 17,776-key row in a quarter of all cases, left the pipelined statement for good and held its
+// whole workgroup to the C++ loop's pace (867 vs 1130 TFLOP/s for the same launch on N(0, 1.44^2) scores).  The generated
+// statements carry the same constant (0x67800000; scripts/gen_attn*_pipe*.py).
+#define ALG_LAZY_SUM_LIMIT 1.2089258196146292e24f   /* 2^80 */
+
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;

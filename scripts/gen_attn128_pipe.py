@@ -7,7 +7,7 @@ Per wave (32 queries; a workgroup is four waves, one per SIMD) and 64-key tile, 
     PV(t-1): O^T += V(t-1)^T P(t-1)^T    16 MFMAs (four 32-row d-tiles x four kv blocks), C/D = a[0:63]
     QK(t+1): S(t+1)^T = K(t+1) Q^T       16 MFMAs (two 32-key sub-tiles x eight k-steps), B = Q in a[96:127]
     softmax(t): p = exp2(s * c - m * c) against the CURRENT running max m (attention128.hip's lazy form: the statement bails
-                out when a tile's row sum leaves [0, 2^40), the exact path stays in C++): per score pair 2 fma, 2 exp2, 1 pack,
+                out when a tile's row sum leaves [0, 2^80), the exact path stays in C++): per score pair 2 fma, 2 exp2, 1 pack,
                 2 adds -- one pair per TWO MFMA gaps
 K tile = 64 keys x 256 B (swizzle: 16-byte slot ^ (row & 15)), V^T tile = 128 d-rows x 128 B (swizzle (row >> 1) & 7): 16 KiB
 each, four-slot rings (128 KiB of LDS), two tiles of DMA prefetch, counted vmcnt(8) (eight 1 KiB pieces per wave and
@@ -147,7 +147,7 @@ def iteration(phase, X, Y, U, W, pv=True, softmax=True, qk=True, reads_in_flight
 
 
 def check_and_count(fail_label):
-    return ["v_cmp_ngt_f32 vcc, 0x53800000, %s" % v(TS), "s_nop 4", "s_cbranch_vccnz %s" % fail_label,   # !(2^40 > sum)
+    return ["v_cmp_ngt_f32 vcc, 0x67800000, %s" % v(TS), "s_nop 4", "s_cbranch_vccnz %s" % fail_label,   # !(2^80 > sum)
             "v_add_f32 %%[l], %%[l], %s" % v(TS), "s_add_u32 %[t], %[t], 1"]
 
 

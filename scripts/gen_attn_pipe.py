@@ -12,7 +12,7 @@ The loop is software-pipelined over KV tiles of 64: iteration t issues, per wave
     softmax(t): P(t) = bf16(exp2(S(t))), row sum     16 score pairs, ONE PAIR PER MFMA GAP: exp, exp, cvt_pk (of the previous
                                                      pair), add, add -- none of it depends on this iteration's MFMAs
 Scores arrive in log2 units with the running offset at zero (attention.hip, softmax_tile_zero's common path): the statement is
-entered only by waves whose offsets are all zero and leaves as soon as a tile's row sum leaves [0, 2^40) -- the exact path
+entered only by waves whose offsets are all zero and leaves as soon as a tile's row sum leaves [0, 2^80) -- the exact path
 (tile max, rescale) stays in C++.
 
 Collective protocol (identical in the C++ loop around the statement, so waves of one workgroup may be in either): at the top
@@ -188,7 +188,7 @@ def softmax_pre(S):
 
 def check_and_count(fail_label):
     """row-sum check of the iteration just issued, then t += 1"""
-    return ["v_cmp_ngt_f32 vcc, 0x53800000, %s" % v(TS), "s_nop 4", "s_cbranch_vccnz %s" % fail_label,   # !(2^40 > sum)
+    return ["v_cmp_ngt_f32 vcc, 0x67800000, %s" % v(TS), "s_nop 4", "s_cbranch_vccnz %s" % fail_label,   # !(2^80 > sum)
             "v_add_f32 %%[l], %%[l], %s" % v(TS), "s_add_u32 %[t], %[t], 1"]
 
 

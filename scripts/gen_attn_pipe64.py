@@ -145,8 +145,8 @@ def iteration(phase, X, Y, U, W, pv=True, softmax=True, qk=True, reads_in_flight
 
 
 def check_and_count(fail_label):
-    return ["v_cmp_ngt_f32 vcc, 0x53800000, %s" % v(TS0), "s_nop 4", "s_cbranch_vccnz %s" % fail_label,   # !(2^40 > sum)
-            "v_cmp_ngt_f32 vcc, 0x53800000, %s" % v(TS1), "s_nop 4", "s_cbranch_vccnz %s" % fail_label,
+    return ["v_cmp_ngt_f32 vcc, 0x67800000, %s" % v(TS0), "s_nop 4", "s_cbranch_vccnz %s" % fail_label,   # !(2^80 > sum)
+            "v_cmp_ngt_f32 vcc, 0x67800000, %s" % v(TS1), "s_nop 4", "s_cbranch_vccnz %s" % fail_label,
             "v_add_f32 %%[l0], %%[l0], %s" % v(TS0), "v_add_f32 %%[l1], %%[l1], %s" % v(TS1), "s_add_u32 %[t], %[t], 1"]
 
 

@@ -30,9 +30,14 @@ for w in ${@:-gemmtests bench prof}; do
                   "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
                   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE"; do
         i=$((i+1))
-        timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $P/kb_p$i -o p -- python $R/scripts/kbench.py --only attn_prescaled,gemm_qkv,gemm_out,gemm_ff1,gemm_ff2,ln_mod,qk_norm_rope --iters 2 > /dev/null 2> $P/kb_p$i.err
+        timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $P/kb_p$i -o p -- python $R/scripts/kbench.py --only attn_model_scores,gemm_qkv,gemm_out,gemm_ff1,gemm_ff2,ln_mod,qk_norm_rope --iters 2 > /dev/null 2> $P/kb_p$i.err
       done
       python $R/scripts/pmc_summary.py $P > $O/${TAG}_pmc_summary.txt 2>&1
+      # the same attention launch on N(0, 8^2) scores (the round-3 PMC case): ~25 % of the waves leave the statement early
+      rm -rf $P/kb_p[0-9]
+      timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $P/kbwide_p1 -o p -- python $R/scripts/kbench.py --only attn_prescaled --iters 2 > /dev/null 2> $P/kbwide.err
+      echo "== the attention launch on N(0, 8^2) log2-unit scores (kbench attn_prescaled; round 3's PMC case)" >> $O/${TAG}_pmc_summary.txt
+      python $R/scripts/pmc_summary.py $P 2>&1 | grep -A40 "kbwide_p1" >> $O/${TAG}_pmc_summary.txt
       # calibration of SQ_INSTS_VALU on a kernel whose instruction mix is known exactly (scripts/micro/attn_mix.hip)
       if [ -x $R/scripts/micro/attn_mix ]; then
         timeout 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAVES --output-format csv -d $P/mix_p1 -o p -- $R/scripts/micro/attn_mix > $P/mix.out 2> $P/mix.err

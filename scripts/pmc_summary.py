@@ -24,12 +24,13 @@ for d in sorted(glob.glob(os.path.join(root, "*_p*"))):
         for c, v in sorted(cs.items()):
             print("  %-60s %-28s n=%-4d mean=%.4g" % (k, c, len(v), sum(v) / len(v)))
             allc[k][c] = sum(v) / len(v)
-print("== derived (per kernel; SIMDs = 1024; SQ_INSTS_VALU includes the MFMAs and counts a wave64 VALU instruction as issued)")
+print("== derived (per kernel; SQ_INSTS_VALU counts every VALU instruction once, MFMAs included -- calibrated below; 1024 SIMDs;")
+print("   GRBM_GUI_ACTIVE is summed over 16 instances on this part: shader cycles of the launch = GRBM_GUI_ACTIVE / 16)")
 for k, c in allc.items():
     if c.get("SQ_INSTS_MFMA", 0) > 0:
         m = c["SQ_INSTS_MFMA"]
         line = "  %-60s VALU/MFMA %.2f  SALU/MFMA %.2f  LDS/MFMA %.2f" % (k, c.get("SQ_INSTS_VALU", 0) / m, c.get("SQ_INSTS_SALU", 0) / m,
                                                                           c.get("SQ_INSTS_LDS", 0) / m)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
-            line += "  MFMA-busy %.1f %% of SIMD cycles (busy / 1024 / GRBM_GUI_ACTIVE)" % (100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / c["GRBM_GUI_ACTIVE"])
+            line += "  MFMA-busy %.1f %% of SIMD cycles" % (100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 16.0))
         print(line)

@@ -177,10 +177,10 @@ def test_flash_attention_forced_rescale_and_asymmetry(device, monkeypatch, reque
 
 @pytest.mark.parametrize("variant", ["1", "32", "33"])  # 34 pre-scales q (one more bf16 rounding): fine at real score
 # magnitudes (the other tests), not at the |score| ~ 220 this test drives
-@pytest.mark.parametrize("gain", [0.5, 2.5, 3.4, 4.0, 40.0])
+@pytest.mark.parametrize("gain", [0.5, 2.5, 3.4, 4.0, 6.5, 7.5, 40.0])   # scores ~ 11.5 x gain log2 units: 75 / 86 straddle 2^80
 def test_flash_attention_lazy_max_thresholds(device, monkeypatch, request, variant, gain):
     """The default softmax keeps a LAZY running max: probabilities are formed against the current m and the exact
-    max / rescale path only runs when a row sum leaves [0, 2^40).  Spikes that stay below the threshold (scores up to ~220
+    max / rescale path only runs when a row sum leaves [0, 2^80).  Spikes that stay below the threshold (scores up to ~220
     above m: probabilities up to 2^39), cross it, or overflow exp2 outright (gain 40: +inf) must all give the softmax the
     reference gives -- also on a ragged last tile and with the spike in the first tile (m = -inf start)."""
     _variant(request, monkeypatch, variant)
@@ -512,7 +512,7 @@ def test_pipelined_attention_kernel(device, monkeypatch, Bn, S2, H2):
     (entered at tile 1 by waves whose running offsets are all zero, whole groups of four tiles) inside its C++ frame, against
     fp32 SDPA and against the straight loop (ALG_ATTN_PP=0) on the same tensors.  Rows whose first-tile max is beyond +-64 keep a
     non-zero offset (those waves never enter the statement while their neighbours in the workgroup do: mixed mode under one
-    barrier / DMA protocol); a late dominant key makes a row sum leave [0, 2^40) INSIDE the statement (it bails out, the tile is
+    barrier / DMA protocol); a late dominant key makes a row sum leave [0, 2^80) INSIDE the statement (it bails out, the tile is
     redone on the exact path); ragged tails; S = 512 / 513 stay below the statement's minimum of eight tiles; 8 x 1 heads let
     the split-KV tail plan engage next to the pipelined main launch.  Run-to-run identical."""
     g = torch.Generator().manual_seed(S2 + H2)
