@@ -505,6 +505,40 @@ def test_pingpong_attention_equals_the_straight_loop_bit_for_bit(monkeypatch, ex
         assert torch.equal(run(), want), pp
 
 
+@pytest.mark.parametrize("std", [4.0, 8.0, 15.0, 22.0])
+def test_attention_wide_score_ranges_against_fp64(device, std):
+    """Round 4 raised the lazy running max's row-sum limit from 2^40 to 2^80 (common.h): rows stay on the no-rescale path with
+    probabilities up to 2^80.  Scores ~ N(0, std^2) in log2 units over 2,050 keys put the row maxima at ~ 3.5 std: well inside
+    (4, 8: the regime that used to throw a quarter of the waves out of the pipelined statement), around (15, 22) and beyond the
+    limit (rows cross it mid-sequence: exact path, offsets stop being zero).  d = 64 (pre-scaled, pipelined main launch) and
+    d = 128 (pipelined), every row against an fp64 softmax of the same bf16 inputs."""
+    g = torch.Generator().manual_seed(int(std))
+    S, H = 2050, 2
+    for hd, call in ((64, "d64"), (128, "d128")):
+        q = (torch.randn(1, S, H, hd, generator=g) * (std / hd ** 0.5)).to(BF)      # q . k ~ N(0, std^2)
+        k, v = rnd((1, S, H, hd), g), rnd((1, S, H, hd), g)
+        D = H * hd
+        S_pad = (S + 127) // 128 * 128
+        vt = torch.zeros(1, D, S_pad, dtype=BF)
+        vt[:, :, torch.tensor([swap23(n) for n in range(S)])] = v.reshape(1, S, D).transpose(1, 2)
+        o = torch.full((1, S, D), 3.0, dtype=BF, device=device)
+        if call == "d64":
+            qkb = torch.cat([q.reshape(1, S, D), k.reshape(1, S, D)], dim=-1).contiguous().to(device)
+            _lib.flash_attn_d64(qkb, qkb, vt.to(device), o, 1, H, S, S * 2 * D, 2 * D, D * S_pad, S_pad, S * D, D, 0.125, k_off=D,
+                                q_prescaled=True)
+            logits = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * math.log(2.0)
+        else:
+            scale = math.log(2.0)                                                   # (q . k) * scale * log2(e) = q . k log2 units
+            _lib.flash_attn_d128(q.reshape(1, S, D).to(device), k.reshape(1, S, D).to(device), vt.to(device), o, 1, H, S, S,
+                                 S * D, D, S * D, D, D * S_pad, S_pad, S * D, D, scale)
+            logits = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * math.log(2.0)
+        ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(logits, dim=-1), v.double())
+        got = o.cpu().reshape(1, S, H, hd).double()
+        assert torch.isfinite(got).all(), (call, std)
+        err = (got - ref).abs()
+        assert err.max().item() <= 3e-2 and err.mean().item() <= 2e-3, (call, std, err.max().item(), err.mean().item())
+
+
 @pytest.mark.parametrize("Bn,S2,H2", [(1, 512, 2), (2, 1000, 3), (1, 513, 1), (1, 640, 1), (1, 832, 1), (1, 2050, 2), (1, 4097, 1),
                                        (8, 1200, 1)])
 def test_pipelined_attention_kernel(device, monkeypatch, Bn, S2, H2):
