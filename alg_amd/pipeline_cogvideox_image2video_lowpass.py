@@ -535,8 +535,9 @@ class CogVideoXImageToVideoPipeline:
         if not isinstance(self.scheduler, CogVideoXDDIMScheduler) or not hasattr(self.transformer, "forward_assembled"):
             raise TypeError("this sampler drives alg_amd's CogVideoXTransformer3DModel and CogVideoXDDIMScheduler "
                             "(fused HIP step); other components are not wired yet")
-        if eta != 0.0:
-            raise NotImplementedError("eta > 0 is not used by the ALG configs")
+        # `eta` (cog:446-461) reaches scheduler.step through extra_step_kwargs in the reference; the published CogVideoXDDIMScheduler /
+        # CogVideoXDPMScheduler accept the argument and never read it (their updates are deterministic given the DPM scheduler's
+        # own noise draw), so any value samples exactly like eta = 0 -- here too (unpinned: diffusers is absent)
         is_dpm = isinstance(self.scheduler, CogVideoXDPMScheduler)
         old_pred_original_sample = None  # cog:998
 

@@ -59,6 +59,8 @@ class CogVideoXTransformerConfig:
     use_rotary_positional_embeddings: bool = True
     use_learned_positional_embeddings: bool = True
     ofs_embed_dim: Optional[int] = None
+    spatial_interpolation_scale: float = 1.875
+    temporal_interpolation_scale: float = 1.0
 
     @property
     def inner_dim(self):
@@ -94,6 +96,7 @@ class CogVideoXTransformer3DModel:
         # True (default): the Q|K projection and the transposed V projection of a block go out as one alg_gemm_bf16_pair
         # launch (bit-identical to the two launches; False keeps them apart: A/B runs, tests)
         self.pair_qkv = True
+        self._sincos = {}
         dev = self.device
         w = weights
         p = cfg.patch_size
@@ -164,6 +167,47 @@ class CogVideoXTransformer3DModel:
         self._ws = {}
         self._rope_cache = {}
         self.profile = None  # set to a dict to collect (start, stop) HIP event pairs per kernel family
+
+    def _positional(self, Hh, Ww, Fr, S):
+        """The joint [text; video] positional embedding added behind the patch embedding, [S, D] bf16, or None.
+        CogVideoXPatchEmbed (the transformer cog:1082 calls): the learned table when the frame count is the configured one,
+        otherwise -- and for checkpoints with neither learned nor rotary embeddings (CogVideoX-2B style) -- the 3-D sincos
+        embedding computed for the actual grid (`get_3d_sincos_pos_embed`: a quarter of the width for time, three quarters for
+        (h, w), positions divided by the interpolation scales), zero rows for the text tokens."""
+        cfg = self.config
+        learned = cfg.use_learned_positional_embeddings
+        if not learned and cfg.use_rotary_positional_embeddings:
+            return None
+        pre_frames = (Fr - 1) * cfg.temporal_compression_ratio + 1
+        if learned and pre_frames == cfg.sample_frames and self.pos_emb is not None and self.pos_emb.shape[0] == S:
+            return self.pos_emb
+        p = cfg.patch_size
+        gh, gw, gt = Hh // p, Ww // p, Fr // self.p_t
+        key = (gh, gw, gt)
+        hit = self._sincos.get(key)
+        if hit is None:
+            D = cfg.inner_dim
+            ds, dt = 3 * D // 4, D // 4
+
+            def sc1(dim, pos):
+                omega = 1.0 / 10000 ** (torch.arange(dim // 2, dtype=torch.float64) / (dim / 2.0))
+                out = torch.outer(pos.reshape(-1).double(), omega)
+                return torch.cat([out.sin(), out.cos()], dim=1)
+
+            hh = torch.arange(gh, dtype=torch.float32) / cfg.spatial_interpolation_scale
+            ww = torch.arange(gw, dtype=torch.float32) / cfg.spatial_interpolation_scale
+            tt = torch.arange(gt, dtype=torch.float32) / cfg.temporal_interpolation_scale
+            grid = torch.stack(torch.meshgrid(ww, hh, indexing="xy"), dim=0).reshape(2, 1, gh, gw)
+            sp = torch.cat([sc1(ds // 2, grid[0]), sc1(ds // 2, grid[1])], dim=1)            # [gh * gw, ds]
+            tp = sc1(dt, tt)                                                                   # [gt, dt]
+            pe = torch.cat([tp[:, None].expand(-1, gh * gw, -1), sp[None].expand(gt, -1, -1)], dim=-1).reshape(gt * gh * gw, D)
+            joint = torch.zeros(cfg.max_text_seq_length + pe.shape[0], D, dtype=torch.float32)
+            joint[cfg.max_text_seq_length:] = pe.float()
+            hit = joint.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            self._sincos[key] = hit
+        if hit.shape[0] != S:
+            raise ValueError("positional embedding covers %d tokens, the sequence has %d" % (hit.shape[0], S))
+        return hit
 
     def _timed(self, name, fn, *args, **kwargs):
         """Launch ``fn``; when profiling is on, bracket it with HIP events on the launch stream."""
@@ -275,8 +319,7 @@ class CogVideoXTransformer3DModel:
                 raise ValueError(
                     "It is currently not possible to generate videos at a different resolution that the defaults. "
                     "This should only be the case with 'THUDM/CogVideoX-5b-I2V'.")
-            if (Fr - 1) * cfg.temporal_compression_ratio + 1 != cfg.sample_frames or self.pos_emb.shape[0] != S:
-                raise NotImplementedError("sincos positional embeddings for a non-default frame count are not built")
+        pos_emb = self._positional(Hh, Ww, Fr, S)
         ws = self._workspace(N, S, P)
         x, y, qk, vt, att, h, mod = ws["x"], ws["y"], ws["qk"], ws["vt"], ws["att"], ws["h"], ws["mod"]
         S_pad = ws["S_pad"]
@@ -311,10 +354,10 @@ class CogVideoXTransformer3DModel:
 
         # 2. patch embedding (+ positional embedding as the residual operand), text tokens first
         G(ehs, self.w_text, x, T, D, cfg.text_embed_dim, cfg.text_embed_dim, cfg.text_embed_dim, D,
-          bias=self.b_text, R=self.pos_emb, ldr=D, batch=N, strideA=T * cfg.text_embed_dim, strideC=S * D)
+          bias=self.b_text, R=pos_emb, ldr=D, batch=N, strideA=T * cfg.text_embed_dim, strideC=S * D)
         _lib.patchify(lat, 0 if Bl == 1 else Fr * C * Hh * Ww, conds, ws["patches"], N, Fr, C, Hh, Ww, p, p_t)
         G(ws["patches"], self.w_patch, x, P, D, self.k_patch, self.k_patch, self.k_patch, D, bias=self.b_patch,
-          R=self.pos_emb, ldr=D, r_off=T * D, batch=N, strideA=P * self.k_patch, strideC=S * D, c_off=T * D)
+          R=pos_emb, ldr=D, r_off=T * D, batch=N, strideA=P * self.k_patch, strideC=S * D, c_off=T * D)
 
         # 3. transformer blocks
         scale = 1.0 / math.sqrt(cfg.attention_head_dim)

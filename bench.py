@@ -49,7 +49,7 @@ def event_ms(pairs):
     return [a.elapsed_time(b) for a, b in pairs]
 
 
-def pmc_traffic(kernel_substr, profiles=("profiles/r3_pmc_summary.txt", "profiles/r2_pmc_summary.txt", "profiles/r1_pmc_summary.txt")):
+def pmc_traffic(kernel_substr, profiles=("profiles/r4_pmc_summary.txt", "profiles/r3_pmc_summary.txt", "profiles/r2_pmc_summary.txt", "profiles/r1_pmc_summary.txt")):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
     collected in separate passes and reported in KiB).  gfx950 correction from MI355X_MICROARCH.md section HBM: a wide
     coalesced 16-B/lane stream (our global_load_lds staging) is tallied at half its bytes in FETCH_SIZE -> x2.

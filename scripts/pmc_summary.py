@@ -25,12 +25,13 @@ for d in sorted(glob.glob(os.path.join(root, "*_p*"))):
             print("  %-60s %-28s n=%-4d mean=%.4g" % (k, c, len(v), sum(v) / len(v)))
             allc[k][c] = sum(v) / len(v)
 print("== derived (per kernel; SQ_INSTS_VALU counts every VALU instruction once, MFMAs included -- calibrated below; 1024 SIMDs;")
-print("   GRBM_GUI_ACTIVE is summed over 16 instances on this part: shader cycles of the launch = GRBM_GUI_ACTIVE / 16)")
+print("   MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over the launch's shader cycles, taken as GRBM_GUI_ACTIVE / 8 (one instance")
+print("   per XCD in this rocprofv3; cross-check: SQ_BUSY_CYCLES / 32 shader engines gives the same cycles to 5 %))")
 for k, c in allc.items():
     if c.get("SQ_INSTS_MFMA", 0) > 0:
         m = c["SQ_INSTS_MFMA"]
         line = "  %-60s VALU/MFMA %.2f  SALU/MFMA %.2f  LDS/MFMA %.2f" % (k, c.get("SQ_INSTS_VALU", 0) / m, c.get("SQ_INSTS_SALU", 0) / m,
                                                                           c.get("SQ_INSTS_LDS", 0) / m)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
-            line += "  MFMA-busy %.1f %% of SIMD cycles" % (100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 16.0))
+            line += "  MFMA-busy %.1f %% of SIMD cycles" % (100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0))
         print(line)
