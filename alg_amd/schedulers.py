@@ -116,8 +116,7 @@ class CogVideoXDDIMScheduler(_ConfigLoading):
              variance_noise=None, return_dict=True):
         """Generic scheduler API (cog:1112): returns the previous sample as a NEW tensor of ``sample``'s dtype
         promoted with fp32 the way the reference's expression does (the loop casts it back, cog:1123)."""
-        if eta != 0.0:
-            raise NotImplementedError("eta > 0 (stochastic DDIM) is not used by the ALG configs")
+        # `eta` is part of the published signature and is never read by the published update (no variance term): ignored here too
         sa, sb, ca, cb = self.step_coefficients(timestep)
         out = sample.clone()
         _lib.cfg_ddim_step_(model_output.contiguous(), out, 1, 1.0, sa, sb, ca, cb)
