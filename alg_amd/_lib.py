@@ -21,7 +21,7 @@ ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
 GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS, GEMM_GATE_F32, GEMM_GATE_SEG_STRIDE = 1, 4, 8, 16
 
 EXPORTS = (
-    "alg_version", "alg_last_error", "alg_reload_env", "alg_build_experiments", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16", "alg_gemm_bf16_pair",
+    "alg_version", "alg_last_error", "alg_reload_env", "alg_build_experiments", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16", "alg_gemm_bf16_pair", "alg_gemm_bf16_pair_qk",
     "alg_flash_attn_d64", "alg_layernorm_modulate", "alg_qk_norm_rope", "alg_patchify", "alg_unpatchify",
     "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128", "alg_layernorm_mod_f32", "alg_layernorm_mod_f32_fp8", "alg_rmsnorm_rope",
     "alg_wan_modulation", "alg_patchify3d", "alg_unpatchify3d", "alg_timestep_embedding_f32", "alg_linear_f32",
@@ -52,6 +52,12 @@ class GemmArgs(Structure):
         ("a_scale", c_void_p), ("b_scale", c_void_p), ("strideAScale", c_int64), ("strideBScale", c_int64),
         ("conv_wp", c_int32), ("conv_hpwp", c_int32), ("conv_kw", c_int32), ("reserved1", c_int32),
     ]
+
+
+class QkNormRopeArgs(Structure):
+    _fields_ = [("wq", c_void_p), ("bq", c_void_p), ("wk", c_void_p), ("bk", c_void_p), ("cos_tab", c_void_p),
+                ("sin_tab", c_void_p), ("heads", c_int32), ("text_len", c_int32), ("eps", c_float),
+                ("q_scale", c_float)]
 
 
 class VaeGeom(Structure):
@@ -148,6 +154,7 @@ def load_library():
     lib.alg_unipc_update.argtypes = [c_void_p] * 5 + [c_int64] + [c_float] * 6 + [c_void_p]
     lib.alg_gemm_bf16.argtypes = [POINTER(GemmArgs), c_void_p]
     lib.alg_gemm_bf16_pair.argtypes = [POINTER(GemmArgs), POINTER(GemmArgs), c_void_p]
+    lib.alg_gemm_bf16_pair_qk.argtypes = [POINTER(GemmArgs), POINTER(GemmArgs), POINTER(QkNormRopeArgs), c_void_p]
     lib.alg_flash_attn_d64.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
                                        c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]
     lib.alg_layernorm_modulate.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
@@ -698,6 +705,19 @@ def gemm_pair(first, second):
     if fa or fb:
         raise AlgHipError("gemm_pair takes bf16 problems")
     _check(lib.alg_gemm_bf16_pair(ctypes.byref(a), ctypes.byref(b), _stream()), "alg_gemm_bf16_pair")
+
+
+def gemm_pair_qk(first, second, wq, bq, wk, bk, cos, sin, heads, text_len, eps, q_scale=1.0):
+    """`gemm_pair` whose FIRST problem is the CogVideoX Q|K projection, with the per-head LayerNorm + rotary embedding of
+    `qk_norm_rope_` applied in its store loop (alg_gemm_bf16_pair_qk); bit-identical to gemm_pair + qk_norm_rope_."""
+    lib = load_library()
+    a, fa = gemm_args(*first[0], **first[1])
+    b, fb = gemm_args(*second[0], **second[1])
+    if fa or fb:
+        raise AlgHipError("gemm_pair_qk takes bf16 problems")
+    ptrs = [t.data_ptr() if t is not None else None for t in (wq, bq, wk, bk, cos, sin)]
+    e = QkNormRopeArgs(*ptrs, heads, text_len, float(eps), float(q_scale))
+    _check(lib.alg_gemm_bf16_pair_qk(ctypes.byref(a), ctypes.byref(b), ctypes.byref(e), _stream()), "alg_gemm_bf16_pair_qk")
 
 
 def quantize_fp8_rows(x, q, scale, rows, K, x_rstride=None, x_off=0, q_off=0, scale_off=0):

@@ -15,6 +15,8 @@ int launch_gemm_p6(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg
 int launch_gemm_p9(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p9_pair(const alg_gemm_args* a, int m_tiles_a, int n_tiles_a, const alg_gemm_args* b, int m_tiles_b, int n_tiles_b,
                         hipStream_t s);
+int launch_gemm_p9_pair_qk(const alg_gemm_args* a, int m_tiles_a, int n_tiles_a, const alg_gemm_args* b, int m_tiles_b, int n_tiles_b,
+                           const alg_qk_norm_rope_args* e, hipStream_t s);
 int launch_gemm_p6_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 // ALG_GEMM_PIPE: 9 (default: 4 waves, asm main loop; round 3: faster than the 8-wave ping-pong on all five C2 shapes) | 6 (the
@@ -170,6 +172,43 @@ extern "C" int alg_gemm_bf16_pair(const alg_gemm_args* a, const alg_gemm_args* b
   }
   rc = gemm_entry(a, stream, false);
   return rc != ALG_OK ? rc : gemm_entry(b, stream, false);
+}
+
+extern "C" int alg_gemm_bf16_pair_qk(const alg_gemm_args* a, const alg_gemm_args* b, const alg_qk_norm_rope_args* e, void* stream) {
+  int rc = gemm_entry(a, stream, false, true);
+  if (rc == ALG_OK) rc = gemm_entry(b, stream, false, true);
+  if (rc != ALG_OK) return rc;
+  if (!e || !e->wq || !e->bq || !e->wk || !e->bk || e->heads <= 0 || e->text_len < 0 || e->text_len > a->M ||
+      (e->cos_tab == nullptr) != (e->sin_tab == nullptr)) {
+    set_error("alg_gemm_bf16_pair_qk: bad LayerNorm / rotary arguments");
+    return ALG_EINVAL;
+  }
+  if (((uintptr_t)e->wq & 15) || ((uintptr_t)e->bq & 15) || ((uintptr_t)e->wk & 15) || ((uintptr_t)e->bk & 15) ||
+      ((uintptr_t)e->cos_tab & 15) || ((uintptr_t)e->sin_tab & 15) || ((uintptr_t)a->C & 15)) {
+    set_error("alg_gemm_bf16_pair_qk: pointers must be 16-byte aligned");
+    return ALG_EINVAL;
+  }
+  if (a->N != 2 * e->heads * 64 || a->ldc != a->N || a->strideC != (int64_t)a->M * a->N || (a->flags & ALG_GEMM_PERMUTE_COLS) ||
+      a->R || a->act != ALG_ACT_NONE) {
+    set_error("alg_gemm_bf16_pair_qk: qk must be a plain GEMM onto the contiguous [batch][S][2][heads][64] tensor (N=%d heads=%d ldc=%lld)",
+              a->N, e->heads, (long long)a->ldc);
+    return ALG_EINVAL;
+  }
+  // the store loop owns whole head vectors and whole Q / K tiles: heads * 64 a multiple of the 256-column tile, staged epilogue
+  // (N % 8 == 0 and 16-byte rows hold by the layout; a per-row bias would take the element-exact path)
+  const bool fused = gemm_pipe() == 9 && pair_eligible(a) && pair_eligible(b) && e->heads % 4 == 0 &&
+                     !(a->bias && (a->flags & ALG_GEMM_BIAS_PER_ROW));
+  if (fused) {
+    const int64_t ta = (int64_t)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN) * a->batch;
+    const int64_t tb = (int64_t)((b->M + BM - 1) / BM) * ((b->N + BN - 1) / BN) * b->batch;
+    if (ta + tb <= 0x7fffffff)
+      return launch_gemm_p9_pair_qk(a, (a->M + BM - 1) / BM, (a->N + BN - 1) / BN, b, (b->M + BM - 1) / BM, (b->N + BN - 1) / BN, e,
+                                    (hipStream_t)stream);
+  }
+  rc = alg_gemm_bf16_pair(a, b, stream);
+  if (rc != ALG_OK) return rc;
+  return alg_qk_norm_rope_scaled(a->C, e->wq, e->bq, e->wk, e->bk, e->cos_tab, e->sin_tab, a->batch, a->M, e->heads, e->text_len,
+                                 e->eps, e->q_scale, stream);
 }
 
 extern "C" int alg_gemm_fp8(const alg_gemm_args* a, void* stream) { return gemm_entry(a, stream, true); }

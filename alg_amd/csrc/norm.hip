@@ -5,27 +5,13 @@
 // Rounding points mirror the reference's bf16 tensors (every torch op returns bf16): LayerNorm output,
 // (1 + scale), the product and the sum are each rounded.
 #include "common.h"
+#include "qk_norm_rope.h"
 
 namespace alg {
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
-
-__device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
-  const uint32_t u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    f[2 * k] = __uint_as_float(u[k] << 16);
-    f[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u);
-  }
-}
-
-__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
-  uint4 v;
-  v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]); v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
   return v;
 }
 
@@ -205,52 +191,33 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
   bf16_t* ptr = qk + vv * 64 + sub * 8;
   float v[8];
   unpack8(*(const uint4*)ptr, v);
-  float sum = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) sum += v[k];
+  float sum = qk_chunk_sum(v);
   sum += __shfl_xor(sum, 1, 64);
   sum += __shfl_xor(sum, 2, 64);
   sum += __shfl_xor(sum, 4, 64);
-  const float mean = sum * (1.0f / 64);
-  float q = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float d = v[k] - mean;
-    q = fmaf(d, d, q);
-  }
+  const float mean = qk_mean(sum);
+  float q = qk_chunk_sqdev(v, mean);
   q += __shfl_xor(q, 1, 64);
   q += __shfl_xor(q, 2, 64);
   q += __shfl_xor(q, 4, 64);
-  const float rstd = rsqrtf(q * (1.0f / 64) + eps);
+  const float rstd = qk_rstd(q, eps);
   float wv[8], bv[8];
   unpack8(*(const uint4*)((is_k ? wk : wq) + sub * 8), wv);
   unpack8(*(const uint4*)((is_k ? bk : bq) + sub * 8), bv);
   float o[8];
   // q_scale (alg_qk_norm_rope_scaled): the softmax scale * log2(e) folded into Q where it is produced, inside the LAST
   // rounding of the row (after the rope for video tokens, in the LayerNorm rounding for text tokens): the attention kernel
-  // then needs no per-score multiply.  K is never scaled.
+  // then needs no per-score multiply.  K is never scaled.  (Arithmetic: qk_norm_rope.h, shared with the GEMM store loop.)
   const float qs = is_k ? 1.0f : q_scale;
   const bool roped = s >= text_len && cos_tab;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float ln = (v[k] - mean) * rstd * wv[k] + bv[k];
-    o[k] = roped ? rbf(ln) : (qs == 1.0f ? rbf(ln) : rbf(ln * qs));
-  }
+  qk_ln_chunk(v, mean, rstd, wv, bv, roped, qs, o);
   if (roped) {
     const int64_t pos = (int64_t)(s - text_len) * 64 + sub * 8;
     const float4 c0 = *(const float4*)(cos_tab + pos), c1 = *(const float4*)(cos_tab + pos + 4);
     const float4 s0 = *(const float4*)(sin_tab + pos), s1 = *(const float4*)(sin_tab + pos + 4);
     const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    float r[8];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      // x.float() * cos + rotate(x).float() * sin, rotate = (-x_odd, x_even) interleaved; unfused like eager
-      r[2 * k] = __fadd_rn(__fmul_rn(o[2 * k], cs[2 * k]), __fmul_rn(-o[2 * k + 1], sn[2 * k]));
-      r[2 * k + 1] = __fadd_rn(__fmul_rn(o[2 * k + 1], cs[2 * k + 1]), __fmul_rn(o[2 * k], sn[2 * k + 1]));
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = qs == 1.0f ? r[k] : r[k] * qs;
+    qk_rope_chunk(o, cs, sn, qs);
   }
   if (live) *(uint4*)ptr = pack8(o);
 }

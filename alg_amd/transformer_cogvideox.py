@@ -96,6 +96,11 @@ class CogVideoXTransformer3DModel:
         # True (default): the Q|K projection and the transposed V projection of a block go out as one alg_gemm_bf16_pair
         # launch (bit-identical to the two launches; False keeps them apart: A/B runs, tests)
         self.pair_qkv = True
+        # True: the per-head QK LayerNorm + rotary embedding runs inside the Q|K projection's store loop (alg_gemm_bf16_pair_qk;
+        # bit-identical to the stand-alone kernel behind the pair launch, one read + one write of qk less).  Off by default:
+        # measured on the same box (profiles/r4_fuse_qk_norm_ab.txt) the ~20 VALU operations per element cost more in a
+        # one-wave-per-SIMD store loop (+9.5 ms per step) than the stand-alone kernel at full occupancy (8.4 ms per step)
+        self.fuse_qk_norm = False
         self._sincos = {}
         dev = self.device
         w = weights
@@ -372,14 +377,18 @@ class CogVideoXTransformer3DModel:
             qk_call = ((y, L["wqk"], qk, S, 2 * D, D, D, D, 2 * D), dict(bias=L["bqk"], batch=N, strideA=S * D, strideC=S * 2 * D))
             vt_call = ((L["wv"], y, vt, D, S, D, D, D, S_pad), dict(bias=L["bv"], batch=N, strideB=S * D, strideC=D * S_pad,
                                                                    flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS))
-            if self.pair_qkv:   # both projections read y: ONE persistent launch, the two partial last rounds become one
-                TM("gemm_qkv", _lib.gemm_pair, qk_call, vt_call)
-            else:
-                TM("gemm_qk", G, *qk_call[0], **qk_call[1])
-                TM("gemm_vt", G, *vt_call[0], **vt_call[1])
             # the softmax scale * log2(e) rides in Q's last rounding (attn_prescale = False: scaled per score in the attention)
-            TM("qk_norm_rope", _lib.qk_norm_rope_, qk, L["norm_q_w"], L["norm_q_b"], L["norm_k_w"], L["norm_k_b"], cos, sin, N, S, Hn, T,
-                               cfg.qk_norm_eps, q_scale=q_scale)
+            if self.pair_qkv and self.fuse_qk_norm:   # ... and QK LayerNorm + rope in the Q|K store loop: qk is written once
+                TM("gemm_qkv", _lib.gemm_pair_qk, qk_call, vt_call, L["norm_q_w"], L["norm_q_b"], L["norm_k_w"], L["norm_k_b"], cos, sin,
+                               Hn, T, cfg.qk_norm_eps, q_scale=q_scale)
+            else:
+                if self.pair_qkv:   # both projections read y: ONE persistent launch, the two partial last rounds become one
+                    TM("gemm_qkv", _lib.gemm_pair, qk_call, vt_call)
+                else:
+                    TM("gemm_qk", G, *qk_call[0], **qk_call[1])
+                    TM("gemm_vt", G, *vt_call[0], **vt_call[1])
+                TM("qk_norm_rope", _lib.qk_norm_rope_, qk, L["norm_q_w"], L["norm_q_b"], L["norm_k_w"], L["norm_k_b"], cos, sin, N, S, Hn, T,
+                                   cfg.qk_norm_eps, q_scale=q_scale)
             TM("attn", _lib.flash_attn_d64, qk, qk, vt, att, N, Hn, S, S * 2 * D, 2 * D, D * S_pad, S_pad, S * D, D, scale,
                                 k_off=D, q_prescaled=prescale)
             TM("gemm_out", G, att, L["wo"], x, S, D, D, D, D, D, bias=L["bo"], R=x, ldr=D, gate=mod, gate_off=m1 + 4 * D,

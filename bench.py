@@ -393,12 +393,27 @@ class C2(Workload):
                 per = (2.0 * S * D * 2) if k == "ln_mod" else (2.0 * S * 2 * D * 2)
                 launches_per_layer = 2 if k == "ln_mod" else 1
                 extra[k + "_gbs"] = per * forwards_local * L * launches_per_layer / tt / 1e9
+        if "qk_norm_rope" not in ms and "gemm_qkv" in ms:
+            extra["qk_norm_rope"] = "inside gemm_qkv's store loop (alg_gemm_bf16_pair_qk): gemm_qkv's time includes it"
         extra["time_share"] = {k: round(sum(v) / 1e3 / elapsed, 4) for k, v in ms.items()}
         attn_tflops = attn_flops_total / attn_time_total / 1e12 if attn_time_total > 0 else 0.0
         roofline = dict(bound="mfma", kernel=self.attn_kernel, achieved=attn_tflops, peak=self.peak,
                         unit="TFLOP/s", frac=attn_tflops / self.peak, traffic=None,
                         launches=len(ms.get("attn", [])),
                         mean_launch_ms=(sum(ms["attn"]) / len(ms["attn"])) if ms.get("attn") else None, extra=extra)
+        # A launch's duration is proportional to the samples in its forward (3 on an ALG step, 2 otherwise): the mean per kind, and
+        # the mean rocprofv3 --stats would print for the same command (its average runs over warm-up + timed launches alike)
+        passes = getattr(self, "step_passes", [])
+        if ms.get("attn") and len(ms["attn"]) == len(passes) * L:
+            by = {}
+            for j, n in enumerate(passes):
+                by.setdefault(str(n), []).extend(ms["attn"][j * L:(j + 1) * L])
+            roofline["mean_launch_ms_by_samples"] = {k: sum(v) / len(v) for k, v in by.items()}
+            roofline["launches_by_samples"] = {k: len(v) for k, v in by.items()}
+            allp = list(getattr(self, "warmup_passes", [])) + list(passes)
+            per = {int(k): sum(v) / len(v) for k, v in by.items()}
+            if all(n in per for n in allp):
+                roofline["mean_launch_ms_incl_warmup_expected"] = sum(per[n] for n in allp) / len(allp)
         tr = pmc_traffic(self.attn_kernel)
         if tr is not None:  # `traffic` = HBM bytes per launch (PMC, corrected); how it was derived goes next to it
             roofline["traffic"] = tr["bytes_per_launch"]
@@ -601,7 +616,9 @@ def run_steps(wl, k_steps):
         wl.last_out = wl.pipe(callback_on_step_end=cb, step_trace=trace, **wl.kwargs).frames
         for rec in trace:
             n = rec[2]
-            forwards += len(wl.split.my_passes(n)) if wl.split is not None else n
+            mine = len(wl.split.my_passes(n)) if wl.split is not None else n
+            forwards += mine
+            wl.__dict__.setdefault("step_passes", []).append(mine)      # samples per DiT forward of this step, in launch order (roofline: launch mix)
         left -= take
     return forwards
 
@@ -641,8 +658,11 @@ def timed_region(wl, warmup, steps, parallel):
     """W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; HIP-event brackets of the
     kernel families live only inside the timed region.  Returns (elapsed seconds = max over ranks, sample-forwards of this
     rank, per-family event times in ms)."""
+    wl.step_passes = []
     run_steps(wl, max(warmup, wl.min_warmup))
+    wl.warmup_passes = list(wl.step_passes)
     kinds = {}  # kernel family -> list of event pairs
+    wl.step_passes = []
     wl.instrument(kinds)
     parallel.barrier()
     torch.cuda.synchronize()

@@ -175,6 +175,20 @@ int alg_gemm_bf16(const alg_gemm_args* args, void* stream);
  * C of one problem must not alias an operand of the other. */
 int alg_gemm_bf16_pair(const alg_gemm_args* a, const alg_gemm_args* b, void* stream);
 
+/* alg_gemm_bf16_pair with the CogVideoX block's per-head QK LayerNorm + rotary embedding (alg_qk_norm_rope_scaled; diffusers
+ * CogVideoXAttnProcessor2_0: norm_q / norm_k / apply_rotary_emb, cog:1082-1090) applied to problem `qk` inside its store loop:
+ * qk->C is the [batch][S][2][heads][64] tensor (M = S, N = ldc = 2*heads*64, strideC = S*N), written ONCE in its final
+ * form.  Bit-identical to alg_gemm_bf16_pair followed by alg_qk_norm_rope_scaled(qk->C, ..., qk->batch, qk->M, heads,
+ * text_len, eps, q_scale) -- which is exactly what runs when the fused form cannot take the call (heads % 4 != 0, schedule 6,
+ * a pair the persistent launch cannot take). */
+typedef struct alg_qk_norm_rope_args {
+  const void *wq, *bq, *wk, *bk;      /* [64] bf16 LayerNorm weight / bias of norm_q and norm_k */
+  const float *cos_tab, *sin_tab;      /* [S - text_len][64] float32, or both NULL (no rotary embedding) */
+  int32_t heads, text_len;
+  float eps, q_scale;                  /* q_scale: see alg_qk_norm_rope_scaled (1 = plain) */
+} alg_qk_norm_rope_args;
+int alg_gemm_bf16_pair_qk(const alg_gemm_args* qk, const alg_gemm_args* vt, const alg_qk_norm_rope_args* e, void* stream);
+
 /* BASELINE config 5 (fp8 weights on the CDNA4 fp8 MFMA): same contract and epilogues with A and B holding OCP e4m3 bytes
  * (lda / ldb / strides in elements = bytes) and per-row float32 scales: C = epilogue(a_scale[m] * b_scale[n] * (A @ B^T)).
  * K % 128 == 0.  Operands come from alg_quantize_fp8_rows (activations: per token, weights: per output channel). */

@@ -81,6 +81,12 @@ def main():
             ((wv, y, vt, D, S, D, D, D, S_pad), dict(bias=bv, batch=N, strideB=S * D, strideC=D * S_pad,
                                                     flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS))),
             2.0 * N * S * D * 3 * D, "flop"),
+        # the pair launch with QK LayerNorm + rope inside the Q|K store loop (compare with gemm_qkv + qk_norm_rope)
+        "gemm_qkv_qk": (lambda: _lib.gemm_pair_qk(
+            ((y, wqk, qk, S, 2 * D, D, D, D, 2 * D), dict(bias=bqk, batch=N, strideA=S * D, strideC=S * 2 * D)),
+            ((wv, y, vt, D, S, D, D, D, S_pad), dict(bias=bv, batch=N, strideB=S * D, strideC=D * S_pad,
+                                                    flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)),
+            nq[0], nq[1], nq[2], nq[3], cos, sin, H, T, 1e-6, q_scale=0.18033688), 2.0 * N * S * D * 3 * D, "flop"),
         "gemm_out": (lambda: G(att, wo, x, S, D, D, D, D, D, bias=bo, R=x, ldr=D, gate=mod, gate_off=4 * D,
                                strideGate=12 * D, seg_split=T, batch=N, strideA=S * D, strideC=S * D, strideR=S * D),
                      2.0 * N * S * D * D, "flop"),

@@ -440,6 +440,57 @@ def test_gemm_pair_is_bit_identical_to_the_two_launches(monkeypatch, S, D, N):
         _lib.gemm_pair(bad[1], bad[0])
 
 
+@pytest.mark.parametrize("S,heads,N,T,rope,qs", [(17776, 48, 2, 226, True, 0.18033688), (300, 8, 3, 17, True, 1.0),
+                                                  (1000, 4, 1, 0, True, 0.18033688), (257, 12, 2, 257, True, 1.0),
+                                                  (530, 4, 2, 100, False, 0.18033688), (300, 6, 1, 17, True, 0.18033688)])
+def test_gemm_pair_qk_is_bit_identical_to_the_pair_launch_plus_qk_norm_rope(monkeypatch, S, heads, N, T, rope, qs):
+    """alg_gemm_bf16_pair_qk: the per-head QK LayerNorm + rotary embedding (+ softmax scale on Q) inside the Q|K projection's
+    store loop.  Same arithmetic, same reduction tree, same rounding points as qk_norm_rope_kernel (csrc/qk_norm_rope.h), so
+    the bits are those of alg_gemm_bf16_pair followed by alg_qk_norm_rope_scaled: at the C2 shape, with edge tiles in M, text /
+    video boundaries inside a 16-row group, no text tokens, only text tokens, no rotary tables, and (heads = 6: a tile would
+    straddle Q | K) through the documented fallback; V^T is untouched by the fusion; ALG_GEMM_PIPE=6 takes the fallback too."""
+    D = heads * 64
+    g = torch.Generator(device="cuda").manual_seed(S + heads)
+    rn = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g, device="cuda") * sc).to(BF)
+    S_pad = (S + 63) // 64 * 64
+    y, wqk, bqk, wv, bv = rn(N, S, D), rn(2 * D, D, sc=0.05), rn(2 * D), rn(D, D, sc=0.05), rn(D)
+    wq, bq, wk, bk = (1 + rn(64, sc=0.2)), rn(64, sc=0.2), (1 + rn(64, sc=0.2)), rn(64, sc=0.2)
+    ang = torch.rand(max(S - T, 1), 32, generator=g, device="cuda") * 6.28
+    cos = ang.cos().repeat_interleave(2, dim=1).contiguous() if rope else None
+    sin = ang.sin().repeat_interleave(2, dim=1).contiguous() if rope else None
+
+    def calls(qk, vt):
+        return (((y, wqk, qk, S, 2 * D, D, D, D, 2 * D), dict(bias=bqk, batch=N, strideA=S * D, strideC=S * 2 * D)),
+                ((wv, y, vt, D, S, D, D, D, S_pad), dict(bias=bv, batch=N, strideB=S * D, strideC=D * S_pad,
+                                                        flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)))
+
+    def fresh():
+        return torch.full((N, S, 2 * D), 7.0, dtype=BF, device="cuda"), torch.zeros(N, D, S_pad, dtype=BF, device="cuda")
+
+    qk0, vt0 = fresh()
+    _lib.gemm_pair(*calls(qk0, vt0))
+    raw = qk0.clone()
+    _lib.qk_norm_rope_(qk0, wq, bq, wk, bk, cos, sin, N, S, heads, T, 1e-6, q_scale=qs)
+    assert not torch.equal(raw, qk0)
+    for _ in range(3):
+        qk1, vt1 = fresh()
+        _lib.gemm_pair_qk(*calls(qk1, vt1), wq, bq, wk, bk, cos, sin, heads, T, 1e-6, q_scale=qs)
+        assert torch.equal(vt1, vt0)
+        if not torch.equal(qk1, qk0):
+            d = (qk1.float() - qk0.float()).abs()
+            idx = (d > 0).nonzero()
+            raise AssertionError("fused != separate: %d elements, max %.4g, first %s" % (idx.shape[0], d.max().item(), idx[:4].tolist()))
+    monkeypatch.setenv("ALG_GEMM_PIPE", "6")
+    qk1, vt1 = fresh()
+    _lib.gemm_pair_qk(*calls(qk1, vt1), wq, bq, wk, bk, cos, sin, heads, T, 1e-6, q_scale=qs)
+    assert torch.equal(qk1, qk0) and torch.equal(vt1, vt0)
+    monkeypatch.delenv("ALG_GEMM_PIPE")
+    with pytest.raises(_lib.AlgHipError):                                   # not the [S][2][heads][64] layout: rejected, nothing launched
+        _lib.gemm_pair_qk(*calls(qk1, vt1), wq, bq, wk, bk, cos, sin, heads + 1, T, 1e-6)
+    with pytest.raises(_lib.AlgHipError):                                   # cos without sin
+        _lib.gemm_pair_qk(*calls(qk1, vt1), wq, bq, wk, bk, ang, None, heads, T, 1e-6)
+
+
 @pytest.mark.parametrize("form", ["plain", "gelu", "vt", "res", "res_gate_seg", "res_gate_f32", "res_gate_f32_straddle"])
 def test_schedule9_equals_the_drain_and_barrier_schedule_bit_for_bit(monkeypatch, form):
     """Schedule 9 (hand-written asm K loop, accumulators in AGPRs, residual quads fetched INSIDE the loop over its first eight

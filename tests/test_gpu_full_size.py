@@ -322,7 +322,8 @@ def test_c2_forward_at_its_real_shape_two_layers_vs_fp32_oracle(device):
 
 def test_paired_qkv_launch_leaves_the_forward_bit_identical(device):
     """`pair_qkv` (default): the Q|K and V^T projections of every block as one alg_gemm_bf16_pair launch.  A tile is computed
-    exactly as by its own launch, so the full-width 2-layer C2 forward must not change by a bit (N = 2 and N = 3)."""
+    exactly as by its own launch, so the full-width 2-layer C2 forward must not change by a bit (N = 2 and N = 3); neither
+    does `fuse_qk_norm` (opt-in: QK LayerNorm + rope inside the Q|K store loop, alg_gemm_bf16_pair_qk) change one."""
     cfg = CogVideoXTransformerConfig(num_layers=2)
     model = CogVideoXTransformer3DModel.from_synthetic(cfg, seed=17, device=device)
     g = torch.Generator().manual_seed(9)
@@ -334,9 +335,11 @@ def test_paired_qkv_launch_leaves_the_forward_bit_identical(device):
     for n in (2, 3):
         ehs = torch.cat([ne] * (n - 1) + [pe])
         ts = torch.full((n,), 700.0)
-        assert model.pair_qkv
+        assert model.pair_qkv and not model.fuse_qk_norm
         a = model.forward_assembled(lat, [c0] * n, ehs, ts, rope)
-        model.pair_qkv = False
+        model.fuse_qk_norm = True            # QK LayerNorm + rope inside the Q|K store loop instead of the stand-alone kernel
+        c = model.forward_assembled(lat, [c0] * n, ehs, ts, rope)
+        model.pair_qkv, model.fuse_qk_norm = False, False
         b = model.forward_assembled(lat, [c0] * n, ehs, ts, rope)
         model.pair_qkv = True
-        assert bool(torch.isfinite(a.float()).all()) and torch.equal(a, b)
+        assert bool(torch.isfinite(a.float()).all()) and torch.equal(a, b) and torch.equal(a, c)
