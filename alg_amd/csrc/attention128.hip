@@ -265,14 +265,12 @@ static int flash_attn_d128_entry(const void* q, const void* k, const void* vt, v
               a128::KVB);
     return ALG_EINVAL;
   }
-#ifdef ALG_EXPERIMENTS
-  if (!causal && kv_group == 1) {   // opt-in (ALG_ATTN128_Q64): 64 queries per wave (attention128_q64.hip); 1 = not covered
+  if (!causal && kv_group == 1) {   // 4,096 keys and more: 64 queries per wave (attention128_q64.hip; default since round 4), 1 = not covered
     const int rc = flash_attn_d128_q64(q, k, vt, o, batch, heads, Sq, Skv, q_bstride, q_rstride, k_bstride, k_rstride, vt_bstride,
                                        vt_rstride, o_bstride, o_rstride, scale, (hipStream_t)stream);
     if (rc <= 0) return rc;
   }
-#endif
-  if (!causal && kv_group == 1) {   // long self-attention: the pipelined kernel (attention128_pipe.hip; default), 1 = not covered
+  if (!causal && kv_group == 1) {   // shorter: the pipelined 32-query kernel (attention128_pipe.hip), 1 = not covered
     const int rp = flash_attn_d128_pipe(q, k, vt, o, batch, heads, Sq, Skv, q_bstride, q_rstride, k_bstride, k_rstride, vt_bstride,
                                         vt_rstride, o_bstride, o_rstride, scale, (hipStream_t)stream);
     if (rp <= 0) return rp;

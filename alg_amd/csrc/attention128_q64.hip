@@ -17,8 +17,12 @@
 // the exact rescale path out of the region (it runs after it, rarely).  K and V^T tiles stream through two 4-slot LDS rings
 // (2 x 64 KiB, 16-byte global_load_lds) three tiles ahead: per 64-key tile ONE counted wait (vmcnt(16)) and ONE barrier.
 //
-// Used for non-causal, ungrouped attention over at least MIN_TILES KV tiles (the Wan / HunyuanVideo self-attention); the
-// cross-attentions, the causal grouped-query form and short sequences stay on attention128.hip.  Same operand layout, same
+// DEFAULT since round 4 for non-causal, ungrouped attention over at least POLICY_TILES KV tiles (the Wan / HunyuanVideo
+// self-attention: +3.2 % over attention128_pipe.hip at C4); ALG_ATTN128_Q64=0 switches it off, =2 takes every call of at
+// least MIN_TILES tiles (tests).  The cross-attentions, the causal grouped-query form and short sequences stay on
+// attention128_pipe.hip / attention128.hip.  Rounds 2 - 4 kept it out of the product because 1 - 2 % of fp8 C5 forwards differed
+// from their repeat; the cause (an asm MFMA's dead destination registers recycled by hipcc while the MFMA still writes them) is
+// described where it is fixed, at the end of the kernel, and in profiles/r4_attention128_q64_probe.txt.  Same operand layout, same
 // swizzles, same accumulation order per query as that kernel (S^T = K Q^T, P as the B operand of O^T = V^T P^T).
 #include <stdlib.h>
 
@@ -26,8 +30,9 @@
 
 #include "common.h"
 
-// EXPERIMENTS-only kernel: keeps the row-sum limit it was validated with (2^40; the product kernels moved to 2^80 in round 4 --
-// the d = 64 sibling returned wrong rows at 2,050 keys with the larger limit, not investigated)
+// Row-sum limit of the lazy running max: 2^40 (what the kernel was validated with).  Unlike the single-statement kernels, whose
+// waves leave the fast path for good (hence their 2^80), the exact path here is an in-line branch that returns to the fast path:
+// no cliff, so the smaller limit costs nothing on model data.
 #define ALG_Q64_SUM_LIMIT 1.0995116e12f
 
 namespace alg {
@@ -40,7 +45,8 @@ constexpr int K_TILE = KVB * 128 * 2;    // 16 KiB
 constexpr int V_TILE = 128 * KVB * 2;    // 16 KiB
 constexpr int NS = 4;                    // ring slots per operand
 constexpr int LDS_BYTES = NS * (K_TILE + V_TILE);
-constexpr int MIN_TILES = 8;
+constexpr int MIN_TILES = 8;             // what the kernel can take (ALG_ATTN128_Q64=2)
+constexpr int POLICY_TILES = 64;         // what it takes by default: 4,096 keys and more
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -53,6 +59,9 @@ struct P {
   int batch, heads, Sq, Skv, q_blocks;
   int64_t q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs;
   float scale_log2;
+#ifdef ALG_EXPERIMENTS
+  float* dbg;   // investigation tap (alg_debug_q64_tap): per (batch, head, query) [l_run, m_run, l_tot, 1 / l_tot] per lane
+#endif
 };
 
 // The K / V^T fragment ring (four 16-byte fragments, three reads in flight at any time, ACROSS regions, branches and the loop
@@ -538,7 +547,7 @@ __device__ __forceinline__ void read_o(float (&f)[16]) {
                  : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]) : : ALG_O_CLOBBER);
 }
 
-// MODE (round-3 experiment arms, selected at run time by ALG_ATTN128_Q64 = 1 / 2 / 3 / 4):
+// MODE 1 is the kernel.  2 - 4 are round 3's experiment arms (EXPERIMENTS build, ALG_ATTN128_Q64 = 12 / 13 / 14):
 //   1  the round-2 kernel: counted vmcnt(8) at the tile boundary (three DMA groups in the ring, one may still be in flight)
 //   2  vmcnt(0) at the tile boundary: no reliance on LDS-DMA completing in issue order (the group issued one tile ago is
 //      ~2,000 cycles old by then)
@@ -975,6 +984,15 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
     region(2 * t + 2, S0{}, SLR{}, se, so, pe, po);
   }
   region(2 * n_tiles - 1, S1{}, SLR{}, so, se, po, pe);
+  // ROOT CAUSE of the round-2..4 "first round of workgroups" mismatches (profiles/r4_attention128_q64_probe.txt): the S of the
+  // half-tile past the end is never used, so hipcc treated the destination registers of the asm MFMAs that compute it as free
+  // and recycled them as TEMPORARIES of the softmax right behind those MFMAs -- which write them 32+ cycles after issue (the
+  // compiler cannot see an MFMA inside asm text).  An instruction-cache miss between `v_fma` (a0 = s c - m c into the recycled
+  // register) and `v_exp` let the MFMA's write land in between: exp2 of a raw score accumulator entered the row sum of the
+  // LAST half-tile, whose keys are all masked and whose V^T pad columns are zero -- l inflated, O untouched: whole output rows
+  // scaled by 1 / (1 + 2^garbage / l), only the query half whose softmax runs in steps 8 - 15, only where the code was not
+  // cached yet.  Keeping the dropped S alive to the end of the region removes the reuse.
+  asm volatile("" ::"v"(se[0]), "v"(se[1]));
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   pv(n_tiles - 1, S1{}, po);
@@ -991,6 +1009,12 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
     const float l_tot = l_run[qh] + __shfl_xor(l_run[qh], 32, 64);
     const float inv = 1.0f / l_tot;
     const int q_row = q_row0 + qh * 32;
+#ifdef ALG_EXPERIMENTS
+    if (p.dbg && q_row < Sq) {
+      float* dp = p.dbg + (((int64_t)b * p.heads + h) * Sq + q_row) * 8 + h2 * 4;   // both lanes of a query: their own partial sums
+      dp[0] = l_run[qh], dp[1] = m_run[qh], dp[2] = l_tot, dp[3] = inv;   // (nothing is tracked inside the loop: its code stays as it was)
+    }
+#endif
     if (q_row < Sq) {
       bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + h * 128;
 #pragma unroll
@@ -1014,26 +1038,31 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
 
 }  // namespace a128q
 
-// Returns ALG_OK when launched, 1 when this call is not covered (the caller runs attention128.hip's kernel).
+#ifdef ALG_EXPERIMENTS
+static float* g_q64_tap = nullptr;
+#endif
+// Returns ALG_OK when launched, 1 when this call is not covered (the caller goes on to attention128_pipe.hip / attention128.hip).
 int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq, int Skv,
                         int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t vt_bs, int64_t vt_rs, int64_t o_bs,
                         int64_t o_rs, float scale, hipStream_t stream) {
   using namespace a128q;
-  // OPT-IN (ALG_ATTN128_Q64=1).  The kernel is bit-reproducible on its own (thousands of stressed launches, cold and warm),
-  // but inside the fp8 Wan forward at the C5 token count 2 - 8 % of the forwards differed from their repeat in a few dozen
-  // tokens of the first wave of workgroups, and never with attention128.hip's 32-query kernel in its place
-  // (profiles/r2_attention128_q64_flake.txt: what was tried, what moved the rate).  Until that is understood the
-  // product default is the kernel that has never produced a mismatch.
+  // ALG_ATTN128_Q64: 1 (default) = calls over at least POLICY_TILES KV tiles; 2 = every call the kernel can take; 0 = off.
+  // (EXPERIMENTS build: 12 / 13 / 14 = round 3's diagnostic arms, every call the kernel can take.)
   const int enabled = opt(OPT_ATTN128_Q64);
-  if (!enabled || (Skv + KVB - 1) / KVB < MIN_TILES) return 1;
+  const int n_tiles = (Skv + KVB - 1) / KVB;
+  if (!enabled || n_tiles < (enabled == 1 ? POLICY_TILES : MIN_TILES)) return 1;
   // 31-bit BYTE offsets inside one (batch, head) for the DMA's lane offsets; V^T rows cover whole 64-key tiles
   if ((int64_t)(Skv + 64) * k_rs * 2 >= (1ll << 31) || (int64_t)129 * vt_rs * 2 >= (1ll << 31)) return 1;
   if (vt_rs < (int64_t)((Skv + KVB - 1) / KVB) * KVB) return 1;
   static PerDeviceOnce attr_set;
   const int dev_slot = current_device_slot();
   if (!device_done(attr_set, dev_slot)) {
+#ifdef ALG_EXPERIMENTS
     for (const void* fn : {(const void*)flash_attn_d128_q64_kernel<1>, (const void*)flash_attn_d128_q64_kernel<2>,
                            (const void*)flash_attn_d128_q64_kernel<3>, (const void*)flash_attn_d128_q64_kernel<4>})
+#else
+    for (const void* fn : {(const void*)flash_attn_d128_q64_kernel<1>})
+#endif
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return 1;
     device_mark(attr_set, dev_slot);
   }
@@ -1043,16 +1072,27 @@ int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, i
   p.q_blocks = (Sq + NW * QW - 1) / (NW * QW);
   p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.vt_bs = vt_bs; p.vt_rs = vt_rs; p.o_bs = o_bs; p.o_rs = o_rs;
   p.scale_log2 = scale * 1.4426950408889634f;
+#ifdef ALG_EXPERIMENTS
+  p.dbg = g_q64_tap;
+#endif
   const int64_t grid = (int64_t)((batch * heads + 7) / 8) * 8 * p.q_blocks;
   if (grid > 0x7fffffff) return 1;
   const dim3 g((unsigned)grid), blk(NW * 64);
   switch (enabled) {
-    case 2: hipLaunchKernelGGL(flash_attn_d128_q64_kernel<2>, g, blk, LDS_BYTES, stream, p); break;
-    case 3: hipLaunchKernelGGL(flash_attn_d128_q64_kernel<3>, g, blk, LDS_BYTES, stream, p); break;
-    case 4: hipLaunchKernelGGL(flash_attn_d128_q64_kernel<4>, g, blk, LDS_BYTES, stream, p); break;
+#ifdef ALG_EXPERIMENTS
+    case 12: hipLaunchKernelGGL(flash_attn_d128_q64_kernel<2>, g, blk, LDS_BYTES, stream, p); break;
+    case 13: hipLaunchKernelGGL(flash_attn_d128_q64_kernel<3>, g, blk, LDS_BYTES, stream, p); break;
+    case 14: hipLaunchKernelGGL(flash_attn_d128_q64_kernel<4>, g, blk, LDS_BYTES, stream, p); break;
+#endif
     default: hipLaunchKernelGGL(flash_attn_d128_q64_kernel<1>, g, blk, LDS_BYTES, stream, p); break;
   }
   return check_launch("alg_flash_attn_d128");
 }
 
 }  // namespace alg
+
+#ifdef ALG_EXPERIMENTS
+// EXPERIMENTS build only: where the 64-query kernel's launches write their per-query softmax state ([batch][heads][Sq][2 lanes][4]
+// float32: partial row sum, running max, pair row sum, its reciprocal), or NULL (default) for nothing.
+extern "C" void alg_debug_q64_tap(float* buffer) { alg::g_q64_tap = buffer; }
+#endif

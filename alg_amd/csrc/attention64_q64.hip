@@ -649,6 +649,15 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const P p) 
     half_tile(2 * t + 2, S0{}, SLR{}, se, so, pe, po);
   }
   half_tile(2 * n_tiles - 1, S1{}, SLR{}, so, se, po, pe);
+  // ROOT CAUSE of the round-2..4 "first round of workgroups" mismatches (profiles/r4_attention128_q64_probe.txt): the S of the
+  // half-tile past the end is never used, so hipcc treated the destination registers of the asm MFMAs that compute it as free
+  // and recycled them as TEMPORARIES of the softmax right behind those MFMAs -- which write them 32+ cycles after issue (the
+  // compiler cannot see an MFMA inside asm text).  An instruction-cache miss between `v_fma` (a0 = s c - m c into the recycled
+  // register) and `v_exp` let the MFMA's write land in between: exp2 of a raw score accumulator entered the row sum of the
+  // LAST half-tile, whose keys are all masked and whose V^T pad columns are zero -- l inflated, O untouched: whole output rows
+  // scaled by 1 / (1 + 2^garbage / l), only the query half whose softmax runs in steps 8 - 15, only where the code was not
+  // cached yet.  Keeping the dropped S alive to the end of the region removes the reuse.
+  asm volatile("" ::"v"(se[0]), "v"(se[1]));
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   pv(n_tiles - 1, S1{}, po);

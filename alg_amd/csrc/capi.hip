@@ -43,6 +43,11 @@ static const OptDef g_defs[OPT_COUNT] = {
 #endif
     {"ALG_ATTN128_PIPE", 1, 2, {0, 1}},
 #ifdef ALG_EXPERIMENTS
+    {"ALG_ATTN128_Q64", 1, 0, {}},
+#else
+    {"ALG_ATTN128_Q64", 1, 3, {0, 1, 2}},
+#endif
+#ifdef ALG_EXPERIMENTS
     {"ALG_GEMM_PIPE", 9, 0, {}},
 #else
     {"ALG_GEMM_PIPE", 9, 2, {6, 9}},
@@ -51,7 +56,6 @@ static const OptDef g_defs[OPT_COUNT] = {
 #ifdef ALG_EXPERIMENTS
     {"ALG_ATTN_PRIO", 0, 2, {0, 1}},
     {"ALG_ATTN64_Q64", 0, 2, {0, 1}},
-    {"ALG_ATTN128_Q64", 0, 2, {0, 1}},
     {"ALG_GEMM_PERSIST", 1, 2, {0, 1}},
     {"ALG_GEMM_GROUP_M", 0, 0, {}},
     {"ALG_GEMM_ABLATE", 0, 0, {}},

@@ -23,13 +23,14 @@ enum Opt {
   OPT_ATTN_PP,          // ALG_ATTN_PP           4 (default: pipelined main launch) | 0: the straight loop
   OPT_ATTN_VARIANT,     // ALG_ATTN_VARIANT      33 (default: lazy running max) | 1: exact running max, fp32 row sums
   OPT_ATTN128_PIPE,     // ALG_ATTN128_PIPE      1 (default: pipelined d = 128 kernel) | 0: the straight loop
+  OPT_ATTN128_Q64,      // ALG_ATTN128_Q64       1 (default: 64-queries-per-wave kernel for >= 4,096 keys) | 2: for every call it can
+                        //                       take (>= 512 keys) | 0: off
   OPT_GEMM_PIPE,        // ALG_GEMM_PIPE         9 (default) | 6: the 8-wave ping-pong schedule (bit-identical results)
   OPT_LOWPASS_PATH,     // ALG_LOWPASS_PATH      0 auto | 1 plane-per-workgroup | 2 lowpass_v2 | 3 lowpass_v3 at any plane
                         //                       count | 4 global-memory passes (all bit-identical)
 #ifdef ALG_EXPERIMENTS
   OPT_ATTN_PRIO,        // ALG_ATTN_PRIO         static s_setprio 1 for the younger half of an 8-wave workgroup
   OPT_ATTN64_Q64,       // ALG_ATTN64_Q64        64-queries-per-wave d = 64 main launch (attention64_q64.hip)
-  OPT_ATTN128_Q64,      // ALG_ATTN128_Q64       64-queries-per-wave d = 128 kernel (attention128_q64.hip; NOT run-to-run stable)
   OPT_GEMM_PERSIST,     // ALG_GEMM_PERSIST      0: one workgroup per tile
   OPT_GEMM_GROUP_M,     // ALG_GEMM_GROUP_M      tile-order group override
   OPT_GEMM_ABLATE,      // ALG_GEMM_ABLATE       timing-only ablation bits (WRONG RESULTS)

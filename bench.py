@@ -442,7 +442,7 @@ class C2(Workload):
 
 
 class _WanBase(Workload):
-    attn_kernel = "flash_attn_d128_pipe_kernel"   # the default d = 128 self-attention since round 3 (attention128_pipe.hip)
+    attn_kernel = "flash_attn_d128_q64_kernel"   # the default d = 128 self-attention since round 4 (attention128_q64.hip)
     D, heads, ffn = 5120, 40, 13824
     fp8 = False
 
@@ -541,7 +541,7 @@ class C4(Workload):
     name = "c4"
     metric = "frames/sec (whole node) HunyuanVideo-I2V 129f @ 1280x720 x 50-step ALG (down_up)"
     frames, steps_per_video = 129, 50
-    attn_kernel = "flash_attn_d128_pipe_kernel"   # the default d = 128 self-attention since round 3 (attention128_pipe.hip)
+    attn_kernel = "flash_attn_d128_q64_kernel"   # the default d = 128 self-attention since round 4 (attention128_q64.hip)
     describe = ("BASELINE config 4: HunyuanVideo-I2V bf16, 129 frames @ 1280x720, 50 steps, ALG interval down_up (factor "
                 "0.625, interval [0, 0.04]), embedded guidance 6.0 (single-pass ALG branch); one prompt per GPU")
     data = "synthetic (seeded random-init weights at HunyuanVideo-I2V shapes, seeded latents/embeddings)"

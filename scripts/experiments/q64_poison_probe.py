@@ -78,9 +78,9 @@ for _ in range(3):          # same-kernel repeats: the classic stress loop
 stream = torch.cuda.current_stream().cuda_stream
 report = {"kernel": kernel, "S": S, "iters": iters, "experiments": _lib.experiments_build(), "arms": []}
 PATTERNS = {"nan": 0x7FC00000, "big": 0x7F000000, "neg": 0xFF000000, "ones": 0x3F803F80, "allbits": 0xFFFFFFFF, "alt": 0xAAAAAAAA,
-            "zero": 0}
+            "zero": 0, "eighty": 0x42A042A0, "minus80": 0xC2A0C2A0}
 for parts, pname in [(0, "nan"), (31, "nan"), (31, "big"), (31, "neg"), (31, "ones"), (1, "nan"), (2, "nan"), (4, "nan"), (8, "nan"),
-                     (16, "nan"), (32, "allbits"), (32, "alt"), (32, "zero"), (63, "allbits"), (63, "zero")]:
+                     (16, "nan"), (32, "allbits"), (32, "alt"), (32, "zero"), (63, "allbits"), (63, "zero"), (63, "eighty"), (16, "eighty"), (16, "minus80"), (31, "eighty")]:
     bad, worst, nonfinite = 0, 0.0, 0
     for i in range(iters):
         rc = poison.reg_poison(PATTERNS[pname], parts, 512, stream)

@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libreg_poison.so")
 PATTERNS = {"nan": 0x7FC00000, "big": 0x7F000000, "neg": 0xFF000000, "ones": 0x3F803F80, "allbits": 0xFFFFFFFF, "alt": 0xAAAAAAAA,
-            "zero": 0}
+            "zero": 0, "eighty": 0x42A042A0, "minus80": 0xC2A0C2A0}
 VGPR_LO, VGPR_HI, AGPR_LO, AGPR_HI, LDS, SGPR = 1, 2, 4, 8, 16, 32
 ALL = 63
 

@@ -64,13 +64,11 @@ def _check_rows(o, ref, what):
                                                                                 int(err.argmax().item()))
 
 
-@pytest.mark.parametrize("q64", ["pipe", "0", "1"])   # the pipelined kernel (default), attention128.hip, the 64-query kernel
+@pytest.mark.parametrize("q64", ["pipe", "0", "1"])   # the pipelined 32-query kernel, attention128.hip, the 64-query kernel (default)
 @pytest.mark.parametrize("name,S", [("c3_wan480p", 32760), ("c5_wan720p", 75600), ("c4_hunyuan720p", 118800 + 256)])
 def test_flash_attn_d128_every_row_vs_fp32_sdpa_at_full_s(name, S, q64, monkeypatch, request):
     monkeypatch.setenv("ALG_ATTN128_PIPE", "1" if q64 == "pipe" else "0")
-    if q64 == "1":                                     # the 64-query kernel exists in the EXPERIMENTS build only
-        request.getfixturevalue("experiments")
-        monkeypatch.setenv("ALG_ATTN128_Q64", "1")
+    monkeypatch.setenv("ALG_ATTN128_Q64", "1" if q64 == "1" else "0")   # "1": the 64-query kernel, the default at these lengths
     H = 3
     D = H * 128
     g = torch.Generator(device=DEV).manual_seed(S)

@@ -557,15 +557,17 @@ def test_pingpong_attention_equals_the_straight_loop_bit_for_bit(monkeypatch, ex
 
 
 @pytest.mark.parametrize("std", [4.0, 8.0, 15.0, 22.0])
-def test_attention_wide_score_ranges_against_fp64(device, std):
+def test_attention_wide_score_ranges_against_fp64(device, std, monkeypatch):
     """Round 4 raised the lazy running max's row-sum limit from 2^40 to 2^80 (common.h): rows stay on the no-rescale path with
     probabilities up to 2^80.  Scores ~ N(0, std^2) in log2 units over 2,050 keys put the row maxima at ~ 3.5 std: well inside
     (4, 8: the regime that used to throw a quarter of the waves out of the pipelined statement), around (15, 22) and beyond the
     limit (rows cross it mid-sequence: exact path, offsets stop being zero).  d = 64 (pre-scaled, pipelined main launch) and
-    d = 128 (pipelined), every row against an fp64 softmax of the same bf16 inputs."""
+    d = 128 (the pipelined 32-query kernel, and the 64-query kernel forced onto this length: its limit is 2^40 with an in-line
+    exact path), every row against an fp64 softmax of the same bf16 inputs."""
     g = torch.Generator().manual_seed(int(std))
     S, H = 2050, 2
-    for hd, call in ((64, "d64"), (128, "d128")):
+    for hd, call in ((64, "d64"), (128, "d128"), (128, "d128_q64")):
+        monkeypatch.setenv("ALG_ATTN128_Q64", "2" if call == "d128_q64" else "0")
         q = (torch.randn(1, S, H, hd, generator=g) * (std / hd ** 0.5)).to(BF)      # q . k ~ N(0, std^2)
         k, v = rnd((1, S, H, hd), g), rnd((1, S, H, hd), g)
         D = H * hd

@@ -35,7 +35,7 @@ def _cases():
     rn = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g, device="cuda") * sc).to(BF)
     S = 4160
     cases = {}
-    for name, Hh, d in (("flash_attn_d64_pipe", 48, 64), ("flash_attn_d128_pipe", 40, 128)):
+    for name, Hh, d in (("flash_attn_d64_pipe", 48, 64), ("flash_attn_d128_q64 (default at this length)", 40, 128)):
         D, S_pad = Hh * d, (S + 63) // 64 * 64
         qk = rn(1, S, 2 * D)
         vt = torch.zeros(1, D, S_pad, dtype=BF, device="cuda")
@@ -72,10 +72,15 @@ def _cases():
     return cases
 
 
-def test_asm_kernels_ignore_what_the_previous_kernel_left_behind(poison):
+def test_asm_kernels_ignore_what_the_previous_kernel_left_behind(poison, monkeypatch):
     lib, P = poison
     st = torch.cuda.current_stream().cuda_stream
-    for name, (run, out) in _cases().items():
+    cases = _cases()
+    cases["flash_attn_d128_pipe"] = cases["flash_attn_d128_q64 (default at this length)"] + ("ALG_ATTN128_Q64", "0")
+    for name, case in cases.items():
+        run, out = case[:2]
+        if len(case) > 2:
+            monkeypatch.setenv(case[2], case[3])
         run()
         torch.cuda.synchronize()
         ref = out.clone()

@@ -51,9 +51,10 @@ def test_flash_attn_d128_matches_sdpa(B, H, Sq, Skv):
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 1024), (2, 3, 257, 1000), (1, 1, 256, 513), (1, 2, 1300, 2050),
                                           (1, 1, 64, 544), (1, 2, 520, 575), (1, 1, 300, 640), (1, 2, 100, 700),
                                           (1, 1, 200, 832)])
-def test_flash_attn_d128_q64_kernel(B, H, Sq, Skv, monkeypatch, experiments):
-    """The long self-attention form (attention128_q64.hip: 64 queries per wave, software-pipelined 32-key half-tiles, taken for
-    >= 8 KV tiles): against fp32 SDPA and against the 32-query kernel (ALG_ATTN128_Q64=0) on the same tensors.  Ragged key
+def test_flash_attn_d128_q64_kernel(B, H, Sq, Skv, monkeypatch):
+    """The long self-attention form (attention128_q64.hip: 64 queries per wave, software-pipelined 32-key half-tiles; the default
+    from 4,096 keys on, here forced onto every call of >= 8 KV tiles with ALG_ATTN128_Q64=2): against fp32 SDPA and against the
+    32-query kernels (ALG_ATTN128_Q64=0) on the same tensors.  Ragged key
     counts: a last tile whose second half is partly (1000, 2050), entirely (513, 544: 1 / 32 keys) masked, or exactly half
     (575 = 8 x 64 + 63), query blocks that end mid-wave, scores large enough to trip the lazy running max's exact path; tile
     counts that leave 0, 1, 2 and 3 tiles to the runtime-slot remainder of the four-tile unrolled main loop."""
@@ -65,7 +66,7 @@ def test_flash_attn_d128_q64_kernel(B, H, Sq, Skv, monkeypatch, experiments):
     vt = make_vt(v, s_pad)
     scale = 1.0 / math.sqrt(128)
     outs = {}
-    for flag in ("1", "0"):
+    for flag in ("2", "0"):
         monkeypatch.setenv("ALG_ATTN128_Q64", flag)
         o = torch.full((B, Sq, D), 7.0, dtype=BF, device=DEV)
         _lib.flash_attn_d128(q, k, vt, o, B, H, Sq, Skv, Sq * D, D, Skv * D, D, D * s_pad, s_pad, Sq * D, D, scale)
@@ -79,11 +80,11 @@ def test_flash_attn_d128_q64_kernel(B, H, Sq, Skv, monkeypatch, experiments):
         assert (o.float() - ref).abs().max().item() < 3e-2, flag
         assert (o.float() - ref).abs().mean().item() < 2e-3, flag
     # same arithmetic per query (S^T = K Q^T, bf16 P, fp32 O); only the lazy max's offsets may differ (32- vs 64-key steps)
-    assert (outs["1"].float() - outs["0"].float()).abs().max().item() < 1.6e-2
-    monkeypatch.setenv("ALG_ATTN128_Q64", "1")
-    o2 = torch.empty_like(outs["1"])
+    assert (outs["2"].float() - outs["0"].float()).abs().max().item() < 1.6e-2
+    monkeypatch.setenv("ALG_ATTN128_Q64", "2")
+    o2 = torch.empty_like(outs["2"])
     _lib.flash_attn_d128(q, k, vt, o2, B, H, Sq, Skv, Sq * D, D, Skv * D, D, D * s_pad, s_pad, Sq * D, D, scale)
-    assert torch.equal(o2, outs["1"])             # deterministic
+    assert torch.equal(o2, outs["2"])             # deterministic
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 1024), (2, 3, 257, 1000), (1, 1, 256, 833), (1, 2, 1300, 2050),
@@ -104,6 +105,7 @@ def test_flash_attn_d128_pipelined_kernel(B, H, Sq, Skv, monkeypatch):
     vt = make_vt(v, s_pad)
     scale = 1.0 / math.sqrt(128)
     outs = {}
+    monkeypatch.setenv("ALG_ATTN128_Q64", "0")   # (4,097 keys would go to the 64-query kernel by default)
     for flag in ("1", "0"):
         monkeypatch.setenv("ALG_ATTN128_PIPE", flag)
         o = torch.full((B, Sq, D), 7.0, dtype=BF, device=DEV)
