@@ -57,6 +57,24 @@ PY
       fi
       rm -rf $P
       grep -c mean $O/${TAG}_pmc_summary.txt ;;
+    pmc128)
+      # instruction mix of the two d = 128 self-attention kernels at the Wan-480p shape: 64 queries per wave (default) vs 32
+      cd /tmp
+      P=$O/pmc128_r4; rm -rf $P; mkdir -p $P
+      : > $O/${TAG}_pmc128_summary.txt
+      for arm in 1 0; do
+        i=0
+        for ctrs in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_BUSY_CYCLES" \
+                    "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+          i=$((i+1))
+          ALG_ATTN128_Q64=$arm timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $P/q$arm\_p$i -o p -- python $R/scripts/kbench.py --only attn128 --iters 2 > /dev/null 2> $P/q$arm\_p$i.err
+        done
+        echo "== ALG_ATTN128_Q64=$arm (1: flash_attn_d128_q64_kernel, 0: flash_attn_d128_pipe_kernel), kbench attn128: N x 40 heads x 32,760 tokens" >> $O/${TAG}_pmc128_summary.txt
+        mkdir -p $P/arm$arm; mv $P/q$arm\_p* $P/arm$arm/
+        python $R/scripts/pmc_summary.py $P/arm$arm 2>&1 | grep -v "^$" >> $O/${TAG}_pmc128_summary.txt
+      done
+      rm -rf $P
+      tail -30 $O/${TAG}_pmc128_summary.txt | cut -c1-200 ;;
     workloads)
       cd $R
       for wl in c3 c4 c5; do
