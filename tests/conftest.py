@@ -91,3 +91,34 @@ def make_tokenizer_dir():
         return d
 
     return make
+
+
+@pytest.fixture(autouse=True)
+def _poison_in_front_of_every_launch(request):
+    """`ALG_TEST_POISON=<pattern>` (nan | big | neg | allbits | zero | eighty ...; tests/helpers/poison.py): every launch of the
+    suite that goes through alg_amd._lib is preceded, on the same stream, by a kernel that rewrites all vector registers, the
+    160 KiB of LDS and s[16:99] + vcc of every CU with the pattern.  A kernel that reads only what it wrote cannot tell, so the
+    whole GPU suite must stay green.  Off by default (it doubles the number of launches); graph-capture tests are left alone
+    (the poison launch would be captured too)."""
+    pat = os.environ.get("ALG_TEST_POISON")
+    if not pat or "graph" in request.node.nodeid or request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+
+    from alg_amd import _lib
+    from helpers import poison as P
+
+    lib, orig = P.load(), _lib._stream
+
+    def poisoned():
+        s = orig()
+        if not torch.cuda.is_current_stream_capturing():
+            lib.reg_poison(P.PATTERNS[pat], P.ALL, 512, s)
+        return s
+
+    _lib._stream = poisoned
+    try:
+        yield
+    finally:
+        _lib._stream = orig
