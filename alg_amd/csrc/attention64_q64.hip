@@ -615,7 +615,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const P p) 
   stage_v(1);
   stage_k(3);
   stage_v(2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the whole prologue: LDS-DMA does not complete in issue order at a cold start (attention128_q64.hip)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the whole prologue drained (kept from the time a cold-start DMA-order race was suspected in attention128_q64.hip; the cause turned out to be elsewhere -- see the end of this kernel)
   __builtin_amdgcn_s_barrier();
   qk(0, S0{}, se);
   {

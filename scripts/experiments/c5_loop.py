@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-process run-to-run determinism of the C5 (Wan 14B fp8, 3 x 75,600 tokens) 2-block forward: N forwards against the
-majority result, with the d = 128 attention arm given by ALG_ATTN128_Q64 (0 = 32-query kernel, 1-4 = q64 arms).
+majority result, with the d = 128 attention arm given by ALG_ATTN128_Q64 (0 = 32-query kernels, 1 = the 64-query kernel (default), EXPERIMENTS build: 12 - 14 = round 3 diagnostic arms).
 python scripts/experiments/c5_loop.py [forwards] [fp8 0|1]"""
 import json
 import os

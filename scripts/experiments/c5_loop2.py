@@ -3,7 +3,7 @@
 the first, into a second output buffer, and the two outputs are compared on the device (no host sync; one counter per call site).
     first != second  -> the attention kernel's own output depends on WHEN it runs (stale inputs at its start, or a race inside)
     first == second always, final outputs still flake -> the event sits on the consumer side of the attention output
-python scripts/experiments/c5_loop2.py [forwards] [mode plain|twice] ; the arm comes from ALG_ATTN128_Q64 (EXPERIMENTS build)"""
+python scripts/experiments/c5_loop2.py [forwards] [mode plain|twice|diagnose|ramp|ramp_valu] ; the kernel comes from ALG_ATTN128_Q64 (diagnose needs the EXPERIMENTS build: softmax-state tap)"""
 import json
 import os
 import sys

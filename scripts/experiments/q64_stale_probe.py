@@ -10,7 +10,7 @@ default pipelined kernel).  A stale read of Q, K or V^T now lands on another dat
 
     ALG_HIP_LIB=alg_amd/libalg_hip_exp.so python scripts/experiments/q64_stale_probe.py [iters] [S] [heads] [producer] [arm]
 producer: copy (torch copy_ from the rotating sources) | rope (copy + our rmsnorm_rope in place on q and k, as the Wan block does)
-arm: value of ALG_ATTN128_Q64 (1..4); 0 = the default pipelined kernel as a control
+arm: value of ALG_ATTN128_Q64 (1 or 2: the 64-query kernel; EXPERIMENTS build 12..14: round 3 diagnostic arms); 0 = the pipelined 32-query kernel as a control
 """
 import json
 import os
