@@ -17,8 +17,9 @@ from alg_amd import WanTransformer3DModel, WanTransformerConfig, _lib  # noqa: E
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 mode = sys.argv[2] if len(sys.argv) > 2 else "plain"
 DEV, BF = "cuda:0", torch.bfloat16
-F, H, W = 21, 90, 160
-model = WanTransformer3DModel.from_synthetic(WanTransformerConfig(num_layers=2), seed=21, device=DEV, fp8=True)
+preset = sys.argv[3] if len(sys.argv) > 3 else "c5"          # c5: 720p fp8 (75,600 tokens) | c3: 480p bf16 (32,760 tokens)
+F, H, W = (21, 90, 160) if preset == "c5" else (21, 60, 104)
+model = WanTransformer3DModel.from_synthetic(WanTransformerConfig(num_layers=2), seed=21, device=DEV, fp8=(preset == "c5"))
 g = torch.Generator(device=DEV).manual_seed(5)
 x = torch.randn(3, 36, F, H, W, generator=g, device=DEV).to(BF)
 txt = torch.randn(3, 512, 4096, generator=g, device=DEV).to(BF)
@@ -248,6 +249,6 @@ if mode == "diagnose" and state.get("flag") is not None and int(state["flag"]) >
                               "A_fixup_twice": {"u": u2_, "mean_abs_err": round(float(e2[u2_]), 4)},
                               "B_additive": {"l_true": [round(float(x), 1) for x in ltrue.tolist()], "G": [round(float(x), 1) for x in G.tolist()]},
                               "global_max_minus_m0": [round(float(x), 3) for x in (M.amax(dim=1) - m0).tolist()]}))
-print(json.dumps({"arm": os.environ.get("ALG_ATTN128_Q64", "0"), "mode": mode, "forwards": reps, "mismatching": len(bad),
+print(json.dumps({"arm": os.environ.get("ALG_ATTN128_Q64", "default"), "preset": preset, "mode": mode, "forwards": reps, "mismatching": len(bad),
                   "s_per_forward": (time.time() - t0) / max(reps - 3, 1), "attn_twice_differed": counters[:4].tolist(),
                   "attn_rows_differed": rows_bad[:4].tolist(), "events": events[:8]}))

@@ -10,7 +10,7 @@ For every v_mfma whose destination is a VGPR block the scan looks at the instruc
 and reports vector / memory instructions that touch a register of that block with fewer than `min_nops` wait states of s_nop
 in between.  MFMAs the compiler sees are followed by its own s_nop padding and pass; an unpadded touch is the bug.
 
-    python scripts/isa_mfma_shadow_scan.py file.s [min_nops=4] [window=10]   -> exit 1 when something is found
+    python scripts/isa_mfma_shadow_scan.py file.s [min_nops=4] [window=10] [span=1]   -> exit 1 when something is found
 """
 import re
 import sys
@@ -26,7 +26,7 @@ def regs(tok):
     return out
 
 
-def scan(path, min_nops=4, window=10):
+def scan(path, min_nops=4, window=10, span=1):
     ins, kern = [], None
     for i, line in enumerate(open(path)):
         t = line.strip()
@@ -44,10 +44,15 @@ def scan(path, min_nops=4, window=10):
         if not dst.startswith("v"):
             continue                      # AccVGPR destinations are named in asm text / clobber lists, never compiler temporaries
         n_mfma += 1
-        d, nops = regs(dst), 0
-        for ln2, t2, _ in ins[k + 1:k + 1 + window]:
+        d, nops, seen = regs(dst), 0, 0
+        for ln2, t2, _ in ins[k + 1:k + 1 + window * span]:
             if t2.startswith(("v_mfma", "v_smfmac")):
-                break
+                seen += 1                 # span = 2: also the instructions behind the NEXT MFMA (its issue waits for the pipe,
+                if seen >= span:          # i.e. for this one's last pass -- whose write-back may still be a few cycles out)
+                    break
+                if regs(t2.split(None, 1)[1].split(",")[0]) == d:
+                    break                 # the same block accumulates again: ordered by the pipe
+                continue
             if t2.startswith("s_nop"):
                 nops += int(t2.split()[1]) + 1
             elif t2.startswith(("v_", "ds_", "global_", "buffer_", "scratch_", "flat_")):
@@ -57,7 +62,8 @@ def scan(path, min_nops=4, window=10):
 
 
 if __name__ == "__main__":
-    n, hits = scan(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4, int(sys.argv[3]) if len(sys.argv) > 3 else 10)
+    n, hits = scan(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4, int(sys.argv[3]) if len(sys.argv) > 3 else 10,
+                   int(sys.argv[4]) if len(sys.argv) > 4 else 1)
     for kn, ln, t, ln2, t2, nops in hits[:40]:
         print("%s\n  %d: %s\n  %d: %s   (%d wait states of s_nop in between)" % (kn, ln, t[:90], ln2, t2[:90], nops))
     print("%s: %d MFMAs with a VGPR destination, %d unpadded touches in their shadow" % (sys.argv[1], n, len(hits)))
