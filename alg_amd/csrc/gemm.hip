@@ -18,6 +18,7 @@ int launch_gemm_p9_pair(const alg_gemm_args* a, int m_tiles_a, int n_tiles_a, co
 int launch_gemm_p9_pair_qk(const alg_gemm_args* a, int m_tiles_a, int n_tiles_a, const alg_gemm_args* b, int m_tiles_b, int n_tiles_b,
                            const alg_qk_norm_rope_args* e, hipStream_t s);
 int launch_gemm_p6_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
+int launch_gemm_p9_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 // ALG_GEMM_PIPE: 9 (default: 4 waves, asm main loop; round 3: faster than the 8-wave ping-pong on all five C2 shapes) | 6 (the
 // 8-wave ping-pong; bit-identical results).  Calls schedule 9 cannot take (K < 128, byte offsets past 32 bits) and the fp8 /
@@ -128,7 +129,11 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8, bool valid
     return ALG_ELIMIT;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (fp8) return launch_gemm_p6_fp8(a, m_tiles, n_tiles, nwg, s);
+  if (fp8) {   // schedule 9 (round 4: the asm loop on the block-scaled MFMA) needs two k-tiles of 128 and 32-bit byte offsets
+    if (gemm_pipe() == 9 && a->K >= 256 && 256 * a->lda + (int64_t)a->K < (1ll << 32) && 256 * a->ldb + (int64_t)a->K < (1ll << 32))
+      return launch_gemm_p9_fp8(a, m_tiles, n_tiles, nwg, s);
+    return launch_gemm_p6_fp8(a, m_tiles, n_tiles, nwg, s);
+  }
   if (a->conv_wp) return launch_gemm_p6_conv(a, m_tiles, n_tiles, nwg, s);
   switch (gemm_pipe()) {
 #ifdef ALG_EXPERIMENTS

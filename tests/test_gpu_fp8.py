@@ -126,3 +126,50 @@ def test_bad_arguments_of_a_tall_call_are_refused_before_any_slab_runs():
     with pytest.raises(_lib.AlgHipError):
         _lib.gemm(qa, qw, c, M, N, K, K, K, N, R=c, ldr=N + 2, a_scale=sa, b_scale=sw)
     assert bool((c[:1024] == 3.0).all()) and bool((c[-1024:] == 3.0).all())
+
+
+@pytest.mark.parametrize("form", ["plain", "gelu", "vt", "res", "res_gate_f32", "res_gate_f32_straddle"])
+def test_fp8_schedule9_equals_the_ping_pong_schedule_bit_for_bit(monkeypatch, form):
+    """Round 4: e4m3 operands on schedule 9 (generated asm K loop on v_mfma_scale_f32_32x32x64_f8f6f4, gemm_p9_fp8_loop.inc) against
+    schedule 6 (compiler-scheduled ping-pong, the same instruction): both feed an MFMA the fragments of k-steps (2 kp, 2 kp + 1) of
+    a 128-byte k-tile, k-tiles in order -- the same contraction order, so equal bits.  K / 128 = 2 ... 12 runs the residual
+    catch-up chain from each of its labels and past it (K = 128 stays on schedule 6: the loop needs two k-tiles); shapes with edge
+    tiles in M and N; every epilogue the Wan DiT uses."""
+    g = torch.Generator(device=DEV).manual_seed(9)
+    rn = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g, device=DEV) * sc).to(BF)
+    for M, N, K in [(300, 520, 128 * k) for k in range(1, 13)] + [(1111, 96, 5120), (2100, 1024, 128 * 11)]:
+        a, w, bias, x0 = rn(M, K), rn(N, K, sc=0.05), rn(N), rn(M, N)
+        qa, sa = quant(a)
+        qw, sw = quant(w)
+        gate32, brow = torch.randn(1, 2 * N, generator=g, device=DEV), rn(M)
+
+        def run():
+            if form == "plain":
+                c = torch.full((M, N), 7.0, dtype=BF, device=DEV)
+                _lib.gemm(qa, qw, c, M, N, K, K, K, N, bias=bias, a_scale=sa, b_scale=sw)
+            elif form == "gelu":
+                c = torch.full((M, N), 7.0, dtype=BF, device=DEV)
+                _lib.gemm(qa, qw, c, M, N, K, K, K, N, bias=bias, act=_lib.ACT_GELU_TANH, a_scale=sa, b_scale=sw)
+            elif form == "vt":      # transposed V projection: A = weights, per-row bias, permuted columns
+                n_pad = (M + 63) // 64 * 64
+                c = torch.zeros(N, n_pad, dtype=BF, device=DEV)
+                _lib.gemm(qw, qa, c, N, M, K, K, K, n_pad, bias=bias, a_scale=sw, b_scale=sa,
+                          flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
+            else:
+                c = x0.clone()
+                kw = dict(bias=bias, R=c, ldr=N, a_scale=sa, b_scale=sw)
+                if form == "res_gate_f32":
+                    kw.update(gate=gate32, strideGate=2 * N, seg_split=1 << 30, flags=_lib.GEMM_GATE_F32)
+                elif form == "res_gate_f32_straddle":
+                    kw.update(gate=gate32, strideGate=2 * N, seg_split=M // 3, flags=_lib.GEMM_GATE_F32)
+                _lib.gemm(qa, qw, c, M, N, K, K, K, N, **kw)
+            return c
+
+        monkeypatch.setenv("ALG_GEMM_PIPE", "6")
+        want = run()
+        monkeypatch.setenv("ALG_GEMM_PIPE", "9")
+        for _ in range(2):
+            got = run()
+            if not torch.equal(got, want):
+                d = (got.float() - want.float()).abs()
+                raise AssertionError("%s M=%d N=%d K=%d: %d elements differ, max %.4g" % (form, M, N, K, int((d > 0).sum()), d.max().item()))
