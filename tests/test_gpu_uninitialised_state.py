@@ -59,6 +59,22 @@ def _cases():
         o2.copy_(x0)
         _lib.gemm(a, w, o2, M, N, K, K, K, N, bias=bias, R=o2, ldr=N, gate=gate, strideGate=2 * N, seg_split=226)
     cases["gemm schedule 9 (gate * x + residual, in-loop residual fetch)"] = (res, o2)
+    # e4m3 operands on schedule 9 (round 4), plain and residual + fp32 gate forms
+    qa = torch.randint(0, 255, (M, K), dtype=torch.uint8, device="cuda")
+    qw = torch.randint(0, 255, (N, K), dtype=torch.uint8, device="cuda")
+    for t in (qa, qw):
+        t[t == 0x7F] = 0x3F
+        t[t == 0xFF] = 0xBF
+    sa, sw = torch.rand(M, device="cuda") * 1e-2, torch.rand(N, device="cuda") * 1e-2
+    o3, o4 = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, N, dtype=BF, device="cuda")
+    g32 = torch.randn(1, 2 * N, generator=g, device="cuda")
+    cases["fp8 gemm schedule 9 (plain)"] = (lambda: _lib.gemm(qa, qw, o3, M, N, K, K, K, N, bias=bias, a_scale=sa, b_scale=sw), o3)
+
+    def res8():
+        o4.copy_(x0)
+        _lib.gemm(qa, qw, o4, M, N, K, K, K, N, bias=bias, R=o4, ldr=N, gate=g32, strideGate=2 * N, seg_split=1 << 30,
+                  flags=_lib.GEMM_GATE_F32, a_scale=sa, b_scale=sw)
+    cases["fp8 gemm schedule 9 (fp32 gate * x + residual)"] = (res8, o4)
     yq, wqk, wv, bv = rn(1, M, K), rn(2 * K, K, sc=0.05), rn(K, K, sc=0.05), rn(K)
     Mp = (M + 63) // 64 * 64
     qkb, vtb = torch.empty(1, M, 2 * K, dtype=BF, device="cuda"), torch.zeros(1, K, Mp, dtype=BF, device="cuda")
