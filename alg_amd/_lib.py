@@ -30,7 +30,7 @@ EXPORTS = (
     "alg_vae_pack_latent", "alg_vae_unpack_video", "alg_vae_group_norm", "alg_vae_pad", "alg_vae_repitch",
     "alg_vae_unpack_planes", "alg_rms_norm_rows", "alg_softmax_hilo", "alg_flash_attn_d128_ex", "alg_rope_half", "alg_patchify_t", "alg_unpatchify_t", "alg_qk_norm_rope_scaled", "alg_flash_attn_d64_ex", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
     "alg_lowpass_tables_bytes", "alg_lowpass_tables_build", "alg_down_up_workspace_bytes", "alg_gaussian_blur_workspace_bytes",
-    "alg_flash_attn_d64_workspace_bytes",
+    "alg_flash_attn_d64_workspace_bytes", "alg_calib_mfma_bf16", "alg_wall_clock_khz", "alg_attn_clock_tap",
 )
 _RET_I64 = ("alg_vae_groupnorm_workspace", "alg_lowpass_tables_bytes", "alg_down_up_workspace_bytes",
             "alg_gaussian_blur_workspace_bytes", "alg_flash_attn_d64_workspace_bytes")
@@ -170,9 +170,13 @@ def load_library():
     lib.alg_patchify_t.argtypes = [c_void_p, c_int64, POINTER(c_void_p), c_void_p] + [c_int] * 7 + [c_void_p]
     lib.alg_unpatchify_t.argtypes = [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]
     lib.alg_timestep_embedding.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.alg_calib_mfma_bf16.argtypes = [c_void_p, c_int, ctypes.c_uint, c_int, c_void_p, c_void_p]
+    lib.alg_attn_clock_tap.argtypes = [c_void_p, c_int]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("alg_version", "alg_last_error", "alg_reload_env"):
+        if name == "alg_attn_clock_tap":
+            fn.restype = None
+        elif name not in ("alg_version", "alg_last_error", "alg_reload_env"):
             fn.restype = c_int64 if name in _RET_I64 else c_int
     _lib = lib
     return lib
@@ -290,10 +294,52 @@ def scratch(ref, nbytes, tag):
         return None
     key = _stream_key(ref) + (tag,)
     t = _SCRATCH.get(key)
+    cap = _capturing()
     if t is None or t.numel() < nbytes:
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=ref.device)
+        if cap:
+            # allocated inside a capture: the block lives in the graph's private pool and belongs to that graph's replays.
+            # It must not reach later EAGER calls (a replay on another stream could run beside them on the same bytes;
+            # ADVICE r4) -- same rule as lowpass_tables: pinned for the graph, never entered into the eager cache.
+            return _pin(t)
         _SCRATCH[key] = t       # a superseded buffer that a capture saw stays alive in _PINNED
-    return _pin(t) if _capturing() else t
+    return _pin(t) if cap else t
+
+
+def calib_mfma_bf16(sink, iters, seed=1, blocks=0, clocks=None):
+    """One launch of the register-only random-operand MFMA loop (csrc/calibrate.hip) on the current stream; returns the number
+    of workgroups launched (each 4 waves x 32 * iters MFMAs of 32,768 FLOP)."""
+    lib = load_library()
+    rc = lib.alg_calib_mfma_bf16(_ptr(_dev(sink, "sink")), int(iters), int(seed), int(blocks), _ptr(clocks), _stream())
+    if rc <= 0:
+        _check(rc if rc < 0 else -1, "alg_calib_mfma_bf16")
+    return rc
+
+
+def wall_clock_khz():
+    return int(load_library().alg_wall_clock_khz())
+
+
+def attn_clock_tap(buffer):
+    """buffer: int64 device tensor [slots, 4] (or None to switch the taps off) -- see include/alg_hip.h: alg_attn_clock_tap."""
+    lib = load_library()
+    if buffer is None:
+        lib.alg_attn_clock_tap(None, 0)
+        return
+    if not (buffer.is_cuda and buffer.dtype == torch.int64 and buffer.is_contiguous() and buffer.dim() == 2 and buffer.shape[1] == 4):
+        raise AlgHipError("attn_clock_tap needs a contiguous int64 device tensor [slots, 4]")
+    lib.alg_attn_clock_tap(_ptr(buffer), int(buffer.shape[0]))
+
+
+def clock_mhz_from_taps(taps, wall_khz):
+    """taps: int64 [n, 4] = {cycles0, wall0, cycles1, wall1} per sampled workgroup -> (mean MHz, min, max, n used)."""
+    t = taps.detach().cpu().to(torch.float64)
+    dc, dw = t[:, 2] - t[:, 0], t[:, 3] - t[:, 1]
+    ok = (dc > 0) & (dw > 0)
+    if not bool(ok.any()) or wall_khz <= 0:
+        return None
+    mhz = dc[ok] / dw[ok] * (wall_khz / 1e3)
+    return {"mean": float(mhz.mean()), "min": float(mhz.min()), "max": float(mhz.max()), "workgroups": int(ok.sum())}
 
 
 def down_up(x, h1, w1, round_intermediate=True):

@@ -81,7 +81,11 @@ struct AttnP {
   float* ws_o;   // [8 * tail_units][tail_split][q rows per block][64] fp32, unnormalised
   float* ws_ml;  // [8 * tail_units][tail_split][q rows per block][2]: running max (raw score units), row sum
   int prio;      // 1: the younger half of an 8-wave workgroup (waves 4-7) runs at s_setprio 1 (ALG_ATTN_PRIO, A/B knob)
+  uint64_t* clk;   // clock tap (calibrate.hip: alg_attn_clock_tap) or NULL: {cycles, wall} at start / end of every 64th workgroup
+  int clk_slots;
 };
+extern std::atomic<uint64_t*> g_clock_tap;
+extern std::atomic<int> g_clock_tap_slots;
 
 struct Frag {
   int row_off;  // l31 * 128
@@ -765,6 +769,13 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_pipe_kernel(const Attn
   const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 64 * p.vt_rs;
   const int T = (S + KVB - 1) / KVB;
   const bool ragged = (S & (KVB - 1)) != 0;
+  // clock tap (bench.py: the shader clock THIS kernel ran at): scalar reads of two counters, wave 0 of every 64th workgroup
+  const bool tap = p.clk != nullptr && (blockIdx.x & 63) == 0 && wave == 0;
+  uint64_t tap_c0 = 0, tap_r0 = 0;
+  if (tap) {
+    tap_c0 = __builtin_readcyclecounter();
+    tap_r0 = wall_clock64();
+  }
   f32x16 oa[2];
 #pragma unroll
   for (int i = 0; i < 32; ++i) oa[i >> 4][i & 15] = 0.0f;
@@ -909,6 +920,10 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_pipe_kernel(const Attn
         *(uint2*)(op + d) = v;
       }
   }
+  if (tap && c.lane == 0) {
+    uint64_t* cp = p.clk + (size_t)((blockIdx.x >> 6) % p.clk_slots) * 4;
+    cp[0] = tap_c0, cp[1] = tap_r0, cp[2] = __builtin_readcyclecounter(), cp[3] = wall_clock64();
+  }
 }
 
 #ifdef ALG_EXPERIMENTS
@@ -1043,6 +1058,9 @@ extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* v
 #else
   p.prio = 0;
 #endif
+  p.clk = g_clock_tap.load(std::memory_order_acquire);
+  p.clk_slots = p.clk ? g_clock_tap_slots.load(std::memory_order_relaxed) : 0;
+  if (p.clk_slots <= 0) p.clk = nullptr;
   const int nbh = batch * heads;
   const int64_t grid = (int64_t)((nbh + 7) / 8) * 8 * p.q_blocks;
   const dim3 blk(nw * 64);

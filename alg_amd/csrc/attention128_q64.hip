@@ -47,6 +47,10 @@ constexpr int NS = 4;                    // ring slots per operand
 constexpr int LDS_BYTES = NS * (K_TILE + V_TILE);
 constexpr int MIN_TILES = 8;             // what the kernel can take (ALG_ATTN128_Q64=2)
 constexpr int POLICY_TILES = 64;         // what it takes by default: 4,096 keys and more
+}  // namespace a128q
+extern std::atomic<uint64_t*> g_clock_tap;
+extern std::atomic<int> g_clock_tap_slots;
+namespace a128q {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -59,6 +63,8 @@ struct P {
   int batch, heads, Sq, Skv, q_blocks;
   int64_t q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs;
   float scale_log2;
+  uint64_t* clk;   // clock tap (calibrate.hip: alg_attn_clock_tap) or NULL
+  int clk_slots;
 #ifdef ALG_EXPERIMENTS
   float* dbg;   // investigation tap (alg_debug_q64_tap): per (batch, head, query) [l_run, m_run, l_tot, 1 / l_tot] per lane
 #endif
@@ -575,6 +581,12 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
   }
   const int b = bh / p.heads, h = bh - b * p.heads;
   const int Sq = p.Sq, Skv = p.Skv;
+  const bool tap = p.clk != nullptr && (blockIdx.x & 63) == 0 && wave == 0;   // clock tap: see attention.hip
+  uint64_t tap_c0 = 0, tap_r0 = 0;
+  if (tap) {
+    tap_c0 = __builtin_readcyclecounter();
+    tap_r0 = wall_clock64();
+  }
   const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 128;
   const bf16_t* K = p.k + (int64_t)b * p.k_bs + h * 128;
   const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)h * 128 * p.vt_rs;
@@ -1034,6 +1046,10 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  if (tap && lane == 0) {
+    uint64_t* cp = p.clk + (size_t)((blockIdx.x >> 6) % p.clk_slots) * 4;
+    cp[0] = tap_c0, cp[1] = tap_r0, cp[2] = __builtin_readcyclecounter(), cp[3] = wall_clock64();
+  }
 }
 
 }  // namespace a128q
@@ -1072,6 +1088,9 @@ int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, i
   p.q_blocks = (Sq + NW * QW - 1) / (NW * QW);
   p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.vt_bs = vt_bs; p.vt_rs = vt_rs; p.o_bs = o_bs; p.o_rs = o_rs;
   p.scale_log2 = scale * 1.4426950408889634f;
+  p.clk = g_clock_tap.load(std::memory_order_acquire);
+  p.clk_slots = p.clk ? g_clock_tap_slots.load(std::memory_order_relaxed) : 0;
+  if (p.clk_slots <= 0) p.clk = nullptr;
 #ifdef ALG_EXPERIMENTS
   p.dbg = g_q64_tap;
 #endif

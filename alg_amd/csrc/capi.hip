@@ -71,10 +71,13 @@ static void load_options() {
     int v = d.def;
     const char* e = getenv(d.name);
     if (e && *e) {
-      const int x = atoi(e);
-      bool ok = d.n_ok == 0;
-      for (int j = 0; j < d.n_ok; ++j) ok |= d.ok[j] == x;
-      if (ok) v = x;     // a value this build does not know leaves the default in place
+      // a whole decimal integer or nothing: "off", "1x", " 2" must not silently parse as a number and flip the option
+      char* end = nullptr;
+      const long x = strtol(e, &end, 10);
+      bool ok = end != e && *end == '\0' && x >= -2147483647L && x <= 2147483647L && (d.n_ok == 0);
+      if (end != e && *end == '\0')
+        for (int j = 0; j < d.n_ok; ++j) ok |= d.ok[j] == x;
+      if (ok) v = (int)x;     // a value this build does not know leaves the default in place
     }
     g_opt[i].store(v, std::memory_order_relaxed);
   }

@@ -75,6 +75,146 @@ def pmc_traffic(kernel_substr, profiles=("profiles/r4_pmc_summary.txt", "profile
     return None
 
 
+class SmiSampler:
+    """Package power / shader clock of GPU `index` sampled by a background thread (librocm_smi64 through ctypes: no process
+    spawn, ~50 us per sample; falls back to parsing `rocm-smi` output once per second, and to nothing).  `with SmiSampler(i) as
+    s: ...; s.summary()` -> {"power_w": {mean, max, n}, "sclk_mhz": {...}, "power_cap_w": ..., "source": ...} or None."""
+
+    def __init__(self, index=0, period=0.2):
+        import threading
+        self.index, self.period = index, period
+        self.samples, self.cap, self.source = [], None, None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._read = self._open_rsmi() or self._open_cli()
+
+    def _open_rsmi(self):
+        import ctypes as C
+        for path in ("/opt/rocm/lib/librocm_smi64.so", "librocm_smi64.so", "librocm_smi64.so.1"):
+            try:
+                lib = C.CDLL(path)
+                break
+            except OSError:
+                lib = None
+        if lib is None:
+            return None
+        try:
+            if lib.rsmi_init(C.c_uint64(0)) != 0:
+                return None
+
+            class Freq(C.Structure):
+                _fields_ = [("has_deep_sleep", C.c_bool), ("num_supported", C.c_uint32), ("current", C.c_uint32),
+                            ("frequency", C.c_uint64 * 33)]
+
+            idx = C.c_uint32(self.index)
+            cap = C.c_uint64(0)
+            if lib.rsmi_dev_power_cap_get(idx, C.c_uint32(0), C.byref(cap)) == 0 and cap.value:
+                self.cap = cap.value / 1e6
+
+            def read():
+                pw, kind, f = C.c_uint64(0), C.c_int(0), Freq()
+                watts = mhz = None
+                if lib.rsmi_dev_power_get(idx, C.byref(pw), C.byref(kind)) == 0 and pw.value:
+                    watts = pw.value / 1e6
+                elif lib.rsmi_dev_current_socket_power_get(idx, C.byref(pw)) == 0 and pw.value:
+                    watts = pw.value / 1e6
+                if lib.rsmi_dev_gpu_clk_freq_get(idx, C.c_int(0), C.byref(f)) == 0 and f.current < 33:
+                    mhz = f.frequency[f.current] / 1e6
+                return watts, mhz
+
+            w, m = read()
+            if w is None and m is None:
+                return None
+            self.source = "librocm_smi64 (rsmi_dev_power_get / rsmi_dev_gpu_clk_freq_get SYS)"
+            return read
+        except Exception:
+            return None
+
+    def _open_cli(self):
+        import re
+        import shutil
+        exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+        if exe is None:
+            return None
+
+        def read():
+            try:
+                out = subprocess.run([exe, "-d", str(self.index), "--showpower", "--showclocks"], capture_output=True, text=True,
+                                     timeout=10).stdout
+            except Exception:
+                return None, None
+            w = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+            m = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", out)
+            return (float(w.group(1)) if w else None), (float(m.group(1)) if m else None)
+
+        self.period = max(self.period, 1.0)
+        self.source = "rocm-smi --showpower --showclocks"
+        return read
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(self._read())
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self._read is not None:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread.is_alive():
+            self._thread.join(timeout=15)
+        return False
+
+    def summary(self):
+        if self._read is None:
+            return None
+        stat = lambda v: {"mean": round(sum(v) / len(v), 1), "max": round(max(v), 1), "min": round(min(v), 1), "n": len(v)} if v else None
+        return {"power_w": stat([w for w, _ in self.samples if w is not None]),
+                "sclk_mhz": stat([m for _, m in self.samples if m is not None]), "power_cap_w": self.cap, "source": self.source}
+
+
+def calibrate_box(dev, seconds=1.5):
+    """what THIS chip's matrix pipe sustains right now -- a register-only v_mfma_f32_32x32x16_bf16 loop on
+    pseudo-random operands (csrc/calibrate.hip; two waves per SIMD, no memory traffic) run for `seconds` -- with the shader clock
+    it ran at (cycle counter / constant-rate counter, read by every workgroup) and the package power meanwhile.  The number
+    replaces round 4's hard-coded 1765 TFLOP/s; it is the matrix-pipe ceiling under the package power cap on real data, i.e. the
+    practical denominator next to the guide's 2500."""
+    from alg_amd import _lib
+    iters = 4000
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    blocks = 2 * cus
+    clocks = torch.zeros(blocks, 4, dtype=torch.int64, device=dev)
+    flop = 2.0 * 32 * 32 * 16 * 32 * iters * 4 * blocks
+    _lib.calib_mfma_bf16(sink, iters, 1, blocks, clocks)
+    torch.cuda.synchronize()
+    rates, t0 = [], time.perf_counter()
+    with SmiSampler(dev.index or 0) as smi:
+        while time.perf_counter() - t0 < seconds:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(4):
+                _lib.calib_mfma_bf16(sink, iters, 2 + i, blocks, clocks)
+            b.record()
+            b.synchronize()
+            rates.append(4 * flop / (a.elapsed_time(b) / 1e3) / 1e12)
+    tail = rates[len(rates) // 2:] or rates
+    khz = _lib.wall_clock_khz()
+    out = {"mfma_sustained_random_operands_tflops": sum(tail) / len(tail), "first_tflops": rates[0], "launch_groups": len(rates),
+           "seconds": round(time.perf_counter() - t0, 2), "frac_of_peak": sum(tail) / len(tail) / MFMA_PEAK_TFLOPS,
+           "shader_clock_mhz": _lib.clock_mhz_from_taps(clocks, khz), "wall_clock_khz": khz, "smi": smi.summary(),
+           "what": "register-only v_mfma_f32_32x32x16_bf16 loop, pseudo-random bf16 operands, 2 waves per SIMD on %d CUs" % cus}
+    clk = out["shader_clock_mhz"]
+    if clk:   # 32 cycles per MFMA per SIMD: what the pipe would deliver at that clock if it never idled
+        out["pipe_busy_at_that_clock"] = out["mfma_sustained_random_operands_tflops"] / (cus * 4 * 32768.0 / 32.0 * clk["mean"] * 1e6 / 1e12)
+    return out
+
+
 def filter_microbench(dev):
     """HBM GB/s of the low-pass kernels at the BASELINE shapes: algorithmic bytes = 2 * planes * H * W *
     sizeof(dtype) per call.  One video is launch-bound (208 planes), so the 8-video batch is reported too."""
@@ -171,7 +311,7 @@ def cpu_filter_baseline():
     return res
 
 
-def cpu_c1_call(threads, budget_s=45.0):
+def cpu_c1_call(threads, budget_s=150.0):
     """BASELINE.md CPU row 2 / BASELINE config 1: the whole ALG sampler __call__ at CogVideoX-5B widths, fp32, 9 frames @
     256x256 (994 tokens), 2 steps = 1 three-pass + 1 two-pass = 5 sample-forwards, through the CPU oracle
     (loop_oracle.alg_denoise_loop driving dit_oracle.dit_forward).  The 42 blocks SHARE one block's seeded weights (the
@@ -219,7 +359,7 @@ def cpu_c1_call(threads, budget_s=45.0):
                 finite=bool(torch.isfinite(out).all()), what=what)
 
 
-def cpu_baseline(with_c1=True, c1_budget=45.0):
+def cpu_baseline(with_c1=True, c1_budget=150.0):
     """One of the 42 DiT blocks of one sample-forward at the C2 token count, fp32, on the host cores, through the CPU
     oracle; PROJECTED to frames/s of the whole workload (x 42 layers x 102 forwards per 49 frames)."""
     from oracle import dit_oracle
@@ -293,7 +433,8 @@ class Workload:
         self.args, self.dev, self.rank, self.world, self.split = args, dev, rank, world, split
 
     def seed(self):
-        return 42 + (self.rank // 2 if self.split is not None else self.rank)   # run.py:94 uses 42
+        # run.py:94 uses 42; --seed-offset lets a 1-rank run reproduce rank r of an N-rank run (tests/test_gpu_dp_launch.py)
+        return 42 + self.args.seed_offset + (self.rank // 2 if self.split is not None else self.rank)
 
 
 class C2(Workload):
@@ -419,9 +560,7 @@ class C2(Workload):
             roofline["traffic"] = tr["bytes_per_launch"]
             roofline["traffic_detail"] = tr
         flops_total = attn_flops_total + sum(gemm_flops.values()) * forwards_local * L
-        # measured on this chip (profiles/r1_power_and_issue_rates.txt): a register-only MFMA loop on random bf16 operands
-        # sustains 1765 TFLOP/s under the 1400 W package cap -- the matrix-pipe ceiling for real data; `peak` is the guide's
-        extra["mfma_sustained_random_operands_tflops"] = 1765.0
+        # (the matrix-pipe ceiling of THIS box on random operands is measured in the run: main() -> calibrate_box(), `calibration`)
         extra["whole_step_mfma_frac"] = flops_total / elapsed / 1e12 / MFMA_PEAK_TFLOPS
         # tile-count quantisation of the persistent GEMM (256x256 tiles on `cus` workgroups)
         cus = torch.cuda.get_device_properties(self.dev).multi_processor_count & ~7
@@ -585,6 +724,8 @@ class C4(Workload):
         tt = sum(ms.get("attn_self", [])) / 1e3
         a = per_fwd * forwards_local * self.layers / tt / 1e12 if tt > 0 else 0.0
         extra = {"time_share": {k: round(sum(v) / 1e3 / elapsed, 4) for k, v in ms.items()}}
+        # every block is 12 D^2 multiply-adds per token of linears (dual: qkv 3 + out 1 + mlp 8; single: 7 + 5) + its attention
+        extra["whole_step_tflops"] = (24.0 * self.J * D * D + per_fwd) * forwards_local * self.layers / elapsed / 1e12
         return dict(bound="mfma", kernel=self.attn_kernel, achieved=a, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=a / MFMA_PEAK_TFLOPS, traffic=None, launches=len(ms.get("attn_self", [])),
                     mean_launch_ms=(sum(ms["attn_self"]) / len(ms["attn_self"])) if ms.get("attn_self") else None,
@@ -654,26 +795,114 @@ def private_loop_crosscheck(wl, k_steps):
     return (time.perf_counter() - t0) / k_steps * 1e3
 
 
-def timed_region(wl, warmup, steps, parallel):
+def timed_region(wl, warmup, steps, parallel, measure_box=False):
     """W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; HIP-event brackets of the
-    kernel families live only inside the timed region.  Returns (elapsed seconds = max over ranks, sample-forwards of this
-    rank, per-family event times in ms)."""
+    kernel families live only inside the timed region (their cost is measured by the `events` arm of --ab).  Returns (elapsed
+    seconds = max over ranks, sample-forwards of this rank, per-family event times in ms).  measure_box: the attention
+    kernel's own clock taps are switched on (two scalar counter reads in every 64th workgroup; results unaffected) and a
+    background thread samples package power / sclk for the length of the region -> wl.box."""
+    from alg_amd import _lib
     wl.step_passes = []
     run_steps(wl, max(warmup, wl.min_warmup))
     wl.warmup_passes = list(wl.step_passes)
     kinds = {}  # kernel family -> list of event pairs
     wl.step_passes = []
     wl.instrument(kinds)
+    taps = None
+    if measure_box:
+        taps = torch.zeros(512, 4, dtype=torch.int64, device=wl.dev)
+        _lib.attn_clock_tap(taps)
     parallel.barrier()
     torch.cuda.synchronize()
+    smi = SmiSampler(wl.dev.index or 0) if measure_box else None
+    if smi is not None:
+        smi.__enter__()
     t0 = time.perf_counter()
     forwards = run_steps(wl, steps)
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = time.perf_counter() - t0
+    if smi is not None:
+        smi.__exit__(None, None, None)
     wl.instrument(None)
+    if measure_box:
+        _lib.attn_clock_tap(None)
+        wl.box = {"attn_kernel_shader_clock_mhz": _lib.clock_mhz_from_taps(taps, _lib.wall_clock_khz()),
+                  "attn_kernel_clock_note": "cycle counter / constant-rate counter over the life of every 64th workgroup of the "
+                                            "LAST attention launch of the timed region (%s)" % wl.attn_kernel,
+                  "smi_during_timed_region": smi.summary()}
     elapsed = parallel.max_over_ranks(elapsed, wl.dev)
     return elapsed, forwards, {k: event_ms(v) for k, v in kinds.items()}
+
+
+# A/B arms of the default bench line (VERDICT r4 item 2c): each switches ONE schedule choice off (or on), 5 steps after 2 warm-up
+# steps, same process, same box, no event brackets; the default arm is timed before and after.  kind "attr": attribute of the
+# transformer; "env": an ALG_* option of the library (re-read with alg_reload_env); "events": the bench's own HIP-event brackets
+# switched ON (what the instrumented headline region pays for them).
+AB_ARMS = [
+    ("attn_pipelined", "env", "ALG_ATTN_PP", "0", "round 3: pipelined d = 64 attention vs the straight loop"),
+    ("attn_split_tail", "env", "ALG_ATTN_SPLIT_TAIL", "0", "round 2: split-KV tail of the attention launch vs a single launch"),
+    ("gemm_schedule9", "env", "ALG_GEMM_PIPE", "6", "round 3: GEMM schedule 9 (asm K loop) vs the 8-wave ping-pong"),
+    ("pair_qkv", "attr", "pair_qkv", 0, "round 4: Q|K and V^T projections as one persistent launch vs two launches"),
+    ("events", "events", None, None, "the bench's own HIP-event brackets around every kernel family, switched ON (headline region has them)"),
+]
+
+
+def ab_arms(wl, arms, steps=5, warmup=2):
+    from alg_amd import _lib
+
+    def timed(with_events=False):
+        run_steps(wl, warmup)
+        kinds = {} if with_events else None
+        if with_events:
+            wl.instrument(kinds)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(wl, steps)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps * 1e3
+        if with_events:
+            wl.instrument(None)
+        return dt
+
+    res = {"steps": steps, "warmup": warmup, "default_ms_per_step": [timed()], "arms": {}}
+    for name, kind, key, off, what in arms:
+        rec = {"what": what}
+        try:
+            if kind == "attr":
+                if not hasattr(wl.model, key):
+                    continue
+                old = getattr(wl.model, key)
+                setattr(wl.model, key, type(old)(off))
+                try:
+                    rec["off_ms_per_step"] = timed()
+                finally:
+                    setattr(wl.model, key, old)
+            elif kind == "env":
+                old = os.environ.get(key)
+                os.environ[key] = off
+                _lib.reload_env()
+                try:
+                    rec["off_ms_per_step"] = timed()
+                finally:
+                    if old is None:
+                        os.environ.pop(key, None)
+                    else:
+                        os.environ[key] = old
+                    _lib.reload_env()
+                rec["off"] = "%s=%s" % (key, off)
+            else:
+                rec["off_ms_per_step"] = timed(with_events=True)
+        except Exception as e:
+            rec["error"] = repr(e)
+        res["arms"][name] = rec
+    res["default_ms_per_step"].append(timed())
+    base = sum(res["default_ms_per_step"]) / 2
+    res["default_spread_pct"] = round(abs(res["default_ms_per_step"][0] - res["default_ms_per_step"][1]) / base * 100, 2)
+    for rec in res["arms"].values():
+        if "off_ms_per_step" in rec:   # > 0: the default (change ON) is faster by that much
+            rec["default_gain_pct"] = round((rec["off_ms_per_step"] - base) / base * 100, 2)
+    return res
 
 
 def other_workloads(args, dev, parallel):
@@ -710,6 +939,28 @@ def other_workloads(args, dev, parallel):
     return res
 
 
+def coerce_like(current, text, name):
+    """--set ATTR=VALUE: the value converted to the attribute's CURRENT type, or SystemExit ('pair_qkv=false' used
+    to be stored as the truthy string 'false')."""
+    t = text.strip().lower()
+    if isinstance(current, bool):
+        if t in ("1", "true", "on", "yes"):
+            return True
+        if t in ("0", "false", "off", "no"):
+            return False
+        raise SystemExit("--set %s=%s: expected a boolean (0/1/true/false/on/off)" % (name, text))
+    try:
+        if isinstance(current, int):
+            return int(t, 0)
+        if isinstance(current, float):
+            return float(t)
+    except ValueError:
+        raise SystemExit("--set %s=%s: cannot convert to %s" % (name, text, type(current).__name__))
+    if isinstance(current, str) or current is None:
+        return text
+    raise SystemExit("--set %s: attributes of type %s cannot be set from the command line" % (name, type(current).__name__))
+
+
 def self_launch(args):
     """`python bench.py --gpus N` run plainly: become the launcher of N ranks (one per GPU) on this node."""
     with socket.socket() as s:
@@ -732,7 +983,12 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers invalidates the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c1", action="store_true", help="skip the timed C1 __call__ leg of the CPU baseline")
-    ap.add_argument("--c1-budget", type=float, default=45.0,
+    ap.add_argument("--seed-offset", type=int, default=0, help="debug: added to every rank's video seed")
+    ap.add_argument("--dump-latents", default="", metavar="PREFIX",
+                    help="debug: every rank saves the final latents of its last __call__ to PREFIX.rank<r>.pt")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the 1.5 s matrix-pipe calibration of the box")
+    ap.add_argument("--no-ab", action="store_true", help="c2 at 1 GPU: skip the in-run A/B arms (roofline.extra.ab, ~40 s)")
+    ap.add_argument("--c1-budget", type=float, default=150.0,
                     help="seconds the C1 CPU leg may take (a 2-layer probe projects it first; beyond the budget the projection is reported)")
     ap.add_argument("--cfg-split", action="store_true",
                     help="opt-in: cond/uncond CFG passes of one video on a pair of GPUs (latency mode, one all-gather per step)")
@@ -779,9 +1035,14 @@ def main():
         k, v_ = kv.split("=", 1)
         if not hasattr(wl.model, k):
             raise SystemExit("--set: the transformer has no attribute %r" % k)
-        setattr(wl.model, k, type(getattr(wl.model, k))(int(v_)) if v_.lstrip("-").isdigit() else v_)
-    elapsed, forwards, ms = timed_region(wl, args.warmup, args.steps, parallel)
+        setattr(wl.model, k, coerce_like(getattr(wl.model, k), v_, k))
+    calibration = None
+    if rank == 0 and world == 1 and not args.no_calibration:
+        calibration = calibrate_box(dev)
+    elapsed, forwards, ms = timed_region(wl, args.warmup, args.steps, parallel, measure_box=(world == 1))
 
+    if args.dump_latents:
+        torch.save(wl.last_out.detach().cpu(), "%s.rank%d.pt" % (args.dump_latents, rank))
     n_videos_parallel = world // 2 if split else world
     value = wl.frames * args.steps / wl.steps_per_video * n_videos_parallel / elapsed
     roofline = wl.roofline(ms, forwards, elapsed)
@@ -805,6 +1066,19 @@ def main():
         out["bcast_gbytes"] = parallel.BCAST_STATS["bytes"] / 1e9
         out["bcast_collectives"] = parallel.BCAST_STATS["collectives"]
     out["build_seconds"] = build_seconds
+    if calibration is not None:
+        out["calibration"] = calibration
+    if getattr(wl, "box", None):
+        out["roofline"]["extra"]["box"] = wl.box
+        clk = wl.box.get("attn_kernel_shader_clock_mhz")
+        if clk and out["roofline"].get("achieved"):
+            # matrix-pipe busy share of the attention kernel AT THE CLOCK IT RAN AT: achieved / (CUs x 4 SIMDs x 1024 FLOP/cycle x f)
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            out["roofline"]["extra"]["attn_pipe_busy_at_its_clock"] = out["roofline"]["achieved"] / (cus * 4 * 1024.0 * clk["mean"] * 1e6 / 1e12)
+        if calibration is not None and out["roofline"].get("achieved"):
+            out["roofline"]["extra"]["attn_frac_of_box_sustained_mfma"] = out["roofline"]["achieved"] / calibration["mfma_sustained_random_operands_tflops"]
+    if rank == 0 and world == 1 and args.workload == "c2" and not args.no_ab and not args.layers and not args.set:
+        out["roofline"]["extra"]["ab"] = ab_arms(wl, AB_ARMS)
     if args.set:
         out["config"]["overrides"] = args.set
     if args.layers:

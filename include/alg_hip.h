@@ -40,10 +40,13 @@ const char* alg_last_error(void);
 
 /* Run-time options.  The library reads its ALG_* environment variables ONCE, when it is loaded; no launch path calls getenv.
  * A host that changes one of them afterwards calls alg_reload_env() (host-only, no GPU work; not to be called while another
- * thread is inside the library).  The default build knows six, each selecting between bit-identical or documented-equivalent
+ * thread is inside the library).  The default build knows seven, each selecting between bit-identical or documented-equivalent
  * schedules (README.md "Run-time options"): ALG_ATTN_SPLIT_TAIL, ALG_ATTN_PP, ALG_ATTN_VARIANT, ALG_ATTN128_PIPE,
- * ALG_GEMM_PIPE, ALG_LOWPASS_PATH.  Timing-only ablations and opt-in experimental kernels exist only in a
- * `make EXPERIMENTS=1` build, for which alg_build_experiments() returns 1. */
+ * ALG_ATTN128_Q64 (1 = the 64-queries-per-wave d = 128 kernel from 4,096 keys on, the default; 2 = for every call it can
+ * take; 0 = off: the escape hatch back to the 32-query pipelined kernel), ALG_GEMM_PIPE, ALG_LOWPASS_PATH.  A value must be
+ * a whole decimal integer the build knows; anything else (including "off", "1x", an empty string) leaves the default in
+ * place.  Timing-only ablations and opt-in experimental kernels exist only in a `make EXPERIMENTS=1` build, for which
+ * alg_build_experiments() returns 1. */
 void alg_reload_env(void);
 int alg_build_experiments(void);
 
@@ -470,6 +473,26 @@ int alg_rms_norm_rows(const void* x, const void* gamma, void* y, int64_t rows, i
 /* Row softmax of the VAE mid-block attention over scores split in two bf16 matrices (hi = -neg_hi, lo): p[r][j] =
  * softmax_j((lo - neg_hi) * scale), zero in the padding columns cols <= j < ld.  All three [rows][ld] bf16. */
 int alg_softmax_hilo(const void* neg_hi, const void* lo, void* p, int64_t rows, int cols, int64_t ld, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Box calibration for the benchmark line (no reference call site: the reference times nothing, readme.md:1-170; SURVEY 8d asks
+ * for rooflines measured on the box).  csrc/calibrate.hip.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One launch of a register-only v_mfma_f32_32x32x16_bf16 loop on pseudo-random bf16 operands: `blocks` workgroups of 256
+ * threads (0 = two per CU, i.e. two waves per SIMD); every wave issues 32 * iters MFMAs = 32 * iters * 32768 FLOP.  The caller
+ * brackets the launch with events.  clocks (optional): uint64 [blocks][4] = {shader cycles, constant-rate ticks} at the start and
+ * at the end of each workgroup.  Returns the number of workgroups launched (> 0) or a negative ALG_E* code. */
+int alg_calib_mfma_bf16(float* sink, int iters, unsigned seed, int blocks, uint64_t* clocks, void* stream);
+
+/* Rate of the constant counter of the clock taps in kHz (100,000 on MI355X); 0 when unknown. */
+int alg_wall_clock_khz(void);
+
+/* While `buffer` is non-NULL, every launch of the pipelined d = 64 attention and of the 64-query d = 128 attention has one lane
+ * of each workgroup whose index is a multiple of 64 store {shader cycles, constant-rate ticks} at its start and end into
+ * buffer[(block / 64) % slots][4] (uint64): d cycles / d ticks = the shader clock that kernel ran at.  Results are
+ * unaffected.  Host-only call; NULL (the default) switches the taps off. */
+void alg_attn_clock_tap(uint64_t* buffer, int slots);
 
 #ifdef __cplusplus
 }

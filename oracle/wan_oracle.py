@@ -145,33 +145,61 @@ def _rope(x, cos, sin):
     """x [B, H, S, 128]: complex product of interleaved pairs with (cos + i sin), evaluated in float64."""
     xr = x.to(torch.float64).unflatten(3, (-1, 2))
     a, b = xr[..., 0], xr[..., 1]
+    cos, sin = cos.to(x.device), sin.to(x.device)
     out = torch.stack([a * cos - b * sin, a * sin + b * cos], dim=-1).flatten(3, 4)
     return out.type_as(x)
 
 
-def _sdpa(q, k, v, heads):
+def _sdpa(q, k, v, heads, max_scores=1 << 28):
+    """softmax(q k^T / sqrt(d)) v per head in fp32.  Rows of a softmax are independent, so long sequences are evaluated in
+    (head, query-block) pieces of at most `max_scores` scores -- the same arithmetic per row, bounded memory (the C5 token
+    count has 5.7e9 scores per head)."""
     B, Sq, D = q.shape
     d = D // heads
+    Skv = k.shape[1]
     qh, kh, vh = (t.view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
-    o = torch.softmax(qh.float() @ kh.float().transpose(-1, -2) / math.sqrt(d), dim=-1) @ vh.float()
+    if B * heads * Sq * Skv <= max_scores:
+        o = torch.softmax(qh.float() @ kh.float().transpose(-1, -2) / math.sqrt(d), dim=-1) @ vh.float()
+        return o.transpose(1, 2).reshape(B, Sq, D).to(q.dtype)
+    o = torch.empty(B, heads, Sq, d, dtype=torch.float32, device=q.device)
+    rows = max(1, max_scores // Skv)
+    for b in range(B):
+        for h in range(heads):
+            kf, vf = kh[b, h].float(), vh[b, h].float()
+            for r0 in range(0, Sq, rows):
+                o[b, h, r0:r0 + rows] = torch.softmax(qh[b, h, r0:r0 + rows].float() @ kf.t() / math.sqrt(d), dim=-1) @ vf
     return o.transpose(1, 2).reshape(B, Sq, D).to(q.dtype)
 
 
+FP8_LINEARS = ("attn1.to_q", "attn1.to_k", "attn1.to_v", "attn1.to_out.0", "attn2.to_q", "attn2.to_out.0", "ffn.net.0.proj",
+               "ffn.net.2")   # the seven large linears of a block (to_q | to_k are one GEMM in the product) -- BASELINE config 5
+
+
 def wan_forward(cfg: WanConfig, sd, hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image,
-                dtype=torch.float32, collect=None):
+                dtype=torch.float32, collect=None, fp8=False):
     """hidden_states [B, 36, F, H, W]; timestep [B]; text [B, 512, 4096]; image [B, 257, 1280] or None.
-    ``dtype`` is the activation dtype (float32: the mathematical reference; bfloat16: the reference's rounding points)."""
+    ``dtype`` is the activation dtype (float32: the mathematical reference; bfloat16: the reference's rounding points).
+    ``fp8=True`` (BASELINE config 5): the block linears named in FP8_LINEARS quantise-dequantise both operands to OCP e4m3
+    (oracle/fp8_oracle.py: per token / per output channel) in eager op order; everything else is unchanged."""
     W_ = lambda n: sd[n].to(dtype) if sd[n].dtype != torch.float32 or "time_embedder" not in n else sd[n]
-    lin = lambda x, n: F.linear(x, W_(n + ".weight"), W_(n + ".bias"))
+    if fp8:
+        from . import fp8_oracle
+
+    def lin(x, n):
+        if fp8 and n.startswith("blocks.") and n.split(".", 2)[2] in FP8_LINEARS:
+            return fp8_oracle.linear(x, W_(n + ".weight"), W_(n + ".bias"), out_dtype=x.dtype)
+        return F.linear(x, W_(n + ".weight"), W_(n + ".bias"))
     B, C, F_, H, Wd = hidden_states.shape
     pt, ph, pw = cfg.patch_size
     D, heads = cfg.dim, cfg.num_attention_heads
     cos, sin = rope_tables(cfg, F_, H, Wd)
-    x = F.conv3d(hidden_states.to(dtype), W_("patch_embedding.weight"), W_("patch_embedding.bias"), stride=cfg.patch_size)
-    x = x.flatten(2).transpose(1, 2)
+    # patch_embedding = Conv3d(kernel = stride = patch_size): every output voxel is one dot product over its own patch, i.e.
+    # a linear layer over the unfolded patches (rows (c, dt, dy, dx), the weight's own memory order)
+    hp = hidden_states.to(dtype).reshape(B, C, F_ // pt, pt, H // ph, ph, Wd // pw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
+    x = F.linear(hp.reshape(B, -1, C * pt * ph * pw), W_("patch_embedding.weight").reshape(D, -1), W_("patch_embedding.bias"))
     ce = "condition_embedder."
     half = cfg.freq_dim // 2
-    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=hidden_states.device) / half
     emb = timestep.float()[:, None] * torch.exp(exponent)[None]
     emb = torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)             # flip_sin_to_cos
     temb = F.linear(F.silu(F.linear(emb, sd[ce + "time_embedder.linear_1.weight"],

@@ -173,3 +173,38 @@ def test_fp8_schedule9_equals_the_ping_pong_schedule_bit_for_bit(monkeypatch, fo
             if not torch.equal(got, want):
                 d = (got.float() - want.float()).abs()
                 raise AssertionError("%s M=%d N=%d K=%d: %d elements differ, max %.4g" % (form, M, N, K, int((d > 0).sum()), d.max().item()))
+
+
+@pytest.mark.parametrize("K,what", [(5120, "out-projection / Q|K / cross-attention contraction"), (13824, "ff2 contraction (Wan ffn_dim)")])
+def test_schedule9_fp8_gemm_at_the_c5_shape_against_a_float64_dequantised_matmul(K, what):
+    """the schedule-9 fp8 loop (the default) had only met an independent reference at K <= 1152; at the C5
+    shapes it was checked by bit-identity with schedule 6.  Here: M = 75,600 tokens (the C5 sequence), N = 5120, K = 5120 and
+    K = 13,824 (`ffn_dim`: 108 k-tiles of 128), the DEFAULT schedule, against the de-quantised operands multiplied in float64
+    on the host for 96 sampled rows (first / last tile rows, tile borders, random rows).  Bound per element: one bf16 rounding
+    of the result (2^-8 relative) + the fp32 accumulation slack 2^-20 * sum_k |a_k w_k| (K fp32 additions of exact products)."""
+    M, N = 75_600, 5120
+    g = torch.Generator(device=DEV).manual_seed(100 + K)
+    a = (torch.randn(M, K, generator=g, device=DEV) * torch.rand(M, 1, generator=g, device=DEV).mul(4).exp()).to(BF)   # row scales over e^4
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.03).to(BF)
+    bias = (torch.randn(N, generator=g, device=DEV) * 0.1).to(BF)
+    qa, sa = quant(a)
+    qw, sw = quant(w)
+    del a, w
+    c = torch.empty(M, N, dtype=BF, device=DEV)
+    _lib.gemm(qa, qw, c, M, N, K, K, K, N, bias=bias, a_scale=sa, b_scale=sw)
+    rows = torch.cat([torch.tensor([0, 1, 127, 128, 255, 256, 257, 75_263, 75_264, 75_519, 75_520, 75_598, 75_599]),
+                      torch.randint(0, M, (83,), generator=torch.Generator().manual_seed(K))]).to(DEV)
+    A = (qa[rows].view(F8).double() * sa[rows, None].double()).cpu()
+    W = (qw.view(F8).double() * sw[:, None].double()).cpu()
+    ref = A @ W.t() + bias.double().cpu()
+    mag = A.abs() @ W.abs().t()
+    got = c[rows].double().cpu()
+    err = (got - ref).abs()
+    bound = 2.0 ** -8 * ref.abs() + 2.0 ** -20 * mag + 1e-30
+    assert bool(torch.isfinite(got).all())
+    assert bool((err <= bound).all()), (K, what, float((err / bound).max()))
+    # and almost every element IS the correctly rounded bf16 of the exact result
+    assert (got != ref.to(BF).double()).double().mean().item() < 0.02
+    # the whole output is live (no tile skipped): every 256-row x 256-column tile has a non-trivial checksum
+    tiles = c[: (M // 256) * 256].view(M // 256, 256, N // 256, 256).float().abs().sum(dim=(1, 3))
+    assert bool((tiles > 0).all()) and bool(torch.isfinite(tiles).all())

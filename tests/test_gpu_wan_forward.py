@@ -99,8 +99,12 @@ def test_wan_alg_sampler_with_hip_dit():
 
 def test_wan_forward_fp8_weights():
     """BASELINE config 5: e4m3 weights (per output channel) x e4m3 activations (per token) on the fp8 MFMA for the seven
-    large linears of every block.  Stated tolerance: 8 % relative to the fp32 oracle after 2 blocks (e4m3 has 3 mantissa
-    bits; the bf16 path is at 3 %), and within 8 % of the bf16 HIP path."""
+    large linears of every block.  VERDICT r4 item 1: the bound is ANCHORED like every bf16 comparison -- the fp32 oracle is
+    the reference, the floor is the same oracle in the configuration's own execution mode (bf16 activations, the seven
+    linears quantise-dequantised to e4m3 in eager op order: `wan_oracle.wan_forward(dtype=bf16, fp8=True)`,
+    oracle/fp8_oracle.py), and HIP-fp8 has to land within 1.5 x that floor globally, 4 x its p99.9 per token, 2 x its worst
+    element (tests/_parity.py).  (The scheme itself -- amax / 448 per token and per channel -- is the build's, the reference
+    has no fp8 code: run.py:38,59-61 only forward a dtype.)"""
     cfg, ocfg = small()
     sd = wan_oracle.init_weights(ocfg, seed=3)
     x, txt, img = inputs(2, 3, 16, 24, 4)
@@ -109,10 +113,10 @@ def test_wan_forward_fp8_weights():
     run = lambda m: m(x.to(DEV), t.to(DEV), txt.to(DEV), img.to(DEV), return_dict=False)[0].cpu()
     out8 = run(WanTransformer3DModel(cfg, sd, device=DEV, fp8=True))
     out16 = run(WanTransformer3DModel(cfg, sd, device=DEV))
-    assert torch.isfinite(out8.float()).all()
-    assert rel(out8, ref) < 8e-2, rel(out8, ref)
-    assert rel(out8, out16) < 8e-2
-    assert rel(out16, ref) < rel(out8, ref)            # quantisation costs accuracy, it does not hide it
+    eager8 = wan_oracle.wan_forward(ocfg, sd, x, t, txt, img, dtype=BF, fp8=True)
+    e8, floor8 = check_floor("wan_forward_fp8_e4m3_2blocks", out8, ref, eager8)
+    assert rel(out16, ref) < e8                        # quantisation costs accuracy, it does not hide it
+    assert floor8 > rel(wan_oracle.wan_forward(ocfg, sd, x, t, txt, img, dtype=BF), ref)   # and the e4m3 floor is above the bf16 one
     # the norm -> e4m3 fusion (default) produces the same bytes as the separate quantiser pass
     m = WanTransformer3DModel(cfg, sd, device=DEV, fp8=True)
     m.fuse_quant = False
