@@ -178,7 +178,7 @@ class SmiSampler:
                 "sclk_mhz": stat([m for _, m in self.samples if m is not None]), "power_cap_w": self.cap, "source": self.source}
 
 
-def calibrate_box(dev, seconds=1.5):
+def calibrate_box(dev, seconds=3.0):
     """what THIS chip's matrix pipe sustains right now -- a register-only v_mfma_f32_32x32x16_bf16 loop on
     pseudo-random operands (csrc/calibrate.hip; two waves per SIMD, no memory traffic) run for `seconds` -- with the shader clock
     it ran at (cycle counter / constant-rate counter, read by every workgroup) and the package power meanwhile.  The number
@@ -203,7 +203,7 @@ def calibrate_box(dev, seconds=1.5):
             b.record()
             b.synchronize()
             rates.append(4 * flop / (a.elapsed_time(b) / 1e3) / 1e12)
-    tail = rates[len(rates) // 2:] or rates
+    tail = rates[2 * len(rates) // 3:] or rates      # the last third: the package has reached its power limit by then
     khz = _lib.wall_clock_khz()
     out = {"mfma_sustained_random_operands_tflops": sum(tail) / len(tail), "first_tflops": rates[0], "launch_groups": len(rates),
            "seconds": round(time.perf_counter() - t0, 2), "frac_of_peak": sum(tail) / len(tail) / MFMA_PEAK_TFLOPS,
@@ -986,7 +986,7 @@ def main():
     ap.add_argument("--seed-offset", type=int, default=0, help="debug: added to every rank's video seed")
     ap.add_argument("--dump-latents", default="", metavar="PREFIX",
                     help="debug: every rank saves the final latents of its last __call__ to PREFIX.rank<r>.pt")
-    ap.add_argument("--no-calibration", action="store_true", help="skip the 1.5 s matrix-pipe calibration of the box")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the 3 s matrix-pipe calibration of the box")
     ap.add_argument("--no-ab", action="store_true", help="c2 at 1 GPU: skip the in-run A/B arms (roofline.extra.ab, ~40 s)")
     ap.add_argument("--c1-budget", type=float, default=150.0,
                     help="seconds the C1 CPU leg may take (a 2-layer probe projects it first; beyond the budget the projection is reported)")

@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Generates alg_amd/csrc/attn128_q64_loop.inc (and, same construction at half the head width, attn64_q64_loop.inc): the
+steady-state KV loop of the 64-QUERIES-PER-WAVE flash attention as ONE inline-asm statement.
+
+Why (profiles/r4_pmc_d128_q64_vs_pipe.txt): with 64 queries per wave every K / V^T fragment read from LDS feeds
+TWO MFMAs (the wave's two 32-query halves) -- half the LDS instructions and half the L2 -> LDS traffic per FLOP of the 32-query
+statements (gen_attn_pipe.py, gen_attn128_pipe.py) -- but round 4's 64-query kernel left the order of everything between its asm
+MFMAs to hipcc (matrix pipe busy 62 % of its cycles, and a three-round hunt for a register the compiler recycled in the shadow
+of an MFMA it cannot see).  Here every instruction of the loop has a fixed place between two MFMAs, as in the 32-query
+statements, and no compiler-scheduled instruction exists between the first and the last MFMA of the statement.
+
+One wave = 64 queries (two halves qh = 0, 1 of 32), a workgroup = 4 waves = 256 queries, one wave per SIMD.  Software pipeline
+over KV tiles of 64 keys; iteration t issues, per wave (d = 128 | d = 64):
+    PV(t-1):  O^T[qh][dt] += V(t-1)^T[dt][kk] P(t-1)^T[qh][kk]      32 | 16 MFMAs, 16 | 8 V^T fragment reads, C/D = the O operands
+    QK(t+1):  S(t+1)^T[sub][qh] = K(t+1)[sub] Q[qh]^T                32 | 16 MFMAs, 16 | 8 K fragment reads, first k-step from C = 0
+    softmax(t): 32 score pairs per lane (64 keys x 64 queries / 64 lanes / 2), spread one pair per two | one MFMA gaps:
+                f = s * c - m * c (v_fma; dropped in the pre-scaled zero-offset form), e = exp2(f), P = cvt_pk(e, e'), row sum
+The running max m is the LAZY one of the frame (attention128_q64.hip): probabilities are formed against the current m, the
+statement leaves (code 1) as soon as a tile's row sum leaves [0, 2^80), the exact path (tile max, rescale) stays in C++.
+
+Collective protocol (identical in the C++ loop around the statement, so the waves of a workgroup may be inside or outside
+independently): top of iteration t   s_waitcnt vmcnt(NP); s_barrier; DMA K(t+3) -> K slot (t+3) & 3, V^T(t+2) -> V slot (t+2) & 3
+(NP = 8 | 4 pieces of 1 KiB per wave and iteration; the counted wait leaves the previous iteration's pieces in flight).
+Unrolled x 4 (ring slots as immediates).  Entered at t = 1 (mod 4) through a warm-up (QK(t) alone, then QK(t+1) under
+softmax(t)); runs groups of four while t + 4 <= tend; drains PV of its last tile.  See emit() for the operand list.
+
+Register plan (literal names, clobbered):
+    v[VB : VB+63] SA, v[VB+64 : VB+127] SB    score tiles [sub][qh][16]; roles alternate with t & 1
+    v[VB+128 : +159] PA, v[VB+160 : +191] PB  packed probabilities [qh][kk][4]
+    v[VB+192 ..] TS0 TS1 EA0 EA1 EB0 EB1 F0 F1
+    a[QA ..] Q fragments [qh][ks][4], a[FR : FR+31] eight fragment buffers (ring); O^T: 16-register "+a" operands o0 .. o(2 DT - 1)
+"""
+import os
+import sys
+
+
+class Cfg:
+    def __init__(self, d, fma=True, name=None):
+        self.d = d
+        self.KS = d // 16            # k-steps of QK
+        self.DT = d // 32            # 32-row d-tiles of O^T
+        self.TILE = 64 * d * 2       # bytes of a K tile = bytes of a V^T tile
+        self.KSUB = 32 * d * 2       # bytes of a 32-key sub-tile of K
+        self.NP = 2 * self.TILE // 1024 // 4     # DMA pieces per wave and iteration (K + V^T)
+        self.fma = fma               # False: scores arrive pre-scaled in log2 units with a zero offset (d = 64 frame)
+        self.VB = 52                 # first literal ArchVGPR
+        self.SA, self.SB = self.VB, self.VB + 64
+        self.PA, self.PB = self.VB + 128, self.VB + 160
+        t = self.VB + 192
+        self.TS = (t, t + 1)
+        self.EA = (t + 2, t + 3)
+        self.EB = (t + 4, t + 5)
+        self.F0, self.F1 = t + 6, t + 7
+        self.VEND = t + 8
+        self.NO = 2 * self.DT        # O operands (16 registers each)
+        self.QA = 128                # AccVGPR layout: O operands are the compiler's (outside [QA, AEND)), Q, fragment ring
+        self.FR = self.QA + 2 * self.KS * 4
+        self.AEND = self.FR + 32
+        self.name = name or ("ATTN%d_Q64" % d)
+        self.n_frag = 2 * self.KS + 4 * self.DT      # fragments per full iteration (K: sub x ks, V: kk x dt)
+        self.n_mfma = 2 * self.n_frag
+        assert self.VEND <= 256 and self.AEND <= 256
+
+
+v = lambda i: "v%d" % i
+vr = lambda i, n: "v[%d:%d]" % (i, i + n - 1)
+ar = lambda i, n: "a[%d:%d]" % (i, i + n - 1)
+AHEAD = 4          # fragment reads in flight ahead of the fragment being multiplied
+
+
+def frag_read(c, buf, which, slot, half, step):
+    """ds_read_b128 of one fragment into ring buffer `buf`: K sub-tile `half` k-step `step`, or V^T d-tile `half` kv block `step`.
+    The lane part (operand lk<step> / lv<step>) carries the ring base and the swizzled 16-byte slot of the step."""
+    off = slot * c.TILE + half * (c.KSUB if which == "k" else 4096)
+    return "ds_read_b128 %s, %%[l%s%d] offset:%d" % (ar(c.FR + 4 * buf, 4), which, step, off)
+
+
+def pair_regs(c, S, n):
+    """score pair n (0..31) of the tile in S: (register of the first score, qh, P register index within the 32-register P tile)
+    order: qh fastest (the two row sums alternate), then j (pair inside a register quad), g (quad), sub"""
+    qh, r = n & 1, n >> 1
+    j, g, sub = r & 3, (r >> 2) & 1, r >> 3
+    s0 = S + (sub * 2 + qh) * 16 + 8 * g + 2 * j
+    kk = sub * 2 + g
+    return s0, qh, qh * 16 + kk * 4 + j
+
+
+def softmax_stream(c, S, P):
+    """The VALU work of softmax(t) as `pre` (in front of the barrier), 64 half-pair groups and `post` (behind the last MFMA):
+        group 2n:     exp ea(n) | fma fb(n) | cvt P(n-1) | row sum += eb(n-1)
+        group 2n + 1: exp eb(n) | fma fa(n+1) | row sum += ea(n)
+    one transcendental per group; every result is read at least one group (= one MFMA in the steady state) after it was written."""
+    groups = []
+    first_sum = {0: True, 1: True}
+
+    def add(qh, reg):
+        if first_sum[qh]:
+            first_sum[qh] = False
+            return "v_mov_b32 %s, %s" % (v(c.TS[qh]), v(reg))
+        return "v_add_f32 %s, %s, %s" % (v(c.TS[qh]), v(c.TS[qh]), v(reg))
+
+    def fma(dst, src, qh):
+        return "v_fma_f32 %s, %s, %%[c], %%[negmc%d]" % (v(dst), v(src), qh)
+
+    s0, qh0, _ = pair_regs(c, S, 0)
+    pre = [fma(c.F0, s0, qh0)] if c.fma else []
+    for n in range(32):
+        s0, qh, _ = pair_regs(c, S, n)
+        ea, eb = c.EA[n & 1], c.EB[n & 1]
+        g = ["v_exp_f32 %s, %s" % (v(ea), v(c.F0 if c.fma else s0))]
+        if c.fma:
+            g.append(fma(c.F1, s0 + 1, qh))
+        if n >= 1:
+            _, qp, pp = pair_regs(c, S, n - 1)
+            g.append("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(P + pp), v(c.EA[(n - 1) & 1]), v(c.EB[(n - 1) & 1])))
+            g.append(add(qp, c.EB[(n - 1) & 1]))
+        groups.append(g)
+        g = ["v_exp_f32 %s, %s" % (v(eb), v(c.F1 if c.fma else s0 + 1))]
+        if c.fma and n + 1 < 32:
+            s1, q1, _ = pair_regs(c, S, n + 1)
+            g.append(fma(c.F0, s1, q1))
+        g.append(add(qh, ea))
+        groups.append(g)
+    _, qp, pp = pair_regs(c, S, 31)
+    post = ["s_nop 1", "v_cvt_pk_bf16_f32 %s, %s, %s" % (v(P + pp), v(c.EA[1]), v(c.EB[1])), add(qp, c.EB[1])]
+    return pre, groups, post
+
+
+def top_protocol(c, phase):
+    """(head, DMA pieces) of iteration t, t & 3 == phase: all but the previous iteration's NP pieces have landed (K(t+1), V(t) and
+    older); behind the barrier this wave's pieces of K(t+3) and V^T(t+2).  A piece is (M0 write, [load, offset advance]): the two
+    halves go into two consecutive MFMA gaps, so the M0 write is separated from the LDS-DMA that reads it by real work instead
+    of an s_nop."""
+    ks, vs = (phase + 3) & 3, (phase + 2) & 3
+    head = ["s_waitcnt vmcnt(%d)" % c.NP, "s_barrier"]
+    pieces = []
+    for r in range(c.NP // 2):
+        pieces.append(("s_add_u32 m0, %%[wk], %d" % (ks * c.TILE + r * 4096),
+                       ["global_load_lds_dwordx4 %%[kvo%d], %%[kb]" % r, "v_add_u32 %%[kvo%d], %%[kstep], %%[kvo%d]" % (r, r)]))
+    for r in range(c.NP // 2):
+        pieces.append(("s_add_u32 m0, %%[wv], %d" % (vs * c.TILE + r * 4096),
+                       ["global_load_lds_dwordx4 %%[vvo%d], %%[vb]" % r, "v_add_u32 %%[vvo%d], 0x80, %%[vvo%d]" % (r, r)]))
+    return head, pieces
+
+
+def flat_pieces(pieces):
+    out = []
+    for m0, rest in pieces:
+        out += [m0, "s_nop 0"] + rest
+    return out
+
+
+def frag_order(c, pv, qk):
+    """fragment stream of one iteration: V^T kv block 0 first (prefetched across the barrier), then K and the middle kv blocks
+    interleaved (K, K, V), the last kv block at the end -- S(t+1) is complete a kv block's worth of MFMAs before the next
+    iteration's softmax reads it, and an accumulator is touched again at the earliest six MFMAs later."""
+    ks_frags = [("k", sub, ks) for ks in range(c.KS) for sub in range(2)] if qk else []
+    vfr = lambda kk: [("v", dt, kk) for dt in range(c.DT)]
+    if not pv:
+        return ks_frags
+    if not qk:
+        return [f for kk in range(4) for f in vfr(kk)]
+    out = vfr(0)
+    mid = vfr(1) + vfr(2)
+    i = 0
+    while i < len(ks_frags) or mid:
+        out += ks_frags[i:i + 2]
+        i += 2
+        if mid:
+            out.append(mid.pop(0))
+    return out + vfr(3)
+
+
+def first_reads(c, phase):
+    """the first AHEAD fragment reads of a full iteration at `phase`: V^T(t-1) kv block 0 -- independent of the iteration's
+    barrier (the tile landed two iterations earlier), so the PREVIOUS iteration issues them behind its last fragments"""
+    vslot = (phase - 1) & 3
+    fr = [("v", dt, 0) for dt in range(c.DT)]
+    if len(fr) < AHEAD:                      # d = 64: two d-tiles per kv block; the next fragments are K(t+1) -- NOT barrier-free
+        return None
+    return [frag_read(c, j, "v", vslot, dt, 0) for j, (_, dt, _) in enumerate(fr[:AHEAD])]
+
+
+def iteration(c, phase, X, Y, U, W, pv=True, softmax=True, qk=True, reads_in_flight=0, prefetch_next=None, dma=None):
+    """one iteration at ring phase t & 3 == phase.  X: S(t) (read by the softmax), Y: S(t+1) (written by QK), U: P(t-1) (PV's B
+    operand), W: P(t) (written by the softmax).  reads_in_flight: how many of its first fragment reads the caller has issued.
+    MFMA gap g (the instructions behind MFMA g): the fragment read that reuses a ring buffer (odd g: behind the second MFMA of a
+    fragment), half a DMA piece (even g: M0, odd g: the LDS-DMA and its offset advance), one half-pair group of the softmax.
+    Fragment waits: one counted lgkmcnt per TWO fragments (reads run four fragments ahead: lgkmcnt(2) in front of fragment j
+    leaves j + 2, j + 3 in flight)."""
+    kslot, vslot = (phase + 1) & 3, (phase - 1) & 3
+    fr = frag_order(c, pv, qk)
+    n_f = len(fr)
+    assert n_f % 2 == 0
+    lines = []
+
+    def read(j):
+        kind, half, step = fr[j]
+        return frag_read(c, j % 8, kind, kslot if kind == "k" else vslot, half, step)
+
+    for j in range(reads_in_flight, min(AHEAD, n_f)):
+        lines.append(read(j))
+    groups, post = [], []
+    if softmax:
+        _, groups, post = softmax_stream(c, X, W)
+    per_gap = -(-len(groups) // (2 * n_f)) if softmax else 0          # 1 in the steady state, 2 in the warm-up (half the MFMAs)
+    gi = 0
+    seen = set()
+    nxt = first_reads(c, prefetch_next) if prefetch_next is not None else None
+    gap = 0
+    for j, (kind, half, step) in enumerate(fr):
+        if j % 2 == 0:
+            issued = (n_f + AHEAD if nxt is not None else n_f) - 1           # index of the last read that will ever be issued
+            younger = min(j + AHEAD - 1, issued) - (j + 1)                   # reads issued behind read j + 1 at this point
+            lines.append("s_waitcnt lgkmcnt(%d)" % max(younger, 0))
+        frag = ar(c.FR + 4 * (j % 8), 4)
+        for qh in range(2):
+            if kind == "k":
+                acc = vr(Y + (half * 2 + qh) * 16, 16)
+                cin = acc if (half, qh) in seen else "0"
+                seen.add((half, qh))
+                lines.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, frag, ar(c.QA + (qh * c.KS + step) * 4, 4), cin))
+            else:
+                acc = "%%[o%d]" % (qh * c.DT + half)
+                lines.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, frag, vr(U + qh * 16 + step * 4, 4), acc))
+            if qh == 1:      # the fragment's buffer is free again four fragments from now: the read that reuses it
+                if j + AHEAD < n_f:
+                    lines.append(read(j + AHEAD))
+                elif nxt is not None:
+                    lines.append(nxt[j + AHEAD - n_f])
+            piece = dma[gap // 2] if dma and gap // 2 < len(dma) else None
+            if piece and gap % 2 == 0:
+                lines.append(piece[0])
+            for _ in range(per_gap):
+                if gi < len(groups):
+                    lines += groups[gi]
+                    gi += 1
+            if piece and gap % 2 == 1:
+                lines += piece[1]
+            gap += 1
+    assert gi == len(groups)
+    return lines + post
+
+
+def check_and_count(c, fail_label):
+    """row-sum check of the iteration just issued: both query halves at once through their sum (inf and NaN propagate; two sums
+    below 2^79 each would be the exact condition, 2^80 for their total is the same guard one bit earlier), then l += tile sums,
+    t += 1"""
+    out = ["v_add_f32 %s, %s, %s" % (v(c.F1), v(c.TS[0]), v(c.TS[1])), "v_cmp_ngt_f32 vcc, 0x67800000, %s" % v(c.F1),   # !(2^80 > sum)
+           "s_nop 4", "s_cbranch_vccnz %s" % fail_label]
+    out += ["v_add_f32 %%[l%d], %%[l%d], %s" % (qh, qh, v(c.TS[qh])) for qh in range(2)]
+    return out + ["s_add_u32 %[t], %[t], 1"]
+
+
+def emit(c):
+    L = []
+    # ---- entry: Q fragments of both query halves ----
+    for qh in range(2):
+        L += ["global_load_dwordx4 %s, %%[qvo%d], %%[qb] offset:%d" % (ar(c.QA + (qh * c.KS + ks) * 4, 4), qh, 32 * ks)
+              for ks in range(c.KS)]
+    roles = {1: (c.SA, c.SB, c.PA, c.PB), 2: (c.SB, c.SA, c.PB, c.PA), 3: (c.SA, c.SB, c.PA, c.PB), 0: (c.SB, c.SA, c.PB, c.PA)}
+    L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"]   # Q (and, once, whatever the caller had in flight)
+    # ---- warm-up at phase 1: iteration t's protocol, QK(t) alone into X, then QK(t+1) under softmax(t) ----
+    head, pieces = top_protocol(c, 1)
+    L += head + flat_pieces(pieces)
+    X, Y, U, W = roles[1]
+    L += iteration(c, 0, Y, X, U, W, pv=False, softmax=False)       # phase 0's "next" K slot is slot 1 = t & 3: S(t) -> X
+    L += ["s_nop 15", "s_nop 15"]                                     # S(t) complete before the first VALU reads it
+    pre, _, _ = softmax_stream(c, X, W)
+    L += pre
+    nxt = first_reads(c, 2)
+    L += iteration(c, 1, X, Y, U, W, pv=False, prefetch_next=2 if nxt else None)
+    L += check_and_count(c, "90f")
+    L += ["s_branch 12f"]
+    # ---- the loop: phases 1, 2, 3, 0 ----
+    L += ["11:"]
+    for ph in (1, 2, 3, 0):
+        if ph == 2:
+            L += ["12:"]
+        X, Y, U, W = roles[ph]
+        head, pieces = top_protocol(c, ph)
+        pre, _, _ = softmax_stream(c, X, W)
+        L += pre + head
+        L += iteration(c, ph, X, Y, U, W, reads_in_flight=AHEAD if nxt else 0, prefetch_next=((ph + 1) & 3) if nxt else None,
+                       dma=pieces)
+        L += check_and_count(c, "90f")
+    L += ["s_add_u32 %[code], %[t], 4", "s_cmp_le_u32 %[code], %[tend]", "s_cbranch_scc1 11b"]
+    # ---- drain: PV of the last tile (its P is the W of phase 0); V slot (1 - 1) & 3 = slot of tile t - 1 ----
+    X, Y, U, W = roles[0]
+    L += iteration(c, 1, Y, X, W, U, pv=True, softmax=False, qk=False, reads_in_flight=AHEAD if nxt else 0)
+    L += ["s_mov_b32 %[code], 0", "s_branch 99f"]
+    # ---- failed row-sum check in iteration t: its protocol, PV(t-1) and QK(t+1) are done, softmax(t) is not ----
+    L += ["90:", "s_mov_b32 %[code], 1"]
+    L += ["99:", "s_nop 15", "s_nop 15", "s_waitcnt lgkmcnt(0)"]
+    return L
+
+
+def write(c, path):
+    lines = emit(c)
+    with open(path, "w") as f:
+        f.write("// GENERATED by scripts/gen_attn_q64.py -- do not edit.  Steady-state KV loop of the 64-queries-per-wave d = %d attention.\n" % c.d)
+        f.write("#define ALG_%s_LOOP_ASM \\\n" % c.name)
+        for ln in lines:
+            f.write('  "%s\\n\\t" \\\n' % ln)
+        f.write('  ""\n')
+        regs = ["a%d" % i for i in range(c.QA, c.AEND)] + ["v%d" % i for i in range(c.VB, c.VEND)]
+        f.write("#define ALG_%s_CLOBBERS \\\n  " % c.name + ", ".join('"%s"' % r for r in regs) + "\n")
+        f.write("#define ALG_%s_O_OPERANDS(o) \\\n  " % c.name + ", ".join('[o%d] "+a"(o[%d])' % (i, i) for i in range(c.NO)) + "\n")
+    return lines
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    out128 = os.environ.get("ATTN128_Q64_OUT") or os.path.join(here, "..", "alg_amd", "csrc", "attn128_q64_loop.inc")
+    lines = write(Cfg(128, fma=True), out128)
+    print("wrote", os.path.normpath(out128), len(lines), "lines,", sum(1 for l in lines if l.startswith("v_mfma")), "MFMAs")
+
+
+if __name__ == "__main__":
+    main()

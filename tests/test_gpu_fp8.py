@@ -181,7 +181,8 @@ def test_schedule9_fp8_gemm_at_the_c5_shape_against_a_float64_dequantised_matmul
     shapes it was checked by bit-identity with schedule 6.  Here: M = 75,600 tokens (the C5 sequence), N = 5120, K = 5120 and
     K = 13,824 (`ffn_dim`: 108 k-tiles of 128), the DEFAULT schedule, against the de-quantised operands multiplied in float64
     on the host for 96 sampled rows (first / last tile rows, tile borders, random rows).  Bound per element: one bf16 rounding
-    of the result (2^-8 relative) + the fp32 accumulation slack 2^-20 * sum_k |a_k w_k| (K fp32 additions of exact products)."""
+    of the result (half an ulp: up to 2^-8 relative) + the fp32 accumulation slack 2^-16 * sum_k |a_k w_k| (K fp32 additions of
+    exact products, each within 2^-24 of its partial sum: ~ sqrt(K) 2^-24 <= 2^-17 typical, K 2^-24 = 2^-10 worst case)."""
     M, N = 75_600, 5120
     g = torch.Generator(device=DEV).manual_seed(100 + K)
     a = (torch.randn(M, K, generator=g, device=DEV) * torch.rand(M, 1, generator=g, device=DEV).mul(4).exp()).to(BF)   # row scales over e^4
@@ -200,7 +201,7 @@ def test_schedule9_fp8_gemm_at_the_c5_shape_against_a_float64_dequantised_matmul
     mag = A.abs() @ W.abs().t()
     got = c[rows].double().cpu()
     err = (got - ref).abs()
-    bound = 2.0 ** -8 * ref.abs() + 2.0 ** -20 * mag + 1e-30
+    bound = 2.0 ** -8 * ref.abs() + 2.0 ** -16 * mag + 1e-30
     assert bool(torch.isfinite(got).all())
     assert bool((err <= bound).all()), (K, what, float((err / bound).max()))
     # and almost every element IS the correctly rounded bf16 of the exact result
