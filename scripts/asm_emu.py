@@ -148,6 +148,12 @@ class Machine:
         w.pc += 1
         w.n_inst += 1
         op, _, rest = ln.partition(" ")
+        if op == "s_nop":
+            return
+        if op == "s_waitcnt":
+            for m in re.finditer(r"(vmcnt|lgkmcnt)\((\d+)\)", rest):
+                self.drain(w.vm if m.group(1) == "vmcnt" else w.lgkm, int(m.group(2)))
+            return
         args = [a.strip() for a in rest.split(",")] if rest else []
         mods = {}
         if args and " " in args[-1]:            # trailing modifiers: "v1 offset:32"
@@ -156,12 +162,6 @@ class Machine:
             for p in parts[1:]:
                 k, _, val = p.partition(":")
                 mods[k] = int(val, 0)
-        if op == "s_nop":
-            return
-        if op == "s_waitcnt":
-            for m in re.finditer(r"(vmcnt|lgkmcnt)\((\d+)\)", rest):
-                self.drain(w.vm if m.group(1) == "vmcnt" else w.lgkm, int(m.group(2)))
-            return
         if op == "s_barrier":
             w.at_barrier = True
             return
@@ -261,7 +261,7 @@ class Machine:
             return
         if op == "global_load_lds_dwordx4":
             addr = self.rd(w, args[0]).astype(np.int64) + self.s64(w, args[1]) + mods.get("offset", 0)
-            dst = (w.m0 & 0xFFFF) + mods.get("offset", 0) + np.arange(64, dtype=np.int64) * 16
+            dst = int(w.m0) + mods.get("offset", 0) + np.arange(64, dtype=np.int64) * 16
             src = self.gmem[addr[:, None] + np.arange(16)[None, :]].copy()     # global data is read-only here: sample at issue
 
             def complete(dst=dst, src=src):

@@ -151,17 +151,19 @@ def flat_pieces(pieces):
 
 
 def frag_order(c, pv, qk):
-    """fragment stream of one iteration: V^T kv block 0 first (prefetched across the barrier), then K and the middle kv blocks
-    interleaved (K, K, V), the last kv block at the end -- S(t+1) is complete a kv block's worth of MFMAs before the next
-    iteration's softmax reads it, and an accumulator is touched again at the earliest six MFMAs later."""
+    """fragment stream of one iteration: the first AHEAD V^T fragments (one | two kv blocks: barrier-free, prefetched by the
+    previous iteration), then K and the middle kv blocks interleaved (K, K, V), the last kv block at the end -- S(t+1) is
+    complete a kv block's worth of MFMAs before the next iteration's softmax reads it, and an accumulator is touched again at the
+    earliest four MFMAs later."""
     ks_frags = [("k", sub, ks) for ks in range(c.KS) for sub in range(2)] if qk else []
     vfr = lambda kk: [("v", dt, kk) for dt in range(c.DT)]
     if not pv:
         return ks_frags
     if not qk:
         return [f for kk in range(4) for f in vfr(kk)]
-    out = vfr(0)
-    mid = vfr(1) + vfr(2)
+    lead = -(-AHEAD // c.DT)                      # kv blocks that make up the first AHEAD fragments
+    out = [f for kk in range(lead) for f in vfr(kk)]
+    mid = [f for kk in range(lead, 3) for f in vfr(kk)]
     i = 0
     while i < len(ks_frags) or mid:
         out += ks_frags[i:i + 2]
@@ -172,13 +174,12 @@ def frag_order(c, pv, qk):
 
 
 def first_reads(c, phase):
-    """the first AHEAD fragment reads of a full iteration at `phase`: V^T(t-1) kv block 0 -- independent of the iteration's
-    barrier (the tile landed two iterations earlier), so the PREVIOUS iteration issues them behind its last fragments"""
+    """the first AHEAD fragment reads of a full iteration at `phase`: V^T(t-1), kv block 0 (| 0 and 1) -- independent of the
+    iteration's barrier (the tile landed two iterations earlier), so the PREVIOUS iteration issues them behind its last fragments"""
     vslot = (phase - 1) & 3
-    fr = [("v", dt, 0) for dt in range(c.DT)]
-    if len(fr) < AHEAD:                      # d = 64: two d-tiles per kv block; the next fragments are K(t+1) -- NOT barrier-free
-        return None
-    return [frag_read(c, j, "v", vslot, dt, 0) for j, (_, dt, _) in enumerate(fr[:AHEAD])]
+    fr = frag_order(c, True, True)[:AHEAD]
+    assert all(kind == "v" for kind, _, _ in fr)
+    return [frag_read(c, j, "v", vslot, dt, kk) for j, (_, dt, kk) in enumerate(fr)]
 
 
 def iteration(c, phase, X, Y, U, W, pv=True, softmax=True, qk=True, reads_in_flight=0, prefetch_next=None, dma=None):
@@ -314,6 +315,9 @@ def main():
     out128 = os.environ.get("ATTN128_Q64_OUT") or os.path.join(here, "..", "alg_amd", "csrc", "attn128_q64_loop.inc")
     lines = write(Cfg(128, fma=True), out128)
     print("wrote", os.path.normpath(out128), len(lines), "lines,", sum(1 for l in lines if l.startswith("v_mfma")), "MFMAs")
+    out64 = os.environ.get("ATTN64_Q64_OUT") or os.path.join(here, "..", "alg_amd", "csrc", "attn64_q64_loop.inc")
+    lines = write(Cfg(64, fma=False), out64)
+    print("wrote", os.path.normpath(out64), len(lines), "lines,", sum(1 for l in lines if l.startswith("v_mfma")), "MFMAs")
 
 
 if __name__ == "__main__":

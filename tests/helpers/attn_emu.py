@@ -1,0 +1,194 @@
+"""Harness that runs a generated 64-queries-per-wave attention statement (scripts/gen_attn_q64.py) in the instruction-level
+emulator (scripts/asm_emu.py) exactly the way the C++ frame (alg_amd/csrc/attention128_q64.hip) drives it: the same per-lane
+operand values, the same LDS ring layout and DMA lane mapping, tile 0 and the tail tiles done in numpy in the frame's place."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+import asm_emu  # noqa: E402
+import gen_attn_q64 as G  # noqa: E402
+
+KVB = 64
+
+
+def perm8(kv):
+    """physical V^T column of key kv: index bits 2 and 3 swapped (the GEMM that writes V^T stores it so)"""
+    return (kv & ~12) | ((kv & 4) << 1) | ((kv & 8) >> 1)
+
+
+def bf16_round(x):
+    return asm_emu.bf16_to_f32(asm_emu.f32_to_bf16(np.asarray(x, dtype=np.float32)))
+
+
+class Problem:
+    def __init__(self, d, T, seed=0, q_rs=None, k_rs=None, score_scale=1.0):
+        rng = np.random.default_rng(seed)
+        self.d, self.T, self.Skv, self.Sq = d, T, T * KVB, 256
+        self.q_rs, self.k_rs = q_rs or 2 * d, k_rs or 2 * d          # row pitches in elements (a [S, 2, d] qk tensor by default)
+        self.vt_rs = self.Skv + 64
+        self.q = bf16_round(rng.standard_normal((self.Sq, d)) * score_scale)
+        self.k = bf16_round(rng.standard_normal((self.Skv, d)))
+        self.v = bf16_round(rng.standard_normal((self.Skv, d)))
+        self.c = np.float32(1.0 / np.sqrt(d) * 1.4426950408889634)
+        # global memory: Q panel, K panel, V^T panel (permuted columns), each at an odd offset to catch base mix-ups
+        self.QOFF, self.KOFF = 4096, 4096 + 2 * self.Sq * self.q_rs + 512
+        self.VOFF = self.KOFF + 2 * (self.Skv + 4 * KVB) * self.k_rs + 1024
+        self.pack()
+
+    def pack(self):
+        """(re)build the global-memory image from q / k / v"""
+        d = self.d
+        size = self.VOFF + 2 * (d + 1) * self.vt_rs + 4096
+        g16 = np.zeros(size // 2, dtype=np.uint16)
+        tobf = lambda a: asm_emu.f32_to_bf16(a)
+        for r in range(self.Sq):
+            g16[self.QOFF // 2 + r * self.q_rs: self.QOFF // 2 + r * self.q_rs + d] = tobf(self.q[r])
+        for r in range(self.Skv):
+            g16[self.KOFF // 2 + r * self.k_rs: self.KOFF // 2 + r * self.k_rs + d] = tobf(self.k[r])
+        cols = perm8(np.arange(self.Skv))
+        for dd in range(d):
+            g16[self.VOFF // 2 + dd * self.vt_rs + cols] = tobf(self.v[:, dd])
+        self.gmem = g16.view(np.uint8)
+
+    def reference(self):
+        s = self.q.astype(np.float64) @ self.k.astype(np.float64).T * (1.0 / np.sqrt(self.d))
+        p = np.exp(s - s.max(axis=1, keepdims=True))
+        return (p / p.sum(axis=1, keepdims=True)) @ self.v.astype(np.float64)
+
+
+def lane_ctx(wave, lane):
+    l31, h2, tid = lane & 31, lane >> 5, wave * 64 + lane
+    return l31, h2, tid
+
+
+def stage(pb, lds, cfg, which, tile, slot_base):
+    """what the four waves' DMA pieces of one K / V^T tile put into ring slot tile & 3 (frame: stage_k / stage_v)"""
+    d = cfg.d
+    for wave in range(4):
+        for lane in range(64):
+            l31, h2, tid = lane_ctx(wave, lane)
+            for i in range(cfg.NP // 2):
+                if which == "k":
+                    slots = d * 2 // 16                                                        # 16-byte slots per K row
+                    row = tid // slots + (256 // slots) * i
+                    slot = (tid % slots) ^ (row % slots)
+                    src = pb.KOFF + ((tile * KVB + row) * pb.k_rs + slot * 8) * 2
+                else:
+                    row = tid // 8 + 32 * i
+                    slot = (tid & 7) ^ ((tid >> 4) & 7)
+                    src = pb.VOFF + (row * pb.vt_rs + slot * 8 + tile * KVB) * 2
+                dst = slot_base + (tile & 3) * cfg.TILE + (i * 4 + wave) * 1024 + lane * 16
+                lds[dst:dst + 16] = pb.gmem[src:src + 16]
+
+
+def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None):
+    """Emulates the statement entered at iteration t0 (tile 0 .. t0 - 1 done by `the frame` = numpy here).  Returns the
+    normalised attention output [Sq, d] after the frame's tail, the exit iteration and the exit code of wave 0."""
+    d, T, c = cfg.d, pb.T, pb.c
+    tend = (T - 3) if tend is None else tend
+    lines = G.emit(cfg)
+    if mutate is not None:
+        lines = mutate(lines)
+    KL, VL = 0, 4 * cfg.TILE
+    # ---- operand binding: "v" operands in v0 .., "s" in s0 .., O tuples in a[0 : 16 NO) ----
+    tab, nv, ns = {}, 0, 0
+    def vreg(name):
+        nonlocal nv
+        tab[name] = "v%d" % nv
+        nv += 1
+    def sreg(name, n=1):
+        nonlocal ns
+        ns += ns % n
+        tab[name] = "s%d" % ns if n == 1 else "s[%d:%d]" % (ns, ns + n - 1)
+        ns += n
+    for i in range(cfg.NO):
+        tab["o%d" % i] = "a[%d:%d]" % (16 * i, 16 * i + 15)
+    for n in ["l0", "l1", "negmc0", "negmc1", "qvo0", "qvo1"] + ["lk%d" % i for i in range(cfg.KS)] + ["lv%d" % i for i in range(4)] + \
+             ["kvo%d" % i for i in range(cfg.NP // 2)] + ["vvo%d" % i for i in range(cfg.NP // 2)]:
+        vreg(n)
+    assert nv <= cfg.VB
+    for n in ("t", "code", "c", "kstep", "tend", "wk", "wv"):
+        sreg(n)
+    for n in ("kb", "vb", "qb"):
+        sreg(n, 2)
+    m = asm_emu.Machine(asm_emu.bind(lines, tab), n_waves=4, gmem=pb.gmem, lazy_reads=lazy_reads, lazy_dma=lazy_dma)
+    # ---- the frame's state at entry: tiles 0 .. t0 - 1 folded into (m, l, O); K(t0 - 1 .. t0 + 2), V(t0 - 1 .. t0 + 1) resident ----
+    qf, kf, vf = pb.q.astype(np.float64), pb.k.astype(np.float64), pb.v.astype(np.float64)
+    s_all = qf @ kf.T                                       # raw scores [Sq, Skv]
+    m_run = s_all[:, :KVB].max(axis=1)                      # the frame takes tile 0's maximum as the (lazy) offset
+    def probs(t):
+        return bf16_round(np.exp2((s_all[:, t * KVB:(t + 1) * KVB] - m_run[:, None]) * float(c))).astype(np.float64)
+    def fsum(t):
+        return np.exp2((s_all[:, t * KVB:(t + 1) * KVB] - m_run[:, None]) * float(c)).astype(np.float32).astype(np.float64).sum(axis=1)
+    O = np.zeros((pb.Sq, d))
+    l = np.zeros(pb.Sq)
+    for t in range(t0):
+        O += probs(t) @ vf[t * KVB:(t + 1) * KVB]
+        l += fsum(t)
+    for t in range(t0 - 1, t0 + 3):
+        stage(pb, m.lds, cfg, "k", t, KL)
+    for t in range(t0 - 1, t0 + 2):
+        stage(pb, m.lds, cfg, "v", t, VL)
+    def sset(w, name, val):
+        r = asm_emu.parse_reg(tab[name])
+        if r[2] == 1:
+            w.s[r[1]] = np.uint32(int(val) & 0xFFFFFFFF)
+        else:
+            w.s[r[1]], w.s[r[1] + 1] = np.uint32(int(val) & 0xFFFFFFFF), np.uint32(int(val) >> 32)
+    def vset(w, name, arr):
+        w.v[asm_emu.parse_reg(tab[name])[1]] = np.asarray(arr).astype(np.int64).astype(np.uint32) if np.asarray(arr).dtype != np.float32 else np.asarray(arr).view(np.uint32)
+    slots_k = d * 2 // 16
+    for w in m.waves:
+        lane = np.arange(64)
+        l31, h2, tid = lane & 31, lane >> 5, w.id * 64 + lane
+        q_row = w.id * 64 + l31
+        sset(w, "t", t0), sset(w, "tend", tend), sset(w, "kstep", KVB * pb.k_rs * 2)
+        sset(w, "c", int(np.float32(c).view(np.uint32)))
+        sset(w, "wk", KL + w.id * 1024), sset(w, "wv", VL + w.id * 1024)
+        sset(w, "kb", pb.KOFF), sset(w, "vb", pb.VOFF), sset(w, "qb", pb.QOFF)
+        for qh in range(2):
+            vset(w, "qvo%d" % qh, ((q_row + 32 * qh) * pb.q_rs + h2 * 8) * 2)
+            vset(w, "negmc%d" % qh, (-(m_run[q_row + 32 * qh]) * float(c)).astype(np.float32))
+            vset(w, "l%d" % qh, np.where(h2 == 0, l[q_row + 32 * qh], 0.0).astype(np.float32))   # tile sums so far: all in lane h2 = 0
+        k_row_off, k_sw = l31 * (d * 2), l31 % slots_k
+        for ks in range(cfg.KS):
+            vset(w, "lk%d" % ks, KL + k_row_off + (((2 * ks + h2) ^ k_sw) * 16))
+        for kk in range(4):
+            vset(w, "lv%d" % kk, VL + l31 * 128 + (((2 * kk + h2) ^ ((l31 >> 1) & 7)) * 16))
+        for i in range(cfg.NP // 2):
+            row = tid // slots_k + (256 // slots_k) * i
+            slot = (tid % slots_k) ^ (row % slots_k)
+            vset(w, "kvo%d" % i, (((t0 + 3) * KVB + row) * pb.k_rs + slot * 8) * 2)
+            vrow, vslot = tid // 8 + 32 * i, (tid & 7) ^ ((tid >> 4) & 7)
+            vset(w, "vvo%d" % i, (vrow * pb.vt_rs + vslot * 8 + (t0 + 2) * KVB) * 2)
+        for qh in range(2):
+            for dt in range(cfg.DT):
+                base = 16 * (qh * cfg.DT + dt)
+                for e in range(16):
+                    drow = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2
+                    w.a[base + e] = O[q_row + 32 * qh, drow].astype(np.float32).view(np.uint32)
+    n = m.run()
+    # ---- read back, then the frame's tail in numpy ----
+    t_exit = int(m.waves[0].s[asm_emu.parse_reg(tab["t"])[1]])
+    codes = [int(w.s[asm_emu.parse_reg(tab["code"])[1]]) for w in m.waves]
+    O2, l2 = np.zeros((pb.Sq, d)), np.zeros(pb.Sq)
+    for w in m.waves:
+        lane = np.arange(64)
+        l31, h2 = lane & 31, lane >> 5
+        q_row = w.id * 64 + l31
+        for qh in range(2):
+            lv = w.v[asm_emu.parse_reg(tab["l%d" % qh])[1]].view(np.float32).astype(np.float64)
+            np.add.at(l2, q_row + 32 * qh, lv)
+            for dt in range(cfg.DT):
+                base = 16 * (qh * cfg.DT + dt)
+                for e in range(16):
+                    drow = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2
+                    O2[q_row + 32 * qh, drow] = w.a[base + e].view(np.float32)
+    for t in range(t_exit, T):
+        O2 += probs(t) @ vf[t * KVB:(t + 1) * KVB]
+        l2 += fsum(t)
+    return O2 / l2[:, None], t_exit, codes, n, lines

@@ -1,0 +1,182 @@
+"""The generated 64-queries-per-wave attention statement (scripts/gen_attn_q64.py -> alg_amd/csrc/attn128_q64_loop.inc) checked AS A
+PROGRAM on the CPU, without a GPU:
+
+  * an instruction-level emulator (scripts/asm_emu.py) runs the asm text for a 4-wave workgroup the way the C++ frame drives it
+    (tests/helpers/attn_emu.py: same operand values, LDS ring layout and DMA lane mapping) and the attention it computes is
+    compared with a float64 softmax(QK^T)V -- under the WEAKEST memory ordering the ISA allows: fragment reads that complete
+    only at the counted lgkmcnt wait that covers them, LDS-DMA pieces that land only at the counted vmcnt wait of the issuing
+    wave (visible to the others behind the next barrier), and both extremes crossed;
+  * the same harness rejects mutated programs (a wait one too loose, a missing barrier, a wrong ring slot), i.e. it can see the
+    defects it is there for;
+  * static hazard rules on the text the emulator does not model: an MFMA's VGPR result is read by the VALU only after at least
+    two later MFMAs have been issued, a transcendental's result is not read by the next instruction, M0 is written at least one
+    instruction before the LDS-DMA that uses it, VCC at least five wait states before the branch on it, no more than seven
+    single-issue fillers sit behind any MFMA of the steady state (5 per gap on average is what one wave per SIMD hides)."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+import attn_emu as H  # noqa: E402
+import gen_attn_q64 as G  # noqa: E402
+
+MODES = [(True, False), (False, True), (True, True)]     # (lazy fragment reads, lazy DMA)
+TOL = 6e-3     # bf16 probabilities: 2^-9 relative per term; measured 2.0e-3 on these problems
+
+
+def relerr(out, ref):
+    return float(np.abs(out - ref).max() / np.abs(ref).max())
+
+
+@pytest.fixture(scope="module")
+def cfg128():
+    return G.Cfg(128, fma=True)
+
+
+@pytest.mark.parametrize("T,seed", [(14, 1), (19, 2)])
+def test_d128_statement_computes_attention_under_the_weakest_memory_ordering(cfg128, T, seed):
+    pb = H.Problem(128, T, seed=seed)
+    ref = pb.reference()
+    for lazy_reads, lazy_dma in MODES:
+        out, t_exit, codes, n_inst, _ = H.run_statement(pb, cfg128, lazy_reads, lazy_dma)
+        groups = (T - 3 - 1) // 4                     # whole groups of four while t + 4 <= tend = T - 3, from t = 1
+        assert t_exit == 1 + 4 * groups and codes == [0, 0, 0, 0]
+        assert relerr(out, ref) < TOL, (lazy_reads, lazy_dma, relerr(out, ref))
+
+
+def test_d128_statement_re_entered_at_a_later_t_with_strided_panels(cfg128):
+    """the frame re-enters the statement at any t = 1 (mod 4) (after a refused tile): entry at t = 5 with the ring in the state
+    the straight loop leaves it in; K and Q rows with a different pitch (a [S, 3, D] tensor)"""
+    pb = H.Problem(128, 18, seed=3, q_rs=384, k_rs=384)
+    ref = pb.reference()
+    out, t_exit, codes, _, _ = H.run_statement(pb, cfg128, True, True, t0=5)
+    assert t_exit == 13 and codes == [0, 0, 0, 0]
+    assert relerr(out, ref) < TOL
+
+
+def test_d128_statement_leaves_with_code_1_when_a_row_sum_passes_2_to_the_80(cfg128):
+    """scores far above the offset the frame established on tile 0 (x 2^7 in one later tile's keys): the statement must refuse
+    that tile -- exit code 1 with t = the refused iteration, l and O untouched by it -- on every wave that sees it"""
+    pb = H.Problem(128, 14, seed=4)
+    pb.k[3 * 64:4 * 64] = H.bf16_round(pb.q[:64] * 40.0)          # tile 3's keys: aligned with queries 0..63, 40 x larger
+    pb.pack()
+    with np.errstate(all="ignore"):
+        _, t_exit, codes, _, _ = H.run_statement(pb, cfg128, True, True)
+    assert codes[0] == 1 and t_exit == 3, (codes, t_exit)
+
+
+MUTATIONS = {
+    "fragment wait one too loose": lambda L: _replace_nth(L, "s_waitcnt lgkmcnt(2)", "s_waitcnt lgkmcnt(4)", 40),
+    "DMA wait one too loose": lambda L: [("s_waitcnt vmcnt(12)" if ln == "s_waitcnt vmcnt(8)" else ln) for ln in L],
+    "no barrier": lambda L: [ln for ln in L if ln != "s_barrier"],
+    "K fragment from the wrong ring slot": lambda L: _replace_nth(L, "offset:32768", "offset:16384", 5),
+    "softmax reads the tile QK is writing": lambda L: _replace_nth(L, "v_fma_f32 v250, v52,", "v_fma_f32 v250, v116,", 2),
+}
+
+
+def _replace_nth(lines, old, new, n):
+    out, seen = [], 0
+    for ln in lines:
+        if old in ln:
+            seen += 1
+            if seen == n:
+                ln = ln.replace(old, new)
+        out.append(ln)
+    assert seen >= n, (old, seen)
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(MUTATIONS))
+def test_the_harness_sees_the_defects_it_is_there_for(cfg128, name):
+    pb = H.Problem(128, 14, seed=1)
+    ref = pb.reference()
+    worst = 0.0
+    for lazy_reads, lazy_dma in MODES:
+        try:
+            out, _, _, _, _ = H.run_statement(pb, cfg128, lazy_reads, lazy_dma, mutate=MUTATIONS[name])
+            e = relerr(out, ref)
+            worst = max(worst, e if np.isfinite(e) else 1.0)
+        except RuntimeError:          # deadlock / runaway: also a detection
+            worst = 1.0
+    assert worst > 10 * TOL, (name, worst)
+
+
+def _instructions(lines):
+    return [ln for ln in lines if not re.match(r"^\d+:$", ln)]
+
+
+def _regs(tok):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def test_static_hazard_rules_of_the_d128_statement(cfg128):
+    ins = _instructions(G.emit(cfg128))
+    # straight-line order is the worst case here: every backward branch re-enters at a point that follows MORE filler than this
+    mfma_at = [i for i, ln in enumerate(ins) if ln.startswith("v_mfma")]
+    # (1) XDL write of a VGPR block -> VALU read: at least two later MFMAs issued, or >= 18 wait states of s_nop, in between
+    for i in mfma_at:
+        dst = ins[i].split(None, 1)[1].split(",")[0].strip()
+        if not dst.startswith("v["):
+            continue
+        d = _regs(dst)
+        later_mfma, nops = 0, 0
+        for j in range(i + 1, min(i + 400, len(ins))):
+            t = ins[j]
+            if t.startswith("v_mfma"):
+                later_mfma += 1
+                if later_mfma >= 2:
+                    break
+                continue
+            if t.startswith("s_nop"):
+                nops += int(t.split()[1]) + 1
+            elif t.startswith(("v_", "ds_", "global_")):
+                src = t.split(None, 1)[1] if " " in t else ""
+                assert not (_regs(src) & d) or nops >= 18, (ins[i], t, later_mfma, nops)
+    # (2) transcendental result not read by the NEXT instruction; (3) M0; (4) VCC -> branch
+    for i, t in enumerate(ins[:-1]):
+        if t.startswith("v_exp_f32"):
+            dst = _regs(t.split(None, 1)[1].split(",")[0])
+            nxt = ins[i + 1]
+            if nxt.startswith("v_") and not nxt.startswith("v_mfma"):
+                srcs = nxt.split(None, 1)[1].split(",", 1)[1] if "," in nxt else ""
+                assert not (_regs(srcs) & dst), (t, nxt)
+        if t.startswith("s_add_u32 m0"):
+            assert not ins[i + 1].startswith("global_load_lds"), (t, ins[i + 1])
+        if t.startswith("v_cmp_"):
+            j, waits = i + 1, 0
+            while not ins[j].startswith("s_cbranch_vcc"):
+                waits += int(ins[j].split()[1]) + 1 if ins[j].startswith("s_nop") else 1
+                j += 1
+            assert waits >= 5, (t, ins[i:j + 1])
+    # (5) filler load of the steady state: the loop body between labels 11 and the loop-back branch
+    body = G.emit(cfg128)
+    a, b = body.index("11:"), body.index("s_cbranch_scc1 11b")
+    gaps, cur = [], 0
+    for ln in body[a + 1:b]:
+        if ln.startswith("v_mfma"):
+            gaps.append(cur)
+            cur = 0
+        elif not re.match(r"^\d+:$", ln):
+            cur += 1
+    n_mfma = len(gaps)
+    assert n_mfma == 4 * cfg128.n_mfma == 256
+    inner = [g for k, g in enumerate(gaps) if k % cfg128.n_mfma != 0]        # gaps inside an iteration (not the iteration boundary)
+    assert max(inner) <= 7 and sum(gaps) / n_mfma <= 5.0, (max(inner), sum(gaps) / n_mfma)
+
+
+def test_committed_inc_is_what_the_generator_emits(tmp_path, cfg128):
+    out = tmp_path / "attn128_q64_loop.inc"
+    G.write(cfg128, str(out))
+    assert out.read_bytes() == open(os.path.join(ROOT, "alg_amd", "csrc", "attn128_q64_loop.inc"), "rb").read()
