@@ -21,7 +21,7 @@ ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
 GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS, GEMM_GATE_F32, GEMM_GATE_SEG_STRIDE = 1, 4, 8, 16
 
 EXPORTS = (
-    "alg_version", "alg_last_error", "alg_reload_env", "alg_build_experiments", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16", "alg_gemm_bf16_pair", "alg_gemm_bf16_pair_qk",
+    "alg_version", "alg_last_error", "alg_reload_env", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16", "alg_gemm_bf16_pair", "alg_gemm_bf16_pair_qk",
     "alg_flash_attn_d64", "alg_layernorm_modulate", "alg_qk_norm_rope", "alg_patchify", "alg_unpatchify",
     "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128", "alg_layernorm_mod_f32", "alg_layernorm_mod_f32_fp8", "alg_rmsnorm_rope",
     "alg_wan_modulation", "alg_patchify3d", "alg_unpatchify3d", "alg_timestep_embedding_f32", "alg_linear_f32",
@@ -68,19 +68,18 @@ class VaeGeom(Structure):
 _lib = None
 
 
-def build_library(verbose=False, experiments=False):
-    """Compile libalg_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).  ``experiments=True`` builds the
-    EXPERIMENTS flavour next to it (alg_amd/libalg_hip_exp.so: shelved kernels + timing-only ablations, csrc/Makefile)."""
+def build_library(verbose=False):
+    """Compile libalg_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
     import subprocess
 
     src = os.path.join(_HERE, "csrc")
-    r = subprocess.run(["make", "-C", src, "-j8"] + (["EXPERIMENTS=1"] if experiments else []), capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", src, "-j8"], capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout[-4000:])
         print(r.stderr[-4000:])
     if r.returncode != 0:
         raise AlgHipError("building libalg_hip.so failed (see output above)")
-    return os.path.join(_HERE, "libalg_hip_exp.so") if experiments else LIB_PATH
+    return LIB_PATH
 
 
 def load_library():
@@ -97,7 +96,6 @@ def load_library():
     lib.alg_last_error.restype = c_char_p
     lib.alg_reload_env.restype = None
     lib.alg_reload_env.argtypes = []
-    lib.alg_build_experiments.argtypes = []
     lib.alg_down_up.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_int64, c_void_p]
     lib.alg_gaussian_blur.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int64,
@@ -185,11 +183,6 @@ def load_library():
 def reload_env():
     """The library reads its ALG_* options once, at load (include/alg_hip.h); call this after changing one in os.environ."""
     load_library().alg_reload_env()
-
-
-def experiments_build():
-    """True for a `make EXPERIMENTS=1` library (opt-in kernels and timing-only ablations compiled in)."""
-    return bool(load_library().alg_build_experiments())
 
 
 def _check(rc, what):

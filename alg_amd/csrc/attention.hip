@@ -53,9 +53,6 @@
 
 #include "common.h"
 #include "attn_pipe_loop.inc"
-#ifdef ALG_EXPERIMENTS
-#include "attn_pipe64_loop.inc"
-#endif
 
 namespace alg {
 
@@ -926,9 +923,6 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_pipe_kernel(const Attn
   }
 }
 
-#ifdef ALG_EXPERIMENTS
-#include "attention_experiments.inc"
-#endif
 
 // Workgroup-count quantisation (measured, scripts/attn_tail_probe.py): every XCD runs 64 workgroups at a time (32 CUs x
 // 2), a workgroup takes ~0.64 ms at S = 17,776, and a 2-sample C2 launch is 840 units per XCD = 13.125 rounds: the
@@ -952,17 +946,10 @@ static TailPlan plan_tail(int nbh, int q_blocks, int n_tiles) {
 }
 
 // 33 = the default (dot2 row sums + lazy running max); 1 = the exact-running-max reference (fp32 row sums) the parity tests
-// compare it with.  Every other number exists only in an EXPERIMENTS build (capi.hip accepts only {1, 33} otherwise).
+// compare it with (capi.hip accepts only {1, 33}).
 static int attn_variant() {
   const int v = opt(OPT_ATTN_VARIANT);
-#ifdef ALG_EXPERIMENTS
-  if (v >= 32 && v <= 36 && v != 35) return v;
-  if (v == 17 || v == 18 || v == 19 || v == 24) return v;  // ablations of the default kernel: WRONG RESULTS, timing only
-  if (v == 39 || v == 40) return v;                        // duo kernels with the lazy softmax (8 / 4 waves)
-  return (v < 0 || v > 16 || v == 10 || v == 11) ? 1 : v;
-#else
   return v == 1 ? 1 : 33;
-#endif
 }
 
 }  // namespace alg
@@ -971,33 +958,19 @@ using namespace alg;
 
 // Main launch of the pre-scaled form: 4 = the pipelined kernel, one 8-wave workgroup per 256-query unit (default since round 3:
 // asm steady-state loop, every MFMA followed by one score pair of the softmax), 0 = the straight loop (variant 41; same
-// softmax, fp32 summation order differs).  EXPERIMENTS builds add 3 (4-wave workgroups), 1 / 2 (ping-pong), 5 (64 queries
-// per wave) and the attention64_q64.hip main launch (ALG_ATTN64_Q64=1).
-#ifdef ALG_EXPERIMENTS
+// softmax, fp32 summation order differs); 6 = attention64_q64.hip (64 queries per wave), taken by flash_attn_d64_q64() before
+// this function is reached.
 namespace alg {
+// attention64_q64.hip: the 64-queries-per-wave statement kernel as the main launch (ALG_ATTN_PP=6); 1 = not covered
 int flash_attn_d64_q64(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S, int q_blocks,
                        int64_t q_bs, int64_t q_rs, int64_t vt_bs, int64_t vt_rs, int64_t o_bs, int64_t o_rs, unsigned blocks,
                        hipStream_t stream);
 }
-#else
-namespace alg {
-static inline int flash_attn_d64_q64(const void*, const void*, const void*, void*, int, int, int, int, int64_t, int64_t, int64_t,
-                                     int64_t, int64_t, int64_t, unsigned, hipStream_t) {
-  return 1;  // not covered: the caller launches the default kernel
-}
-}
-#endif
 static void launch_main41(dim3 g, dim3 blk, hipStream_t s, const alg::AttnP& p) {
   int pp = opt(OPT_ATTN_PP);
   // the pipelined statements address K / V^T / Q with 31-bit byte offsets from the (batch, head) panel bases
   if (pp >= 3 && ((int64_t)(p.S + 4 * alg::KVB) * p.q_rs * 2 >= (1ll << 31) || (int64_t)65 * p.vt_rs * 2 >= (1ll << 31))) pp = 0;
   switch (pp) {
-#ifdef ALG_EXPERIMENTS
-    case 1: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<42, 8>), g, blk, 0, s, p); break;
-    case 2: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<43, 8>), g, blk, 0, s, p); break;
-    case 3: hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel<4>, dim3(g.x * 2), dim3(256), 0, s, p); break;   // two 128-query workgroups per unit
-    case 5: hipLaunchKernelGGL(alg::flash_attn_d64_pipe64_kernel, g, dim3(256), 0, s, p); break;                // 64 queries per wave, one 4-wave workgroup per unit
-#endif
     case 4: hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel<8>, g, dim3(512), 0, s, p); break;             // the default: one 8-wave workgroup per unit
     default: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<41, 8>), g, blk, 0, s, p); break;
   }
@@ -1053,11 +1026,7 @@ extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* v
   p.q_bs = q_bstride; p.q_rs = q_rstride; p.vt_bs = vt_bstride; p.vt_rs = vt_rstride;
   p.o_bs = o_bstride; p.o_rs = o_rstride;
   p.scale_log2 = (flags & ALG_ATTN_Q_PRESCALED) ? 1.0f : scale * 1.4426950408889634f;  // m is in log2 units already
-#ifdef ALG_EXPERIMENTS
-  p.prio = opt(OPT_ATTN_PRIO);
-#else
   p.prio = 0;
-#endif
   p.clk = g_clock_tap.load(std::memory_order_acquire);
   p.clk_slots = p.clk ? g_clock_tap_slots.load(std::memory_order_relaxed) : 0;
   if (p.clk_slots <= 0) p.clk = nullptr;
@@ -1102,31 +1071,6 @@ extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* v
   switch (variant) {
     case 1: hipLaunchKernelGGL(flash_attn_d64_kernel<1>, g, blk, 0, s, p); break;
     case 41: launch_main41(g, blk, s, p); break;
-#ifdef ALG_EXPERIMENTS
-    case 0: hipLaunchKernelGGL(flash_attn_d64_kernel<0>, g, blk, 0, s, p); break;
-    case 2: hipLaunchKernelGGL(flash_attn_d64_kernel<2>, g, blk, 0, s, p); break;
-    case 3: hipLaunchKernelGGL(flash_attn_d64_lean_kernel<false>, g, blk, 0, s, p); break;
-    case 4: hipLaunchKernelGGL(flash_attn_d64_lean_kernel<true>, g, blk, 0, s, p); break;
-    case 5: hipLaunchKernelGGL((flash_attn_d64_kernel<1, 4>), g, blk, 0, s, p); break;
-    case 6: hipLaunchKernelGGL(flash_attn_d64_q64_kernel<8>, g, blk, 0, s, p); break;
-    case 7: hipLaunchKernelGGL(flash_attn_d64_q64_kernel<4>, g, blk, 0, s, p); break;
-    case 12: hipLaunchKernelGGL((flash_attn_d64_kernel<1, 16>), g, blk, 0, s, p); break;
-    case 13: hipLaunchKernelGGL((flash_attn_d64_kernel<13, 8>), g, blk, 0, s, p); break;
-    case 14: hipLaunchKernelGGL((flash_attn_d64_kernel<14, 8>), g, blk, 0, s, p); break;
-    case 32: hipLaunchKernelGGL((flash_attn_d64_kernel<32, 8>), g, blk, 0, s, p); break;
-    case 34: hipLaunchKernelGGL((flash_attn_d64_kernel<34, 8>), g, blk, 0, s, p); break;
-    case 36: hipLaunchKernelGGL((flash_attn_d64_kernel<36, 8>), g, blk, 0, s, p); break;
-    case 17: hipLaunchKernelGGL((flash_attn_d64_kernel<17, 8>), g, blk, 0, s, p); break;  // no DMA after tile 0   (WRONG RESULTS)
-    case 18: hipLaunchKernelGGL((flash_attn_d64_kernel<18, 8>), g, blk, 0, s, p); break;  // no LDS fragment reads (WRONG RESULTS)
-    case 19: hipLaunchKernelGGL((flash_attn_d64_kernel<19, 8>), g, blk, 0, s, p); break;  // neither               (WRONG RESULTS)
-    case 24: hipLaunchKernelGGL((flash_attn_d64_kernel<24, 8>), g, blk, 0, s, p); break;  // no per-tile wait + barrier (WRONG RESULTS)
-    case 15: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<8>, g, blk, 0, s, p); break;
-    case 39: hipLaunchKernelGGL((flash_attn_d64_duo_kernel<8, true>), g, blk, 0, s, p); break;
-    case 40: hipLaunchKernelGGL((flash_attn_d64_duo_kernel<4, true>), g, blk, 0, s, p); break;
-    case 16: hipLaunchKernelGGL(flash_attn_d64_duo_kernel<4>, g, blk, 0, s, p); break;
-    case 8: hipLaunchKernelGGL(flash_attn_d64_kv128_kernel<false>, g, blk, 0, s, p); break;
-    case 9: hipLaunchKernelGGL(flash_attn_d64_kv128_kernel<true>, g, blk, 0, s, p); break;
-#endif
     default: hipLaunchKernelGGL((flash_attn_d64_kernel<33, 8>), g, blk, 0, s, p); break;
   }
   return check_launch("alg_flash_attn_d64");

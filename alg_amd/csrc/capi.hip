@@ -34,34 +34,12 @@ struct OptDef {
 };
 static const OptDef g_defs[OPT_COUNT] = {
     {"ALG_ATTN_SPLIT_TAIL", 1, 2, {0, 1}},
-#ifdef ALG_EXPERIMENTS
-    {"ALG_ATTN_PP", 4, 0, {}},
-    {"ALG_ATTN_VARIANT", 33, 0, {}},
-#else
-    {"ALG_ATTN_PP", 4, 2, {0, 4}},
+    {"ALG_ATTN_PP", 4, 3, {0, 4, 6}},
     {"ALG_ATTN_VARIANT", 33, 2, {1, 33}},
-#endif
     {"ALG_ATTN128_PIPE", 1, 2, {0, 1}},
-#ifdef ALG_EXPERIMENTS
-    {"ALG_ATTN128_Q64", 1, 0, {}},
-#else
     {"ALG_ATTN128_Q64", 1, 3, {0, 1, 2}},
-#endif
-#ifdef ALG_EXPERIMENTS
-    {"ALG_GEMM_PIPE", 9, 0, {}},
-#else
     {"ALG_GEMM_PIPE", 9, 2, {6, 9}},
-#endif
     {"ALG_LOWPASS_PATH", 0, 0, {}},
-#ifdef ALG_EXPERIMENTS
-    {"ALG_ATTN_PRIO", 0, 2, {0, 1}},
-    {"ALG_ATTN64_Q64", 0, 2, {0, 1}},
-    {"ALG_GEMM_PERSIST", 1, 2, {0, 1}},
-    {"ALG_GEMM_GROUP_M", 0, 0, {}},
-    {"ALG_GEMM_ABLATE", 0, 0, {}},
-    {"ALG_LOWPASS_V3_WGS", 0, 0, {}},
-    {"ALG_LOWPASS_V3_THREADS", 0, 0, {}},
-#endif
 };
 static std::atomic<int> g_opt[OPT_COUNT];
 
@@ -93,12 +71,5 @@ int opt(Opt o) { return g_opt[o].load(std::memory_order_relaxed); }
 }  // namespace alg
 
 extern "C" void alg_reload_env(void) { alg::load_options(); }
-extern "C" int alg_build_experiments(void) {
-#ifdef ALG_EXPERIMENTS
-  return 1;
-#else
-  return 0;
-#endif
-}
 extern "C" int alg_version(void) { return ALG_VERSION; }
 extern "C" const char* alg_last_error(void) { return alg::g_err; }

@@ -16,11 +16,11 @@ int check_launch(const char* what);
 // Run-time options (capi.hip).  The environment is read ONCE, when the library is loaded; launch paths read an int from a
 // table and never call getenv.  A host that changes a variable afterwards calls alg_reload_env() (tests do).  Every option of
 // the default build selects between schedules that are bit-identical or documented equivalents (the names are in
-// capi.hip's table and in README.md); timing-only ablations and opt-in experimental kernels exist only in a
-// `make EXPERIMENTS=1` build (-DALG_EXPERIMENTS).
+// capi.hip's table and in README.md).
 enum Opt {
   OPT_ATTN_SPLIT_TAIL,  // ALG_ATTN_SPLIT_TAIL   1 (default) | 0: the d = 64 attention as a single launch (no split-KV tail)
-  OPT_ATTN_PP,          // ALG_ATTN_PP           4 (default: pipelined main launch) | 0: the straight loop
+  OPT_ATTN_PP,          // ALG_ATTN_PP           4 (8-wave pipelined main launch) | 6: the 64-queries-per-wave statement kernel
+                        //                       (attention64_q64.hip) | 0: the straight loop
   OPT_ATTN_VARIANT,     // ALG_ATTN_VARIANT      33 (default: lazy running max) | 1: exact running max, fp32 row sums
   OPT_ATTN128_PIPE,     // ALG_ATTN128_PIPE      1 (default: pipelined d = 128 kernel) | 0: the straight loop
   OPT_ATTN128_Q64,      // ALG_ATTN128_Q64       1 (default: 64-queries-per-wave kernel for >= 4,096 keys) | 2: for every call it can
@@ -28,15 +28,6 @@ enum Opt {
   OPT_GEMM_PIPE,        // ALG_GEMM_PIPE         9 (default) | 6: the 8-wave ping-pong schedule (bit-identical results)
   OPT_LOWPASS_PATH,     // ALG_LOWPASS_PATH      0 auto | 1 plane-per-workgroup | 2 lowpass_v2 | 3 lowpass_v3 at any plane
                         //                       count | 4 global-memory passes (all bit-identical)
-#ifdef ALG_EXPERIMENTS
-  OPT_ATTN_PRIO,        // ALG_ATTN_PRIO         static s_setprio 1 for the younger half of an 8-wave workgroup
-  OPT_ATTN64_Q64,       // ALG_ATTN64_Q64        64-queries-per-wave d = 64 main launch (attention64_q64.hip)
-  OPT_GEMM_PERSIST,     // ALG_GEMM_PERSIST      0: one workgroup per tile
-  OPT_GEMM_GROUP_M,     // ALG_GEMM_GROUP_M      tile-order group override
-  OPT_GEMM_ABLATE,      // ALG_GEMM_ABLATE       timing-only ablation bits (WRONG RESULTS)
-  OPT_LOWPASS_V3_WGS,   // ALG_LOWPASS_V3_WGS    resident-workgroup cap of the persistent filter grid
-  OPT_LOWPASS_V3_THREADS,  // ALG_LOWPASS_V3_THREADS  256 | 512 | 1024
-#endif
   OPT_COUNT
 };
 int opt(Opt o);

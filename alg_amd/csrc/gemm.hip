@@ -6,11 +6,6 @@
 
 namespace alg {
 constexpr int BM = 256, BN = 256;
-#ifdef ALG_EXPERIMENTS
-int launch_gemm_p0(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
-int launch_gemm_p7(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
-int launch_gemm_p8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
-#endif
 int launch_gemm_p6(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p9(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p9_pair(const alg_gemm_args* a, int m_tiles_a, int n_tiles_a, const alg_gemm_args* b, int m_tiles_b, int n_tiles_b,
@@ -22,7 +17,7 @@ int launch_gemm_p9_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t
 int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 // ALG_GEMM_PIPE: 9 (default: 4 waves, asm main loop; round 3: faster than the 8-wave ping-pong on all five C2 shapes) | 6 (the
 // 8-wave ping-pong; bit-identical results).  Calls schedule 9 cannot take (K < 128, byte offsets past 32 bits) and the fp8 /
-// convolution operands run schedule 6.  EXPERIMENTS builds also know 0, 7, 8.
+// convolution operands run schedule 6.
 static int gemm_pipe() { return opt(OPT_GEMM_PIPE); }
 }  // namespace alg
 
@@ -136,11 +131,6 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8, bool valid
   }
   if (a->conv_wp) return launch_gemm_p6_conv(a, m_tiles, n_tiles, nwg, s);
   switch (gemm_pipe()) {
-#ifdef ALG_EXPERIMENTS
-    case 0: return launch_gemm_p0(a, m_tiles, n_tiles, nwg, s);   // 2-stage ring, 8 waves
-    case 7: return launch_gemm_p7(a, m_tiles, n_tiles, nwg, s);   // 4 waves, every memory op behind an MFMA
-    case 8: return launch_gemm_p8(a, m_tiles, n_tiles, nwg, s);   // 4 waves, 4-stage BK = 32 ring, never drains
-#endif
     case 9:   // 4 waves, hand-written asm main loop; needs two k-tiles and 32-bit byte offsets inside a 256-row panel
       if (a->K >= 128 && 256 * a->lda * 2 + (int64_t)a->K * 2 < (1ll << 32) && 256 * a->ldb * 2 + (int64_t)a->K * 2 < (1ll << 32))
         return launch_gemm_p9(a, m_tiles, n_tiles, nwg, s);

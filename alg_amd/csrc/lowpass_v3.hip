@@ -495,12 +495,7 @@ static int64_t min_planes() { return opt(OPT_LOWPASS_PATH) == 3 ? 1 : num_cus() 
 static bool v3_off() { return opt(OPT_LOWPASS_PATH) == 2; }                               // ALG_LOWPASS_PATH=2: lowpass_v2.hip
 
 static int wgs_cap() {   // EXPERIMENTS tuning knob: resident workgroups per CU the persistent grid is sized for
-#ifdef ALG_EXPERIMENTS
-  const int v = opt(OPT_LOWPASS_V3_WGS);
-  return v > 0 ? v : 1 << 20;
-#else
   return 1 << 20;
-#endif
 }
 
 // Workgroups of `kernel` a CU really holds (registers AND LDS): the persistent grid must not be larger than that, or the
@@ -517,12 +512,7 @@ static int resident_wgs(K kernel, int nt, size_t lds) {
 }
 
 static int threads_override() {
-#ifdef ALG_EXPERIMENTS
-  const int v = opt(OPT_LOWPASS_V3_THREADS);
-  return (v == 256 || v == 512 || v == 1024) ? v : 0;
-#else
   return 0;
-#endif
 }
 
 // per kernel instantiation: raise the LDS limit when needed and ask the runtime how many workgroups a CU holds; both are

@@ -66,6 +66,11 @@ v = lambda i: "v%d" % i
 vr = lambda i, n: "v[%d:%d]" % (i, i + n - 1)
 ar = lambda i, n: "a[%d:%d]" % (i, i + n - 1)
 AHEAD = 4          # fragment reads in flight ahead of the fragment being multiplied
+# timing-only experiment knobs (WRONG RESULTS; never set for the committed .inc): "noadd" drops the row-sum adds, "ones" issues the
+# MFMAs a ones-row of V^T would cost, "nofma" (d = 128) generates the pre-scaled zero-offset form behind the unchanged frame
+EXP = set(filter(None, os.environ.get("ATTN_Q64_EXP", "").split(",")))
+DMA_STRIDE = int(os.environ.get("ATTN_Q64_DMA_STRIDE", "2"))    # a DMA piece every DMA_STRIDE-th gap (M0 write, then the load one gap later)
+DMA_SHIFT = int(os.environ.get("ATTN_Q64_DMA_SHIFT", "0"))      # first gap that carries a DMA half
 
 
 def frag_read(c, buf, which, slot, half, step):
@@ -97,6 +102,8 @@ def softmax_stream(c, S, P):
         if first_sum[qh]:
             first_sum[qh] = False
             return "v_mov_b32 %s, %s" % (v(c.TS[qh]), v(reg))
+        if "noadd" in EXP:
+            return None
         return "v_add_f32 %s, %s, %s" % (v(c.TS[qh]), v(c.TS[qh]), v(reg))
 
     def fma(dst, src, qh):
@@ -123,7 +130,8 @@ def softmax_stream(c, S, P):
         groups.append(g)
     _, qp, pp = pair_regs(c, S, 31)
     post = ["s_nop 1", "v_cvt_pk_bf16_f32 %s, %s, %s" % (v(P + pp), v(c.EA[1]), v(c.EB[1])), add(qp, c.EB[1])]
-    return pre, groups, post
+    groups = [[x for x in g if x is not None] for g in groups]
+    return pre, groups, [x for x in post if x is not None]
 
 
 def top_protocol(c, phase):
@@ -133,6 +141,10 @@ def top_protocol(c, phase):
     of an s_nop."""
     ks, vs = (phase + 3) & 3, (phase + 2) & 3
     head = ["s_waitcnt vmcnt(%d)" % c.NP, "s_barrier"]
+    if "nobarrier" in EXP:
+        head = head[:1]
+    if "nowait" in EXP:
+        head = []
     pieces = []
     for r in range(c.NP // 2):
         pieces.append(("s_add_u32 m0, %%[wk], %d" % (ks * c.TILE + r * 4096),
@@ -140,6 +152,10 @@ def top_protocol(c, phase):
     for r in range(c.NP // 2):
         pieces.append(("s_add_u32 m0, %%[wv], %d" % (vs * c.TILE + r * 4096),
                        ["global_load_lds_dwordx4 %%[vvo%d], %%[vb]" % r, "v_add_u32 %%[vvo%d], 0x80, %%[vvo%d]" % (r, r)]))
+    if "nodma" in EXP:
+        pieces = []
+    elif "dmasalu" in EXP:      # EXPERIMENT: the offset advance on the scalar unit is not modelled; drop the per-piece v_add (timing only)
+        pieces = [(m0, rest[:1]) for m0, rest in pieces]
     return head, pieces
 
 
@@ -185,60 +201,73 @@ def first_reads(c, phase):
 def iteration(c, phase, X, Y, U, W, pv=True, softmax=True, qk=True, reads_in_flight=0, prefetch_next=None, dma=None):
     """one iteration at ring phase t & 3 == phase.  X: S(t) (read by the softmax), Y: S(t+1) (written by QK), U: P(t-1) (PV's B
     operand), W: P(t) (written by the softmax).  reads_in_flight: how many of its first fragment reads the caller has issued.
-    MFMA gap g (the instructions behind MFMA g): the fragment read that reuses a ring buffer (odd g: behind the second MFMA of a
-    fragment), half a DMA piece (even g: M0, odd g: the LDS-DMA and its offset advance), one half-pair group of the softmax.
-    Fragment waits: one counted lgkmcnt per TWO fragments (reads run four fragments ahead: lgkmcnt(2) in front of fragment j
-    leaves j + 2, j + 3 in flight)."""
+    MFMA gap g (the instructions behind MFMA g): the fragment read that reuses a ring buffer (behind the second MFMA of a
+    fragment), half a DMA piece (even g: M0, odd g: the LDS-DMA and its offset advance), its share of the softmax's half-pair
+    groups (spread evenly over the gaps).  Fragment waits: one counted lgkmcnt per TWO fragments (reads run four fragments ahead:
+    lgkmcnt(2) in front of fragment j leaves j + 2, j + 3 in flight)."""
     kslot, vslot = (phase + 1) & 3, (phase - 1) & 3
     fr = frag_order(c, pv, qk)
     n_f = len(fr)
     assert n_f % 2 == 0
-    lines = []
 
     def read(j):
         kind, half, step = fr[j]
         return frag_read(c, j % 8, kind, kslot if kind == "k" else vslot, half, step)
 
-    for j in range(reads_in_flight, min(AHEAD, n_f)):
-        lines.append(read(j))
-    groups, post = [], []
-    if softmax:
-        _, groups, post = softmax_stream(c, X, W)
-    per_gap = -(-len(groups) // (2 * n_f)) if softmax else 0          # 1 in the steady state, 2 in the warm-up (half the MFMAs)
-    gi = 0
-    seen = set()
+    head = [read(j) for j in range(reads_in_flight, min(AHEAD, n_f))]
     nxt = first_reads(c, prefetch_next) if prefetch_next is not None else None
-    gap = 0
+    # ---- the MFMA stream: (instructions in front, the MFMA, the read behind it) ----
+    stream, seen = [], set()
     for j, (kind, half, step) in enumerate(fr):
+        pre = []
         if j % 2 == 0:
             issued = (n_f + AHEAD if nxt is not None else n_f) - 1           # index of the last read that will ever be issued
             younger = min(j + AHEAD - 1, issued) - (j + 1)                   # reads issued behind read j + 1 at this point
-            lines.append("s_waitcnt lgkmcnt(%d)" % max(younger, 0))
+            pre.append("s_waitcnt lgkmcnt(%d)" % max(younger, 0))
         frag = ar(c.FR + 4 * (j % 8), 4)
         for qh in range(2):
             if kind == "k":
                 acc = vr(Y + (half * 2 + qh) * 16, 16)
                 cin = acc if (half, qh) in seen else "0"
                 seen.add((half, qh))
-                lines.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, frag, ar(c.QA + (qh * c.KS + step) * 4, 4), cin))
+                text = "v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, frag, ar(c.QA + (qh * c.KS + step) * 4, 4), cin)
             else:
                 acc = "%%[o%d]" % (qh * c.DT + half)
-                lines.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, frag, vr(U + qh * 16 + step * 4, 4), acc))
+                text = "v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, frag, vr(U + qh * 16 + step * 4, 4), acc)
+            behind = []
             if qh == 1:      # the fragment's buffer is free again four fragments from now: the read that reuses it
                 if j + AHEAD < n_f:
-                    lines.append(read(j + AHEAD))
+                    behind.append(read(j + AHEAD))
                 elif nxt is not None:
-                    lines.append(nxt[j + AHEAD - n_f])
-            piece = dma[gap // 2] if dma and gap // 2 < len(dma) else None
-            if piece and gap % 2 == 0:
-                lines.append(piece[0])
-            for _ in range(per_gap):
-                if gi < len(groups):
-                    lines += groups[gi]
-                    gi += 1
-            if piece and gap % 2 == 1:
-                lines += piece[1]
-            gap += 1
+                    behind.append(nxt[j + AHEAD - n_f])
+            stream.append((pre if qh == 0 else [], text, behind))
+            if "ones" in EXP and kind == "v" and qh == 1 and half == c.DT - 1:
+                # EXPERIMENT (timing only): the row sums on the matrix pipe -- one more MFMA per (kv block, query half) with P as
+                # the B operand, as a ones-row of V^T would cost
+                for q2 in range(2):
+                    acc = ar(c.AEND + 16 * q2, 16)
+                    stream.append(([], "v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, ar(c.QA, 4), vr(U + q2 * 16 + step * 4, 4), acc), []))
+    # ---- the softmax's groups, spread evenly over the gaps ----
+    groups, post = [], []
+    if softmax:
+        _, groups, post = softmax_stream(c, X, W)
+    n_m = len(stream)
+    lines = list(head)
+    gi = 0
+    for g, (pre, text, behind) in enumerate(stream):
+        lines += pre
+        lines.append(text)
+        lines += behind
+        gg = g - DMA_SHIFT
+        piece = dma[gg // DMA_STRIDE] if dma and gg >= 0 and gg % DMA_STRIDE < 2 and gg // DMA_STRIDE < len(dma) else None
+        if piece and gg % DMA_STRIDE == 0:
+            lines.append(piece[0])
+        upto = (g + 1) * len(groups) // n_m
+        while gi < upto:
+            lines += groups[gi]
+            gi += 1
+        if piece and gg % DMA_STRIDE == 1:
+            lines += piece[1]
     assert gi == len(groups)
     return lines + post
 
@@ -304,7 +333,7 @@ def write(c, path):
         for ln in lines:
             f.write('  "%s\\n\\t" \\\n' % ln)
         f.write('  ""\n')
-        regs = ["a%d" % i for i in range(c.QA, c.AEND)] + ["v%d" % i for i in range(c.VB, c.VEND)]
+        regs = ["a%d" % i for i in range(c.QA, c.AEND + (32 if "ones" in EXP else 0))] + ["v%d" % i for i in range(c.VB, c.VEND)]
         f.write("#define ALG_%s_CLOBBERS \\\n  " % c.name + ", ".join('"%s"' % r for r in regs) + "\n")
         f.write("#define ALG_%s_O_OPERANDS(o) \\\n  " % c.name + ", ".join('[o%d] "+a"(o[%d])' % (i, i) for i in range(c.NO)) + "\n")
     return lines
@@ -313,7 +342,7 @@ def write(c, path):
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     out128 = os.environ.get("ATTN128_Q64_OUT") or os.path.join(here, "..", "alg_amd", "csrc", "attn128_q64_loop.inc")
-    lines = write(Cfg(128, fma=True), out128)
+    lines = write(Cfg(128, fma="nofma" not in EXP), out128)
     print("wrote", os.path.normpath(out128), len(lines), "lines,", sum(1 for l in lines if l.startswith("v_mfma")), "MFMAs")
     out64 = os.environ.get("ATTN64_Q64_OUT") or os.path.join(here, "..", "alg_amd", "csrc", "attn64_q64_loop.inc")
     lines = write(Cfg(64, fma=False), out64)

@@ -47,16 +47,6 @@ def _alg_env_follows_monkeypatch(monkeypatch):
 
 
 @pytest.fixture(scope="session")
-def experiments():
-    """Skip unless the loaded library is the `make EXPERIMENTS=1` build (ALG_HIP_LIB=alg_amd/libalg_hip_exp.so): opt-in
-    kernels, shelved schedules and the timing-only ablations do not exist in the default library."""
-    from alg_amd import _lib
-    if not _lib.experiments_build():
-        pytest.skip("needs the EXPERIMENTS build: ALG_HIP_LIB=alg_amd/libalg_hip_exp.so")
-    return True
-
-
-@pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
 

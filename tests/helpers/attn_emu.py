@@ -25,15 +25,19 @@ def bf16_round(x):
 
 
 class Problem:
-    def __init__(self, d, T, seed=0, q_rs=None, k_rs=None, score_scale=1.0):
+    def __init__(self, d, T, seed=0, q_rs=None, k_rs=None, score_scale=1.0, prescaled=False):
+        """prescaled: Q carries scale * log2(e) already (the d = 64 frame: alg_qk_norm_rope_scaled), scores arrive in log2 units
+        and the statement runs with a ZERO offset (no subtraction at all)"""
         rng = np.random.default_rng(seed)
         self.d, self.T, self.Skv, self.Sq = d, T, T * KVB, 256
         self.q_rs, self.k_rs = q_rs or 2 * d, k_rs or 2 * d          # row pitches in elements (a [S, 2, d] qk tensor by default)
         self.vt_rs = self.Skv + 64
-        self.q = bf16_round(rng.standard_normal((self.Sq, d)) * score_scale)
+        c_true = 1.0 / np.sqrt(d) * 1.4426950408889634
+        self.prescaled = prescaled
+        self.q = bf16_round(rng.standard_normal((self.Sq, d)) * score_scale * (c_true if prescaled else 1.0))
         self.k = bf16_round(rng.standard_normal((self.Skv, d)))
         self.v = bf16_round(rng.standard_normal((self.Skv, d)))
-        self.c = np.float32(1.0 / np.sqrt(d) * 1.4426950408889634)
+        self.c = np.float32(1.0 if prescaled else c_true)           # what one raw score unit is worth in log2 units
         # global memory: Q panel, K panel, V^T panel (permuted columns), each at an odd offset to catch base mix-ups
         self.QOFF, self.KOFF = 4096, 4096 + 2 * self.Sq * self.q_rs + 512
         self.VOFF = self.KOFF + 2 * (self.Skv + 4 * KVB) * self.k_rs + 1024
@@ -55,9 +59,27 @@ class Problem:
         self.gmem = g16.view(np.uint8)
 
     def reference(self):
-        s = self.q.astype(np.float64) @ self.k.astype(np.float64).T * (1.0 / np.sqrt(self.d))
-        p = np.exp(s - s.max(axis=1, keepdims=True))
+        s = self.q.astype(np.float64) @ self.k.astype(np.float64).T * float(self.c)      # log2 units
+        p = np.exp2(s - s.max(axis=1, keepdims=True))
         return (p / p.sum(axis=1, keepdims=True)) @ self.v.astype(np.float64)
+
+
+def k_dma_lane(d, tid, i):
+    """(K row within the tile, LOGICAL 16-byte slot of that row) thread `tid` fetches in DMA piece i -- the frames' stage_k:
+    d = 128: 256-byte rows, 16 slots, 16 rows per piece, physical slot p holds logical p ^ (row & 15);
+    d = 64:  128-byte rows, 8 slots, 32 rows per piece, physical slot p holds logical p ^ ((row >> 1) & 7)"""
+    if d == 128:
+        row = (tid >> 4) + 16 * i
+        return row, (tid & 15) ^ (row & 15)
+    row = (tid >> 3) + 32 * i
+    return row, (tid & 7) ^ ((row >> 1) & 7)
+
+
+def k_frag_addr(d, l31, h2, ks):
+    """byte offset (inside a K tile, sub-tile 0) of the fragment lane (l31, h2) reads for k-step ks"""
+    if d == 128:
+        return l31 * 256 + (((2 * ks + h2) ^ (l31 & 15)) * 16)
+    return l31 * 128 + (((2 * ks + h2) ^ ((l31 >> 1) & 7)) * 16)
 
 
 def lane_ctx(wave, lane):
@@ -73,9 +95,7 @@ def stage(pb, lds, cfg, which, tile, slot_base):
             l31, h2, tid = lane_ctx(wave, lane)
             for i in range(cfg.NP // 2):
                 if which == "k":
-                    slots = d * 2 // 16                                                        # 16-byte slots per K row
-                    row = tid // slots + (256 // slots) * i
-                    slot = (tid % slots) ^ (row % slots)
+                    row, slot = k_dma_lane(d, tid, i)
                     src = pb.KOFF + ((tile * KVB + row) * pb.k_rs + slot * 8) * 2
                 else:
                     row = tid // 8 + 32 * i
@@ -107,11 +127,11 @@ def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None):
         ns += n
     for i in range(cfg.NO):
         tab["o%d" % i] = "a[%d:%d]" % (16 * i, 16 * i + 15)
-    for n in ["l0", "l1", "negmc0", "negmc1", "qvo0", "qvo1"] + ["lk%d" % i for i in range(cfg.KS)] + ["lv%d" % i for i in range(4)] + \
+    for n in ["l0", "l1"] + (["negmc0", "negmc1"] if cfg.fma else []) + ["qvo0", "qvo1"] + ["lk%d" % i for i in range(cfg.KS)] + ["lv%d" % i for i in range(4)] + \
              ["kvo%d" % i for i in range(cfg.NP // 2)] + ["vvo%d" % i for i in range(cfg.NP // 2)]:
         vreg(n)
     assert nv <= cfg.VB
-    for n in ("t", "code", "c", "kstep", "tend", "wk", "wv"):
+    for n in ("t", "code") + (("c",) if cfg.fma else ()) + ("kstep", "tend", "wk", "wv"):
         sreg(n)
     for n in ("kb", "vb", "qb"):
         sreg(n, 2)
@@ -120,6 +140,8 @@ def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None):
     qf, kf, vf = pb.q.astype(np.float64), pb.k.astype(np.float64), pb.v.astype(np.float64)
     s_all = qf @ kf.T                                       # raw scores [Sq, Skv]
     m_run = s_all[:, :KVB].max(axis=1)                      # the frame takes tile 0's maximum as the (lazy) offset
+    if not cfg.fma:
+        m_run = np.zeros(pb.Sq)                             # pre-scaled zero-offset form: p = exp2(s)
     def probs(t):
         return bf16_round(np.exp2((s_all[:, t * KVB:(t + 1) * KVB] - m_run[:, None]) * float(c))).astype(np.float64)
     def fsum(t):
@@ -141,27 +163,26 @@ def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None):
             w.s[r[1]], w.s[r[1] + 1] = np.uint32(int(val) & 0xFFFFFFFF), np.uint32(int(val) >> 32)
     def vset(w, name, arr):
         w.v[asm_emu.parse_reg(tab[name])[1]] = np.asarray(arr).astype(np.int64).astype(np.uint32) if np.asarray(arr).dtype != np.float32 else np.asarray(arr).view(np.uint32)
-    slots_k = d * 2 // 16
     for w in m.waves:
         lane = np.arange(64)
         l31, h2, tid = lane & 31, lane >> 5, w.id * 64 + lane
         q_row = w.id * 64 + l31
         sset(w, "t", t0), sset(w, "tend", tend), sset(w, "kstep", KVB * pb.k_rs * 2)
-        sset(w, "c", int(np.float32(c).view(np.uint32)))
+        if cfg.fma:
+            sset(w, "c", int(np.float32(c).view(np.uint32)))
         sset(w, "wk", KL + w.id * 1024), sset(w, "wv", VL + w.id * 1024)
         sset(w, "kb", pb.KOFF), sset(w, "vb", pb.VOFF), sset(w, "qb", pb.QOFF)
         for qh in range(2):
             vset(w, "qvo%d" % qh, ((q_row + 32 * qh) * pb.q_rs + h2 * 8) * 2)
-            vset(w, "negmc%d" % qh, (-(m_run[q_row + 32 * qh]) * float(c)).astype(np.float32))
+            if cfg.fma:
+                vset(w, "negmc%d" % qh, (-(m_run[q_row + 32 * qh]) * float(c)).astype(np.float32))
             vset(w, "l%d" % qh, np.where(h2 == 0, l[q_row + 32 * qh], 0.0).astype(np.float32))   # tile sums so far: all in lane h2 = 0
-        k_row_off, k_sw = l31 * (d * 2), l31 % slots_k
         for ks in range(cfg.KS):
-            vset(w, "lk%d" % ks, KL + k_row_off + (((2 * ks + h2) ^ k_sw) * 16))
+            vset(w, "lk%d" % ks, KL + k_frag_addr(d, l31, h2, ks))
         for kk in range(4):
             vset(w, "lv%d" % kk, VL + l31 * 128 + (((2 * kk + h2) ^ ((l31 >> 1) & 7)) * 16))
         for i in range(cfg.NP // 2):
-            row = tid // slots_k + (256 // slots_k) * i
-            slot = (tid % slots_k) ^ (row % slots_k)
+            row, slot = k_dma_lane(d, tid, i)
             vset(w, "kvo%d" % i, (((t0 + 3) * KVB + row) * pb.k_rs + slot * 8) * 2)
             vrow, vslot = tid // 8 + 32 * i, (tid & 7) ^ ((tid >> 4) & 7)
             vset(w, "vvo%d" % i, (vrow * pb.vt_rs + vslot * 8 + (t0 + 2) * KVB) * 2)

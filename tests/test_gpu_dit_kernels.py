@@ -26,25 +26,17 @@ def rel_err(got, ref):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.fixture(params=["9", "8", "7", "6", "0"],
-                ids=["4waves-asm-loop", "4waves-bk32-ring", "4waves-interleaved", "pingpong-halftiles", "dbufBK64"])
+@pytest.fixture(params=["9", "6"], ids=["4waves-asm-loop", "pingpong-halftiles"])
 def gemm_pipe(request, monkeypatch):
-    """Every GEMM test runs on every built schedule (9 = the default since round 3; 6 = the fp8 / convolution schedule and the
-    default library's bit-identity reference; 8 / 7 / 0 exist in the EXPERIMENTS build only: skipped on the default library)."""
-    if request.param not in ("9", "6"):
-        request.getfixturevalue("experiments")
+    """Every GEMM test runs on both built schedules (9 = the default since round 3; 6 = the fp8-small-K / convolution schedule and
+    the bit-identity reference)."""
     monkeypatch.setenv("ALG_GEMM_PIPE", request.param)
     return request.param
 
 
-def _exp():
-    return _lib.experiments_build()
-
-
 def _variant(request, monkeypatch, variant):
-    """ALG_ATTN_VARIANT: 33 (default) and 1 (exact running max) are the product's; everything else needs the EXPERIMENTS build."""
-    if variant not in ("1", "33"):
-        request.getfixturevalue("experiments")
+    """ALG_ATTN_VARIANT: 33 (default) and 1 (exact running max)."""
+    assert variant in ("1", "33")
     monkeypatch.setenv("ALG_ATTN_VARIANT", variant)
 
 
@@ -300,12 +292,12 @@ def test_qk_norm_rope_scaled_and_prescaled_attention(device):
 
 @pytest.mark.parametrize("Bn,S2,H2", [(1, 512, 2), (2, 1000, 3), (1, 513, 1), (1, 575, 2), (1, 640, 1), (1, 700, 2), (1, 832, 1),
                                        (1, 2050, 2), (8, 1200, 1)])
-def test_flash_attention_d64_q64_kernel(device, monkeypatch, experiments, Bn, S2, H2):
-    """attention64_q64.hip (64 queries per wave; OPT-IN with ALG_ATTN64_Q64=1 for pre-scaled calls over >= 8 KV tiles: slower than
-    the default at d = 64, kept as the measured A/B reference) against fp32 SDPA and against attention.hip's 32-query kernel
-    (ALG_ATTN64_Q64=0) on the same tensors: ragged tails (second half-tile partly / wholly
-    masked), 0-3 tiles left to the runtime-slot remainder, rows whose first-tile max is beyond +-64 (non-zero offset: the
-    subtracting form) next to rows in the zero-offset form, late dominant keys (exact rescale path), query blocks ending
+def test_flash_attention_d64_q64_kernel(device, monkeypatch, Bn, S2, H2):
+    """attention64_q64.hip (64 queries per wave, the generated statement attn64_q64_loop.inc behind a C++ frame; ALG_ATTN_PP=6 for
+    pre-scaled calls over >= 12 KV tiles) against fp32 SDPA and against attention.hip's 8-wave 32-query kernel (ALG_ATTN_PP=4)
+    on the same tensors: ragged tails, tile counts that leave 0-3 tiles behind the statement's groups of four, rows whose
+    first-tile max is beyond +-64 (non-zero offset: those waves never enter the statement) next to rows in the zero-offset form,
+    late dominant keys (the statement refuses the tile, the exact path runs, the statement is RE-ENTERED), query blocks ending
     mid-wave; 8 x 1 heads = enough units for the split-KV tail plan to engage next to the q64 main launch."""
     g = torch.Generator().manual_seed(S2 + H2)
     c = 0.125 * 1.4426950408889634
@@ -324,8 +316,8 @@ def test_flash_attention_d64_q64_kernel(device, monkeypatch, experiments, Bn, S2
     vt[:, :, torch.tensor([swap23(n) for n in range(S2)])] = v.reshape(Bn, S2, D).transpose(1, 2)
     vt = vt.to(device)
     outs, errs = {}, {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("ALG_ATTN64_Q64", flag)
+    for flag in ("6", "4"):
+        monkeypatch.setenv("ALG_ATTN_PP", flag)
         o = torch.full((Bn, S2, D), 3.0, dtype=BF, device=device)
         _lib.flash_attn_d64(qkb, qkb, vt, o, Bn, H2, S2, S2 * 2 * D, 2 * D, D * S_pad, S_pad, S2 * D, D, 0.125, k_off=D,
                             q_prescaled=True)
@@ -333,14 +325,14 @@ def test_flash_attention_d64_q64_kernel(device, monkeypatch, experiments, Bn, S2
         got = o.cpu().reshape(Bn, S2, H2, 64).double()
         assert torch.isfinite(got).all(), flag
         errs[flag] = ((got - ref).abs().max().item(), (got - ref).abs().mean().item())
-    assert errs["0"][0] <= 3e-2 and errs["0"][1] <= 2e-3, errs
-    assert errs["1"][0] <= 3e-2 and errs["1"][1] <= 2e-3, errs
-    assert (outs["1"].float() - outs["0"].float()).abs().max().item() <= 3.2e-2
-    monkeypatch.setenv("ALG_ATTN64_Q64", "1")
-    o2 = torch.empty_like(outs["1"])
+    assert errs["4"][0] <= 3e-2 and errs["4"][1] <= 2e-3, errs
+    assert errs["6"][0] <= 3e-2 and errs["6"][1] <= 2e-3, errs
+    assert (outs["6"].float() - outs["4"].float()).abs().max().item() <= 3.2e-2
+    monkeypatch.setenv("ALG_ATTN_PP", "6")
+    o2 = torch.empty_like(outs["6"])
     _lib.flash_attn_d64(qkb, qkb, vt, o2, Bn, H2, S2, S2 * 2 * D, 2 * D, D * S_pad, S_pad, S2 * D, D, 0.125, k_off=D,
                         q_prescaled=True)
-    assert torch.equal(o2, outs["1"])
+    assert torch.equal(o2, outs["6"])
 
 
 def test_patchify_unpatchify_timestep(device):
@@ -379,8 +371,8 @@ def test_pingpong_gemm_race_screen(monkeypatch):
         a = torch.randn(M, K, generator=g, device="cuda").to(BF)
         w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(BF)
         outs = {}
-        base = "0" if _exp() else "6"          # the drain-and-barrier schedule exists in the EXPERIMENTS build only
-        for pipe in ((base, "6", "6", "9", "9", "9") + (("8", "8") if _exp() else ())):
+        base = "6"          # the 8-wave ping-pong schedule: the bit-identity reference
+        for pipe in (base, "6", "6", "9", "9", "9"):
             monkeypatch.setenv("ALG_GEMM_PIPE", pipe)
             c = torch.empty(M, N, dtype=BF, device="cuda")
             _lib.gemm(a, w, c, M, N, K, K, K, N)
@@ -388,8 +380,6 @@ def test_pingpong_gemm_race_screen(monkeypatch):
                 assert torch.equal(c, outs[base]), (M, N, K)
             outs.setdefault(pipe, c)
         assert torch.equal(outs["6"], outs[base]) and torch.equal(outs["9"], outs[base]), (M, N, K)
-        if _exp():
-            assert torch.equal(outs["8"], outs["0"]), (M, N, K)
 
 
 @pytest.mark.parametrize("S,D,N", [(17776, 3072, 2), (300, 512, 3), (1000, 256, 1), (257, 128, 2)])
@@ -525,35 +515,11 @@ def test_schedule9_equals_the_drain_and_barrier_schedule_bit_for_bit(monkeypatch
             _lib.gemm(a, w, x, M, N, K, K, K, N, bias=bias, R=x, ldr=N, **kw)
             return x
 
-        monkeypatch.setenv("ALG_GEMM_PIPE", "0" if _exp() else "6")   # default library: the ping-pong schedule 6 (== 0 bitwise)
+        monkeypatch.setenv("ALG_GEMM_PIPE", "6")   # the ping-pong schedule
         want = run()
         monkeypatch.setenv("ALG_GEMM_PIPE", "9")
         for _ in range(2):
             assert torch.equal(run(), want), (form, M, N, K)
-
-
-@pytest.mark.parametrize("S", [64, 100, 1000, 4097])
-def test_pingpong_attention_equals_the_straight_loop_bit_for_bit(monkeypatch, experiments, S):
-    """ALG_ATTN_PP=1/2 (flash_attn_d64_kernel<42/43>): the same per-wave arithmetic as the default pre-scaled kernel with the
-    two waves of a SIMD half a tile apart -- only the order of phases ACROSS waves differs, so the output bits must not."""
-    H, D, N = 6, 64, 2
-    s_pad = (S + 127) // 128 * 128
-    g = torch.Generator(device="cuda").manual_seed(S)
-    qk = (torch.randn(N, S, 2 * H * D, generator=g, device="cuda") * 0.5).to(BF)
-    vt = torch.zeros(N, H * D, s_pad, dtype=BF, device="cuda")
-    vt[:, :, :S] = torch.randn(N, H * D, S, generator=g, device="cuda").to(BF)
-
-    def run():
-        o = torch.empty(N, S, H * D, dtype=BF, device="cuda")
-        _lib.flash_attn_d64(qk, qk, vt, o, N, H, S, S * 2 * H * D, 2 * H * D, H * D * s_pad, s_pad, S * H * D, H * D, 0.125,
-                            k_off=H * D, q_prescaled=True)
-        return o
-
-    monkeypatch.setenv("ALG_ATTN_PP", "0")
-    want = run()
-    for pp in ("1", "2"):
-        monkeypatch.setenv("ALG_ATTN_PP", pp)
-        assert torch.equal(run(), want), pp
 
 
 @pytest.mark.parametrize("std", [4.0, 8.0, 15.0, 22.0])
@@ -617,7 +583,7 @@ def test_pipelined_attention_kernel(device, monkeypatch, Bn, S2, H2):
     vt[:, :, torch.tensor([swap23(n) for n in range(S2)])] = v.reshape(Bn, S2, D).transpose(1, 2)
     vt = vt.to(device)
     outs, errs = {}, {}
-    forms = ("4", "3", "5", "0") if _exp() else ("4", "0")           # EXPERIMENTS: 3 = 4-wave workgroups, 5 = 64 queries per wave
+    forms = ("4", "6", "0")           # 4 = the 8-wave statement, 6 = the 64-queries-per-wave statement, 0 = the straight loop
     for pp in forms:
         monkeypatch.setenv("ALG_ATTN_PP", pp)
         o = torch.full((Bn, S2, D), 3.0, dtype=BF, device=device)
@@ -631,8 +597,6 @@ def test_pipelined_attention_kernel(device, monkeypatch, Bn, S2, H2):
     for pp in forms[:-1]:
         assert errs[pp][0] <= 3e-2 and errs[pp][1] <= 2e-3, errs
         assert errs[pp][1] <= 1.25 * errs["0"][1] + 1e-5, errs       # not worse than the straight loop on average
-    if _exp():
-        assert torch.equal(outs["4"], outs["3"])                     # same arithmetic per query row in both workgroup shapes
     monkeypatch.setenv("ALG_ATTN_PP", "4")
     for _ in range(3):
         o2 = torch.empty_like(outs["4"])

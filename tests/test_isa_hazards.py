@@ -27,9 +27,10 @@ def _listing(src, extra=()):
         return open(os.path.join(d, lst[0])).read()
 
 
-# (source, build flavour, least number of asm MFMAs with a VGPR destination the listing must contain)
-CASES = [("attention128_q64.hip", (), 150), ("attention128_q64.hip", ("-DALG_EXPERIMENTS",), 150),
-         ("attention64_q64.hip", ("-DALG_EXPERIMENTS",), 1)]
+# (source, extra flags, least number of asm MFMAs with a VGPR destination the listing must contain): both 64-query kernels keep
+# their QK MFMAs' results in literal ArchVGPR blocks INSIDE one generated statement; the scan proves that nothing the compiler
+# placed (and nothing in the statement) touches such a block in the MFMA's shadow
+CASES = [("attention128_q64.hip", (), 150), ("attention64_q64.hip", (), 80)]
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
