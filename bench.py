@@ -840,6 +840,7 @@ def timed_region(wl, warmup, steps, parallel, measure_box=False):
 # transformer; "env": an ALG_* option of the library (re-read with alg_reload_env); "events": the bench's own HIP-event brackets
 # switched ON (what the instrumented headline region pays for them).
 AB_ARMS = [
+    ("attn_8wave_statement_vs_q64", "env", "ALG_ATTN_PP", "6", "round 5: the default 8-wave 32-query d = 64 statement vs the 64-queries-per-wave statement (attention64_q64.hip, ALG_ATTN_PP=6); > 0: the default is faster"),
     ("attn_pipelined", "env", "ALG_ATTN_PP", "0", "round 3: pipelined d = 64 attention vs the straight loop"),
     ("attn_split_tail", "env", "ALG_ATTN_SPLIT_TAIL", "0", "round 2: split-KV tail of the attention launch vs a single launch"),
     ("gemm_schedule9", "env", "ALG_GEMM_PIPE", "6", "round 3: GEMM schedule 9 (asm K loop) vs the 8-wave ping-pong"),
@@ -921,6 +922,25 @@ def other_workloads(args, dev, parallel):
             t_build = time.perf_counter() - t_build
             elapsed, forwards, ms = timed_region(wl, 1, 2, parallel)
             rl = wl.roofline(ms, forwards, elapsed)
+            # same process, same box, same steps: the 64-query statement kernel (default) against the 32-query pipelined kernel
+            # (ALG_ATTN128_Q64=0; round 4's compiler-scheduled 64-query kernel measured +2.6 ... 3.2 % over it at C4)
+            ab = None
+            if not args.no_ab:
+                from alg_amd import _lib
+                old_env = os.environ.get("ALG_ATTN128_Q64")
+                os.environ["ALG_ATTN128_Q64"] = "0"
+                _lib.reload_env()
+                try:
+                    e0, _, ms0 = timed_region(wl, 1, 2, parallel)
+                    ab = {"off": "ALG_ATTN128_Q64=0 (flash_attn_d128_pipe_kernel)", "off_ms_per_step": e0 / 2 * 1e3,
+                          "default_gain_pct": round((e0 - elapsed) / elapsed * 100, 2),
+                          "off_attn_ms_per_step": sum(ms0.get("attn_self", [])) / 2, "default_attn_ms_per_step": sum(ms.get("attn_self", [])) / 2}
+                finally:
+                    if old_env is None:
+                        os.environ.pop("ALG_ATTN128_Q64", None)
+                    else:
+                        os.environ["ALG_ATTN128_Q64"] = old_env
+                    _lib.reload_env()
             res[name] = {
                 "metric": wl.metric, "frames_per_s": wl.frames * 2 / wl.steps_per_video / elapsed, "ms_per_step": elapsed / 2 * 1e3,
                 "steps": 2, "warmup": 1, "dit_sample_forwards": forwards, "layers": wl.layers, "tokens": wl.config(forwards)["tokens"],
@@ -929,6 +949,7 @@ def other_workloads(args, dev, parallel):
                 "gemm_tflops": {k: round(v, 1) for k, v in rl["extra"].items() if k.startswith("gemm_") and k.endswith("_tflops")},
                 "finite": bool(torch.isfinite(wl.last_out.float()).all().item()), "build_seconds": round(t_build, 1),
                 "peak_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                "ab_attn128_q64_statement": ab,
             }
         except Exception as e:   # an auxiliary workload must never take the headline line down
             res[name] = {"error": repr(e)}

@@ -140,7 +140,7 @@ def rope_tables(cfg: HyConfig, F_, H, W):
 
 def _timesteps(t):
     half = 128
-    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half
     emb = t.float()[:, None] * torch.exp(exponent)[None]
     return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
 
@@ -153,16 +153,30 @@ def _rms_head(x, w, dt, eps=1e-6):
 def _rope(x, cos, sin):
     xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
     rot = torch.stack([-xi, xr], dim=-1).flatten(3)
-    return (x.float() * cos + rot.float() * sin).to(x.dtype)
+    return (x.float() * cos.to(x.device) + rot.float() * sin.to(x.device)).to(x.dtype)
 
 
-def _sdpa(q, k, v, kv_len):
-    """q, k, v [B, H, S, d]; keys >= kv_len[b] are masked."""
+def _sdpa(q, k, v, kv_len, max_scores=1 << 28):
+    """q, k, v [B, H, S, d]; keys >= kv_len[b] are masked.  Rows of a softmax are independent: long sequences are evaluated in
+    (batch, head, query-block) pieces of at most `max_scores` scores -- the same arithmetic per row, bounded memory (the C4 token
+    count has 1.4e10 scores per head)."""
     B, H, S, d = q.shape
-    s = q.float() @ k.float().transpose(-1, -2) / math.sqrt(d)
-    idx = torch.arange(k.shape[2])[None, None, None, :]
-    s = s.masked_fill(idx >= kv_len.view(B, 1, 1, 1), float("-inf"))
-    return (torch.softmax(s, dim=-1) @ v.float()).to(q.dtype)
+    Skv = k.shape[2]
+    idx = torch.arange(Skv, device=q.device)[None, None, None, :]
+    if B * H * S * Skv <= max_scores:
+        s = q.float() @ k.float().transpose(-1, -2) / math.sqrt(d)
+        s = s.masked_fill(idx >= kv_len.view(B, 1, 1, 1), float("-inf"))
+        return (torch.softmax(s, dim=-1) @ v.float()).to(q.dtype)
+    out = torch.empty(B, H, S, d, dtype=q.dtype, device=q.device)
+    rows = max(1, max_scores // Skv)
+    for b in range(B):
+        dead = idx[0, 0] >= kv_len[b]                                     # [1, Skv]
+        for h in range(H):
+            kf, vf = k[b, h].float(), v[b, h].float()
+            for r0 in range(0, S, rows):
+                s = q[b, h, r0:r0 + rows].float() @ kf.t() / math.sqrt(d)
+                out[b, h, r0:r0 + rows] = (torch.softmax(s.masked_fill(dead, float("-inf")), dim=-1) @ vf).to(q.dtype)
+    return out
 
 
 def hy_forward(cfg: HyConfig, sd, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask,
@@ -191,8 +205,10 @@ def hy_forward(cfg: HyConfig, sd, hidden_states, timestep, encoder_hidden_states
         temb = temb + temb_of(guidance, te + "guidance_embedder")
 
     # ---- patch embed ----
-    x = F.conv3d(hidden_states.to(dtype), W_("x_embedder.proj.weight"), W_("x_embedder.proj.bias"), stride=(pt, p, p))
-    x = x.flatten(2).transpose(1, 2)
+    # x_embedder = Conv3d(kernel = stride = patch): one dot product per output voxel over its own patch, i.e. a linear layer over
+    # the unfolded patches (rows (c, dt, dy, dx): the weight's own memory order)
+    hp = hidden_states.to(dtype).reshape(B, C, F_ // pt, pt, H // p, p, Wd // p, p).permute(0, 2, 4, 6, 1, 3, 5, 7)
+    x = F.linear(hp.reshape(B, -1, C * pt * p * p), W_("x_embedder.proj.weight").reshape(D, -1), W_("x_embedder.proj.bias"))
 
     # ---- token refiner ----
     ce = "context_embedder."

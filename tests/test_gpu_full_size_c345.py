@@ -102,6 +102,57 @@ def test_c5_fp8_forward_at_its_real_shape_vs_fp32_oracle_on_the_e4m3_floor():
     check_floor("wan_forward_c5_fp8_real_shape_2blocks_75600tokens", out, ref, eager)
 
 
+def test_c3_forward_at_its_real_shape_vs_fp32_oracle():
+    """BASELINE config 3 at its own size -- Wan-14B width, 21 x 30 x 52 = 32,760 tokens, N = 2 (a CFG step), 2 of the 40 blocks,
+    bf16 -- HIP against `oracle/wan_oracle.wan_forward` in fp32, floor = the same function with bf16 weights / activations (the
+    reference's execution mode, run.py:38,59).  Both oracle runs execute on the device by torch's own ops (see the C5 test)."""
+    from _parity import check_floor
+    from alg_amd.transformer_wan import synthetic_state_dict
+    from oracle import wan_oracle
+    F, H, W = 21, 60, 104
+    cfg, ocfg = WanTransformerConfig(num_layers=2), wan_oracle.WanConfig(num_layers=2)
+    sd = synthetic_state_dict(cfg, seed=22, device=DEV)
+    model = WanTransformer3DModel(cfg, sd, device=DEV)
+    lat, cond, txt, img = wan_inputs(F, H, W, seed=7)
+    lp = lp_utils.apply_low_pass_filter(cond, "gaussian_blur", 7.5, 9, 1.0)      # a mid-schedule strength of C3's linear decay
+    _, (x2, t2, i2) = wan_step_batches(lat, cond, lp, txt, img)
+    ts = torch.full((2,), 700.0, device=DEV)
+    out = model(hidden_states=x2, timestep=ts, encoder_hidden_states=t2, encoder_hidden_states_image=i2, return_dict=False)[0]
+    with torch.no_grad():
+        eager = wan_oracle.wan_forward(ocfg, sd, x2, ts, t2, i2, dtype=BF).cpu()
+        ref = wan_oracle.wan_forward(ocfg, sd, x2.float(), ts, t2.float(), i2.float()).cpu()
+    check_floor("wan_forward_c3_real_shape_2blocks_32760tokens", out, ref, eager)
+
+
+def test_c4_forward_at_its_real_shape_vs_fp32_oracle():
+    """BASELINE config 4 at its own size -- HunyuanVideo width (3072, 24 heads x 128), 33 x 45 x 80 = 118,800 latent tokens + 256
+    prompt tokens (48 valid), 1 dual-stream + 1 single-stream block of the 20 + 40, token-replace conditioning -- HIP against
+    `oracle/hy_oracle.hy_forward` in fp32, floor = the same function in bf16 eager mode; both on the device by torch's own ops."""
+    from _parity import check_floor
+    from alg_amd.transformer_hunyuan_video import synthetic_state_dict
+    from oracle import hy_oracle
+    kw = dict(num_layers=1, num_single_layers=1)
+    cfg, ocfg = HunyuanVideoTransformerConfig(**kw), hy_oracle.HyConfig(**kw)
+    F, H, W, L = 33, 90, 160, 256
+    sd = synthetic_state_dict(cfg, seed=24, device=DEV)
+    assert set(sd) == set(hy_oracle.param_shapes(ocfg))
+    model = HunyuanVideoTransformer3DModel(cfg, sd, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(8)
+    x = torch.randn(1, 16, F, H, W, generator=g, device=DEV).to(BF)
+    txt = torch.randn(1, L, cfg.text_embed_dim, generator=g, device=DEV).to(BF)
+    mask = torch.zeros(1, L, device=DEV)
+    mask[:, :48] = 1
+    pooled = torch.randn(1, cfg.pooled_projection_dim, generator=g, device=DEV).to(BF)
+    t = torch.full((1,), 996.0, device=DEV)
+    out = model(hidden_states=x, timestep=t, encoder_hidden_states=txt, encoder_attention_mask=mask.to(BF),
+                pooled_projections=pooled, guidance=None, return_dict=False)[0]
+    assert out.shape == (1, 16, F, H, W)
+    with torch.no_grad():
+        eager = hy_oracle.hy_forward(ocfg, sd, x, t, txt, mask, pooled, dtype=BF).cpu()
+        ref = hy_oracle.hy_forward(ocfg, {k: v.float() for k, v in sd.items()}, x.float(), t, txt.float(), mask, pooled.float()).cpu()
+    check_floor("hunyuan_forward_c4_real_shape_1dual_1single_119056tokens", out, ref, eager)
+
+
 def test_hunyuan_13b_width_c4_token_count():
     cfg = HunyuanVideoTransformerConfig(num_layers=1, num_single_layers=1)      # 1 dual + 1 single block of 20 + 40
     assert cfg.dim == 3072
