@@ -302,11 +302,16 @@ static bool force_global() { return opt(OPT_LOWPASS_PATH) == 4; }
 template <typename K>
 static int set_lds_limit(K kernel, size_t bytes) {
   if (bytes > 160 * 1024) return ALG_ELIMIT;
+  // hipFuncSetAttribute is a per-DEVICE property: the memo is keyed by the current device too (a process that drives
+  // two GPUs launched the > 48 KiB kernels on the second one without the opt-in); an unknown device (-1) is never memoised
   static thread_local const void* last_fn = nullptr;
   static thread_local size_t last_bytes = 0;
-  if (bytes > 48 * 1024 && !(last_fn == (const void*)kernel && last_bytes >= bytes)) {
+  static thread_local int last_dev = -2;
+  const int dev = current_device_slot();
+  if (bytes > 48 * 1024 && !(last_fn == (const void*)kernel && last_bytes >= bytes && dev >= 0 && last_dev == dev)) {
     last_fn = (const void*)kernel;
     last_bytes = bytes;
+    last_dev = dev;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", bytes, hipGetErrorString(e));

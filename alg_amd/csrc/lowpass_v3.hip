@@ -520,11 +520,13 @@ static int threads_override() {
 struct Prep {
   std::atomic<size_t> lds{0};
   std::atomic<int> wgs{0};
+  std::atomic<int> dev{-2};   // the device the two values above were set / queried on (both are per-device)
 };
 
 template <typename K>
 static int prepare(Prep& p, K kernel, int nt, size_t lds, int* wgs) {
-  if (p.lds.load() != lds) {
+  const int dev = current_device_slot();
+  if (p.lds.load() != lds || dev < 0 || p.dev.load() != dev) {
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) {
@@ -533,6 +535,7 @@ static int prepare(Prep& p, K kernel, int nt, size_t lds, int* wgs) {
       }
     }
     p.wgs.store(resident_wgs(kernel, nt, lds));
+    p.dev.store(dev);
     p.lds.store(lds);
   }
   *wgs = std::min(std::max(p.wgs.load(), 1), wgs_cap());
