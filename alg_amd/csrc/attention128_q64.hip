@@ -54,6 +54,7 @@ struct P {
   float scale_log2;
   uint64_t* clk;   // clock tap (calibrate.hip: alg_attn_clock_tap) or NULL
   int clk_slots;
+  int use_statement;   // 0: every tile through the C++ tile body (ALG_ATTN128_Q64=3: tests of the frame on its own)
 };
 
 __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p) {
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
     straight_tile(x, 0, false);     // tile 0: establishes the running max of both query halves
   }
   for (;;) {
-    if ((t & 3) == 1 && t + 4 <= tend && __all(m_run[0] > -3.0e38f && m_run[1] > -3.0e38f)) {
+    if (p.use_statement && (t & 3) == 1 && t + 4 <= tend && __all(m_run[0] > -3.0e38f && m_run[1] > -3.0e38f)) {
       const LaneCtx x = make_ctx(fresh_lane());
       auto sreg = [](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
       auto uniform64 = [](const void* ptr) -> uint64_t {
@@ -306,7 +307,8 @@ int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, i
                         int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t vt_bs, int64_t vt_rs, int64_t o_bs,
                         int64_t o_rs, float scale, hipStream_t stream) {
   using namespace a128q;
-  // ALG_ATTN128_Q64: 1 (default) = calls over at least POLICY_TILES KV tiles; 2 = every call the kernel can take; 0 = off.
+  // ALG_ATTN128_Q64: 1 (default) = calls over at least POLICY_TILES KV tiles; 2 = every call the kernel can take; 3 = as 2 with the
+  // statement switched off (every tile through the frame's C++ body: tests); 0 = off.
   const int enabled = opt(OPT_ATTN128_Q64);
   const int n_tiles = (Skv + KVB - 1) / KVB;
   if (!enabled || n_tiles < (enabled == 1 ? POLICY_TILES : MIN_TILES)) return 1;
@@ -332,6 +334,7 @@ int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, i
   p.clk = g_clock_tap.load(std::memory_order_acquire);
   p.clk_slots = p.clk ? g_clock_tap_slots.load(std::memory_order_relaxed) : 0;
   if (p.clk_slots <= 0) p.clk = nullptr;
+  p.use_statement = enabled != 3;
   const int64_t grid = (int64_t)((batch * heads + 7) / 8) * 8 * p.q_blocks;
   if (grid > 0x7fffffff) return 1;
   hipLaunchKernelGGL(flash_attn_d128_q64_kernel, dim3((unsigned)grid), dim3(NW * 64), LDS_BYTES, stream, p);

@@ -24,7 +24,7 @@ enum Opt {
   OPT_ATTN_VARIANT,     // ALG_ATTN_VARIANT      33 (default: lazy running max) | 1: exact running max, fp32 row sums
   OPT_ATTN128_PIPE,     // ALG_ATTN128_PIPE      1 (default: pipelined d = 128 kernel) | 0: the straight loop
   OPT_ATTN128_Q64,      // ALG_ATTN128_Q64       1 (default: 64-queries-per-wave kernel for >= 4,096 keys) | 2: for every call it can
-                        //                       take (>= 512 keys) | 0: off
+                        //                       take (>= 512 keys) | 3: as 2, statement off (the frame's C++ tile body only: tests) | 0: off
   OPT_GEMM_PIPE,        // ALG_GEMM_PIPE         9 (default) | 6: the 8-wave ping-pong schedule (bit-identical results)
   OPT_LOWPASS_PATH,     // ALG_LOWPASS_PATH      0 auto | 1 plane-per-workgroup | 2 lowpass_v2 | 3 lowpass_v3 at any plane
                         //                       count | 4 global-memory passes (all bit-identical)

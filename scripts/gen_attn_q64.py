@@ -65,7 +65,7 @@ class Cfg:
 v = lambda i: "v%d" % i
 vr = lambda i, n: "v[%d:%d]" % (i, i + n - 1)
 ar = lambda i, n: "a[%d:%d]" % (i, i + n - 1)
-AHEAD = 4          # fragment reads in flight ahead of the fragment being multiplied
+AHEAD = int(os.environ.get("ATTN_Q64_AHEAD", "4"))     # fragment reads in flight ahead of the fragment being multiplied (ring: 8 buffers)
 # timing-only experiment knobs (WRONG RESULTS; never set for the committed .inc): "noadd" drops the row-sum adds, "ones" issues the
 # MFMAs a ones-row of V^T would cost, "nofma" (d = 128) generates the pre-scaled zero-offset form behind the unchanged frame
 EXP = set(filter(None, os.environ.get("ATTN_Q64_EXP", "").split(",")))
@@ -223,7 +223,8 @@ def iteration(c, phase, X, Y, U, W, pv=True, softmax=True, qk=True, reads_in_fli
         if j % 2 == 0:
             issued = (n_f + AHEAD if nxt is not None else n_f) - 1           # index of the last read that will ever be issued
             younger = min(j + AHEAD - 1, issued) - (j + 1)                   # reads issued behind read j + 1 at this point
-            pre.append("s_waitcnt lgkmcnt(%d)" % max(younger, 0))
+            if "nolgkm" not in EXP:
+                pre.append("s_waitcnt lgkmcnt(%d)" % max(younger, 0))
         frag = ar(c.FR + 4 * (j % 8), 4)
         for qh in range(2):
             if kind == "k":

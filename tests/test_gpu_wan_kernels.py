@@ -66,7 +66,7 @@ def test_flash_attn_d128_q64_kernel(B, H, Sq, Skv, monkeypatch):
     vt = make_vt(v, s_pad)
     scale = 1.0 / math.sqrt(128)
     outs = {}
-    for flag in ("2", "0"):
+    for flag in ("2", "3", "0"):       # 2: statement + frame, 3: the frame's C++ tile body on its own, 0: the 32-query kernels
         monkeypatch.setenv("ALG_ATTN128_Q64", flag)
         o = torch.full((B, Sq, D), 7.0, dtype=BF, device=DEV)
         _lib.flash_attn_d128(q, k, vt, o, B, H, Sq, Skv, Sq * D, D, Skv * D, D, D * s_pad, s_pad, Sq * D, D, scale)
