@@ -96,13 +96,14 @@ def softmax_stream(c, S, P):
         group 2n + 1: exp eb(n) | fma fa(n+1) | row sum += ea(n)
     one transcendental per group; every result is read at least one group (= one MFMA in the steady state) after it was written."""
     groups = []
+    pend = []
     first_sum = {0: True, 1: True}
 
     def add(qh, reg):
         if first_sum[qh]:
             first_sum[qh] = False
             return "v_mov_b32 %s, %s" % (v(c.TS[qh]), v(reg))
-        if "noadd" in EXP:
+        if "noadd" in EXP or "mfma4" in EXP:
             return None
         return "v_add_f32 %s, %s, %s" % (v(c.TS[qh]), v(c.TS[qh]), v(reg))
 
@@ -121,12 +122,18 @@ def softmax_stream(c, S, P):
             _, qp, pp = pair_regs(c, S, n - 1)
             g.append("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(P + pp), v(c.EA[(n - 1) & 1]), v(c.EB[(n - 1) & 1])))
             g.append(add(qp, c.EB[(n - 1) & 1]))
+            if "mfma4" in EXP and (pp & 1) == 1:
+                # EXPERIMENT (timing only so far): row sums on the matrix pipe -- v_mfma_f32_4x4x4_16b_bf16 with A = ones sums the four
+                # probabilities of two packed P registers per lane (2 passes); issued one group behind the cvt that completes the pair
+                pend.append("v_mfma_f32_4x4x4_16b_bf16 %s, %s, %s, %s" % (ar(c.AEND + 4 * qp, 4), ar(c.AEND + 8, 2), vr(P + pp - 1, 2), ar(c.AEND + 4 * qp, 4)))
         groups.append(g)
         g = ["v_exp_f32 %s, %s" % (v(eb), v(c.F1 if c.fma else s0 + 1))]
         if c.fma and n + 1 < 32:
             s1, q1, _ = pair_regs(c, S, n + 1)
             g.append(fma(c.F0, s1, q1))
         g.append(add(qh, ea))
+        g += pend
+        del pend[:]
         groups.append(g)
     _, qp, pp = pair_regs(c, S, 31)
     post = ["s_nop 1", "v_cvt_pk_bf16_f32 %s, %s, %s" % (v(P + pp), v(c.EA[1]), v(c.EB[1])), add(qp, c.EB[1])]
@@ -290,6 +297,9 @@ def emit(c):
         L += ["global_load_dwordx4 %s, %%[qvo%d], %%[qb] offset:%d" % (ar(c.QA + (qh * c.KS + ks) * 4, 4), qh, 32 * ks)
               for ks in range(c.KS)]
     roles = {1: (c.SA, c.SB, c.PA, c.PB), 2: (c.SB, c.SA, c.PB, c.PA), 3: (c.SA, c.SB, c.PA, c.PB), 0: (c.SB, c.SA, c.PB, c.PA)}
+    if "mfma4" in EXP:
+        L += ["v_mov_b32 %s, 0x3f803f80" % v(c.F0)] + ["v_accvgpr_write_b32 a%d, %s" % (c.AEND + 8 + i, v(c.F0)) for i in range(2)]
+        L += ["v_accvgpr_write_b32 a%d, 0" % (c.AEND + i) for i in range(8)]
     L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"]   # Q (and, once, whatever the caller had in flight)
     # ---- warm-up at phase 1: iteration t's protocol, QK(t) alone into X, then QK(t+1) under softmax(t) ----
     head, pieces = top_protocol(c, 1)
@@ -334,7 +344,7 @@ def write(c, path):
         for ln in lines:
             f.write('  "%s\\n\\t" \\\n' % ln)
         f.write('  ""\n')
-        regs = ["a%d" % i for i in range(c.QA, c.AEND + (32 if "ones" in EXP else 0))] + ["v%d" % i for i in range(c.VB, c.VEND)]
+        regs = ["a%d" % i for i in range(c.QA, c.AEND + (32 if EXP & {"ones", "mfma4"} else 0))] + ["v%d" % i for i in range(c.VB, c.VEND)]
         f.write("#define ALG_%s_CLOBBERS \\\n  " % c.name + ", ".join('"%s"' % r for r in regs) + "\n")
         f.write("#define ALG_%s_O_OPERANDS(o) \\\n  " % c.name + ", ".join('[o%d] "+a"(o[%d])' % (i, i) for i in range(c.NO)) + "\n")
     return lines
