@@ -15,7 +15,7 @@
 //
 // This file is the frame, and everything in it is plain C++ the compiler sees whole: workgroup -> (head, q block) order, operand
 // layouts and swizzles of attention128_pipe.hip, O as eight f32x16 values (handed to the statement as "+a" operands), a C++
-// tile body for tile 0 (where the lazy running max is established), the last tiles (ragged tail) and any tile the statement
+// tile body for tile 0 (where the lazy running max is established), the last one or two tiles (the masked one) and any tile the statement
 // refuses (row sum outside [0, 2^80): exact max / rescale), all under the statement's collective protocol
 //     top of iteration t:  s_waitcnt vmcnt(8); s_barrier; DMA K(t+3) -> K slot (t+3) & 3, V^T(t+2) -> V slot (t+2) & 3
 // so the waves of a workgroup may be inside or outside the statement independently.  A wave that left the statement RE-ENTERS
@@ -212,8 +212,9 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
     }
   };
 
-  // the statement only runs iterations t whose DMA target K(t + 3) is a whole tile and whose tile t + 1 needs no mask
-  const int tend = ragged ? T - 4 : T - 3;
+  // the statement runs iterations t < tend: QK(t + 1) must not touch the masked (ragged) last tile.  Its DMA of K(t + 3) / V^T(t + 2)
+  // reaches past the end in the last iterations: the advanced offsets are clamped to the lane's last valid source (klim / vlim)
+  const int tend = ragged ? T - 2 : T - 1;
   int t = 1;
   bool top_done = false;
   {
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
     straight_tile(x, 0, false);     // tile 0: establishes the running max of both query halves
   }
   for (;;) {
-    if (p.use_statement && (t & 3) == 1 && t + 4 <= tend && __all(m_run[0] > -3.0e38f && m_run[1] > -3.0e38f)) {
+    if (p.use_statement && (t & 3) == 1 && t < tend && __all(m_run[0] > -3.0e38f && m_run[1] > -3.0e38f)) {
       const LaneCtx x = make_ctx(fresh_lane());
       auto sreg = [](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
       auto uniform64 = [](const void* ptr) -> uint64_t {
@@ -241,11 +242,13 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
       for (int ks = 0; ks < 8; ++ks) lk[ks] = kl + x.k_row_off + (((2 * ks + x.h2) ^ x.k_sw) * 16);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) lv[kk] = vl + x.v_row_off + (((2 * kk + x.h2) ^ x.v_sw) * 16);
-      int kvo[4], vvo[4];
+      int kvo[4], vvo[4], klim[4], vlim[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        kvo[i] = (int)(((int64_t)((t + 3) * KVB + x.k_row + 16 * i) * p.k_rs + x.k_slot * 8) * 2);
-        vvo[i] = (int)(((int64_t)(x.v_row + 32 * i) * p.vt_rs + x.v_slot * 8 + (t + 2) * KVB) * 2);
+        klim[i] = (int)(((int64_t)min((T - 1) * KVB + x.k_row + 16 * i, Skv - 1) * p.k_rs + x.k_slot * 8) * 2);
+        vlim[i] = (int)(((int64_t)(x.v_row + 32 * i) * p.vt_rs + x.v_slot * 8 + (T - 1) * KVB) * 2);
+        kvo[i] = min((int)(((int64_t)((t + 3) * KVB + x.k_row + 16 * i) * p.k_rs + x.k_slot * 8) * 2), klim[i]);
+        vvo[i] = min((int)(((int64_t)(x.v_row + 32 * i) * p.vt_rs + x.v_slot * 8 + (t + 2) * KVB) * 2), vlim[i]);
       }
       const int qvo0 = (int)(((int64_t)min(x.q_row, Sq - 1) * p.q_rs + x.h2 * 8) * 2);
       const int qvo1 = (int)(((int64_t)min(x.q_row + 32, Sq - 1) * p.q_rs + x.h2 * 8) * 2);
@@ -261,6 +264,8 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
                      [vvo1] "+v"(vvo[1]), [vvo2] "+v"(vvo[2]), [vvo3] "+v"(vvo[3])
                    : [lk0] "v"(lk[0]), [lk1] "v"(lk[1]), [lk2] "v"(lk[2]), [lk3] "v"(lk[3]), [lk4] "v"(lk[4]), [lk5] "v"(lk[5]),
                      [lk6] "v"(lk[6]), [lk7] "v"(lk[7]), [lv0] "v"(lv[0]), [lv1] "v"(lv[1]), [lv2] "v"(lv[2]), [lv3] "v"(lv[3]),
+                     [klim0] "v"(klim[0]), [klim1] "v"(klim[1]), [klim2] "v"(klim[2]), [klim3] "v"(klim[3]), [vlim0] "v"(vlim[0]),
+                     [vlim1] "v"(vlim[1]), [vlim2] "v"(vlim[2]), [vlim3] "v"(vlim[3]),
                      [qvo0] "v"(qvo0), [qvo1] "v"(qvo1), [negmc0] "v"(negmc0), [negmc1] "v"(negmc1), [c] "s"(c_s), [kb] "s"(kb),
                      [vb] "s"(vb), [qb] "s"(qbs), [kstep] "s"(kstep), [tend] "s"(tend_s), [wk] "s"(wk), [wv] "s"(wv)
                    : "memory", "vcc", "scc", ALG_ATTN128_Q64_CLOBBERS);

@@ -191,8 +191,9 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const P p) 
     }
   };
 
-  // the statement only runs iterations t whose DMA target K(t + 3) is a whole tile and whose tile t + 1 needs no mask
-  const int tend = ragged ? T - 4 : T - 3;
+  // the statement runs iterations t < tend: QK(t + 1) must not touch the masked (ragged) last tile; DMA offsets past the end are
+  // clamped to the lane's last valid source (klim / vlim)
+  const int tend = ragged ? T - 2 : T - 1;
   int t = 1;
   bool top_done = false;
   {
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const P p) 
     straight_tile(x, 0, false);     // tile 0: establishes the running offset (snapped to zero when its scores allow)
   }
   for (;;) {
-    if ((t & 3) == 1 && t + 4 <= tend && __all(m_run[0] == 0.0f && m_run[1] == 0.0f)) {
+    if ((t & 3) == 1 && t < tend && __all(m_run[0] == 0.0f && m_run[1] == 0.0f)) {
       const LaneCtx x = make_ctx(fresh_lane());
       auto sreg = [](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
       auto uniform64 = [](const void* ptr) -> uint64_t {
@@ -221,11 +222,13 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const P p) 
         const int fl = x.row_off + (((2 * ks + x.h2) ^ x.sw) * 16);
         lk[ks] = kl + fl, lv[ks] = vl + fl;
       }
-      int kvo[2], vvo[2];
+      int kvo[2], vvo[2], klim[2], vlim[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        kvo[i] = (int)(((int64_t)((t + 3) * KVB + x.srow + 32 * i) * p.q_rs + x.sslot * 8) * 2);
-        vvo[i] = (int)(((int64_t)(x.srow + 32 * i) * p.vt_rs + x.sslot * 8 + (t + 2) * KVB) * 2);
+        klim[i] = (int)(((int64_t)min((T - 1) * KVB + x.srow + 32 * i, S - 1) * p.q_rs + x.sslot * 8) * 2);
+        vlim[i] = (int)(((int64_t)(x.srow + 32 * i) * p.vt_rs + x.sslot * 8 + (T - 1) * KVB) * 2);
+        kvo[i] = min((int)(((int64_t)((t + 3) * KVB + x.srow + 32 * i) * p.q_rs + x.sslot * 8) * 2), klim[i]);
+        vvo[i] = min((int)(((int64_t)(x.srow + 32 * i) * p.vt_rs + x.sslot * 8 + (t + 2) * KVB) * 2), vlim[i]);
       }
       const int qvo0 = (int)(((int64_t)min(x.q_row, S - 1) * p.q_rs + x.h2 * 8) * 2);
       const int qvo1 = (int)(((int64_t)min(x.q_row + 32, S - 1) * p.q_rs + x.h2 * 8) * 2);
@@ -237,7 +240,8 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const P p) 
                    : ALG_ATTN64_Q64_O_OPERANDS(oa), [l0] "+v"(l_run[0]), [l1] "+v"(l_run[1]), [t] "+s"(ts), [code] "=&s"(code),
                      [kvo0] "+v"(kvo[0]), [kvo1] "+v"(kvo[1]), [vvo0] "+v"(vvo[0]), [vvo1] "+v"(vvo[1])
                    : [lk0] "v"(lk[0]), [lk1] "v"(lk[1]), [lk2] "v"(lk[2]), [lk3] "v"(lk[3]), [lv0] "v"(lv[0]), [lv1] "v"(lv[1]),
-                     [lv2] "v"(lv[2]), [lv3] "v"(lv[3]), [qvo0] "v"(qvo0), [qvo1] "v"(qvo1), [kb] "s"(kb), [vb] "s"(vb),
+                     [lv2] "v"(lv[2]), [lv3] "v"(lv[3]), [klim0] "v"(klim[0]), [klim1] "v"(klim[1]), [vlim0] "v"(vlim[0]),
+                     [vlim1] "v"(vlim[1]), [qvo0] "v"(qvo0), [qvo1] "v"(qvo1), [kb] "s"(kb), [vb] "s"(vb),
                      [qb] "s"(qbs), [kstep] "s"(kstep), [tend] "s"(tend_s), [wk] "s"(wk), [wv] "s"(wv)
                    : "memory", "vcc", "scc", ALG_ATTN64_Q64_CLOBBERS);
       t = ts;

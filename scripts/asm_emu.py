@@ -16,8 +16,8 @@ A schedule is accepted when it computes the right answer under lazy reads + eage
 MFMA result latency (XDL write -> VALU read wait states) is NOT modelled here: tests check it statically on the listing.
 
 Instruction subset: v_mfma_f32_32x32x16_bf16, ds_read_b128, global_load_dwordx4, global_load_lds_dwordx4, v_exp_f32, v_fma_f32,
-v_add_f32, v_mul_f32, v_mov_b32, v_add_u32, v_cvt_pk_bf16_f32, v_cmp_ngt_f32, v_accvgpr_{read,write,mov}_b32, s_add_u32, s_sub_u32,
-s_mov_b32, s_cmp_le_u32, s_cmp_lt_u32, s_branch, s_cbranch_scc1 / scc0 / vccnz / vccz, s_waitcnt, s_barrier, s_nop.
+v_add_f32, v_mul_f32, v_mov_b32, v_add_u32, v_min_u32, v_cvt_pk_bf16_f32, v_cmp_ngt_f32, v_accvgpr_{read,write,mov}_b32, s_add_u32, s_sub_u32,
+s_mov_b32, s_cmp_le_u32 / lt / ge, s_branch, s_cbranch_scc1 / scc0 / vccnz / vccz, s_waitcnt, s_barrier, s_nop.
 """
 import re
 
@@ -190,15 +190,18 @@ class Machine:
             else:
                 self.wr(w, args[0], np.uint32(val))
             return
-        if op in ("s_cmp_le_u32", "s_cmp_lt_u32"):
+        if op in ("s_cmp_le_u32", "s_cmp_lt_u32", "s_cmp_ge_u32"):
             a, b = int(self.rd(w, args[0])[0]), int(self.rd(w, args[1])[0])
-            w.scc = int(a <= b if op == "s_cmp_le_u32" else a < b)
+            w.scc = int({"s_cmp_le_u32": a <= b, "s_cmp_lt_u32": a < b, "s_cmp_ge_u32": a >= b}[op])
             return
         if op == "v_mov_b32" or op.startswith("v_accvgpr_"):
             self.wr(w, args[0], self.rd(w, args[1]))
             return
         if op == "v_add_u32":
             self.wr(w, args[0], (self.rd(w, args[1]).astype(np.uint64) + self.rd(w, args[2])).astype(np.uint32))
+            return
+        if op == "v_min_u32":
+            self.wr(w, args[0], np.minimum(self.rd(w, args[1]), self.rd(w, args[2])))
             return
         if op in ("v_add_f32", "v_mul_f32"):
             with np.errstate(all="ignore"):

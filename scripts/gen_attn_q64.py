@@ -22,7 +22,8 @@ Collective protocol (identical in the C++ loop around the statement, so the wave
 independently): top of iteration t   s_waitcnt vmcnt(NP); s_barrier; DMA K(t+3) -> K slot (t+3) & 3, V^T(t+2) -> V slot (t+2) & 3
 (NP = 8 | 4 pieces of 1 KiB per wave and iteration; the counted wait leaves the previous iteration's pieces in flight).
 Unrolled x 4 (ring slots as immediates).  Entered at t = 1 (mod 4) through a warm-up (QK(t) alone, then QK(t+1) under
-softmax(t)); runs groups of four while t + 4 <= tend; drains PV of its last tile.  See emit() for the operand list.
+softmax(t)); runs iterations t < tend (tend = the last tile QK may compute unmasked; at least iteration t of the entry must be
+allowed) and leaves through the drain of whatever phase would come next: PV of its last tile.  See emit() for the operand list.
 
 Register plan (literal names, clobbered):
     v[VB : VB+63] SA, v[VB+64 : VB+127] SB    score tiles [sub][qh][16]; roles alternate with t & 1
@@ -145,7 +146,7 @@ def top_protocol(c, phase):
     """(head, DMA pieces) of iteration t, t & 3 == phase: all but the previous iteration's NP pieces have landed (K(t+1), V(t) and
     older); behind the barrier this wave's pieces of K(t+3) and V^T(t+2).  A piece is (M0 write, [load, offset advance]): the two
     halves go into two consecutive MFMA gaps, so the M0 write is separated from the LDS-DMA that reads it by real work instead
-    of an s_nop."""
+    of an s_nop; the clamp of the advanced offset goes into the gap behind them."""
     ks, vs = (phase + 3) & 3, (phase + 2) & 3
     head = ["s_waitcnt vmcnt(%d)" % c.NP, "s_barrier"]
     if "nobarrier" in EXP:
@@ -153,23 +154,28 @@ def top_protocol(c, phase):
     if "nowait" in EXP:
         head = []
     pieces = []
+    # the offset of the NEXT tile is clamped to the lane's last valid source (klim / vlim: the same lane position in the last
+    # tile, rows past the end of K folded onto its last row): a DMA whose tile lies past the end re-fetches valid memory that
+    # nobody reads, so the statement may run up to the last unmasked tile (the frame keeps only the masked tile and tile 0)
     for r in range(c.NP // 2):
         pieces.append(("s_add_u32 m0, %%[wk], %d" % (ks * c.TILE + r * 4096),
-                       ["global_load_lds_dwordx4 %%[kvo%d], %%[kb]" % r, "v_add_u32 %%[kvo%d], %%[kstep], %%[kvo%d]" % (r, r)]))
+                       ["global_load_lds_dwordx4 %%[kvo%d], %%[kb]" % r, "v_add_u32 %%[kvo%d], %%[kstep], %%[kvo%d]" % (r, r)],
+                       "v_min_u32 %%[kvo%d], %%[kvo%d], %%[klim%d]" % (r, r, r)))
     for r in range(c.NP // 2):
         pieces.append(("s_add_u32 m0, %%[wv], %d" % (vs * c.TILE + r * 4096),
-                       ["global_load_lds_dwordx4 %%[vvo%d], %%[vb]" % r, "v_add_u32 %%[vvo%d], 0x80, %%[vvo%d]" % (r, r)]))
+                       ["global_load_lds_dwordx4 %%[vvo%d], %%[vb]" % r, "v_add_u32 %%[vvo%d], 0x80, %%[vvo%d]" % (r, r)],
+                       "v_min_u32 %%[vvo%d], %%[vvo%d], %%[vlim%d]" % (r, r, r)))
     if "nodma" in EXP:
         pieces = []
     elif "dmasalu" in EXP:      # EXPERIMENT: the offset advance on the scalar unit is not modelled; drop the per-piece v_add (timing only)
-        pieces = [(m0, rest[:1]) for m0, rest in pieces]
+        pieces = [(m0, rest[:1], "s_nop 0") for m0, rest, _ in pieces]
     return head, pieces
 
 
 def flat_pieces(pieces):
     out = []
-    for m0, rest in pieces:
-        out += [m0, "s_nop 0"] + rest
+    for m0, rest, clamp in pieces:
+        out += [m0, "s_nop 0"] + rest + [clamp]
     return out
 
 
@@ -268,6 +274,9 @@ def iteration(c, phase, X, Y, U, W, pv=True, softmax=True, qk=True, reads_in_fli
         lines += behind
         gg = g - DMA_SHIFT
         piece = dma[gg // DMA_STRIDE] if dma and gg >= 0 and gg % DMA_STRIDE < 2 and gg // DMA_STRIDE < len(dma) else None
+        prev = dma[(gg - 2) // DMA_STRIDE] if dma and gg >= 2 and (gg - 2) % DMA_STRIDE == 0 and (gg - 2) // DMA_STRIDE < len(dma) else None
+        if prev:
+            lines.append(prev[2])                 # the clamp of the piece whose load went out in the previous gap
         if piece and gg % DMA_STRIDE == 0:
             lines.append(piece[0])
         upto = (g + 1) * len(groups) // n_m
@@ -312,8 +321,8 @@ def emit(c):
     nxt = first_reads(c, 2)
     L += iteration(c, 1, X, Y, U, W, pv=False, prefetch_next=2 if nxt else None)
     L += check_and_count(c, "90f")
-    L += ["s_branch 12f"]
-    # ---- the loop: phases 1, 2, 3, 0 ----
+    L += ["s_cmp_ge_u32 %[t], %[tend]", "s_cbranch_scc1 22f", "s_branch 12f"]
+    # ---- the loop: phases 1, 2, 3, 0; behind every iteration: leave through the drain of the NEXT phase when t has reached tend ----
     L += ["11:"]
     for ph in (1, 2, 3, 0):
         if ph == 2:
@@ -325,11 +334,15 @@ def emit(c):
         L += iteration(c, ph, X, Y, U, W, reads_in_flight=AHEAD if nxt else 0, prefetch_next=((ph + 1) & 3) if nxt else None,
                        dma=pieces)
         L += check_and_count(c, "90f")
-    L += ["s_add_u32 %[code], %[t], 4", "s_cmp_le_u32 %[code], %[tend]", "s_cbranch_scc1 11b"]
-    # ---- drain: PV of the last tile (its P is the W of phase 0); V slot (1 - 1) & 3 = slot of tile t - 1 ----
-    X, Y, U, W = roles[0]
-    L += iteration(c, 1, Y, X, W, U, pv=True, softmax=False, qk=False, reads_in_flight=AHEAD if nxt else 0)
-    L += ["s_mov_b32 %[code], 0", "s_branch 99f"]
+        L += ["s_cmp_ge_u32 %[t], %[tend]"]
+        L += ["s_cbranch_scc1 2%df" % ((ph + 1) & 3)] if ph != 0 else ["s_cbranch_scc0 11b"]
+    # ---- drains: PV of the last tile t - 1 (its P is the U of the phase that would come next); its first fragment reads were
+    # issued by the iteration just left ----
+    for ph in (1, 2, 3, 0):
+        X, Y, U, W = roles[ph]
+        L += ["2%d:" % ph]
+        L += iteration(c, ph, X, Y, U, W, pv=True, softmax=False, qk=False, reads_in_flight=AHEAD if nxt else 0)
+        L += ["s_mov_b32 %[code], 0", "s_branch 99f"]
     # ---- failed row-sum check in iteration t: its protocol, PV(t-1) and QK(t+1) are done, softmax(t) is not ----
     L += ["90:", "s_mov_b32 %[code], 1"]
     L += ["99:", "s_nop 15", "s_nop 15", "s_waitcnt lgkmcnt(0)"]

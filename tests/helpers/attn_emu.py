@@ -25,13 +25,14 @@ def bf16_round(x):
 
 
 class Problem:
-    def __init__(self, d, T, seed=0, q_rs=None, k_rs=None, score_scale=1.0, prescaled=False):
+    def __init__(self, d, T, seed=0, q_rs=None, k_rs=None, score_scale=1.0, prescaled=False, ragged=0):
         """prescaled: Q carries scale * log2(e) already (the d = 64 frame: alg_qk_norm_rope_scaled), scores arrive in log2 units
-        and the statement runs with a ZERO offset (no subtraction at all)"""
+        and the statement runs with a ZERO offset (no subtraction at all).  ragged: keys missing from the last of the T tiles."""
         rng = np.random.default_rng(seed)
-        self.d, self.T, self.Skv, self.Sq = d, T, T * KVB, 256
+        self.d, self.T, self.Skv, self.Sq = d, T, T * KVB - ragged, 256
+        self.ragged = ragged
         self.q_rs, self.k_rs = q_rs or 2 * d, k_rs or 2 * d          # row pitches in elements (a [S, 2, d] qk tensor by default)
-        self.vt_rs = self.Skv + 64
+        self.vt_rs = self.T * KVB + 64
         c_true = 1.0 / np.sqrt(d) * 1.4426950408889634
         self.prescaled = prescaled
         self.q = bf16_round(rng.standard_normal((self.Sq, d)) * score_scale * (c_true if prescaled else 1.0))
@@ -40,14 +41,16 @@ class Problem:
         self.c = np.float32(1.0 if prescaled else c_true)           # what one raw score unit is worth in log2 units
         # global memory: Q panel, K panel, V^T panel (permuted columns), each at an odd offset to catch base mix-ups
         self.QOFF, self.KOFF = 4096, 4096 + 2 * self.Sq * self.q_rs + 512
-        self.VOFF = self.KOFF + 2 * (self.Skv + 4 * KVB) * self.k_rs + 1024
+        self.VOFF = self.KOFF + 2 * self.Skv * self.k_rs + 1024        # NOTHING valid behind the last K row: a DMA must not go there
         self.pack()
 
     def pack(self):
         """(re)build the global-memory image from q / k / v"""
         d = self.d
-        size = self.VOFF + 2 * (d + 1) * self.vt_rs + 4096
-        g16 = np.zeros(size // 2, dtype=np.uint16)
+        size = self.VOFF + 2 * d * self.vt_rs + 256
+        g16 = np.full(size // 2, 0x7FC0, dtype=np.uint16)              # bf16 NaN everywhere: data fetched from outside a panel poisons the result
+        for dd in range(d):                                            # V^T pad columns (up to the pitch) are ZERO by contract
+            g16[self.VOFF // 2 + dd * self.vt_rs: self.VOFF // 2 + (dd + 1) * self.vt_rs] = 0
         tobf = lambda a: asm_emu.f32_to_bf16(a)
         for r in range(self.Sq):
             g16[self.QOFF // 2 + r * self.q_rs: self.QOFF // 2 + r * self.q_rs + d] = tobf(self.q[r])
@@ -96,7 +99,7 @@ def stage(pb, lds, cfg, which, tile, slot_base):
             for i in range(cfg.NP // 2):
                 if which == "k":
                     row, slot = k_dma_lane(d, tid, i)
-                    src = pb.KOFF + ((tile * KVB + row) * pb.k_rs + slot * 8) * 2
+                    src = pb.KOFF + (min(tile * KVB + row, pb.Skv - 1) * pb.k_rs + slot * 8) * 2
                 else:
                     row = tid // 8 + 32 * i
                     slot = (tid & 7) ^ ((tid >> 4) & 7)
@@ -109,7 +112,7 @@ def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None):
     """Emulates the statement entered at iteration t0 (tile 0 .. t0 - 1 done by `the frame` = numpy here).  Returns the
     normalised attention output [Sq, d] after the frame's tail, the exit iteration and the exit code of wave 0."""
     d, T, c = cfg.d, pb.T, pb.c
-    tend = (T - 3) if tend is None else tend
+    tend = (T - 2 if pb.ragged else T - 1) if tend is None else tend     # iterations t < tend run: QK(t + 1) stays unmasked
     lines = G.emit(cfg)
     if mutate is not None:
         lines = mutate(lines)
@@ -128,7 +131,8 @@ def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None):
     for i in range(cfg.NO):
         tab["o%d" % i] = "a[%d:%d]" % (16 * i, 16 * i + 15)
     for n in ["l0", "l1"] + (["negmc0", "negmc1"] if cfg.fma else []) + ["qvo0", "qvo1"] + ["lk%d" % i for i in range(cfg.KS)] + ["lv%d" % i for i in range(4)] + \
-             ["kvo%d" % i for i in range(cfg.NP // 2)] + ["vvo%d" % i for i in range(cfg.NP // 2)]:
+             ["kvo%d" % i for i in range(cfg.NP // 2)] + ["vvo%d" % i for i in range(cfg.NP // 2)] + \
+             ["klim%d" % i for i in range(cfg.NP // 2)] + ["vlim%d" % i for i in range(cfg.NP // 2)]:
         vreg(n)
     assert nv <= cfg.VB
     for n in ("t", "code") + (("c",) if cfg.fma else ()) + ("kstep", "tend", "wk", "wv"):
@@ -183,9 +187,13 @@ def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None):
             vset(w, "lv%d" % kk, VL + l31 * 128 + (((2 * kk + h2) ^ ((l31 >> 1) & 7)) * 16))
         for i in range(cfg.NP // 2):
             row, slot = k_dma_lane(d, tid, i)
-            vset(w, "kvo%d" % i, (((t0 + 3) * KVB + row) * pb.k_rs + slot * 8) * 2)
+            klim = (np.minimum((T - 1) * KVB + row, pb.Skv - 1) * pb.k_rs + slot * 8) * 2
+            vset(w, "klim%d" % i, klim)
+            vset(w, "kvo%d" % i, np.minimum((((t0 + 3) * KVB + row) * pb.k_rs + slot * 8) * 2, klim))
             vrow, vslot = tid // 8 + 32 * i, (tid & 7) ^ ((tid >> 4) & 7)
-            vset(w, "vvo%d" % i, (vrow * pb.vt_rs + vslot * 8 + (t0 + 2) * KVB) * 2)
+            vlim = (vrow * pb.vt_rs + vslot * 8 + (T - 1) * KVB) * 2
+            vset(w, "vlim%d" % i, vlim)
+            vset(w, "vvo%d" % i, np.minimum((vrow * pb.vt_rs + vslot * 8 + (t0 + 2) * KVB) * 2, vlim))
         for qh in range(2):
             for dt in range(cfg.DT):
                 base = 16 * (qh * cfg.DT + dt)

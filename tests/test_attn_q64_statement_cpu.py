@@ -45,9 +45,21 @@ def test_d128_statement_computes_attention_under_the_weakest_memory_ordering(cfg
     ref = pb.reference()
     for lazy_reads, lazy_dma in MODES:
         out, t_exit, codes, n_inst, _ = H.run_statement(pb, cfg128, lazy_reads, lazy_dma)
-        groups = (T - 3 - 1) // 4                     # whole groups of four while t + 4 <= tend = T - 3, from t = 1
-        assert t_exit == 1 + 4 * groups and codes == [0, 0, 0, 0]
+        assert t_exit == T - 1 and codes == [0, 0, 0, 0]      # every tile but the first and the last ran inside the statement
         assert relerr(out, ref) < TOL, (lazy_reads, lazy_dma, relerr(out, ref))
+
+
+@pytest.mark.parametrize("T,ragged,seed", [(14, 23, 7), (15, 63, 8), (16, 1, 9), (17, 40, 10)])
+def test_d128_statement_runs_up_to_the_masked_tile_of_a_ragged_sequence(cfg128, T, ragged, seed):
+    """Skv not a multiple of 64: the statement runs iterations t < T - 2 (QK never touches the masked last tile), its DMA of
+    K(t + 3) / V^T(t + 2) reaches PAST the end of the panels in its last iterations -- the clamped offsets keep every fetch inside
+    valid memory (everything outside the panels is NaN in the harness, and the K panel ends exactly at its last row); all four
+    exit phases (T mod 4) and the drains behind them."""
+    pb = H.Problem(128, T, seed=seed, ragged=ragged)
+    ref = pb.reference()
+    out, t_exit, codes, _, _ = H.run_statement(pb, cfg128, True, True)
+    assert t_exit == T - 2 and codes == [0, 0, 0, 0]
+    assert np.isfinite(out).all() and relerr(out, ref) < TOL, relerr(out, ref)
 
 
 @pytest.fixture(scope="module")
@@ -63,7 +75,7 @@ def test_d64_statement_computes_attention_under_the_weakest_memory_ordering(cfg6
     ref = pb.reference()
     for lazy_reads, lazy_dma in MODES:
         out, t_exit, codes, _, _ = H.run_statement(pb, cfg64, lazy_reads, lazy_dma)
-        assert t_exit == 1 + 4 * ((T - 3 - 1) // 4) and codes == [0, 0, 0, 0]
+        assert t_exit == T - 1 and codes == [0, 0, 0, 0]
         assert relerr(out, ref) < TOL, (lazy_reads, lazy_dma, relerr(out, ref))
 
 
@@ -86,7 +98,7 @@ def test_d128_statement_re_entered_at_a_later_t_with_strided_panels(cfg128):
     pb = H.Problem(128, 18, seed=3, q_rs=384, k_rs=384)
     ref = pb.reference()
     out, t_exit, codes, _, _ = H.run_statement(pb, cfg128, True, True, t0=5)
-    assert t_exit == 13 and codes == [0, 0, 0, 0]
+    assert t_exit == 17 and codes == [0, 0, 0, 0]
     assert relerr(out, ref) < TOL
 
 
@@ -194,7 +206,7 @@ def test_static_hazard_rules_of_the_statements(width):
             assert waits >= 5, (t, ins[i:j + 1])
     # (5) filler load of the steady state: the loop body between labels 11 and the loop-back branch
     body = G.emit(cfg128)
-    a, b = body.index("11:"), body.index("s_cbranch_scc1 11b")
+    a, b = body.index("11:"), body.index("s_cbranch_scc0 11b")
     gaps, cur = [], 0
     for ln in body[a + 1:b]:
         if ln.startswith("v_mfma"):
@@ -203,7 +215,7 @@ def test_static_hazard_rules_of_the_statements(width):
         elif not re.match(r"^\d+:$", ln):
             cur += 1
     n_mfma = len(gaps)
-    assert n_mfma == 4 * cfg128.n_mfma == (256 if width == 128 else 128)
+    assert n_mfma == 4 * cfg128.n_mfma == (256 if width == 128 else 128)     # (the four drains lie behind the loop-back branch)
     inner = [g for k, g in enumerate(gaps) if k % cfg128.n_mfma != 0]        # gaps inside an iteration (not the iteration boundary)
     # d = 128: one half-pair group per gap; d = 64: a whole score pair per gap (the loop is VALU-issue-bound there)
     lim, avg = (7, 5.0) if width == 128 else (9, 6.6)

@@ -131,3 +131,33 @@ def test_flash_attn_d64_every_row_vs_fp32_sdpa_at_c2_length():
             sl = slice(h * 64, (h + 1) * 64)
             ref = _sdpa_rows_fp32(qk[b, :, sl], qk[b, :, Dh + h * 64:Dh + (h + 1) * 64], v[b, :, sl], 0.125)
             _check_rows(got[b, :, sl], ref, "attn64_c2_sample%d_head%d" % (b, h))
+
+
+@pytest.mark.parametrize("pp", ["4", "6", "0"])   # the 8-wave statement (default), the 64-queries-per-wave statement, the straight loop
+def test_flash_attn_d64_prescaled_every_row_vs_fp32_sdpa_at_c2_length(pp, monkeypatch):
+    """The PRODUCT's form of the headline launch -- Q carries scale * log2(e) (alg_qk_norm_rope_scaled), ALG_ATTN_Q_PRESCALED, the
+    split-KV tail next to the main launch -- 17,776 tokens, 2 CFG samples, 8 heads (one per XCD: the tail plan engages), every row
+    of 3 heads against fp32 SDPA of the same rounded Q, for each main-launch kernel; 8 runs bit-equal."""
+    monkeypatch.setenv("ALG_ATTN_PP", pp)
+    S, H, nb = 17776, 8, 2
+    Dh = H * 64
+    g = torch.Generator(device=DEV).manual_seed(19)
+    qk = torch.randn(nb, S, 2 * Dh, generator=g, device=DEV).to(BF)
+    qk[:, :, :Dh] = (qk[:, :, :Dh].float() * (0.125 * 1.4426950408889634)).to(BF)       # scores ~ N(0, 1.44^2) log2 units
+    v = torch.randn(nb, S, Dh, generator=g, device=DEV).to(BF)
+    s_pad = (S + 127) // 128 * 128
+    vt = _make_vt(v, s_pad)
+    o = torch.full((nb, S, Dh), 7.0, dtype=BF, device=DEV)
+
+    def call():
+        o.fill_(7.0)
+        _lib.flash_attn_d64(qk, qk, vt, o, nb, H, S, S * 2 * Dh, 2 * Dh, Dh * s_pad, s_pad, S * Dh, Dh, 0.125, k_off=Dh, q_prescaled=True)
+        return o.clone()
+
+    got = assert_repeatable(call, 8, "d64 prescaled C2 launch, ALG_ATTN_PP=" + pp)
+    for b in range(nb):
+        for h in (0, 4, 7):
+            sl = slice(h * 64, (h + 1) * 64)
+            # scores are in log2 units already: softmax base 2 = softmax of s * ln 2
+            ref = _sdpa_rows_fp32(qk[b, :, sl], qk[b, :, Dh + h * 64:Dh + (h + 1) * 64], v[b, :, sl], 0.6931471805599453)
+            _check_rows(got[b, :, sl], ref, "attn64_c2_prescaled_pp%s_sample%d_head%d" % (pp, b, h))
