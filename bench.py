@@ -835,8 +835,8 @@ def timed_region(wl, warmup, steps, parallel, measure_box=False):
     return elapsed, forwards, {k: event_ms(v) for k, v in kinds.items()}
 
 
-# A/B arms of the default bench line: each switches ONE schedule choice off (or on), 5 steps after 2 warm-up
-# steps, same process, same box, no event brackets; the default arm is timed before and after.  kind "attr": attribute of the
+# A/B arms of the default bench line: each switches ONE schedule choice off (or on), 5 steps after 3 warm-up
+# steps (loop iterations 0-2: both the 3-sample and the 2-sample launch shapes have run under the arm before the clock starts), same process, same box, no event brackets; the default arm is timed before and after.  kind "attr": attribute of the
 # transformer; "env": an ALG_* option of the library (re-read with alg_reload_env); "events": the bench's own HIP-event brackets
 # switched ON (what the instrumented headline region pays for them).
 AB_ARMS = [
@@ -849,7 +849,7 @@ AB_ARMS = [
 ]
 
 
-def ab_arms(wl, arms, steps=5, warmup=2):
+def ab_arms(wl, arms, steps=5, warmup=3):
     from alg_amd import _lib
 
     def timed(with_events=False):
