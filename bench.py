@@ -1057,10 +1057,10 @@ def main():
         if not hasattr(wl.model, k):
             raise SystemExit("--set: the transformer has no attribute %r" % k)
         setattr(wl.model, k, coerce_like(getattr(wl.model, k), v_, k))
+    elapsed, forwards, ms = timed_region(wl, args.warmup, args.steps, parallel, measure_box=(world == 1))
     calibration = None
     if rank == 0 and world == 1 and not args.no_calibration:
-        calibration = calibrate_box(dev)
-    elapsed, forwards, ms = timed_region(wl, args.warmup, args.steps, parallel, measure_box=(world == 1))
+        calibration = calibrate_box(dev)      # right BEHIND the timed region: the chip in the thermal state the headline ran in
 
     if args.dump_latents:
         torch.save(wl.last_out.detach().cpu(), "%s.rank%d.pt" % (args.dump_latents, rank))
