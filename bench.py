@@ -49,7 +49,7 @@ def event_ms(pairs):
     return [a.elapsed_time(b) for a, b in pairs]
 
 
-def pmc_traffic(kernel_substr, profiles=("profiles/r4_pmc_summary.txt", "profiles/r3_pmc_summary.txt", "profiles/r2_pmc_summary.txt", "profiles/r1_pmc_summary.txt")):
+def pmc_traffic(kernel_substr, profiles=("profiles/r5_pmc_summary.txt", "profiles/r4_pmc_summary.txt", "profiles/r3_pmc_summary.txt", "profiles/r2_pmc_summary.txt", "profiles/r1_pmc_summary.txt")):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
     collected in separate passes and reported in KiB).  gfx950 correction from MI355X_MICROARCH.md section HBM: a wide
     coalesced 16-B/lane stream (our global_load_lds staging) is tallied at half its bytes in FETCH_SIZE -> x2.
@@ -1008,6 +1008,8 @@ def main():
     ap.add_argument("--dump-latents", default="", metavar="PREFIX",
                     help="debug: every rank saves the final latents of its last __call__ to PREFIX.rank<r>.pt")
     ap.add_argument("--no-calibration", action="store_true", help="skip the 3 s matrix-pipe calibration of the box")
+    ap.add_argument("--ab", action="store_true", help="in-run A/B arms (roofline.extra.ab; workloads.*.ab_attn128_q64_statement): ON by "
+                                                      "default for c2 at 1 GPU -- the flag exists so that a command line can say so")
     ap.add_argument("--no-ab", action="store_true", help="c2 at 1 GPU: skip the in-run A/B arms (roofline.extra.ab, ~40 s)")
     ap.add_argument("--c1-budget", type=float, default=150.0,
                     help="seconds the C1 CPU leg may take (a 2-layer probe projects it first; beyond the budget the projection is reported)")
