@@ -42,6 +42,8 @@ wk / wv "s" = LDS byte address of the K / V^T ring + wave * 1024 (DMA destinatio
 import os
 
 OACC, FR, Q = 0, 32, 64        # AccVGPRs: O^T tiles, fragment ring, Q fragments
+WAIT_PAIRS = os.environ.get("ATTN_PIPE_WAIT_PAIRS", "0") == "1"   # experiment knob (round 5): one fragment wait per two MFMAs
+NO_NOP = os.environ.get("ATTN_PIPE_NO_NOP", "0") == "1"           # experiment knob (round 5): no s_nop between an M0 write and its LDS-DMA
 NW = 4                         # waves per workgroup (configure())
 
 
@@ -151,8 +153,15 @@ def iteration(phase, X, Y, U, W, pv=True, softmax=True, qk=True, reads_in_flight
     per_gap = max(1, 16 // n_m) if softmax else 0
     seen_first = {"k0": False, "k1": False}
     for j, (kind, half, kstep) in enumerate(mf):
-        outstanding = (AHEAD if prefetch_next is not None else min(AHEAD, n_m - j)) - 1   # reads issued after read j
-        lines.append("s_waitcnt lgkmcnt(%d)" % outstanding)
+        if WAIT_PAIRS:
+            # ONE counted wait per TWO fragments (round 5: every s_waitcnt is an issue slot of a loop that is bound by issue slots):
+            # in front of an even MFMA j the reads up to j + AHEAD - 1 have been issued; fragments j and j + 1 must have arrived
+            if j % 2 == 0:
+                last = (n_m + AHEAD - 1) if prefetch_next is not None else (n_m - 1)
+                lines.append("s_waitcnt lgkmcnt(%d)" % max(0, min(j + AHEAD - 1, last) - (j + 1)))
+        else:
+            outstanding = (AHEAD if prefetch_next is not None else min(AHEAD, n_m - j)) - 1   # reads issued after read j
+            lines.append("s_waitcnt lgkmcnt(%d)" % outstanding)
         fr = ar(FR + 4 * (j % 8), 4)
         if kind == "k":
             acc = vr(Y + 16 * half, 16)
@@ -166,14 +175,21 @@ def iteration(phase, X, Y, U, W, pv=True, softmax=True, qk=True, reads_in_flight
             lines.append(read(j + AHEAD))
         elif prefetch_next is not None and j + AHEAD - n_m < AHEAD:
             lines.append(first_reads(prefetch_next)[j + AHEAD - n_m])   # next iteration's reads 0..3 behind MFMAs 12..15
+        tail_dma = []
         if dma_groups and j < len(dma_groups):
-            lines += dma_groups[j]                                       # one DMA per gap behind the barrier
+            if NO_NOP and softmax and pair <= 16:
+                # the M0 write, then this gap's softmax slice, then the LDS-DMA that reads M0: real work instead of the s_nop
+                lines.append(dma_groups[j][0])
+                tail_dma = [ln for ln in dma_groups[j][1:] if not ln.startswith("s_nop")]
+            else:
+                lines += dma_groups[j]                                   # one DMA per gap behind the barrier
         for g in range(per_gap):
             if softmax and pair <= 16:
                 if g > 0:
                     lines.append("s_nop 1")     # the pack below reads what the two exps just above wrote (trans -> VALU use)
                 lines += softmax_gap(X, W, pair, pair == 0)
                 pair += 1
+        lines += tail_dma
     while softmax and pair <= 16:
         lines.append("s_nop 1")
         lines += softmax_gap(X, W, pair, False)
