@@ -221,3 +221,195 @@ def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None):
         O2 += probs(t) @ vf[t * KVB:(t + 1) * KVB]
         l2 += fsum(t)
     return O2 / l2[:, None], t_exit, codes, n, lines
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the DEFAULT d = 64 kernel's statement (scripts/gen_attn_pipe.py, 8-wave form: 32 queries per wave, attention.hip's frame)
+# ---------------------------------------------------------------------------------------------------------------------
+def run_pipe8_statement(pb, lazy_reads, lazy_dma, t0=1, mutate=None):
+    """flash_attn_d64_pipe_kernel<8>'s statement for one 256-query unit: eight waves x 32 queries, K / V^T tiles of 8 KiB through
+    four-slot rings (one 1 KiB piece of each per wave and tile), O in 32 scalar "+a" operands, pre-scaled scores with a zero
+    offset, whole groups of four iterations while t + 4 <= tend = T - 3 (this statement's own, older exit rule)."""
+    import gen_attn_pipe as GP
+    assert pb.d == 64 and pb.prescaled and not pb.ragged
+    GP.configure(8)
+    lines = GP.emit()
+    GP.configure(4)
+    if mutate is not None:
+        lines = mutate(lines)
+    T, TILE, NW = pb.T, 8192, 8
+    tend = T - 3
+    KL, VL = 0, 4 * TILE
+    tab = {"o%d" % i: "a%d" % (80 + i) for i in range(32)}
+    names_v = ["l", "kvo0", "vvo0", "qvo"] + ["lk%d" % i for i in range(4)] + ["lv%d" % i for i in range(4)]
+    for i, n in enumerate(names_v):
+        tab[n] = "v%d" % i
+    assert len(names_v) <= 26
+    for i, n in enumerate(("t", "code", "kstep", "tend", "wk", "wv")):
+        tab[n] = "s%d" % i
+    for i, n in enumerate(("kb", "vb", "qb")):
+        tab[n] = "s[%d:%d]" % (8 + 2 * i, 9 + 2 * i)
+    m = asm_emu.Machine(asm_emu.bind(lines, tab), n_waves=NW, gmem=pb.gmem, lazy_reads=lazy_reads, lazy_dma=lazy_dma)
+    qf, kf, vf = pb.q.astype(np.float64), pb.k.astype(np.float64), pb.v.astype(np.float64)
+    s_all = qf @ kf.T                                      # log2 units already
+    probs = lambda t: bf16_round(np.exp2(s_all[:, t * KVB:(t + 1) * KVB])).astype(np.float64)
+    fsum = lambda t: np.exp2(s_all[:, t * KVB:(t + 1) * KVB]).astype(np.float32).astype(np.float64).sum(axis=1)
+    O, l = np.zeros((pb.Sq, 64)), np.zeros(pb.Sq)
+    for t in range(t0):
+        O += probs(t) @ vf[t * KVB:(t + 1) * KVB]
+        l += fsum(t)
+
+    def stage8(which, tile):
+        for wave in range(NW):
+            lane = np.arange(64)
+            tid = wave * 64 + lane
+            row, slot = tid >> 3, (tid & 7) ^ ((tid >> 4) & 7)
+            for ln in range(64):
+                if which == "k":
+                    src = pb.KOFF + ((tile * KVB + row[ln]) * pb.k_rs + slot[ln] * 8) * 2
+                    dst = KL + (tile & 3) * TILE + wave * 1024 + ln * 16
+                else:
+                    src = pb.VOFF + (row[ln] * pb.vt_rs + slot[ln] * 8 + tile * KVB) * 2
+                    dst = VL + (tile & 3) * TILE + wave * 1024 + ln * 16
+                m.lds[dst:dst + 16] = pb.gmem[src:src + 16]
+    for t in range(t0 - 1, t0 + 3):
+        stage8("k", t)
+    for t in range(t0 - 1, t0 + 2):
+        stage8("v", t)
+
+    def sset(w, name, val):
+        r = asm_emu.parse_reg(tab[name])
+        w.s[r[1]] = np.uint32(int(val) & 0xFFFFFFFF)
+        if r[2] == 2:
+            w.s[r[1] + 1] = np.uint32(int(val) >> 32)
+
+    def vset(w, name, arr):
+        a = np.asarray(arr)
+        w.v[asm_emu.parse_reg(tab[name])[1]] = a.view(np.uint32) if a.dtype == np.float32 else a.astype(np.int64).astype(np.uint32)
+    for w in m.waves:
+        lane = np.arange(64)
+        l31, h2, tid = lane & 31, lane >> 5, w.id * 64 + lane
+        q_row = w.id * 32 + l31
+        srow, sslot = tid >> 3, (tid & 7) ^ ((tid >> 4) & 7)
+        sset(w, "t", t0), sset(w, "tend", tend), sset(w, "kstep", KVB * pb.k_rs * 2)
+        sset(w, "wk", KL + w.id * 1024), sset(w, "wv", VL + w.id * 1024)
+        sset(w, "kb", pb.KOFF), sset(w, "vb", pb.VOFF), sset(w, "qb", pb.QOFF)
+        vset(w, "qvo", (q_row * pb.q_rs + h2 * 8) * 2)
+        vset(w, "l", np.where(h2 == 0, l[q_row], 0.0).astype(np.float32))
+        for ks in range(4):
+            fl = l31 * 128 + (((2 * ks + h2) ^ ((l31 >> 1) & 7)) * 16)
+            vset(w, "lk%d" % ks, KL + fl)
+            vset(w, "lv%d" % ks, VL + fl)
+        vset(w, "kvo0", (((t0 + 3) * KVB + srow) * pb.k_rs + sslot * 8) * 2)
+        vset(w, "vvo0", (srow * pb.vt_rs + sslot * 8 + (t0 + 2) * KVB) * 2)
+        for i in range(32):
+            dt, e = i >> 4, i & 15
+            drow = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2
+            w.a[80 + i] = O[q_row, drow].astype(np.float32).view(np.uint32)
+    n = m.run()
+    t_exit = int(m.waves[0].s[asm_emu.parse_reg(tab["t"])[1]])
+    codes = [int(w.s[asm_emu.parse_reg(tab["code"])[1]]) for w in m.waves]
+    O2, l2 = np.zeros((pb.Sq, 64)), np.zeros(pb.Sq)
+    for w in m.waves:
+        lane = np.arange(64)
+        l31, h2 = lane & 31, lane >> 5
+        q_row = w.id * 32 + l31
+        np.add.at(l2, q_row, w.v[asm_emu.parse_reg(tab["l"])[1]].view(np.float32).astype(np.float64))
+        for i in range(32):
+            dt, e = i >> 4, i & 15
+            drow = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2
+            O2[q_row, drow] = w.a[80 + i].view(np.float32)
+    for t in range(t_exit, T):
+        O2 += probs(t) @ vf[t * KVB:(t + 1) * KVB]
+        l2 += fsum(t)
+    return O2 / l2[:, None], t_exit, codes, n, lines
+
+
+def run_pipe128_statement(pb, lazy_reads, lazy_dma, t0=1, mutate=None):
+    """flash_attn_d128_pipe_kernel's statement (scripts/gen_attn128_pipe.py; the 32-query d = 128 kernel: ALG_ATTN128_Q64=0 and
+    sequences below the 64-query kernel's policy): four waves x 32 queries = the first 128 queries of the problem, O in 64 "+v"
+    operands, the lazy offset as s * c - m * c, whole groups of four iterations while t + 4 <= tend = T - 3."""
+    import gen_attn128_pipe as GP
+    assert pb.d == 128 and not pb.prescaled and not pb.ragged
+    lines = GP.emit()
+    if mutate is not None:
+        lines = mutate(lines)
+    T, TILE, NW, c = pb.T, 16384, 4, float(pb.c)
+    tend = T - 3
+    KL, VL = 0, 4 * TILE
+    tab = {"o%d" % i: "v%d" % i for i in range(64)}
+    names_v = ["l", "negmc", "qvo"] + ["lk%d" % i for i in range(8)] + ["lv%d" % i for i in range(4)] + \
+              ["kvo%d" % i for i in range(4)] + ["vvo%d" % i for i in range(4)]
+    for i, n in enumerate(names_v):
+        tab[n] = "v%d" % (170 + i)
+    for i, n in enumerate(("t", "code", "c", "kstep", "tend", "wk", "wv")):
+        tab[n] = "s%d" % i
+    for i, n in enumerate(("kb", "vb", "qb")):
+        tab[n] = "s[%d:%d]" % (8 + 2 * i, 9 + 2 * i)
+    m = asm_emu.Machine(asm_emu.bind(lines, tab), n_waves=NW, gmem=pb.gmem, lazy_reads=lazy_reads, lazy_dma=lazy_dma)
+    nq = NW * 32
+    qf, kf, vf = pb.q[:nq].astype(np.float64), pb.k.astype(np.float64), pb.v.astype(np.float64)
+    s_all = qf @ kf.T
+    m_run = s_all[:, :KVB].max(axis=1)
+    probs = lambda t: bf16_round(np.exp2((s_all[:, t * KVB:(t + 1) * KVB] - m_run[:, None]) * c)).astype(np.float64)
+    fsum = lambda t: np.exp2((s_all[:, t * KVB:(t + 1) * KVB] - m_run[:, None]) * c).astype(np.float32).astype(np.float64).sum(axis=1)
+    O, l = np.zeros((nq, 128)), np.zeros(nq)
+    for t in range(t0):
+        O += probs(t) @ vf[t * KVB:(t + 1) * KVB]
+        l += fsum(t)
+    cfg = G.Cfg(128)                                      # (only for the staging helper: same tile geometry and lane mapping)
+    for t in range(t0 - 1, t0 + 3):
+        stage(pb, m.lds, cfg, "k", t, KL)
+    for t in range(t0 - 1, t0 + 2):
+        stage(pb, m.lds, cfg, "v", t, VL)
+
+    def sset(w, name, val):
+        r = asm_emu.parse_reg(tab[name])
+        w.s[r[1]] = np.uint32(int(val) & 0xFFFFFFFF)
+        if r[2] == 2:
+            w.s[r[1] + 1] = np.uint32(int(val) >> 32)
+
+    def vset(w, name, arr):
+        a = np.asarray(arr)
+        w.v[asm_emu.parse_reg(tab[name])[1]] = a.view(np.uint32) if a.dtype == np.float32 else a.astype(np.int64).astype(np.uint32)
+    for w in m.waves:
+        lane = np.arange(64)
+        l31, h2, tid = lane & 31, lane >> 5, w.id * 64 + lane
+        q_row = w.id * 32 + l31
+        sset(w, "t", t0), sset(w, "tend", tend), sset(w, "kstep", KVB * pb.k_rs * 2)
+        sset(w, "c", int(np.float32(c).view(np.uint32)))
+        sset(w, "wk", KL + w.id * 1024), sset(w, "wv", VL + w.id * 1024)
+        sset(w, "kb", pb.KOFF), sset(w, "vb", pb.VOFF), sset(w, "qb", pb.QOFF)
+        vset(w, "qvo", (q_row * pb.q_rs + h2 * 8) * 2)
+        vset(w, "negmc", (-m_run[q_row] * c).astype(np.float32))
+        vset(w, "l", np.where(h2 == 0, l[q_row], 0.0).astype(np.float32))
+        for ks in range(8):
+            vset(w, "lk%d" % ks, KL + k_frag_addr(128, l31, h2, ks))
+        for kk in range(4):
+            vset(w, "lv%d" % kk, VL + l31 * 128 + (((2 * kk + h2) ^ ((l31 >> 1) & 7)) * 16))
+        for i in range(4):
+            row, slot = k_dma_lane(128, tid, i)
+            vset(w, "kvo%d" % i, (((t0 + 3) * KVB + row) * pb.k_rs + slot * 8) * 2)
+            vrow, vslot = tid // 8 + 32 * i, (tid & 7) ^ ((tid >> 4) & 7)
+            vset(w, "vvo%d" % i, (vrow * pb.vt_rs + vslot * 8 + (t0 + 2) * KVB) * 2)
+        for i in range(64):
+            dt, e = i >> 4, i & 15
+            drow = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2
+            w.v[i] = O[q_row, drow].astype(np.float32).view(np.uint32)
+    n = m.run()
+    t_exit = int(m.waves[0].s[asm_emu.parse_reg(tab["t"])[1]])
+    codes = [int(w.s[asm_emu.parse_reg(tab["code"])[1]]) for w in m.waves]
+    O2, l2 = np.zeros((nq, 128)), np.zeros(nq)
+    for w in m.waves:
+        lane = np.arange(64)
+        l31, h2 = lane & 31, lane >> 5
+        q_row = w.id * 32 + l31
+        np.add.at(l2, q_row, w.v[asm_emu.parse_reg(tab["l"])[1]].view(np.float32).astype(np.float64))
+        for i in range(64):
+            dt, e = i >> 4, i & 15
+            drow = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2
+            O2[q_row, drow] = w.v[i].view(np.float32)
+    for t in range(t_exit, T):
+        O2 += probs(t) @ vf[t * KVB:(t + 1) * KVB]
+        l2 += fsum(t)
+    return O2 / l2[:, None], t_exit, codes, n, lines

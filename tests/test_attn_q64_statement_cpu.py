@@ -11,7 +11,10 @@ PROGRAM on the CPU, without a GPU:
   * static hazard rules on the text the emulator does not model: an MFMA's VGPR result is read by the VALU only after at least
     two later MFMAs have been issued, a transcendental's result is not read by the next instruction, M0 is written at least one
     instruction before the LDS-DMA that uses it, VCC at least five wait states before the branch on it, no more than seven
-    single-issue fillers sit behind any MFMA of the steady state (5 per gap on average is what one wave per SIMD hides)."""
+    single-issue fillers sit behind any MFMA of the steady state (5 per gap on average is what one wave per SIMD hides);
+  * the two OLDER generated statements run in the same emulator under the same orderings and mutations: the default d = 64 8-wave
+    statement (gen_attn_pipe.py, the headline's dominant kernel) and the 32-query d = 128 statement (gen_attn128_pipe.py), so every
+    single-statement loop the library ships is executed as a program on the CPU."""
 import os
 import re
 import sys
@@ -228,3 +231,68 @@ def test_committed_incs_are_what_the_generator_emits(tmp_path, cfg128, cfg64):
         out = tmp_path / name
         G.write(cfg, str(out))
         assert out.read_bytes() == open(os.path.join(ROOT, "alg_amd", "csrc", name), "rb").read(), name
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the DEFAULT d = 64 kernel's statement (gen_attn_pipe.py, 8-wave form) in the same emulator
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,seed", [(15, 11), (20, 12)])
+def test_default_d64_8wave_statement_computes_attention_under_the_weakest_memory_ordering(T, seed):
+    """attn_pipe_loop.inc's ALG_ATTN_PIPE8_LOOP_ASM -- the statement of the headline's dominant kernel since round 3 -- for a
+    256-query unit of eight waves: same emulator, same adversarial orderings, same float64 reference."""
+    pb = H.Problem(64, T, seed=seed, prescaled=True)
+    ref = pb.reference()
+    for lazy_reads, lazy_dma in MODES:
+        out, t_exit, codes, _, _ = H.run_pipe8_statement(pb, lazy_reads, lazy_dma)
+        assert t_exit == 1 + 4 * ((T - 3 - 1) // 4) and codes == [0] * 8          # whole groups of four while t + 4 <= T - 3
+        assert relerr(out, ref) < TOL, (lazy_reads, lazy_dma, relerr(out, ref))
+
+
+def test_the_harness_sees_defects_in_the_8wave_statement_too():
+    pb = H.Problem(64, 15, seed=11, prescaled=True)
+    ref = pb.reference()
+    muts = {"fragment wait one too loose": lambda L: _replace_nth(L, "s_waitcnt lgkmcnt(3)", "s_waitcnt lgkmcnt(4)", 60),
+            "DMA wait one too loose": lambda L: [("s_waitcnt vmcnt(4)" if ln == "s_waitcnt vmcnt(2)" else ln) for ln in L],
+            "no barrier": lambda L: [ln for ln in L if ln != "s_barrier"]}
+    for name, mut in muts.items():
+        worst = 0.0
+        for lazy_reads, lazy_dma in MODES:
+            try:
+                out, _, _, _, _ = H.run_pipe8_statement(pb, lazy_reads, lazy_dma, mutate=mut)
+                e = relerr(out, ref)
+                worst = max(worst, e if np.isfinite(e) else 1.0)
+            except RuntimeError:
+                worst = 1.0
+        assert worst > 10 * TOL, (name, worst)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the 32-query d = 128 kernel's statement (gen_attn128_pipe.py): ALG_ATTN128_Q64=0 -- the A/B arm of bench.py's C3-C5 legs --
+# and every sequence the 64-query kernel's policy does not take
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,seed", [(15, 13), (18, 14)])
+def test_d128_32query_statement_computes_attention_under_the_weakest_memory_ordering(T, seed):
+    pb = H.Problem(128, T, seed=seed)
+    ref = pb.reference()[:128]
+    for lazy_reads, lazy_dma in MODES:
+        out, t_exit, codes, _, _ = H.run_pipe128_statement(pb, lazy_reads, lazy_dma)
+        assert t_exit == 1 + 4 * ((T - 3 - 1) // 4) and codes == [0] * 4
+        assert relerr(out, ref) < TOL, (lazy_reads, lazy_dma, relerr(out, ref))
+
+
+def test_the_harness_sees_defects_in_the_d128_32query_statement_too():
+    pb = H.Problem(128, 15, seed=13)
+    ref = pb.reference()[:128]
+    muts = {"fragment wait one too loose": lambda L: _replace_nth(L, "s_waitcnt lgkmcnt(3)", "s_waitcnt lgkmcnt(4)", 60),
+            "DMA wait two too loose": lambda L: [("s_waitcnt vmcnt(10)" if ln == "s_waitcnt vmcnt(8)" else ln) for ln in L],
+            "no barrier": lambda L: [ln for ln in L if ln != "s_barrier"]}
+    for name, mut in muts.items():
+        worst = 0.0
+        for lazy_reads, lazy_dma in MODES:
+            try:
+                out, _, _, _, _ = H.run_pipe128_statement(pb, lazy_reads, lazy_dma, mutate=mut)
+                e = relerr(out, ref)
+                worst = max(worst, e if np.isfinite(e) else 1.0)
+            except RuntimeError:
+                worst = 1.0
+        assert worst > 10 * TOL, (name, worst)
