@@ -44,6 +44,8 @@ import os
 OACC, FR, Q = 0, 32, 64        # AccVGPRs: O^T tiles, fragment ring, Q fragments
 WAIT_PAIRS = os.environ.get("ATTN_PIPE_WAIT_PAIRS", "0") == "1"   # experiment knob (round 5): one fragment wait per two MFMAs
 NO_NOP = os.environ.get("ATTN_PIPE_NO_NOP", "0") == "1"           # experiment knob (round 5): no s_nop between an M0 write and its LDS-DMA
+SUM16 = os.environ.get("ATTN_PIPE_SUM16", "0") == "1"             # experiment knob (round 5, TIMING ONLY -- wrong row sums): row sums on the matrix pipe
+LACC, ONES = 80, 84            # (SUM16) AccVGPRs: 16x16 row-sum accumulator, the selector A operand
 NW = 4                         # waves per workgroup (configure())
 
 
@@ -82,6 +84,8 @@ def softmax_gap(S, P, n, first, last_of_tile=False):
         out.append("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(P + n - 1), v(pa), v(pb)))
         if n - 1 == 0:
             out.append("v_add_f32 %s, %s, %s" % (v(TS), v(pa), v(pb)))
+        elif SUM16:
+            pass
         else:
             out.append("v_add_f32 %s, %s, %s" % (v(SCR), v(pa), v(pb)))
             out.append("v_add_f32 %s, %s, %s" % (v(TS), v(TS), v(SCR)))
@@ -171,6 +175,9 @@ def iteration(phase, X, Y, U, W, pv=True, softmax=True, qk=True, reads_in_flight
         else:
             acc = ar(16 * half, 16)
             lines.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, fr, vr(U + 4 * kstep, 4), acc))
+            if SUM16 and half == 1:
+                # one 4-pass MFMA per kv block: D[0][n] / D[1][n] = sum over the block's 16 keys of P for queries n / 16 + n
+                lines.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (ar(LACC, 4), ar(ONES, 4), vr(U + 4 * kstep, 4), ar(LACC, 4)))
         if j + AHEAD < n_m:
             lines.append(read(j + AHEAD))
         elif prefetch_next is not None and j + AHEAD - n_m < AHEAD:
@@ -215,6 +222,8 @@ def emit():
     L += ["global_load_dwordx4 %s, %%[qvo], %%[qb] offset:%d" % (ar(Q + 4 * ks, 4), 32 * ks) for ks in range(4)]
     roles = {1: (SA, SB, PA, PB), 2: (SB, SA, PB, PA), 3: (SA, SB, PA, PB), 0: (SB, SA, PB, PA)}
     # ---- warm-up at phase 1: top protocol, QK(t) alone into X = SA (K(t) sits in slot 1 = the "next" slot of phase 0) ----
+    if SUM16:
+        L += ["v_accvgpr_write_b32 a%d, 0" % (LACC + i) for i in range(4)] + ["v_mov_b32 %s, 0x3f803f80" % v(SCR)] + ["v_accvgpr_write_b32 a%d, %s" % (ONES + i, v(SCR)) for i in range(4)]
     L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"]   # Q (and, once, whatever the caller had in flight)
     L += top_protocol(1)
     X, Y, U, W = roles[1]
@@ -259,7 +268,7 @@ def main():
             for ln in lines:
                 f.write('  "%s\\n\\t" \\\n' % ln)
             f.write('  ""\n')
-            regs = ["a%d" % i for i in range(80)] + ["v%d" % i for i in range(VBASE, VBASE + 102)]
+            regs = ["a%d" % i for i in range(88 if SUM16 else 80)] + ["v%d" % i for i in range(VBASE, VBASE + 102)]
             f.write("#define ALG_ATTN_PIPE%s_CLOBBERS \\\n  " % tag + ", ".join('"%s"' % r for r in regs) + '\n')
             f.write("#define ALG_ATTN_PIPE%s_O_OPERANDS(o) \\\n  " % tag +
                     ", ".join('[o%d] "+%s"(o[%d])' % (i, "v" if nw == 4 else "a", i) for i in range(32)) + '\n')
