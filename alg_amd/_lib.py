@@ -28,7 +28,7 @@ EXPORTS = (
     "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu", "alg_gemm_fp8", "alg_quantize_fp8_rows",
     "alg_conv_cl_bf16", "alg_vae_groupnorm_workspace", "alg_vae_groupnorm_stats", "alg_vae_spatial_norm", "alg_vae_upsample",
     "alg_vae_pack_latent", "alg_vae_unpack_video", "alg_vae_group_norm", "alg_vae_pad", "alg_vae_repitch",
-    "alg_vae_unpack_planes", "alg_rms_norm_rows", "alg_softmax_hilo", "alg_flash_attn_d128_ex", "alg_rope_half", "alg_patchify_t", "alg_unpatchify_t", "alg_qk_norm_rope_scaled", "alg_flash_attn_d64_ex", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
+    "alg_vae_unpack_planes", "alg_rms_norm_rows", "alg_softmax_hilo", "alg_flash_attn_d128_ex", "alg_flash_attn_d128_dual", "alg_rope_half", "alg_patchify_t", "alg_unpatchify_t", "alg_qk_norm_rope_scaled", "alg_flash_attn_d64_ex", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
     "alg_lowpass_tables_bytes", "alg_lowpass_tables_build", "alg_down_up_workspace_bytes", "alg_gaussian_blur_workspace_bytes",
     "alg_flash_attn_d64_workspace_bytes", "alg_calib_mfma_bf16", "alg_wall_clock_khz", "alg_attn_clock_tap",
 )
@@ -114,6 +114,8 @@ def load_library():
         c_void_p, c_int, c_void_p]
     lib.alg_flash_attn_d128.argtypes = [c_void_p] * 4 + [c_int] * 4 + [c_int64] * 8 + [c_float, c_void_p]
     lib.alg_flash_attn_d128_ex.argtypes = [c_void_p] * 4 + [c_int] * 4 + [c_int64] * 8 + [c_float, c_int, c_int, c_void_p]
+    lib.alg_flash_attn_d128_dual.argtypes = ([c_void_p] * 3 + [c_int] + [c_int64] * 4 + [c_void_p] * 2 + [c_int] + [c_int64] * 4 +
+                                             [c_void_p] + [c_int] * 3 + [c_int64] * 4 + [c_float, c_void_p])
     lib.alg_rope_half.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]
     lib.alg_layernorm_mod_f32.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]
     lib.alg_layernorm_mod_f32_fp8.argtypes = [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]
@@ -441,6 +443,19 @@ def rope_half_(x, cos, sin, pos, rows, heads, x_rstride, x_off=0):
     _check(load_library().alg_rope_half(_p(x, x_off), _p(cos), _p(sin), _p(pos), rows, heads, x_rstride, _stream()),
            "alg_rope_half")
     return x
+
+
+def flash_attn_d128_dual(q, k, vt, Skv, k_bs, k_rs, vt_bs, vt_rs, k2, vt2, Skv2, k2_bs, k2_rs, vt2_bs, vt2_rs, o, batch, heads, Sq,
+                         q_bs, q_rs, o_bs, o_rs, scale):
+    """o = bf16(bf16(attn(q, k, vt)) + bf16(attn(q, k2, vt2))) in one launch, head_dim 128: the text + image cross-attention of the
+    Wan I2V DiT (two short key / value sets for the same queries).  Bit-identical to two flash_attn_d128 calls + lincomb."""
+    lib = load_library()
+    for t in (q, k, vt, k2, vt2, o):
+        _dev(t, "attention operand")
+    _check(lib.alg_flash_attn_d128_dual(_p(q), _p(k), _p(vt), Skv, k_bs, k_rs, vt_bs, vt_rs, _p(k2), _p(vt2), Skv2, k2_bs, k2_rs,
+                                        vt2_bs, vt2_rs, _p(o), batch, heads, Sq, q_bs, q_rs, o_bs, o_rs, float(scale), _stream()),
+           "alg_flash_attn_d128_dual")
+    return o
 
 
 def flash_attn_d128(q, k, vt, o, batch, heads, Sq, Skv, q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs, scale,

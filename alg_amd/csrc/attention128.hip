@@ -38,6 +38,11 @@ struct P {
   int64_t q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs;
   float scale_log2;
   int kv_group;   // query heads per key / value head (grouped-query attention: Llama-3 32 / 8 = 4); 1 = ordinary heads
+  // DUAL only: a second key / value set attended by the same queries, o = bf16(bf16(attn(q, k, vt)) + bf16(attn(q, k2, vt2)))
+  const bf16_t* k2;
+  const bf16_t* vt2;
+  int Skv2;
+  int64_t k2_bs, k2_rs, vt2_bs, vt2_rs;
 };
 
 template <bool B>
@@ -45,7 +50,11 @@ struct BoolC { static constexpr bool value = B; };
 
 // CAUSAL: query row i sees keys 0 .. i (the decoder-only language model inside HunyuanVideo's prompt encoder, hy:282-420);
 // KV tiles entirely above the workgroup's last query are skipped, tiles that reach past a wave's first query are masked.
-template <bool CAUSAL>
+// DUAL: the same queries attend two key / value sets one after the other and the two (bf16-rounded) results are added -- the
+// image + text cross-attention of the Wan I2V DiT (diffusers WanAttnProcessor2_0: sdpa(q, k_img, v_img) + sdpa(q, k, v)) as ONE
+// launch: Q is read once, one output is written, and the separate add kernel (three more passes over [S, 5120]) is gone.  Bit
+// for bit what two launches + alg_lincomb give: each set runs the unchanged tile loop from a fresh softmax state.
+template <bool CAUSAL, bool DUAL = false>
 __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (K_TILE + V_TILE)];
   char* const k_ring = smem;
@@ -66,11 +75,13 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
     if (bh >= nbh) return;
   }
   const int b = bh / p.heads, h = bh - b * p.heads;
-  const int Sq = p.Sq, Skv = p.Skv;
+  const int Sq = p.Sq;
+  int Skv = p.Skv;
   const bf16_t* Q = p.q + (int64_t)b * p.q_bs + h * 128;
   const int hk = h / p.kv_group;
   const bf16_t* K = p.k + (int64_t)b * p.k_bs + hk * 128;
   const bf16_t* VT = p.vt + (int64_t)b * p.vt_bs + (int64_t)hk * 128 * p.vt_rs;
+  int64_t k_rs = p.k_rs, vt_rs = p.vt_rs;
 
   // Q^T fragments (B operand): lane (q = l31, h2) holds Q[q][16 ks + 8 h2 .. +8], ks = 0..7
   const int q_row = qb * (NW * 32) + wave * 32 + l31;
@@ -87,12 +98,12 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
   const int k_slot = (tid & 15) ^ ((tid >> 4) & 15);
   const int v_row = tid >> 3;                                  // + 64 per round
   const int v_slot = (tid & 7) ^ ((tid >> 4) & 7);
-  const bf16_t* v_src0 = VT + (int64_t)v_row * p.vt_rs + v_slot * 8;
-  const bf16_t* v_src1 = v_src0 + (int64_t)64 * p.vt_rs;
+  const bf16_t* v_src0 = VT + (int64_t)v_row * vt_rs + v_slot * 8;
+  const bf16_t* v_src1 = v_src0 + (int64_t)64 * vt_rs;
   auto stage = [&](int slot, int kv0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const bf16_t* ks = K + (int64_t)min(kv0 + k_row + i * 32, Skv - 1) * p.k_rs + k_slot * 8;
+      const bf16_t* ks = K + (int64_t)min(kv0 + k_row + i * 32, Skv - 1) * k_rs + k_slot * 8;
       __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(k_ring + slot * K_TILE + (i * 512 + wave * 64) * 16), 16, 0, 0);
     }
     __builtin_amdgcn_global_load_lds((gptr_t)(v_src0 + kv0), (lptr_t)(v_ring + slot * V_TILE + (wave * 64) * 16), 16, 0, 0);
@@ -111,10 +122,10 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
   float m_run = -INFINITY, l_run = 0.0f;
   const float c = p.scale_log2;
   int n_tiles = (Skv + KVB - 1) / KVB;
-  const bool ragged = (Skv & (KVB - 1)) != 0;
+  bool ragged = (Skv & (KVB - 1)) != 0;
   if (CAUSAL) n_tiles = min(n_tiles, (min(qb * (NW * 32) + NW * 32, Sq) + KVB - 1) / KVB);   // keys <= the block's last query
+  uint2 o1[DUAL ? 16 : 1];     // DUAL: the first set's output, rounded to bf16 as the single launch stores it
 
-  stage(0, 0);
   auto tile = [&](int t, auto masked) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -193,6 +204,36 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
         o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kk], o_acc[dt], 0, 0, 0);
       }
   };
+  for (int set = 0; set < (DUAL ? 2 : 1); ++set) {
+  if (DUAL && set == 1) {
+    // the second key / value set: fresh softmax state, the ring is free once every wave has left the first set's last tile
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        o1[dt * 4 + g].x = pack_bf2(o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv);
+        o1[dt * 4 + g].y = pack_bf2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o_acc[i][e] = 0.0f;
+    m_run = -INFINITY;
+    l_run = 0.0f;
+    Skv = p.Skv2;
+    k_rs = p.k2_rs;
+    vt_rs = p.vt2_rs;
+    K = p.k2 + (int64_t)b * p.k2_bs + hk * 128;
+    VT = p.vt2 + (int64_t)b * p.vt2_bs + (int64_t)hk * 128 * vt_rs;
+    v_src0 = VT + (int64_t)v_row * vt_rs + v_slot * 8;
+    v_src1 = v_src0 + (int64_t)64 * vt_rs;
+    n_tiles = (Skv + KVB - 1) / KVB;
+    ragged = (Skv & (KVB - 1)) != 0;
+    __syncthreads();
+  }
+  stage(0, 0);
   if (CAUSAL) {
     const int first_masked = (qb * (NW * 32) + wave * 32) / KVB;     // first tile that reaches past this wave's first query
     for (int t = 0; t < n_tiles; ++t) {                               // (wave-uniform; the barrier inside is hit by all)
@@ -205,6 +246,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
     const int n_loop = ragged ? n_tiles - 1 : n_tiles;
     for (int t = 0; t < n_loop; ++t) tile(t, BoolC<false>{});
     if (ragged) tile(n_tiles - 1, BoolC<true>{});
+  }
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -219,6 +261,13 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
         uint2 v;
         v.x = pack_bf2(o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv);
         v.y = pack_bf2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
+        if (DUAL) {   // bf16 + bf16 in fp32, rounded once: the eager add of the two attention outputs
+          const uint2 a = o1[dt * 4 + g];
+          auto lo = [](uint32_t u) { return __uint_as_float(u << 16); };
+          auto hi = [](uint32_t u) { return __uint_as_float(u & 0xffff0000u); };
+          v.x = pack_bf2(lo(a.x) + lo(v.x), hi(a.x) + hi(v.x));
+          v.y = pack_bf2(lo(a.y) + lo(v.y), hi(a.y) + hi(v.y));
+        }
         *(uint2*)(op + d) = v;
       }
   }
@@ -283,6 +332,7 @@ static int flash_attn_d128_entry(const void* q, const void* k, const void* vt, v
   p.vt_bs = vt_bstride; p.vt_rs = vt_rstride; p.o_bs = o_bstride; p.o_rs = o_rstride;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.kv_group = kv_group;
+  p.k2 = nullptr; p.vt2 = nullptr; p.Skv2 = 0; p.k2_bs = p.k2_rs = p.vt2_bs = p.vt2_rs = 0;
   const int nbh = batch * heads;
   const int64_t grid = (int64_t)((nbh + 7) / 8) * 8 * p.q_blocks;
   if (grid > 0x7fffffff) {
@@ -294,6 +344,48 @@ static int flash_attn_d128_entry(const void* q, const void* k, const void* vt, v
   else
     hipLaunchKernelGGL(a128::flash_attn_d128_kernel<false>, dim3((unsigned)grid), dim3(a128::NW * 64), 0, (hipStream_t)stream, p);
   return check_launch("alg_flash_attn_d128");
+}
+
+// Two key / value sets, one launch (the DUAL form of the kernel above); both sets are short by construction (encoder tokens)
+extern "C" int alg_flash_attn_d128_dual(const void* q, const void* k, const void* vt, int Skv, int64_t k_bstride, int64_t k_rstride,
+                                        int64_t vt_bstride, int64_t vt_rstride, const void* k2, const void* vt2, int Skv2,
+                                        int64_t k2_bstride, int64_t k2_rstride, int64_t vt2_bstride, int64_t vt2_rstride, void* o,
+                                        int batch, int heads, int Sq, int64_t q_bstride, int64_t q_rstride, int64_t o_bstride,
+                                        int64_t o_rstride, float scale, void* stream) {
+  if (!q || !k || !vt || !k2 || !vt2 || !o || batch <= 0 || heads <= 0 || Sq <= 0 || Skv <= 0 || Skv2 <= 0) {
+    set_error("alg_flash_attn_d128_dual: bad argument (batch=%d heads=%d Sq=%d Skv=%d Skv2=%d)", batch, heads, Sq, Skv, Skv2);
+    return ALG_EINVAL;
+  }
+  if (q_rstride % 8 || q_bstride % 8 || k_rstride % 8 || k_bstride % 8 || vt_rstride % 8 || vt_bstride % 8 || k2_rstride % 8 ||
+      k2_bstride % 8 || vt2_rstride % 8 || vt2_bstride % 8 || o_rstride % 4 || o_bstride % 4 || ((uintptr_t)q & 15) ||
+      ((uintptr_t)k & 15) || ((uintptr_t)vt & 15) || ((uintptr_t)k2 & 15) || ((uintptr_t)vt2 & 15) || ((uintptr_t)o & 7)) {
+    set_error("alg_flash_attn_d128_dual: q/k/vt need 16-byte aligned rows (strides %% 8 == 0), o 8-byte aligned");
+    return ALG_EINVAL;
+  }
+  if (vt_rstride < (int64_t)((Skv + a128::KVB - 1) / a128::KVB) * a128::KVB ||
+      vt2_rstride < (int64_t)((Skv2 + a128::KVB - 1) / a128::KVB) * a128::KVB) {
+    set_error("alg_flash_attn_d128_dual: vt row strides %lld / %lld must cover Skv / Skv2 rounded up to %d", (long long)vt_rstride,
+              (long long)vt2_rstride, a128::KVB);
+    return ALG_EINVAL;
+  }
+  a128::P p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;
+  p.batch = batch; p.heads = heads; p.Sq = Sq; p.Skv = Skv;
+  p.q_blocks = (Sq + a128::NW * 32 - 1) / (a128::NW * 32);
+  p.q_bs = q_bstride; p.q_rs = q_rstride; p.k_bs = k_bstride; p.k_rs = k_rstride;
+  p.vt_bs = vt_bstride; p.vt_rs = vt_rstride; p.o_bs = o_bstride; p.o_rs = o_rstride;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.kv_group = 1;
+  p.k2 = (const bf16_t*)k2; p.vt2 = (const bf16_t*)vt2; p.Skv2 = Skv2;
+  p.k2_bs = k2_bstride; p.k2_rs = k2_rstride; p.vt2_bs = vt2_bstride; p.vt2_rs = vt2_rstride;
+  const int nbh = batch * heads;
+  const int64_t grid = (int64_t)((nbh + 7) / 8) * 8 * p.q_blocks;
+  if (grid > 0x7fffffff) {
+    set_error("alg_flash_attn_d128_dual: grid too large");
+    return ALG_ELIMIT;
+  }
+  hipLaunchKernelGGL((a128::flash_attn_d128_kernel<false, true>), dim3((unsigned)grid), dim3(a128::NW * 64), 0, (hipStream_t)stream, p);
+  return check_launch("alg_flash_attn_d128_dual");
 }
 
 extern "C" int alg_flash_attn_d128(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int Sq,

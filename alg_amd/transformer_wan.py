@@ -141,6 +141,7 @@ class WanTransformer3DModel:
         (alg_quantize_fp8_rows); norms, attention, embedders and the residual stream stay bf16 / fp32."""
         self.fp8 = bool(fp8)
         self.pair_qkv = True     # bf16: Q|K and V^T projections of a block as one alg_gemm_bf16_pair launch (bit-identical)
+        self.dual_cross = True   # I2V: text + image cross-attention of a block as one alg_flash_attn_d128_dual launch (bit-identical to two launches + add)
         self.fuse_quant = True   # fp8: the modulated LayerNorm writes the e4m3 tokens + row scales itself (bit-identical to the quantiser pass)
         if config.qk_norm != "rms_norm_across_heads" or config.attention_head_dim != 128:
             raise NotImplementedError("the Wan DiT path is built for rms_norm_across_heads and head_dim 128")
@@ -294,7 +295,7 @@ class WanTransformer3DModel:
             ws.qk = e(N, S, 2 * D)
             ws.vt = z(N, D, ws.S_pad)              # padding columns stay zero (multiplied by p = 0)
             ws.h = e(N, S, Ff)
-            ws.o2 = e(N, S, D)
+            ws.o2 = None                           # second cross-attention output: only the two-launch form (dual_cross off) needs it
             ws.tok = e(N, S, self.w.out_w.shape[0])
             if self.fp8:
                 ws.q8 = e(N * S, max(D, Ff), dt=torch.uint8)      # e4m3 copy of the current GEMM input
@@ -421,16 +422,23 @@ class WanTransformer3DModel:
             _lib.rmsnorm_rope_(ws.kt, L.cnk, None, None, D, N, n_txt, D, cfg.eps)
             G(L.cv_w, ws.txt, ws.vtt, D, n_txt, D, D, D, ws.txt_pad, bias=L.cv_b, batch=N, strideB=n_txt * D,
               strideC=D * ws.txt_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
-            T("attn_cross", _lib.flash_attn_d128, ws.qc, ws.kt, ws.vtt, ws.att, N, heads, S, n_txt, S * D, D, n_txt * D, D,
-              D * ws.txt_pad, ws.txt_pad, S * D, D, scale)
             if n_img:
                 G(ws.img, L.ak_w, ws.ki, N * n_img, D, D, D, D, D, bias=L.ak_b)
                 _lib.rmsnorm_rope_(ws.ki, L.cnak, None, None, D, N, n_img, D, cfg.eps)
                 G(L.av_w, ws.img, ws.vti, D, n_img, D, D, D, ws.img_pad, bias=L.av_b, batch=N, strideB=n_img * D,
                   strideC=D * ws.img_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
-                T("attn_cross", _lib.flash_attn_d128, ws.qc, ws.ki, ws.vti, ws.o2, N, heads, S, n_img, S * D, D, n_img * D,
-                  D, D * ws.img_pad, ws.img_pad, S * D, D, scale)
-                T("add", _lib.lincomb, [(1.0, ws.att), (1.0, ws.o2)], BF, out=ws.att)
+            if n_img and self.dual_cross:   # sdpa(q, k, v) + sdpa(q, k_img, v_img): one launch, Q read once, no add pass
+                T("attn_cross", _lib.flash_attn_d128_dual, ws.qc, ws.kt, ws.vtt, n_txt, n_txt * D, D, D * ws.txt_pad, ws.txt_pad,
+                  ws.ki, ws.vti, n_img, n_img * D, D, D * ws.img_pad, ws.img_pad, ws.att, N, heads, S, S * D, D, S * D, D, scale)
+            else:
+                T("attn_cross", _lib.flash_attn_d128, ws.qc, ws.kt, ws.vtt, ws.att, N, heads, S, n_txt, S * D, D, n_txt * D, D,
+                  D * ws.txt_pad, ws.txt_pad, S * D, D, scale)
+                if n_img:
+                    if ws.o2 is None:
+                        ws.o2 = torch.empty_like(ws.att)
+                    T("attn_cross", _lib.flash_attn_d128, ws.qc, ws.ki, ws.vti, ws.o2, N, heads, S, n_img, S * D, D, n_img * D,
+                      D, D * ws.img_pad, ws.img_pad, S * D, D, scale)
+                    T("add", _lib.lincomb, [(1.0, ws.att), (1.0, ws.o2)], BF, out=ws.att)
             lin("gemm_cout", ws.att, L.co_w, ws.x, N * S, D, D, D, D, bias=L.co_b, R=ws.x, ldr=D)
             # ---- feed-forward ----
             ln_mod(None, None, ws.mod, ws.mod, mod_bs, scale_off=m0 + 4 * D, shift_off=m0 + 3 * D)

@@ -244,6 +244,15 @@ int alg_flash_attn_d128_ex(const void* q, const void* k, const void* vt, void* o
                            int64_t vt_rstride, int64_t o_bstride, int64_t o_rstride, float scale, int kv_group, int causal,
                            void* stream);
 
+/* Two key / value sets for the same queries, the two attention outputs added: the image + text cross-attention of the Wan I2V DiT
+ * (wan:910-917 calls WanTransformer3DModel; its attention processor computes sdpa(q, k_img, v_img) + sdpa(q, k, v) on bf16 tensors)
+ * as ONE launch -- o = bf16(bf16(attn(q, k, vt)) + bf16(attn(q, k2, vt2))), bit for bit what two alg_flash_attn_d128 calls and
+ * alg_lincomb give.  Layouts as alg_flash_attn_d128; both sets are meant to be short (encoder tokens). */
+int alg_flash_attn_d128_dual(const void* q, const void* k, const void* vt, int Skv, int64_t k_bstride, int64_t k_rstride,
+                             int64_t vt_bstride, int64_t vt_rstride, const void* k2, const void* vt2, int Skv2, int64_t k2_bstride,
+                             int64_t k2_rstride, int64_t vt2_bstride, int64_t vt2_rstride, void* o, int batch, int heads, int Sq,
+                             int64_t q_bstride, int64_t q_rstride, int64_t o_bstride, int64_t o_rstride, float scale, void* stream);
+
 /* Llama rotary embedding ("rotate_half" form) in place on x [rows][heads][128] bf16 (row stride x_rstride elements):
  * x' = x * cos[pos[r]] + rotate_half(x) * sin[pos[r]], every product and the sum rounded to bf16 like the eager graph;
  * cos / sin: fp32 tables [positions][128]; pos: int32 [rows]. */

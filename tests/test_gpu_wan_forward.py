@@ -65,6 +65,24 @@ def test_wan_forward_ragged_tokens_and_scalar_timestep():
     check_floor("wan_forward_ragged", out, ref, wan_oracle.wan_forward(ocfg, sd, x, t.expand(2), txt, img, dtype=BF))
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_wan_forward_dual_cross_attention_is_bit_identical_to_two_launches_and_the_add(fp8):
+    """`dual_cross` (default): the text + image cross-attention of every I2V block as ONE alg_flash_attn_d128_dual launch instead of
+    two attention launches and an add pass -- the same bits, through the whole forward (ragged token count, bf16 and fp8 linears)."""
+    cfg, ocfg = small(layers=2, heads=8)
+    sd = wan_oracle.init_weights(ocfg, seed=5)
+    model = WanTransformer3DModel(cfg, sd, device=DEV, fp8=fp8)
+    # bf16: 315 tokens (ragged query blocks); fp8: 288 (the per-token scale rows of a batch item must start 16-byte aligned)
+    x, txt, img = inputs(2, 3, 16, 24, 4) if fp8 else inputs(2, 5, 14, 18, 6)
+    t = torch.tensor(37.0)
+    assert model.dual_cross
+    run = lambda: model(x.to(DEV), t, txt.to(DEV), img.to(DEV), return_dict=False)[0].clone()
+    one = run()
+    model.dual_cross = False
+    two = run()
+    assert torch.equal(one, two) and bool(torch.isfinite(one.float()).all())
+
+
 def test_wan_alg_sampler_with_hip_dit():
     """wan:843-927 end to end: HIP filters + batch assembly + HIP DiT + CFG combine + UniPC, vs the loop oracle driving
     the fp32 oracle DiT on the CPU."""

@@ -127,6 +127,54 @@ def test_flash_attn_d128_pipelined_kernel(B, H, Sq, Skv, monkeypatch):
         assert torch.equal(o2, outs["1"])             # deterministic
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv,Skv2", [(1, 2, 300, 512, 257), (2, 3, 777, 257, 512), (1, 1, 31, 64, 1), (1, 2, 1024, 130, 70),
+                                               (2, 1, 257, 1, 513)])
+def test_flash_attn_d128_dual_is_two_launches_and_the_add(B, H, Sq, Skv, Skv2):
+    """alg_flash_attn_d128_dual (the text + image cross-attention of the Wan I2V block as one launch) against what it replaces --
+    two alg_flash_attn_d128 launches and alg_lincomb -- bit for bit, and against softmax(QK^T)V + softmax(QK2^T)V2 in fp32."""
+    D = H * 128
+    q, k, v = _rand((B, Sq, D), 1), _rand((B, Skv, D), 2), _rand((B, Skv, D), 3)
+    k2, v2 = _rand((B, Skv2, D), 4, 1.5), _rand((B, Skv2, D), 5)
+    pad, pad2 = (Skv + 63) // 64 * 64, (Skv2 + 127) // 128 * 128          # (two different paddings: the strides are independent)
+    vt, vt2 = make_vt(v, pad), make_vt(v2, pad2)
+    scale = 1.0 / math.sqrt(128)
+    o_a = torch.zeros(B, Sq, D, dtype=BF, device=DEV)
+    o_b = torch.zeros(B, Sq, D, dtype=BF, device=DEV)
+    _lib.flash_attn_d128(q, k, vt, o_a, B, H, Sq, Skv, Sq * D, D, Skv * D, D, D * pad, pad, Sq * D, D, scale)
+    _lib.flash_attn_d128(q, k2, vt2, o_b, B, H, Sq, Skv2, Sq * D, D, Skv2 * D, D, D * pad2, pad2, Sq * D, D, scale)
+    two = torch.empty_like(o_a)
+    _lib.lincomb([(1.0, o_a), (1.0, o_b)], BF, out=two)
+    assert torch.equal(two, o_a + o_b)                                      # (the add kernel is the eager bf16 add)
+    one = torch.full((B, Sq, D), 7.0, dtype=BF, device=DEV)
+    _lib.flash_attn_d128_dual(q, k, vt, Skv, Skv * D, D, D * pad, pad, k2, vt2, Skv2, Skv2 * D, D, D * pad2, pad2, one, B, H, Sq,
+                              Sq * D, D, Sq * D, D, scale)
+    assert torch.equal(one, two)
+
+    def sdpa(kk, vv, n):
+        qh = q.float().view(B, Sq, H, 128).transpose(1, 2)
+        kh = kk.float().view(B, n, H, 128).transpose(1, 2)
+        vh = vv.float().view(B, n, H, 128).transpose(1, 2)
+        return (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(B, Sq, D)
+    ref = sdpa(k, v, Skv) + sdpa(k2, v2, Skv2)
+    assert (one.float() - ref).abs().max().item() < 4e-2
+    assert (one.float() - ref).abs().mean().item() < 4e-3
+
+
+def test_flash_attn_d128_dual_rejects_bad_arguments():
+    q = _rand((1, 64, 128), 4)
+    ok = dict(k=q, vt=q, n=64, k2=q, vt2=q, n2=64)
+    call = lambda **kw: _lib.flash_attn_d128_dual(
+        q, kw.get("k", q), kw.get("vt", q), kw.get("n", 64), 64 * 128, 128, 128 * 64, 64, kw.get("k2", q), kw.get("vt2", q),
+        kw.get("n2", 64), 64 * 128, 128, 128 * 64, 64, q.clone(), 1, 1, 64, 64 * 128, 128, 64 * 128, 128, 0.1)
+    call(**ok)
+    with pytest.raises(_lib.AlgHipError):      # second set's vt row stride shorter than Skv2 rounded up
+        call(n2=100)
+    with pytest.raises(_lib.AlgHipError):
+        call(n=0)
+    with pytest.raises(_lib.AlgHipError):
+        call(k2=q.cpu())
+
+
 def test_flash_attn_d128_rejects_bad_arguments():
     q = _rand((1, 64, 128), 4)
     with pytest.raises(_lib.AlgHipError):  # vt row stride shorter than Skv rounded up
