@@ -215,7 +215,7 @@ class HunyuanVideoTransformer3DModel:
         self.w = w
         self._ws = {}
         self._rope_cache = {}
-        self.profile = None  # set to a dict to collect (start, stop) HIP event pairs of the joint attention launches
+        self.profile = None  # set to a dict to collect (start, stop) HIP event pairs per kernel family of the large launches
 
     @classmethod
     def from_synthetic(cls, config=None, seed=1234, device="cuda"):
@@ -240,6 +240,17 @@ class HunyuanVideoTransformer3DModel:
 
     def to(self, *a, **k):
         return self
+
+    def _timed(self, name, fn, *a, **k):
+        """the launch, bracketed by a HIP event pair under `name` when `profile` is a dict (bench / tests)"""
+        if self.profile is None:
+            return fn(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        self.profile.setdefault(name, []).append((e0, e1))
+        return r
 
     def rope_tables(self, F_, H, W):
         key = (F_, H, W)
@@ -294,7 +305,7 @@ class HunyuanVideoTransformer3DModel:
 
     def __call__(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, pooled_projections,
                  guidance=None, attention_kwargs=None, return_dict=True):
-        cfg, w, G = self.config, self.w, _lib.gemm
+        cfg, w, G, T = self.config, self.w, _lib.gemm, self._timed
         if hidden_states.device.type != "cuda":
             raise _lib.AlgHipError("HunyuanVideoTransformer3DModel needs device tensors; there is no CPU fallback")
         N, C, F_, H, W = hidden_states.shape
@@ -413,38 +424,38 @@ class HunyuanVideoTransformer3DModel:
             mv = ws.mod
             ada(Lw.ada_c, ws.semb1, ws.modc, 6 * D, False)
             # shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp at +0, +D, ... of every 6D vector
-            _lib.layernorm_modulate_seg(ws.x, ws.y, None, None, mv, mv, mod_bs, seg, N, S, D, split, 1e-6, x_bstride=J * D,
-                                        y_bstride=J * D, scale_off=D, shift_off=0)
+            T("ln_mod", _lib.layernorm_modulate_seg, ws.x, ws.y, None, None, mv, mv, mod_bs, seg, N, S, D, split, 1e-6,
+              x_bstride=J * D, y_bstride=J * D, scale_off=D, shift_off=0)
             _lib.layernorm_modulate_seg(ws.x, ws.y, None, None, ws.modc, ws.modc, 6 * D, 0, N, L, D, 0, 1e-6,
                                         x_bstride=J * D, y_bstride=J * D, x_off=S * D, y_off=S * D, scale_off=D, shift_off=0)
-            G(ws.y, Lw.wqk, ws.qk, S, 2 * D, D, D, D, 2 * D, bias=Lw.bqk, batch=N, strideA=J * D, strideC=J * 2 * D)
+            T("gemm_qk", G, ws.y, Lw.wqk, ws.qk, S, 2 * D, D, D, D, 2 * D, bias=Lw.bqk, batch=N, strideA=J * D, strideC=J * 2 * D)
             G(ws.y, Lw.wqk_c, ws.qk, L, 2 * D, D, D, D, 2 * D, bias=Lw.bqk_c, batch=N, strideA=J * D, strideC=J * 2 * D,
               a_off=S * D, c_off=S * 2 * D)
-            G(Lw.v[0], ws.y, ws.vt, D, S, D, D, D, ws.J_pad, bias=Lw.v[1], batch=N, strideB=J * D, strideC=D * ws.J_pad,
-              flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
+            T("gemm_vt", G, Lw.v[0], ws.y, ws.vt, D, S, D, D, D, ws.J_pad, bias=Lw.v[1], batch=N, strideB=J * D,
+              strideC=D * ws.J_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
             G(Lw.v_c[0], ws.y, ws.vt, D, L, D, D, D, ws.J_pad, bias=Lw.v_c[1], batch=N, strideB=J * D,
               strideC=D * ws.J_pad, b_off=S * D, perm_col0=S, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
             # latent rows: norm_q / norm_k + rope; prompt rows: norm_added_q / norm_added_k, no rope
-            _lib.headnorm_rope_(ws.qk, Lw.nq, cos, sin, 2 * D, J * 2 * D, N, S, heads, S, 1e-6)
-            _lib.headnorm_rope_(ws.qk, Lw.nk, cos, sin, 2 * D, J * 2 * D, N, S, heads, S, 1e-6, x_off=D)
+            T("headnorm_rope", _lib.headnorm_rope_, ws.qk, Lw.nq, cos, sin, 2 * D, J * 2 * D, N, S, heads, S, 1e-6)
+            T("headnorm_rope", _lib.headnorm_rope_, ws.qk, Lw.nk, cos, sin, 2 * D, J * 2 * D, N, S, heads, S, 1e-6, x_off=D)
             _lib.headnorm_rope_(ws.qk, Lw.nq_c, None, None, 2 * D, J * 2 * D, N, L, heads, 0, 1e-6, x_off=S * 2 * D)
             _lib.headnorm_rope_(ws.qk, Lw.nk_c, None, None, 2 * D, J * 2 * D, N, L, heads, 0, 1e-6, x_off=S * 2 * D + D)
             attention()
-            G(ws.am, Lw.o[0], ws.x, S, D, D, AM, D, D, bias=Lw.o[1], R=ws.x, ldr=D, gate=mv, gate_off=2 * D,
+            T("gemm_out", G, ws.am, Lw.o[0], ws.x, S, D, D, AM, D, D, bias=Lw.o[1], R=ws.x, ldr=D, gate=mv, gate_off=2 * D,
               strideGate=mod_bs, gate_seg_stride=seg, seg_split=split, batch=N, strideA=J * AM, strideC=J * D, strideR=J * D)
             G(ws.am, Lw.o_c[0], ws.x, L, D, D, AM, D, D, bias=Lw.o_c[1], R=ws.x, ldr=D, gate=ws.modc, gate_off=2 * D,
               strideGate=6 * D, gate_seg_stride=0, batch=N, strideA=J * AM, strideC=J * D, strideR=J * D, a_off=S * AM,
               c_off=S * D, r_off=S * D)
-            _lib.layernorm_modulate_seg(ws.x, ws.y, None, None, mv, mv, mod_bs, seg, N, S, D, split, 1e-6, x_bstride=J * D,
-                                        y_bstride=J * D, scale_off=4 * D, shift_off=3 * D)
+            T("ln_mod", _lib.layernorm_modulate_seg, ws.x, ws.y, None, None, mv, mv, mod_bs, seg, N, S, D, split, 1e-6,
+              x_bstride=J * D, y_bstride=J * D, scale_off=4 * D, shift_off=3 * D)
             _lib.layernorm_modulate_seg(ws.x, ws.y, None, None, ws.modc, ws.modc, 6 * D, 0, N, L, D, 0, 1e-6,
                                         x_bstride=J * D, y_bstride=J * D, x_off=S * D, y_off=S * D, scale_off=4 * D,
                                         shift_off=3 * D)
-            G(ws.y, Lw.f1[0], ws.am, S, M, D, D, D, AM, bias=Lw.f1[1], act=_lib.ACT_GELU_TANH, batch=N, strideA=J * D,
-              strideC=J * AM, c_off=D)
+            T("gemm_ff1", G, ws.y, Lw.f1[0], ws.am, S, M, D, D, D, AM, bias=Lw.f1[1], act=_lib.ACT_GELU_TANH, batch=N,
+              strideA=J * D, strideC=J * AM, c_off=D)
             G(ws.y, Lw.f1_c[0], ws.am, L, M, D, D, D, AM, bias=Lw.f1_c[1], act=_lib.ACT_GELU_TANH, batch=N, strideA=J * D,
               strideC=J * AM, a_off=S * D, c_off=S * AM + D)
-            G(ws.am, Lw.f2[0], ws.x, S, D, M, AM, M, D, bias=Lw.f2[1], R=ws.x, ldr=D, gate=mv, gate_off=5 * D,
+            T("gemm_ff2", G, ws.am, Lw.f2[0], ws.x, S, D, M, AM, M, D, bias=Lw.f2[1], R=ws.x, ldr=D, gate=mv, gate_off=5 * D,
               strideGate=mod_bs, gate_seg_stride=seg, seg_split=split, batch=N, strideA=J * AM, strideC=J * D, strideR=J * D,
               a_off=D)
             G(ws.am, Lw.f2_c[0], ws.x, L, D, M, AM, M, D, bias=Lw.f2_c[1], R=ws.x, ldr=D, gate=ws.modc, gate_off=5 * D,
@@ -458,16 +469,16 @@ class HunyuanVideoTransformer3DModel:
                 G(ws.semb2, Lw.ada[0], ws.mod, 2 * N, 3 * D, D, D, D, 3 * D, bias=Lw.ada[1])       # [N][2][3D]: shift, scale, gate
             else:
                 G(ws.semb1, Lw.ada[0], ws.mod, N, 3 * D, D, D, D, 3 * D, bias=Lw.ada[1])
-            _lib.layernorm_modulate_seg(ws.x, ws.y, None, None, ws.mod, ws.mod, smod_bs, sseg, N, J, D, split, 1e-6,
-                                        scale_off=D, shift_off=0)
-            G(ws.y, Lw.mlp[0], ws.am, N * J, M, D, D, D, AM, bias=Lw.mlp[1], act=_lib.ACT_GELU_TANH, c_off=D)
-            G(ws.y, Lw.wqk, ws.qk, N * J, 2 * D, D, D, D, 2 * D, bias=Lw.bqk)
-            G(Lw.v[0], ws.y, ws.vt, D, J, D, D, D, ws.J_pad, bias=Lw.v[1], batch=N, strideB=J * D, strideC=D * ws.J_pad,
-              flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
-            _lib.headnorm_rope_(ws.qk, Lw.nq, cos, sin, 2 * D, J * 2 * D, N, J, heads, S, 1e-6)
-            _lib.headnorm_rope_(ws.qk, Lw.nk, cos, sin, 2 * D, J * 2 * D, N, J, heads, S, 1e-6, x_off=D)
+            T("ln_mod", _lib.layernorm_modulate_seg, ws.x, ws.y, None, None, ws.mod, ws.mod, smod_bs, sseg, N, J, D, split, 1e-6,
+              scale_off=D, shift_off=0)
+            T("gemm_ff1", G, ws.y, Lw.mlp[0], ws.am, N * J, M, D, D, D, AM, bias=Lw.mlp[1], act=_lib.ACT_GELU_TANH, c_off=D)
+            T("gemm_qk", G, ws.y, Lw.wqk, ws.qk, N * J, 2 * D, D, D, D, 2 * D, bias=Lw.bqk)
+            T("gemm_vt", G, Lw.v[0], ws.y, ws.vt, D, J, D, D, D, ws.J_pad, bias=Lw.v[1], batch=N, strideB=J * D,
+              strideC=D * ws.J_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
+            T("headnorm_rope", _lib.headnorm_rope_, ws.qk, Lw.nq, cos, sin, 2 * D, J * 2 * D, N, J, heads, S, 1e-6)
+            T("headnorm_rope", _lib.headnorm_rope_, ws.qk, Lw.nk, cos, sin, 2 * D, J * 2 * D, N, J, heads, S, 1e-6, x_off=D)
             attention()
-            G(ws.am, Lw.out[0], ws.x, J, D, AM, AM, AM, D, bias=Lw.out[1], R=ws.x, ldr=D, gate=ws.mod, gate_off=2 * D,
+            T("gemm_out_mlp", G, ws.am, Lw.out[0], ws.x, J, D, AM, AM, AM, D, bias=Lw.out[1], R=ws.x, ldr=D, gate=ws.mod, gate_off=2 * D,
               strideGate=smod_bs, gate_seg_stride=sseg, seg_split=split, batch=N, strideA=J * AM, strideC=J * D,
               strideR=J * D)
 

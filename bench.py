@@ -724,6 +724,16 @@ class C4(Workload):
         tt = sum(ms.get("attn_self", [])) / 1e3
         a = per_fwd * forwards_local * self.layers / tt / 1e12 if tt > 0 else 0.0
         extra = {"time_share": {k: round(sum(v) / 1e3 / elapsed, 4) for k, v in ms.items()}}
+        # the large GEMM families (latent rows of the 20 dual-stream blocks, joint rows of the 40 single-stream blocks; the prompt
+        # rows' own small GEMMs are not bracketed): FLOP summed over the blocks of ONE forward
+        S, J, M, nd, ns = self.S, self.J, 4 * D, self.cfg.num_layers, self.cfg.num_single_layers
+        fam = {"gemm_qk": 2.0 * D * 2 * D * (nd * S + ns * J), "gemm_vt": 2.0 * D * D * (nd * S + ns * J),
+               "gemm_out": 2.0 * D * D * nd * S, "gemm_ff1": 2.0 * D * M * (nd * S + ns * J), "gemm_ff2": 2.0 * M * D * nd * S,
+               "gemm_out_mlp": 2.0 * (D + M) * D * ns * J}
+        for k, f in fam.items():
+            t_k = sum(ms.get(k, [])) / 1e3
+            if t_k > 0:
+                extra[k + "_tflops"] = f * forwards_local / t_k / 1e12
         # every block is 12 D^2 multiply-adds per token of linears (dual: qkv 3 + out 1 + mlp 8; single: 7 + 5) + its attention
         extra["whole_step_tflops"] = (24.0 * self.J * D * D + per_fwd) * forwards_local * self.layers / elapsed / 1e12
         return dict(bound="mfma", kernel=self.attn_kernel, achieved=a, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
