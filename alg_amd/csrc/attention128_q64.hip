@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
   };
 
   // the statement runs iterations t < tend: QK(t + 1) must not touch the masked (ragged) last tile.  Its DMA of K(t + 3) / V^T(t + 2)
-  // reaches past the end in the last iterations: the advanced offsets are clamped to the lane's last valid source (klim / vlim)
+  // reaches past the end in the last iterations: the buffer descriptors' num_records end the panel, such pieces fetch nothing
   const int tend = ragged ? T - 2 : T - 1;
   int t = 1;
   bool top_done = false;
@@ -242,32 +242,40 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
       for (int ks = 0; ks < 8; ++ks) lk[ks] = kl + x.k_row_off + (((2 * ks + x.h2) ^ x.k_sw) * 16);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) lv[kk] = vl + x.v_row_off + (((2 * kk + x.h2) ^ x.v_sw) * 16);
-      int kvo[4], vvo[4], klim[4], vlim[4];
+      // DMA: the lane's byte offset inside a tile (constant) against raw buffer descriptors whose base is the tile the statement
+      // fetches first -- K(t + 3), V^T(t + 2) -- and whose num_records is what is left of this (batch, head) panel from there
+      // (0 once the tile lies past the end: the statement prefetches past the last tile it computes, and such pieces fetch nothing)
+      int kvo[4], vvo[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        klim[i] = (int)(((int64_t)min((T - 1) * KVB + x.k_row + 16 * i, Skv - 1) * p.k_rs + x.k_slot * 8) * 2);
-        vlim[i] = (int)(((int64_t)(x.v_row + 32 * i) * p.vt_rs + x.v_slot * 8 + (T - 1) * KVB) * 2);
-        kvo[i] = min((int)(((int64_t)((t + 3) * KVB + x.k_row + 16 * i) * p.k_rs + x.k_slot * 8) * 2), klim[i]);
-        vvo[i] = min((int)(((int64_t)(x.v_row + 32 * i) * p.vt_rs + x.v_slot * 8 + (t + 2) * KVB) * 2), vlim[i]);
+        kvo[i] = (int)(((int64_t)(x.k_row + 16 * i) * p.k_rs + x.k_slot * 8) * 2);
+        vvo[i] = (int)(((int64_t)(x.v_row + 32 * i) * p.vt_rs + x.v_slot * 8) * 2);
       }
+      const int64_t k_tile_bytes = (int64_t)KVB * p.k_rs * 2;
+      const int64_t k_left = ((int64_t)(Skv - 1) * p.k_rs + 128) * 2 - (int64_t)(t + 3) * k_tile_bytes;
+      const int64_t v_left = (int64_t)128 * p.vt_rs * 2 - (int64_t)(t + 2) * KVB * 2;
+      const uint64_t kt = uniform64((const char*)K + (int64_t)(t + 3) * k_tile_bytes);
+      const uint64_t vtb = uniform64((const char*)VT + (int64_t)(t + 2) * KVB * 2);
+      const int kd0 = sreg((int)(uint32_t)kt), kd1 = sreg((int)(uint32_t)(kt >> 32) & 0xffff), kd2 = sreg((int)(uint32_t)(k_left > 0 ? k_left : 0));
+      const int vd0 = sreg((int)(uint32_t)vtb), vd1 = sreg((int)(uint32_t)(vtb >> 32) & 0xffff), vd2 = sreg((int)(uint32_t)(v_left > 0 ? v_left : 0));
+      const int d3 = sreg(0x00020000);
       const int qvo0 = (int)(((int64_t)min(x.q_row, Sq - 1) * p.q_rs + x.h2 * 8) * 2);
       const int qvo1 = (int)(((int64_t)min(x.q_row + 32, Sq - 1) * p.q_rs + x.h2 * 8) * 2);
-      const uint64_t kb = uniform64(K), vb = uniform64(VT), qbs = uniform64(Q);
-      const int kstep = sreg((int)(KVB * p.k_rs * 2)), tend_s = sreg(tend);
+      const uint64_t qbs = uniform64(Q);
+      const int kstep = sreg((int)k_tile_bytes), tend_s = sreg(tend);
       const int wk = sreg((int)kl + wave * 1024), wv = sreg((int)vl + wave * 1024);
       const float c_s = __builtin_bit_cast(float, sreg(__builtin_bit_cast(int, c)));
       const float negmc0 = -m_run[0] * c, negmc1 = -m_run[1] * c;
       int ts = sreg(t), code;
       asm volatile(ALG_ATTN128_Q64_LOOP_ASM
-                   : ALG_ATTN128_Q64_O_OPERANDS(oa), [l0] "+v"(l_run[0]), [l1] "+v"(l_run[1]), [t] "+s"(ts), [code] "=&s"(code),
-                     [kvo0] "+v"(kvo[0]), [kvo1] "+v"(kvo[1]), [kvo2] "+v"(kvo[2]), [kvo3] "+v"(kvo[3]), [vvo0] "+v"(vvo[0]),
-                     [vvo1] "+v"(vvo[1]), [vvo2] "+v"(vvo[2]), [vvo3] "+v"(vvo[3])
+                   : ALG_ATTN128_Q64_O_OPERANDS(oa), [l0] "+v"(l_run[0]), [l1] "+v"(l_run[1]), [t] "+s"(ts), [code] "=&s"(code)
                    : [lk0] "v"(lk[0]), [lk1] "v"(lk[1]), [lk2] "v"(lk[2]), [lk3] "v"(lk[3]), [lk4] "v"(lk[4]), [lk5] "v"(lk[5]),
                      [lk6] "v"(lk[6]), [lk7] "v"(lk[7]), [lv0] "v"(lv[0]), [lv1] "v"(lv[1]), [lv2] "v"(lv[2]), [lv3] "v"(lv[3]),
-                     [klim0] "v"(klim[0]), [klim1] "v"(klim[1]), [klim2] "v"(klim[2]), [klim3] "v"(klim[3]), [vlim0] "v"(vlim[0]),
-                     [vlim1] "v"(vlim[1]), [vlim2] "v"(vlim[2]), [vlim3] "v"(vlim[3]),
-                     [qvo0] "v"(qvo0), [qvo1] "v"(qvo1), [negmc0] "v"(negmc0), [negmc1] "v"(negmc1), [c] "s"(c_s), [kb] "s"(kb),
-                     [vb] "s"(vb), [qb] "s"(qbs), [kstep] "s"(kstep), [tend] "s"(tend_s), [wk] "s"(wk), [wv] "s"(wv)
+                     [kvo0] "v"(kvo[0]), [kvo1] "v"(kvo[1]), [kvo2] "v"(kvo[2]), [kvo3] "v"(kvo[3]), [vvo0] "v"(vvo[0]),
+                     [vvo1] "v"(vvo[1]), [vvo2] "v"(vvo[2]), [vvo3] "v"(vvo[3]),
+                     [qvo0] "v"(qvo0), [qvo1] "v"(qvo1), [negmc0] "v"(negmc0), [negmc1] "v"(negmc1), [c] "s"(c_s),
+                     [kd0] "s"(kd0), [kd1] "s"(kd1), [kd2] "s"(kd2), [kd3] "s"(d3), [vd0] "s"(vd0), [vd1] "s"(vd1), [vd2] "s"(vd2),
+                     [vd3] "s"(d3), [qb] "s"(qbs), [kstep] "s"(kstep), [tend] "s"(tend_s), [wk] "s"(wk), [wv] "s"(wv)
                    : "memory", "vcc", "scc", ALG_ATTN128_Q64_CLOBBERS);
       t = ts;
       top_done = code != 0;   // 1: iteration t's protocol is done, softmax(t) is not: tile t is redone below

@@ -15,9 +15,9 @@ weakest timing the ISA allows:
 A schedule is accepted when it computes the right answer under lazy reads + eager DMA, eager reads + lazy DMA and lazy + lazy.
 MFMA result latency (XDL write -> VALU read wait states) is NOT modelled here: tests check it statically on the listing.
 
-Instruction subset: v_mfma_f32_32x32x16_bf16, ds_read_b128, global_load_dwordx4, global_load_lds_dwordx4, v_exp_f32, v_fma_f32,
+Instruction subset: v_mfma_f32_32x32x16_bf16, ds_read_b128, global_load_dwordx4, global_load_lds_dwordx4, buffer_load_dwordx4 .. offen lds, v_exp_f32, v_fma_f32,
 v_add_f32, v_mul_f32, v_mov_b32, v_add_u32, v_min_u32, v_cvt_pk_bf16_f32, v_cmp_ngt_f32, v_accvgpr_{read,write,mov}_b32, s_add_u32, s_sub_u32,
-s_mov_b32, s_cmp_le_u32 / lt / ge, s_branch, s_cbranch_scc1 / scc0 / vccnz / vccz, s_waitcnt, s_barrier, s_nop.
+s_mov_b32, s_addc_u32, s_cselect_b32, s_cmp_le_u32 / lt / ge, s_branch, s_cbranch_scc1 / scc0 / vccnz / vccz, s_waitcnt, s_barrier, s_nop.
 """
 import re
 
@@ -69,7 +69,7 @@ def parse_reg(tok):
 
 
 class Machine:
-    def __init__(self, text_lines, n_waves=4, lds_bytes=160 * 1024, gmem=None, lazy_reads=True, lazy_dma=True):
+    def __init__(self, text_lines, n_waves=4, lds_bytes=160 * 1024, gmem=None, lazy_reads=True, lazy_dma=True, gmem_va=0):
         self.lines = []
         self.labels = {}
         for ln in text_lines:
@@ -84,6 +84,7 @@ class Machine:
         self.waves = [Wave(i) for i in range(n_waves)]
         self.lds = np.zeros(lds_bytes, dtype=np.uint8)
         self.gmem = gmem if gmem is not None else np.zeros(0, dtype=np.uint8)
+        self.gmem_va = gmem_va            # the virtual address of gmem[0] (tests put a panel across a 4 GiB boundary)
         self.lazy_reads, self.lazy_dma = lazy_reads, lazy_dma
         self.trace = None
 
@@ -137,6 +138,13 @@ class Machine:
         assert f == "s" and n == 2, tok
         return int(w.s[i]) | (int(w.s[i + 1]) << 32)
 
+    def gbytes(self, addr):
+        """16 bytes per lane from virtual addresses addr [64]; anything outside the image is a memory fault"""
+        idx = np.asarray(addr, dtype=np.int64)[:, None] + np.arange(16)[None, :] - self.gmem_va
+        if idx.min() < 0 or idx.max() >= self.gmem.size:
+            raise RuntimeError("memory fault: global address outside the image")
+        return self.gmem[idx]
+
     # ---- memory completion -------------------------------------------------------------------------------------------
     def drain(self, queue, leave):
         while len(queue) > leave:
@@ -160,8 +168,8 @@ class Machine:
             parts = args[-1].split()
             args[-1] = parts[0]
             for p in parts[1:]:
-                k, _, val = p.partition(":")
-                mods[k] = int(val, 0)
+                k, colon, val = p.partition(":")
+                mods[k] = int(val, 0) if colon else True          # "offset:32" | flags such as "offen", "lds"
         if op == "s_barrier":
             w.at_barrier = True
             return
@@ -174,9 +182,12 @@ class Machine:
                 cands = self.labels[m.group(1)]
                 w.pc = max(c for c in cands if c <= here) if m.group(2) == "b" else min(c for c in cands if c > here)
             return
-        if op in ("s_add_u32", "s_sub_u32"):
+        if op == "s_cselect_b32":
+            self.wr(w, args[0], np.uint32(int(self.rd(w, args[1] if w.scc else args[2])[0])))
+            return
+        if op in ("s_add_u32", "s_sub_u32", "s_addc_u32"):
             a, b = int(self.rd(w, args[1])[0]), int(self.rd(w, args[2])[0])
-            r = a + b if op == "s_add_u32" else a - b
+            r = a - b if op == "s_sub_u32" else a + b + (w.scc if op == "s_addc_u32" else 0)
             w.scc = int(r > 0xFFFFFFFF or r < 0)
             if args[0] == "m0":
                 w.m0 = r & 0xFFFFFFFF
@@ -251,8 +262,7 @@ class Machine:
             addr = self.rd(w, args[1]).astype(np.int64) + self.s64(w, args[2]) + mods.get("offset", 0)
 
             def complete(regs=regs, first=first, addr=addr):
-                idx = addr[:, None] + np.arange(16)[None, :]
-                data = self.gmem[idx].reshape(64, 4, 4)
+                data = self.gbytes(addr).reshape(64, 4, 4)
                 words = data[:, :, 0].astype(np.uint32) | (data[:, :, 1].astype(np.uint32) << 8) | \
                     (data[:, :, 2].astype(np.uint32) << 16) | (data[:, :, 3].astype(np.uint32) << 24)
                 for k in range(4):
@@ -265,7 +275,7 @@ class Machine:
         if op == "global_load_lds_dwordx4":
             addr = self.rd(w, args[0]).astype(np.int64) + self.s64(w, args[1]) + mods.get("offset", 0)
             dst = int(w.m0) + mods.get("offset", 0) + np.arange(64, dtype=np.int64) * 16
-            src = self.gmem[addr[:, None] + np.arange(16)[None, :]].copy()     # global data is read-only here: sample at issue
+            src = self.gbytes(addr).copy()     # global data is read-only here: sample at issue
 
             def complete(dst=dst, src=src):
                 self.lds[dst[:, None] + np.arange(16)[None, :]] = src
@@ -273,6 +283,31 @@ class Machine:
                 w.vm.append(complete)
             else:
                 w.vm.append(lambda: None)       # keeps the vmcnt bookkeeping identical in both modes
+                complete()
+            return
+        if op == "buffer_load_dwordx4" and mods.get("lds") and mods.get("offen"):
+            # LDS-DMA through a raw buffer descriptor s[i:i+3] = (base lo, base hi & 0xffff | stride 0, num_records, flags):
+            # address = base + scalar offset + per-lane offset.  Range check as the hardware does it for raw buffers: ONLY the
+            # per-lane offset (+ the instruction offset) is compared with num_records -- the scalar offset is not -- and a lane
+            # out of range fetches nothing and stores zeros
+            f, i, n = parse_reg(args[1])
+            assert f == "s" and n == 4 and i % 4 == 0, args[1]
+            base = int(w.s[i]) | ((int(w.s[i + 1]) & 0xFFFF) << 32)
+            assert (int(w.s[i + 1]) >> 16) == 0, "stride / swizzle bits must be clear"
+            num = int(w.s[i + 2])
+            off = self.rd(w, args[0]).astype(np.int64) + mods.get("offset", 0)
+            base += int(self.rd(w, args[2])[0])
+            inb = off + 16 <= num
+            src = self.gbytes(np.where(inb, base + off, self.gmem_va)).copy()
+            src[~inb] = 0
+            dst = int(w.m0) + mods.get("offset", 0) + np.arange(64, dtype=np.int64) * 16
+
+            def complete(dst=dst, src=src):
+                self.lds[dst[:, None] + np.arange(16)[None, :]] = src
+            if self.lazy_dma:
+                w.vm.append(complete)
+            else:
+                w.vm.append(lambda: None)
                 complete()
             return
         raise NotImplementedError(ln)

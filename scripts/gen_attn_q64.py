@@ -66,6 +66,7 @@ class Cfg:
 v = lambda i: "v%d" % i
 vr = lambda i, n: "v[%d:%d]" % (i, i + n - 1)
 ar = lambda i, n: "a[%d:%d]" % (i, i + n - 1)
+KD, VD = 88, 92       # literal SGPR quads: the raw buffer descriptors of the K / V^T tile being fetched (clobbered)
 AHEAD = int(os.environ.get("ATTN_Q64_AHEAD", "4"))     # fragment reads in flight ahead of the fragment being multiplied (ring: 8 buffers)
 # timing-only experiment knobs (WRONG RESULTS; never set for the committed .inc): "noadd" drops the row-sum adds, "ones" issues the
 # MFMAs a ones-row of V^T would cost, "nofma" (d = 128) generates the pre-scaled zero-offset form behind the unchanged frame
@@ -144,9 +145,9 @@ def softmax_stream(c, S, P):
 
 def top_protocol(c, phase):
     """(head, DMA pieces) of iteration t, t & 3 == phase: all but the previous iteration's NP pieces have landed (K(t+1), V(t) and
-    older); behind the barrier this wave's pieces of K(t+3) and V^T(t+2).  A piece is (M0 write, [load, offset advance]): the two
-    halves go into two consecutive MFMA gaps, so the M0 write is separated from the LDS-DMA that reads it by real work instead
-    of an s_nop; the clamp of the advanced offset goes into the gap behind them."""
+    older); behind the barrier this wave's pieces of K(t+3) and V^T(t+2).  A piece is (M0 write, [load], scalar advance or None):
+    the two halves go into two consecutive MFMA gaps, so the M0 write is separated from the LDS-DMA that reads it by real work
+    instead of an s_nop; the advance of the tile offset goes into the gap behind the last piece of each panel."""
     ks, vs = (phase + 3) & 3, (phase + 2) & 3
     head = ["s_waitcnt vmcnt(%d)" % c.NP, "s_barrier"]
     if "nobarrier" in EXP:
@@ -154,28 +155,38 @@ def top_protocol(c, phase):
     if "nowait" in EXP:
         head = []
     pieces = []
-    # the offset of the NEXT tile is clamped to the lane's last valid source (klim / vlim: the same lane position in the last
-    # tile, rows past the end of K folded onto its last row): a DMA whose tile lies past the end re-fetches valid memory that
-    # nobody reads, so the statement may run up to the last unmasked tile (the frame keeps only the masked tile and tile 0)
-    for r in range(c.NP // 2):
+    # A piece is a buffer-addressed LDS-DMA: per-lane offset (kvo / vvo: the lane's place inside a tile, constant) against a raw
+    # buffer descriptor whose BASE is the tile (KD = s[88:91] for K(t+3), VD = s[92:95] for V^T(t+2), literal SGPRs loaded from the
+    # kd0..3 / vd0..3 operands at entry) and whose num_records is what is left of the (batch, head) panel from there.  The tile
+    # advance is four scalar instructions behind the last piece of each panel (base += step with carry, num_records -= step,
+    # saturating at 0), so a piece whose tile lies past the end of the panel -- the statement prefetches three / two tiles ahead of
+    # the last tile it computes -- fetches nothing and stores zeros that nobody reads, and K rows past the end inside the ragged
+    # last tile arrive as zeros (the frame, which keeps that tile, masks them).  Only the per-lane offset is range-checked by the
+    # hardware, which is why the tile lives in the base and not in the instruction's scalar offset.
+    # (Round 5, first form: global_load_lds with a v_add and a v_min clamp per piece -- 16 VALU instructions per iteration that the
+    # scalar form does not issue.)
+    half = c.NP // 2
+
+    def advance(d0, step):
+        return ["s_add_u32 s%d, s%d, %s" % (d0, d0, step), "s_addc_u32 s%d, s%d, 0" % (d0 + 1, d0 + 1),
+                "s_sub_u32 s%d, s%d, %s" % (d0 + 2, d0 + 2, step), "s_cselect_b32 s%d, 0, s%d" % (d0 + 2, d0 + 2)]
+    for r in range(half):
         pieces.append(("s_add_u32 m0, %%[wk], %d" % (ks * c.TILE + r * 4096),
-                       ["global_load_lds_dwordx4 %%[kvo%d], %%[kb]" % r, "v_add_u32 %%[kvo%d], %%[kstep], %%[kvo%d]" % (r, r)],
-                       "v_min_u32 %%[kvo%d], %%[kvo%d], %%[klim%d]" % (r, r, r)))
-    for r in range(c.NP // 2):
+                       ["buffer_load_dwordx4 %%[kvo%d], s[%d:%d], 0 offen lds" % (r, KD, KD + 3)],
+                       advance(KD, "%[kstep]") if r == half - 1 else []))
+    for r in range(half):
         pieces.append(("s_add_u32 m0, %%[wv], %d" % (vs * c.TILE + r * 4096),
-                       ["global_load_lds_dwordx4 %%[vvo%d], %%[vb]" % r, "v_add_u32 %%[vvo%d], 0x80, %%[vvo%d]" % (r, r)],
-                       "v_min_u32 %%[vvo%d], %%[vvo%d], %%[vlim%d]" % (r, r, r)))
+                       ["buffer_load_dwordx4 %%[vvo%d], s[%d:%d], 0 offen lds" % (r, VD, VD + 3)],
+                       advance(VD, "0x80") if r == half - 1 else []))
     if "nodma" in EXP:
         pieces = []
-    elif "dmasalu" in EXP:      # EXPERIMENT: the offset advance on the scalar unit is not modelled; drop the per-piece v_add (timing only)
-        pieces = [(m0, rest[:1], "s_nop 0") for m0, rest, _ in pieces]
     return head, pieces
 
 
 def flat_pieces(pieces):
     out = []
-    for m0, rest, clamp in pieces:
-        out += [m0, "s_nop 0"] + rest + [clamp]
+    for m0, rest, advance in pieces:
+        out += [m0, "s_nop 0"] + rest + advance
     return out
 
 
@@ -274,9 +285,12 @@ def iteration(c, phase, X, Y, U, W, pv=True, softmax=True, qk=True, reads_in_fli
         lines += behind
         gg = g - DMA_SHIFT
         piece = dma[gg // DMA_STRIDE] if dma and gg >= 0 and gg % DMA_STRIDE < 2 and gg // DMA_STRIDE < len(dma) else None
-        prev = dma[(gg - 2) // DMA_STRIDE] if dma and gg >= 2 and (gg - 2) % DMA_STRIDE == 0 and (gg - 2) // DMA_STRIDE < len(dma) else None
-        if prev:
-            lines.append(prev[2])                 # the clamp of the piece whose load went out in the previous gap
+        # the scalar tile advance behind the last K / V^T piece of the iteration: base += step (add + carry) in the gap behind the
+        # load, num_records -= step (subtract + saturate) in the one after; each pair reads the SCC its first instruction wrote
+        for back, part in ((2, slice(0, 2)), (3, slice(2, 4))):
+            q, rem = divmod(gg - back, DMA_STRIDE)
+            if dma and gg >= back and rem == 0 and q < len(dma):
+                lines += dma[q][2][part]
         if piece and gg % DMA_STRIDE == 0:
             lines.append(piece[0])
         upto = (g + 1) * len(groups) // n_m
@@ -300,11 +314,25 @@ def check_and_count(c, fail_label):
 
 
 def emit(c):
+    """Operands of the statement:
+        o0 .. o(2 DT - 1) "+a" f32x16   O^T accumulators [qh][dt]
+        l0, l1 "+v"                      running row sums of the two query halves (partial per half-wave lane)
+        t "+s"                           in: the first iteration (= 1 mod 4); out: the iteration the frame continues with
+        code "=&s"                       0: t's top-of-iteration protocol NOT done; 1: row-sum check failed in iteration t (its protocol,
+                                         PV(t-1) and QK(t+1) are done, softmax(t) is not: the frame redoes tile t from QK)
+        lk0 .. lk(KS-1), lv0 .. lv3 "v"  LDS byte address of the lane's K / V^T fragment per k-step / kv block (ring base included)
+        kvo0 .., vvo0 .. "v"             the lane's byte offset inside a K / V^T tile, one per DMA piece
+        kd0..3, vd0..3 "s"               raw buffer descriptors at entry: base = K tile t + 3 / V^T tile t + 2 of the (batch, head) panel,
+                                         num_records = bytes of the panel from there (0 when the tile lies past the end), word 3 = 0x20000
+        qvo0, qvo1 "v", qb "s" (64 bit)  Q rows of the two query halves
+        negmc0, negmc1 "v", c "s"        (fma form) -m c per query half and the score scale in log2 units
+        kstep "s" bytes per K tile, tend "s" (iterations t < tend run), wk / wv "s" LDS address of the rings + wave * 1024"""
     L = []
     # ---- entry: Q fragments of both query halves ----
     for qh in range(2):
         L += ["global_load_dwordx4 %s, %%[qvo%d], %%[qb] offset:%d" % (ar(c.QA + (qh * c.KS + ks) * 4, 4), qh, 32 * ks)
               for ks in range(c.KS)]
+    L += ["s_mov_b32 s%d, %%[kd%d]" % (KD + i, i) for i in range(4)] + ["s_mov_b32 s%d, %%[vd%d]" % (VD + i, i) for i in range(4)]
     roles = {1: (c.SA, c.SB, c.PA, c.PB), 2: (c.SB, c.SA, c.PB, c.PA), 3: (c.SA, c.SB, c.PA, c.PB), 0: (c.SB, c.SA, c.PB, c.PA)}
     if "mfma4" in EXP:
         L += ["v_mov_b32 %s, 0x3f803f80" % v(c.F0)] + ["v_accvgpr_write_b32 a%d, %s" % (c.AEND + 8 + i, v(c.F0)) for i in range(2)]
@@ -357,7 +385,8 @@ def write(c, path):
         for ln in lines:
             f.write('  "%s\\n\\t" \\\n' % ln)
         f.write('  ""\n')
-        regs = ["a%d" % i for i in range(c.QA, c.AEND + (32 if EXP & {"ones", "mfma4"} else 0))] + ["v%d" % i for i in range(c.VB, c.VEND)]
+        regs = ["a%d" % i for i in range(c.QA, c.AEND + (32 if EXP & {"ones", "mfma4"} else 0))] + ["v%d" % i for i in range(c.VB, c.VEND)] + \
+               ["s%d" % i for i in range(KD, VD + 4)]
         f.write("#define ALG_%s_CLOBBERS \\\n  " % c.name + ", ".join('"%s"' % r for r in regs) + "\n")
         f.write("#define ALG_%s_O_OPERANDS(o) \\\n  " % c.name + ", ".join('[o%d] "+a"(o[%d])' % (i, i) for i in range(c.NO)) + "\n")
     return lines

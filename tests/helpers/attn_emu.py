@@ -108,7 +108,7 @@ def stage(pb, lds, cfg, which, tile, slot_base):
                 lds[dst:dst + 16] = pb.gmem[src:src + 16]
 
 
-def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None):
+def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None, va=None):
     """Emulates the statement entered at iteration t0 (tile 0 .. t0 - 1 done by `the frame` = numpy here).  Returns the
     normalised attention output [Sq, d] after the frame's tail, the exit iteration and the exit code of wave 0."""
     d, T, c = cfg.d, pb.T, pb.c
@@ -125,21 +125,24 @@ def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None):
         nv += 1
     def sreg(name, n=1):
         nonlocal ns
-        ns += ns % n
+        ns = (ns + n - 1) // n * n
         tab[name] = "s%d" % ns if n == 1 else "s[%d:%d]" % (ns, ns + n - 1)
         ns += n
     for i in range(cfg.NO):
         tab["o%d" % i] = "a[%d:%d]" % (16 * i, 16 * i + 15)
     for n in ["l0", "l1"] + (["negmc0", "negmc1"] if cfg.fma else []) + ["qvo0", "qvo1"] + ["lk%d" % i for i in range(cfg.KS)] + ["lv%d" % i for i in range(4)] + \
-             ["kvo%d" % i for i in range(cfg.NP // 2)] + ["vvo%d" % i for i in range(cfg.NP // 2)] + \
-             ["klim%d" % i for i in range(cfg.NP // 2)] + ["vlim%d" % i for i in range(cfg.NP // 2)]:
+             ["kvo%d" % i for i in range(cfg.NP // 2)] + ["vvo%d" % i for i in range(cfg.NP // 2)]:
         vreg(n)
     assert nv <= cfg.VB
-    for n in ("t", "code") + (("c",) if cfg.fma else ()) + ("kstep", "tend", "wk", "wv"):
+    for n in ("t", "code") + (("c",) if cfg.fma else ()) + ("kstep", "tend", "wk", "wv") + tuple("kd%d" % i for i in range(4)) + \
+             tuple("vd%d" % i for i in range(4)):
         sreg(n)
-    for n in ("kb", "vb", "qb"):
-        sreg(n, 2)
-    m = asm_emu.Machine(asm_emu.bind(lines, tab), n_waves=4, gmem=pb.gmem, lazy_reads=lazy_reads, lazy_dma=lazy_dma)
+    sreg("qb", 2)
+    assert ns <= G.KD
+    # the memory image sits at virtual address `va`; by default the K panel crosses a 4 GiB boundary between its tiles 6 and 7, so
+    # the carry of the descriptor's base advance is exercised
+    va = ((1 << 32) - pb.KOFF - 6 * KVB * pb.k_rs * 2 - 64) if va is None else va
+    m = asm_emu.Machine(asm_emu.bind(lines, tab), n_waves=4, gmem=pb.gmem, lazy_reads=lazy_reads, lazy_dma=lazy_dma, gmem_va=va)
     # ---- the frame's state at entry: tiles 0 .. t0 - 1 folded into (m, l, O); K(t0 - 1 .. t0 + 2), V(t0 - 1 .. t0 + 1) resident ----
     qf, kf, vf = pb.q.astype(np.float64), pb.k.astype(np.float64), pb.v.astype(np.float64)
     s_all = qf @ kf.T                                       # raw scores [Sq, Skv]
@@ -175,7 +178,15 @@ def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None):
         if cfg.fma:
             sset(w, "c", int(np.float32(c).view(np.uint32)))
         sset(w, "wk", KL + w.id * 1024), sset(w, "wv", VL + w.id * 1024)
-        sset(w, "kb", pb.KOFF), sset(w, "vb", pb.VOFF), sset(w, "qb", pb.QOFF)
+        sset(w, "qb", va + pb.QOFF)
+        # the frame's descriptors at entry: base = the tile the first DMA fetches (K(t0 + 3), V^T(t0 + 2)), stride 0, num_records =
+        # what is left of the panel from there (K: up to the end of its last row's head slice; V^T: d rows of the pitch)
+        kbytes, vbytes = ((pb.Skv - 1) * pb.k_rs + d) * 2, d * pb.vt_rs * 2
+        koff, voff = (t0 + 3) * KVB * pb.k_rs * 2, (t0 + 2) * KVB * 2
+        for i, val in enumerate(((va + pb.KOFF + koff) & 0xFFFFFFFF, (va + pb.KOFF + koff) >> 32, max(kbytes - koff, 0), 0x00020000)):
+            sset(w, "kd%d" % i, val)
+        for i, val in enumerate(((va + pb.VOFF + voff) & 0xFFFFFFFF, (va + pb.VOFF + voff) >> 32, max(vbytes - voff, 0), 0x00020000)):
+            sset(w, "vd%d" % i, val)
         for qh in range(2):
             vset(w, "qvo%d" % qh, ((q_row + 32 * qh) * pb.q_rs + h2 * 8) * 2)
             if cfg.fma:
@@ -187,13 +198,9 @@ def run_statement(pb, cfg, lazy_reads, lazy_dma, t0=1, tend=None, mutate=None):
             vset(w, "lv%d" % kk, VL + l31 * 128 + (((2 * kk + h2) ^ ((l31 >> 1) & 7)) * 16))
         for i in range(cfg.NP // 2):
             row, slot = k_dma_lane(d, tid, i)
-            klim = (np.minimum((T - 1) * KVB + row, pb.Skv - 1) * pb.k_rs + slot * 8) * 2
-            vset(w, "klim%d" % i, klim)
-            vset(w, "kvo%d" % i, np.minimum((((t0 + 3) * KVB + row) * pb.k_rs + slot * 8) * 2, klim))
+            vset(w, "kvo%d" % i, (row * pb.k_rs + slot * 8) * 2)                  # the lane's place inside tile 0
             vrow, vslot = tid // 8 + 32 * i, (tid & 7) ^ ((tid >> 4) & 7)
-            vlim = (vrow * pb.vt_rs + vslot * 8 + (T - 1) * KVB) * 2
-            vset(w, "vlim%d" % i, vlim)
-            vset(w, "vvo%d" % i, np.minimum((vrow * pb.vt_rs + vslot * 8 + (t0 + 2) * KVB) * 2, vlim))
+            vset(w, "vvo%d" % i, (vrow * pb.vt_rs + vslot * 8) * 2)
         for qh in range(2):
             for dt in range(cfg.DT):
                 base = 16 * (qh * cfg.DT + dt)

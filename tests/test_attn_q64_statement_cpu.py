@@ -121,6 +121,9 @@ MUTATIONS = {
     "DMA wait one too loose": lambda L: [("s_waitcnt vmcnt(12)" if ln == "s_waitcnt vmcnt(8)" else ln) for ln in L],
     "no barrier": lambda L: [ln for ln in L if ln != "s_barrier"],
     "K fragment from the wrong ring slot": lambda L: _replace_nth(L, "offset:32768", "offset:16384", 5),
+    "K tile base never advances": lambda L: [ln for ln in L if not ln.startswith("s_add_u32 s88, s88")],
+    "V^T piece through the K descriptor": lambda L: _replace_nth(L, "s[92:95], 0 offen lds", "s[88:91], 0 offen lds", 9),
+    "carry of the tile advance dropped": lambda L: [ln.replace("s_addc_u32 s89, s89, 0", "s_add_u32 s89, s89, 0") for ln in L],
     "softmax reads the tile QK is writing": lambda L: _replace_nth(L, "v_fma_f32 v250, v52,", "v_fma_f32 v250, v116,", 2),
 }
 
@@ -200,7 +203,7 @@ def test_static_hazard_rules_of_the_statements(width):
                 srcs = nxt.split(None, 1)[1].split(",", 1)[1] if "," in nxt else ""
                 assert not (_regs(srcs) & dst), (t, nxt)
         if t.startswith("s_add_u32 m0"):
-            assert not ins[i + 1].startswith("global_load_lds"), (t, ins[i + 1])
+            assert not (ins[i + 1].startswith("global_load_lds") or ins[i + 1].endswith(" lds")), (t, ins[i + 1])
         if t.startswith("v_cmp_"):
             j, waits = i + 1, 0
             while not ins[j].startswith("s_cbranch_vcc"):
