@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("ALG_HIP_LIB") or os.path.join(_HERE, "libalg_hip.so")
 
 ALG_F32, ALG_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
-GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS, GEMM_GATE_F32, GEMM_GATE_SEG_STRIDE, GEMM_B_PACKED = 1, 4, 8, 16, 32
+GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS, GEMM_GATE_F32, GEMM_GATE_SEG_STRIDE = 1, 4, 8, 16
 
 EXPORTS = (
     "alg_version", "alg_last_error", "alg_reload_env", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16", "alg_gemm_bf16_pair", "alg_gemm_bf16_pair_qk",
@@ -28,7 +28,7 @@ EXPORTS = (
     "alg_gelu_erf", "alg_layernorm_modulate_seg", "alg_headnorm_rope", "alg_masked_mean", "alg_silu", "alg_gemm_fp8", "alg_quantize_fp8_rows",
     "alg_conv_cl_bf16", "alg_vae_groupnorm_workspace", "alg_vae_groupnorm_stats", "alg_vae_spatial_norm", "alg_vae_upsample",
     "alg_vae_pack_latent", "alg_vae_unpack_video", "alg_vae_group_norm", "alg_vae_pad", "alg_vae_repitch",
-    "alg_vae_unpack_planes", "alg_rms_norm_rows", "alg_softmax_hilo", "alg_flash_attn_d128_ex", "alg_flash_attn_d128_dual", "alg_pack_b_bf16", "alg_gemm_schedule", "alg_rope_half", "alg_patchify_t", "alg_unpatchify_t", "alg_qk_norm_rope_scaled", "alg_flash_attn_d64_ex", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
+    "alg_vae_unpack_planes", "alg_rms_norm_rows", "alg_softmax_hilo", "alg_flash_attn_d128_ex", "alg_flash_attn_d128_dual", "alg_rope_half", "alg_patchify_t", "alg_unpatchify_t", "alg_qk_norm_rope_scaled", "alg_flash_attn_d64_ex", "alg_embed_rows", "alg_t5_layernorm", "alg_attn_bias", "alg_mul_bf16", "alg_quick_gelu",
     "alg_lowpass_tables_bytes", "alg_lowpass_tables_build", "alg_down_up_workspace_bytes", "alg_gaussian_blur_workspace_bytes",
     "alg_flash_attn_d64_workspace_bytes", "alg_calib_mfma_bf16", "alg_wall_clock_khz", "alg_attn_clock_tap",
 )
@@ -114,7 +114,6 @@ def load_library():
         c_void_p, c_int, c_void_p]
     lib.alg_flash_attn_d128.argtypes = [c_void_p] * 4 + [c_int] * 4 + [c_int64] * 8 + [c_float, c_void_p]
     lib.alg_flash_attn_d128_ex.argtypes = [c_void_p] * 4 + [c_int] * 4 + [c_int64] * 8 + [c_float, c_int, c_int, c_void_p]
-    lib.alg_pack_b_bf16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]
     lib.alg_flash_attn_d128_dual.argtypes = ([c_void_p] * 3 + [c_int] + [c_int64] * 4 + [c_void_p] * 2 + [c_int] + [c_int64] * 4 +
                                              [c_void_p] + [c_int] * 3 + [c_int64] * 4 + [c_float, c_void_p])
     lib.alg_rope_half.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]
@@ -719,12 +718,6 @@ def gemm_args(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=No
     """The alg_gemm_args struct of one call (offsets in elements)."""
     args = GemmArgs()
     fp8 = a_scale is not None
-    if isinstance(B, PackedB):      # the fragment-ordered weight where the default schedule can read it, its rows everywhere else
-        if B.usable(K, R, a_scale) and N == B.N and b_off == 0 and strideB == 0:
-            flags |= GEMM_B_PACKED
-            B, ldb = B.packed, K
-        else:
-            B = B.rows
     args.A = A.data_ptr() + A.element_size() * a_off
     args.B = B.data_ptr() + B.element_size() * b_off
     if fp8:
@@ -744,30 +737,6 @@ def gemm_args(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=No
     args.seg_split, args.act, args.flags = seg_split, act, flags
     args.perm_col0 = perm_col0
     return args, fp8
-
-
-def gemm_pipe():
-    """the GEMM schedule the library runs (ALG_GEMM_PIPE as read at load / reload_env)"""
-    return int(load_library().alg_gemm_schedule())
-
-
-class PackedB:
-    """A linear layer's weight [N, K] in the order the MFMA reads its B operand (alg_pack_b_bf16): passed as `B` of `gemm` /
-    `gemm_pair` it sets ALG_GEMM_B_PACKED -- the default GEMM schedule then loads its fragments from L2 straight into registers
-    (no LDS-DMA, no fragment reads for B).  Keeps the row-major weight too: every other schedule / form reads that one."""
-
-    def __init__(self, w):
-        _dev(w, "weight")
-        if w.dim() != 2 or w.dtype != torch.bfloat16 or not w.is_contiguous() or w.shape[1] % 64:
-            raise AlgHipError("PackedB takes a contiguous bf16 [N, K] weight with K % 64 == 0")
-        self.rows = w
-        self.N, self.K = int(w.shape[0]), int(w.shape[1])
-        self.packed = torch.empty((self.N + 31) // 32 * 32, self.K, dtype=torch.bfloat16, device=w.device)
-        _check(load_library().alg_pack_b_bf16(_p(w), _p(self.packed), self.N, self.K, self.K, _stream()), "alg_pack_b_bf16")
-
-    def usable(self, K, R, a_scale):
-        """the packed form is read by schedule 9's plain bf16 statement only"""
-        return gemm_pipe() == 9 and R is None and a_scale is None and K == self.K and K >= 256
 
 
 def gemm(*a, **kw):

@@ -87,16 +87,6 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8, bool valid
       return ALG_EINVAL;
     }
   }
-  if (a->flags & ALG_GEMM_B_PACKED) {
-    // the packed weight is read by the default schedule's plain statement only (gemm_kernel.h); it has no rows to fall back on
-    const int64_t packed_bytes = (int64_t)((a->N + 31) / 32) * 32 * a->K * 2;
-    if (fp8 || a->conv_wp || a->R || a->strideB != 0 || gemm_pipe() != 9 || a->K < 256 ||
-        256 * a->lda * 2 + (int64_t)a->K * 2 >= (1ll << 32) || packed_bytes >= (1ll << 32)) {
-      set_error("alg_gemm_bf16: ALG_GEMM_B_PACKED needs the default schedule (ALG_GEMM_PIPE=9), bf16, no residual / convolution, "
-                "a shared weight (strideB = 0), K >= 256 and a packed weight below 4 GiB");
-      return ALG_EINVAL;
-    }
-  }
   if (validate_only) return ALG_OK;
   if ((int64_t)a->M * a->ldc >= (1ll << 31) || (a->R && (int64_t)a->M * a->ldr >= (1ll << 31))) {
     // Every argument check above has run on the WHOLE call, so a slab can only fail at launch (no error after
@@ -142,7 +132,6 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8, bool valid
   if (a->conv_wp) return launch_gemm_p6_conv(a, m_tiles, n_tiles, nwg, s);
   switch (gemm_pipe()) {
     case 9:   // 4 waves, hand-written asm main loop; needs two k-tiles and 32-bit byte offsets inside a 256-row panel
-      if (a->flags & ALG_GEMM_B_PACKED) return launch_gemm_p9(a, m_tiles, n_tiles, nwg, s);   // (checked above)
       if (a->K >= 128 && 256 * a->lda * 2 + (int64_t)a->K * 2 < (1ll << 32) && 256 * a->ldb * 2 + (int64_t)a->K * 2 < (1ll << 32))
         return launch_gemm_p9(a, m_tiles, n_tiles, nwg, s);
       return launch_gemm_p6(a, m_tiles, n_tiles, nwg, s);
@@ -151,36 +140,6 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8, bool valid
 }
 
 extern "C" int alg_gemm_bf16(const alg_gemm_args* a, void* stream) { return gemm_entry(a, stream, false); }
-extern "C" int alg_gemm_schedule(void) { return gemm_pipe(); }
-
-// One workgroup of 64 lanes writes one 1 KiB fragment: (n-block, k-step) -> lane l: row nb * 32 + (l & 31), 8 elements from k-step
-// * 16 + 8 (l >> 5)  (include/alg_hip.h, alg_pack_b_bf16)
-__global__ __launch_bounds__(256) void pack_b_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int N, int ksteps,
-                                                     int64_t ldw, int64_t chunks) {
-  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= chunks) return;
-  const int l = threadIdx.x & 63;
-  const int nb = (int)(c / ksteps), ks = (int)(c - (int64_t)nb * ksteps);
-  const int row = nb * 32 + (l & 31);
-  uint4 v = make_uint4(0u, 0u, 0u, 0u);
-  if (row < N) v = *(const uint4*)(w + (int64_t)row * ldw + ks * 16 + 8 * (l >> 5));
-  *(uint4*)(out + c * 512 + l * 8) = v;
-}
-
-extern "C" int alg_pack_b_bf16(const void* w, void* out, int N, int K, int64_t ldw, void* stream) {
-  if (!w || !out || N <= 0 || K <= 0 || K % 64 || ldw < K || ldw % 8 || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) {
-    set_error("alg_pack_b_bf16: bad argument (N=%d K=%d ldw=%lld; K %% 64 == 0, 16-byte aligned rows)", N, K, (long long)ldw);
-    return ALG_EINVAL;
-  }
-  const int64_t chunks = (int64_t)((N + 31) / 32) * (K / 16);
-  if ((chunks + 3) / 4 > 0x7fffffff) {
-    set_error("alg_pack_b_bf16: weight too large");
-    return ALG_ELIMIT;
-  }
-  hipLaunchKernelGGL(pack_b_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w,
-                     (bf16_t*)out, N, K / 16, ldw, chunks);
-  return check_launch("alg_pack_b_bf16");
-}
 
 // Two independent plain GEMMs in one persistent launch when schedule 9 can take both (no residual / activation / convolution,
 // K >= 128, 32-bit offsets, no slab split); otherwise -- and always with ALG_GEMM_PIPE=6 -- simply one launch after the other.

@@ -140,10 +140,6 @@ int alg_unipc_update(const float* x, const float* m0, const float* m1, const flo
 #define ALG_GEMM_GATE_F32 8       /* gate is float32 and C = bf16(R + gate * bf16(acc + bias)) with ONE final rounding
                                      (WanTransformerBlock: (x.float() + out * gate_msa).type_as(x)) */
 
-#define ALG_GEMM_B_PACKED 32      /* B is a weight in MFMA-fragment order (alg_pack_b_bf16; ldb / strideB are ignored): its fragments
-                                     are loaded from L2 straight into registers and never touch the LDS.  Plain forms on the
-                                     default schedule only (no residual, no fp8, no convolution, K >= 256): EINVAL otherwise */
-
 typedef struct alg_gemm_args {
   const void* A;      /* [batch][M][K] bf16, row stride lda, batch stride strideA (elements) */
   const void* B;      /* [batch][N][K] bf16 (nn.Linear weight layout), ldb, strideB (0 = shared)  */
@@ -169,14 +165,6 @@ typedef struct alg_gemm_args {
   int32_t conv_kw;   /* taps along x: 3, or 4 when one A row holds two neighbouring voxels (lda = 2 * channels) */
   int32_t reserved1;
 } alg_gemm_args;
-
-/* A linear layer's weight [N][K] bf16 (row stride ldw elements) re-stored in the order v_mfma_f32_32x32x16_bf16 reads its B operand:
- * fragment (n-block nb of 32 rows, k-step ks of 16) = 1 KiB at byte (nb * K / 16 + ks) * 1024, lane l of a wave holds row
- * nb * 32 + (l & 31), elements ks * 16 + 8 (l >> 5) .. + 8 at byte 16 l of the fragment.  out: ceil(N / 32) * 32 * K bf16, rows past N
- * are zeros.  K % 64 == 0.  (Round 5: the packed form of alg_gemm_bf16's B operand, flag ALG_GEMM_B_PACKED.) */
-int alg_pack_b_bf16(const void* w, void* out, int N, int K, int64_t ldw, void* stream);
-/* the GEMM schedule in force (ALG_GEMM_PIPE: 9 = default, 6 = the 8-wave ping-pong reference): only 9 reads packed weights */
-int alg_gemm_schedule(void);
 
 /* C = R + gate * act(A @ B^T + bias)   (bias optional; either act or the residual(+gate) form).  K % 64 == 0, lda/ldb % 8 == 0,
  * A and B 16-byte aligned.  M and N are arbitrary (edge tiles clamp loads and guard stores). */

@@ -236,180 +236,6 @@ def prologue():
     return out
 
 
-# ---------------------------------------------------------------------------------------------------------------------
-# B-PACKED form (round 5): the B operand (the weight of a linear layer) never touches the LDS.
-#
-# Ablation (docs/lab_notebook_r5.md item 20): the loop's two LDS streams -- LDS-DMA in, fragment reads out -- cost 17 % and 18 % of it
-# and nothing else does.  A weight is static, so it can be stored ONCE in the order the MFMA wants it: fragment (n-block of 32
-# rows, k-step of 16) = 1 KiB, lane l holds row l & 31, elements 8 (l >> 5) .. + 8 of the k-step (alg_pack_b_bf16: chunk index =
-# n-block * K / 16 + k-step).  A fragment is then ONE coalesced buffer_load_dwordx4 straight into the registers the MFMA reads:
-# no DMA, no LDS slot, no ds_read for B -- half of both streams gone.
-#   registers  BK(p, ks, nt) = v[32 + 64 p + 16 ks + 4 nt .. + 3], p = k-tile parity: TWO k-tiles of B (128 registers; the plain
-#              statement's FB sets are unused).  The load of (k-tile kt + 2, ks, nt) goes out right behind the last MFMA of k-tile
-#              kt that reads BK(kt & 1, ks, nt) (mt = 3: gap 16 ks + 12 + nt): two k-tiles (128 MFMAs, > 2 us) ahead of its use.
-#              The vector-memory counter retires IN ORDER and counts the A panel's LDS-DMA too: with one k-tile of B prefetch every
-#              counted wait for B also forces the A DMAs issued just before it to land within a k-tile; with two, everything has two.
-#   addresses  v[184 + nt] = lane * 16 + chunk base of the wave's n-block nt (operand bvo + nt * operand bnt); the k-step is the
-#              instruction offset (ks * 1024), the k-tile the scalar offset (MB = 4096 (kt + 2)); descriptor operand db
-#              (num_records = bytes of the packed weight: n-blocks past N read as zeros)
-#   waits      one counted vmcnt in front of every k-step, its immediate = the vector-memory instructions issued since the youngest
-#              one it needs (BK(., ks, 3); at the barrier also the last DMA of A(kt + 1)): computed by simulation of the issue order
-#              over every context a k-tile can run in (bpk_waits()).
-#   A panel    LDS-DMA THREE k-tiles ahead: with B out of the LDS the ten slots hold A alone -- k-tile kt sits in slots 4 kt mod 10
-#              (+1) and the pair 4 kt + 2 (+3), the B slots of the plain form, takes A(kt + 3); fragment reads one k-step ahead, one
-#              barrier per k-tile, as in the plain form.
-#   loop       the body is a PAIR of k-tiles (parity 0, 1); (K / 64 - 4) / 2 trips, then the last four or five k-tiles (K / 64 even /
-#              odd) as straight code.  K >= 256.
-BK = lambda p, ks, nt: "v[%d:%d]" % (32 + 64 * p + 16 * ks + 4 * nt, 32 + 64 * p + 16 * ks + 4 * nt + 3)
-VBN = lambda nt: "v%d" % (184 + nt)
-BPK_A_GAPS = (17, 20, 23, 26, 33, 36, 39, 42)     # the eight A DMAs of a k-tile (no gap shared with a B load: those sit in 12..15 + 16 ks)
-
-
-def b_load(p, ks, nt):
-    return "buffer_load_dwordx4 %s, %s, %%[db], %s offen offset:%d" % (BK(p, ks, nt), VBN(nt), MB, ks * 1024)
-
-
-def bpk_addr_math():
-    """SA and the four A fragment address registers from P"""
-    out = ["s_add_u32 %s, %s, %%[wm]" % (T, P), "s_lshl_b32 %s, %s, 14" % (SA, T)]
-    return out + ["v_add_u32 %s, %s, %%[vl%d]" % (ADA(ks), SA, ks) for ks in range(4)]
-
-
-def bpk_advance():
-    return ["s_add_u32 %s, %s, 4" % (P, P), "s_sub_u32 %s, %s, 10" % (T2, P), "s_cmp_ge_u32 %s, 10" % P,
-            "s_cselect_b32 %s, %s, %s" % (P, T2, P)] + bpk_addr_math()
-
-
-def ktile_bpk(p, dma_on, barrier_on, b_next, waits):
-    """one k-tile of the B-packed form at parity p.  dma_on: stage A(kt + 3); barrier_on: a next k-tile exists (publish / free the
-    ring); b_next: fetch B(kt + 2); waits[ks]: the vmcnt immediate in front of k-step ks"""
-    m0s = [[] for _ in range(64)]
-    mids = [[] for _ in range(64)]
-    posts = [[] for _ in range(64)]
-    pre = []
-    if dma_on:
-        # where A0 of k-tile kt + 3 goes: ring position (P + 12) mod 10 = (P + 2) mod 10
-        pre += ["s_add_u32 %s, %s, 2" % (T, P), "s_sub_u32 %s, %s, 10" % (T2, T), "s_cmp_ge_u32 %s, 10" % T,
-                "s_cselect_b32 %s, %s, %s" % (T, T2, T), "s_lshl_b32 %s, %s, 14" % (T, T), "s_add_u32 %s, %s, %%[wave1k]" % (DA, T)]
-        for i in range(8):
-            m0, rest = dma("a", i)
-            m0s[BPK_A_GAPS[i]].append(m0)
-            posts[BPK_A_GAPS[i]] += rest
-    if b_next:
-        for ks in range(4):
-            for nt in range(4):
-                posts[16 * ks + 12 + nt].append(b_load(p, ks, nt))
-    posts[63].append("s_add_u32 %s, %s, 0x1000" % (MB, MB))
-    for ks in range(4):    # A fragments of the NEXT k-step (k-step 3: of the next k-tile, behind the barrier) in gaps 0, 2, 5, 8
-        if ks == 3 and not barrier_on:
-            continue
-        for r, g in enumerate((0, 2, 5, 8)):
-            mids[16 * ks + g].append("ds_read_b128 %s, %s offset:%d" % (FA((ks + 1) & 1, r), ADA((ks + 1) & 3), r * 4096))
-    body = list(pre)
-    for j in range(64):
-        ks, q = j >> 4, j & 15
-        mt, nt = q >> 2, q & 3
-        if q == 0:
-            # this k-step's A fragments (read during the previous k-step) and B fragments (loaded two k-tiles ago) are in registers
-            body.append("s_waitcnt vmcnt(%d) lgkmcnt(0)" % waits[ks])
-            if ks == 3 and barrier_on:
-                body.append("s_barrier")
-                body += bpk_advance()
-        body.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (ACC(mt, nt), BK(p, ks, nt), FA(ks & 1, mt), ACC(mt, nt)))
-        body += gap(m0s[j], mids[j], posts[j])
-    return body
-
-
-def bpk_prologue():
-    L = []
-    for i in range(8):
-        L += ["v_add_u32 v160, 0x%x, %%[vrow]" % (i * 32), "v_min_u32 v160, %[rmaxa], v160",
-              "v_mul_lo_u32 v161, v160, %[lda2]", "v_add_u32 %s, v161, %%[vslot]" % OFFA(i)]
-    L += ["v_mov_b32 %s, %%[bvo]" % VBN(0)] + ["v_add_u32 %s, %%[bnt], %s" % (VBN(nt), VBN(nt - 1)) for nt in range(1, 4)]
-    L += ["s_mov_b32 %s, 0" % MB]
-    for kt, slot in ((0, 0), (1, 4), (2, 8)):
-        L += ["s_add_u32 %s, %%[wave1k], %d" % (DA, slot * SLOT)]
-        for i in range(8):
-            m0, rest = dma("a", i)
-            L += [m0, "s_nop 0"] + rest
-        if kt == 0:      # B(0), B(1) right behind A(0): the final wait lets A(1) and A(2) fly
-            for pk in range(2):
-                L += [b_load(pk, ks, nt) for ks in range(4) for nt in range(4)] + ["s_add_u32 %s, %s, 0x1000" % (MB, MB)]
-    L += ["v_accvgpr_write_b32 a%d, 0" % i for i in range(256)]
-    L += ["s_mov_b32 %s, 0" % P] + bpk_addr_math()
-    L += ["s_waitcnt vmcnt(16)", "s_barrier"]
-    L += ["ds_read_b128 %s, %s offset:%d" % (FA(0, r), ADA(0), r * 4096) for r in range(4)]
-    return L
-
-
-def bpk_events(lines, kt, prologue=False):
-    """the vector-memory instructions of `lines` in issue order, tagged with what they fetch: ('b', k-tile, ks, nt) / ('a', k-tile, i);
-    counted waits as ('wait', ks).  kt: the k-tile the lines compute (B loads fetch kt + 2, A DMAs kt + 3); the prologue fetches
-    A(0), B(0), B(1), A(1), A(2) in that order"""
-    ev, na, nb = [], 0, 0
-    for ln in lines:
-        if ln.startswith("buffer_load_dwordx4 v[") and not ln.endswith("lds"):
-            reg = int(ln.split("[")[1].split(":")[0]) - 32
-            tgt = (nb // 16) if prologue else kt + 2
-            ev.append(("b", tgt, (reg % 64) // 16, (reg % 16) // 4))
-            nb += 1
-        elif ln.startswith("global_load_lds"):
-            ev.append(("a", (na // 8) if prologue else kt + 3, na % 8))
-            na += 1
-        elif ln.startswith("s_waitcnt") and "vmcnt" in ln and not prologue:
-            ev.append(("wait", sum(1 for e in ev if e[0] == "wait")))
-    return ev
-
-
-def bpk_waits(kinds, first_kt_options):
-    """vmcnt immediates for a straight sequence of k-tiles `kinds` = [(p, dma_on, barrier_on, b_next)]: for every context the sequence
-    can run in (first_kt_options: 0 = right behind the prologue, 2 = behind a steady-state pair) the issue order is simulated and
-    the count of vector-memory instructions issued after the youngest REQUIRED one is taken; the minimum over the contexts is safe
-    in all of them."""
-    result = [[63] * 4 for _ in kinds]
-    for first in first_kt_options:
-        hist = []
-        if first == 0:
-            hist += bpk_events(bpk_prologue(), 0, prologue=True)
-        else:      # two steady-state k-tiles in front (their own predecessors do not matter: everything older is older still)
-            for i in range(2):
-                hist += [e for e in bpk_events(ktile_bpk(i & 1, True, True, True, [63] * 4), first - 2 + i) if e[0] != "wait"]
-        for n, kind in enumerate(kinds):
-            kt = first + n
-            for e in bpk_events(ktile_bpk(*kind, waits=[63] * 4), kt):
-                if e[0] != "wait":
-                    hist.append(e)
-                    continue
-                ks = e[1]
-                need = [("b", kt, ks, 3)] + ([("a", kt + 1, 7)] if (ks == 3 and kind[2]) else [])
-                pos = max(hist.index(x) for x in need)          # (ValueError = the schedule asks for something never fetched)
-                result[n][ks] = min(result[n][ks], len(hist) - 1 - pos)
-    return result
-
-
-def emit_bpk():
-    S0, S1 = (0, True, True, True), (1, True, True, True)
-    L = bpk_prologue()
-    # ---- (K / 64 - 4) / 2 steady-state pairs (operand nloop = K / 64 - 2 >= 2) ----
-    L += ["s_sub_u32 %s, %%[nloop], 2" % CNT, "s_lshr_b32 %s, %s, 1" % (CNT, CNT), "s_cmp_eq_u32 %s, 0" % CNT, "s_cbranch_scc1 2f", "1:"]
-    w = bpk_waits([S0, S1], (0, 2))
-    L += ktile_bpk(*S0, waits=w[0]) + ktile_bpk(*S1, waits=w[1])
-    L += ["s_sub_u32 %s, %s, 1" % (CNT, CNT), "s_cmp_lg_u32 %s, 0" % CNT, "s_cbranch_scc1 1b", "2:"]
-    # ---- the last four (K / 64 even) or five (odd) k-tiles: A(kt + 3) / B(kt + 2) only while they exist ----
-    L += ["s_and_b32 %s, %%[nloop], 1" % CNT, "s_cmp_eq_u32 %s, 0" % CNT, "s_cbranch_scc0 5f"]
-    for label, r in ((None, 4), ("5:", 5)):
-        if label:
-            L += [label]
-        kinds = [(i & 1, i + 3 < r, i + 1 < r, i + 2 < r) for i in range(r)]
-        w = bpk_waits(kinds, (0, 2))
-        for kind, wk in zip(kinds, w):
-            L += ktile_bpk(*kind, waits=wk)
-        if r == 4:
-            L += ["s_branch 6f"]
-    L += ["6:", "s_nop 15", "s_nop 15"]
-    return L
-
-
 def emit(res=False):
     global BUF
     buf_saved = BUF
@@ -457,15 +283,13 @@ def main():
     path = os.environ.get("P9_OUT") or os.path.join(here, "..", "alg_amd", "csrc", "gemm_p9_loop.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by scripts/gen_gemm_p9.py -- do not edit.  The main loop of GEMM schedule 9 as one asm statement.\n")
-        for name, ls in (("ALG_GEMM_P9_LOOP_ASM", lines), ("ALG_GEMM_P9_LOOP_ASM_RES", emit(res=True)), ("ALG_GEMM_P9_LOOP_ASM_BPK", emit_bpk())):
+        for name, ls in (("ALG_GEMM_P9_LOOP_ASM", lines), ("ALG_GEMM_P9_LOOP_ASM_RES", emit(res=True))):
             f.write("#define %s \\\n" % name)
             for ln in ls:
                 f.write('  "%s\\n\\t" \\\n' % ln)
             f.write('  ""\n')
         regs = ["a%d" % i for i in range(256)] + ["v%d" % i for i in range(160, 256)]
         f.write("#define ALG_GEMM_P9_CLOBBERS \\\n  " + ", ".join('"%s"' % r for r in regs) + '\n')
-        regs_bpk = ["a%d" % i for i in range(256)] + ["v%d" % i for i in range(32, 256)]
-        f.write("#define ALG_GEMM_P9_BPK_CLOBBERS \\\n  " + ", ".join('"%s"' % r for r in regs_bpk) + '\n')
         f.write("#define ALG_GEMM_P9_ACC_CLOBBERS \\\n  " + ", ".join('"a%d"' % i for i in range(256)) + '\n')
     n_mfma = sum(1 for ln in lines if ln.startswith("v_mfma"))
     print("wrote", os.path.normpath(path), len(lines), "lines,", n_mfma, "MFMAs")
