@@ -76,24 +76,26 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ 
   }
 }
 
-// The same arithmetic, RPW consecutive rows per wave (round 4).  ln_mod_kernel re-reads the four parameter rows (weight, bias,
+// The same arithmetic, rpw consecutive rows per wave (round 4; round 5: rpw chosen by the launcher so that the whole call is ONE
+// resident round of waves -- 255 registers = two waves per SIMD = 2048 waves on the chip: with a fixed 8 rows per wave the C2 call was
+// 2.17 rounds, and the last sixth of a round cannot keep enough bytes in flight to use the HBM).  ln_mod_kernel re-reads the four parameter rows (weight, bias,
 // scale, shift: 4 x 2 D bytes) for every token row -- 30 KB through the vector L1 per 12 KB of HBM traffic at D = 3072, and the
 // loads sit behind the statistics.  Here a wave keeps the parameters of its 8 ITERS columns packed in registers across its rows
 // (rbf(1 + scale) formed once: the value the per-row form rounds every time), reloads scale / shift only when the (batch item,
 // segment) of the next row changes, and has the NEXT row's 16-byte loads in flight while it works on the current one.
 // Bit-identical to ln_mod_kernel (same operations in the same order per element).
-template <int ITERS, int RPW>
+template <int ITERS>
 __global__ __launch_bounds__(256) void ln_mod_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                           const bf16_t* __restrict__ w, const bf16_t* __restrict__ bs,
                                                           const bf16_t* __restrict__ scale,
                                                           const bf16_t* __restrict__ shift, int64_t mod_bs, int64_t x_bs,
                                                           int64_t y_bs, int64_t total_rows, int rows, int seg_split,
-                                                          int64_t seg_stride, float eps) {
+                                                          int64_t seg_stride, float eps, int rpw) {
   constexpr int D = ITERS * 512;
   const int lane = threadIdx.x & 63;
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw;
   if (row0 >= total_rows) return;
-  const int64_t row_end = row0 + RPW < total_rows ? row0 + RPW : total_rows;
+  const int64_t row_end = row0 + rpw < total_rows ? row0 + rpw : total_rows;
   uint4 wp[ITERS], bp[ITERS], s1p[ITERS], shp[ITERS];
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
@@ -260,14 +262,15 @@ extern "C" int alg_layernorm_modulate_seg(const void* x, void* y, const void* we
   const unsigned grid = (unsigned)((total + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
   // many rows with all four parameter rows present (every AdaLN of the CogVideoX / HunyuanVideo blocks): the multi-row form
-  constexpr int RPW = 8;
   if (weight && bias && scale && D <= 3072 && total >= 4096) {
-    const unsigned g2 = (unsigned)((total + 4 * RPW - 1) / (4 * RPW));
+    const int64_t resident_waves = 2048;                       // 256 CUs x 4 SIMDs x 2 waves of this kernel
+    const int rpw = (int)std::max<int64_t>(8, (total + resident_waves - 1) / resident_waves);
+    const unsigned g2 = (unsigned)((total + 4 * (int64_t)rpw - 1) / (4 * (int64_t)rpw));
 #define LN_ROWS(I)                                                                                                      \
   case I:                                                                                                               \
-    hipLaunchKernelGGL((ln_mod_rows_kernel<I, RPW>), dim3(g2), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,            \
+    hipLaunchKernelGGL((ln_mod_rows_kernel<I>), dim3(g2), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,                 \
                        (const bf16_t*)weight, (const bf16_t*)bias, (const bf16_t*)scale, (const bf16_t*)shift,          \
-                       mod_bstride, x_bstride, y_bstride, total, rows, seg_split, seg_stride, eps);                     \
+                       mod_bstride, x_bstride, y_bstride, total, rows, seg_split, seg_stride, eps, rpw);                \
     break;
     switch (D / 512) { LN_ROWS(1) LN_ROWS(2) LN_ROWS(3) LN_ROWS(4) LN_ROWS(5) LN_ROWS(6) }
 #undef LN_ROWS
