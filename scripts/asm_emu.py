@@ -17,7 +17,7 @@ MFMA result latency (XDL write -> VALU read wait states) is NOT modelled here: t
 
 Instruction subset: v_mfma_f32_32x32x16_bf16, ds_read_b128, global_load_dwordx4, global_load_lds_dwordx4, buffer_load_dwordx4 .. offen lds, v_exp_f32, v_fma_f32,
 v_add_f32, v_mul_f32, v_mov_b32, v_add_u32, v_min_u32, v_cvt_pk_bf16_f32, v_cmp_ngt_f32, v_accvgpr_{read,write,mov}_b32, s_add_u32, s_sub_u32,
-s_mov_b32, s_addc_u32, s_cselect_b32, s_cmp_le_u32 / lt / ge, s_branch, s_cbranch_scc1 / scc0 / vccnz / vccz, s_waitcnt, s_barrier, s_nop.
+s_mov_b32, s_addc_u32, s_cselect_b32, s_lshl_b32 / lshr / and, v_mul_lo_u32, s_cmp_le_u32 / lt / ge / eq / lg, s_branch, s_cbranch_scc1 / scc0 / vccnz / vccz, s_waitcnt, s_barrier, s_nop.
 """
 import re
 
@@ -201,9 +201,19 @@ class Machine:
             else:
                 self.wr(w, args[0], np.uint32(val))
             return
-        if op in ("s_cmp_le_u32", "s_cmp_lt_u32", "s_cmp_ge_u32"):
+        if op in ("s_cmp_le_u32", "s_cmp_lt_u32", "s_cmp_ge_u32", "s_cmp_eq_u32", "s_cmp_lg_u32"):
             a, b = int(self.rd(w, args[0])[0]), int(self.rd(w, args[1])[0])
-            w.scc = int({"s_cmp_le_u32": a <= b, "s_cmp_lt_u32": a < b, "s_cmp_ge_u32": a >= b}[op])
+            w.scc = int({"s_cmp_le_u32": a <= b, "s_cmp_lt_u32": a < b, "s_cmp_ge_u32": a >= b, "s_cmp_eq_u32": a == b,
+                         "s_cmp_lg_u32": a != b}[op])
+            return
+        if op in ("s_lshl_b32", "s_lshr_b32", "s_and_b32"):
+            a, b = int(self.rd(w, args[1])[0]), int(self.rd(w, args[2])[0])
+            r = {"s_lshl_b32": (a << (b & 31)) & 0xFFFFFFFF, "s_lshr_b32": a >> (b & 31), "s_and_b32": a & b}[op]
+            w.scc = int(r != 0)
+            self.wr(w, args[0], np.uint32(r))
+            return
+        if op == "v_mul_lo_u32":
+            self.wr(w, args[0], (self.rd(w, args[1]).astype(np.uint64) * self.rd(w, args[2]).astype(np.uint64)).astype(np.uint32))
             return
         if op == "v_mov_b32" or op.startswith("v_accvgpr_"):
             self.wr(w, args[0], self.rd(w, args[1]))
@@ -278,11 +288,37 @@ class Machine:
             src = self.gbytes(addr).copy()     # global data is read-only here: sample at issue
 
             def complete(dst=dst, src=src):
+                if dst.min() < 0 or dst.max() + 16 > self.lds.size:
+                    raise RuntimeError("memory fault: LDS-DMA destination outside the LDS")
                 self.lds[dst[:, None] + np.arange(16)[None, :]] = src
             if self.lazy_dma:
                 w.vm.append(complete)
             else:
                 w.vm.append(lambda: None)       # keeps the vmcnt bookkeeping identical in both modes
+                complete()
+            return
+        if op == "buffer_load_dwordx4" and mods.get("offen") and not mods.get("lds"):
+            # 16 bytes per lane into four VGPRs through a raw buffer descriptor; range check on the per-lane offset + immediate
+            regs, first, n = self.tuple_regs(w, args[0])
+            assert n == 4
+            f, i, nn = parse_reg(args[2])
+            assert f == "s" and nn == 4 and i % 4 == 0, args[2]
+            base = (int(w.s[i]) | ((int(w.s[i + 1]) & 0xFFFF) << 32)) + int(self.rd(w, args[3])[0])
+            num = int(w.s[i + 2])
+            off = self.rd(w, args[1]).astype(np.int64) + mods.get("offset", 0)
+            inb = off + 16 <= num
+            data = self.gbytes(np.where(inb, base + off, self.gmem_va)).copy()
+            data[~inb] = 0
+
+            def complete(regs=regs, first=first, data=data.reshape(64, 4, 4)):
+                words = data[:, :, 0].astype(np.uint32) | (data[:, :, 1].astype(np.uint32) << 8) | \
+                    (data[:, :, 2].astype(np.uint32) << 16) | (data[:, :, 3].astype(np.uint32) << 24)
+                for k in range(4):
+                    regs[first + k] = words[:, k]
+            if self.lazy_dma:
+                w.vm.append(complete)
+            else:
+                w.vm.append(lambda: None)
                 complete()
             return
         if op == "buffer_load_dwordx4" and mods.get("lds") and mods.get("offen"):
@@ -303,6 +339,8 @@ class Machine:
             dst = int(w.m0) + mods.get("offset", 0) + np.arange(64, dtype=np.int64) * 16
 
             def complete(dst=dst, src=src):
+                if dst.min() < 0 or dst.max() + 16 > self.lds.size:
+                    raise RuntimeError("memory fault: LDS-DMA destination outside the LDS")
                 self.lds[dst[:, None] + np.arange(16)[None, :]] = src
             if self.lazy_dma:
                 w.vm.append(complete)
