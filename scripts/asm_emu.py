@@ -15,7 +15,7 @@ weakest timing the ISA allows:
 A schedule is accepted when it computes the right answer under lazy reads + eager DMA, eager reads + lazy DMA and lazy + lazy.
 MFMA result latency (XDL write -> VALU read wait states) is NOT modelled here: tests check it statically on the listing.
 
-Instruction subset: v_mfma_f32_32x32x16_bf16, ds_read_b128, global_load_dwordx4, global_load_lds_dwordx4, buffer_load_dwordx4 .. offen lds, v_exp_f32, v_fma_f32,
+Instruction subset: v_mfma_f32_32x32x16_bf16, v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3, scales 2^0), ds_read_b128, global_load_dwordx4, global_load_lds_dwordx4, buffer_load_dwordx4 .. offen lds, v_exp_f32, v_fma_f32,
 v_add_f32, v_mul_f32, v_mov_b32, v_add_u32, v_min_u32, v_cvt_pk_bf16_f32, v_cmp_ngt_f32, v_accvgpr_{read,write,mov}_b32, s_add_u32, s_sub_u32,
 s_mov_b32, s_addc_u32, s_cselect_b32, s_lshl_b32 / lshr / and, v_mul_lo_u32, s_cmp_le_u32 / lt / ge / eq / lg, s_branch, s_cbranch_scc1 / scc0 / vccnz / vccz, s_waitcnt, s_barrier, s_nop.
 """
@@ -161,6 +161,10 @@ class Machine:
         if op == "s_waitcnt":
             for m in re.finditer(r"(vmcnt|lgkmcnt)\((\d+)\)", rest):
                 self.drain(w.vm if m.group(1) == "vmcnt" else w.lgkm, int(m.group(2)))
+            return
+        if op == "v_mfma_scale_f32_32x32x64_f8f6f4":
+            assert rest.endswith(" op_sel_hi:[0,0,0]"), ln
+            self.mfma_f8(w, [a.strip() for a in rest[:-len(" op_sel_hi:[0,0,0]")].split(",")])
             return
         args = [a.strip() for a in rest.split(",")] if rest else []
         mods = {}
@@ -349,6 +353,49 @@ class Machine:
                 complete()
             return
         raise NotImplementedError(ln)
+
+    E4M3 = None
+
+    @classmethod
+    def e4m3_table(cls):
+        """OCP e4m3 (fn: no infinities, 0x7f / 0xff = NaN) byte -> value"""
+        if cls.E4M3 is None:
+            t = np.zeros(256, dtype=np.float64)
+            for b in range(256):
+                e, m = (b >> 3) & 15, b & 7
+                v = (m / 8.0) * 2.0 ** -6 if e == 0 else (np.nan if (e == 15 and m == 7) else (1.0 + m / 8.0) * 2.0 ** (e - 7))
+                t[b] = -v if b & 0x80 else v
+            cls.E4M3 = t
+        return cls.E4M3
+
+    def mfma_f8(self, w, args):
+        """v_mfma_scale_f32_32x32x64_f8f6f4 with both operands e4m3 and every block scale 2^0 (scale registers 0x7f7f7f7f): D = A (32 x 64)
+        * B (64 x 32) + C.  Lane l holds row / column l % 32 and the 32 bytes of k-group l / 32 in eight registers; which 32 of the 64 k
+        a group is does not matter to a program that stages A and B the same way (the sum runs over all of them once)."""
+        dregs, d0, dn = self.tuple_regs(w, args[0])
+        assert dn == 16
+        for sc in (args[4], args[5].split()[0]):
+            assert (self.rd(w, sc) == 0x7F7F7F7F).all(), "block scales must be 2^0"
+        tab = self.e4m3_table()
+
+        def frag(tok):
+            regs, f0, n = self.tuple_regs(w, tok)
+            assert n == 8
+            words = regs[f0:f0 + 8]                                   # [8, 64]
+            by = np.stack([(words >> (8 * i)) & 0xFF for i in range(4)], axis=1).reshape(32, 64)   # byte index 4 r + i, lane
+            m = np.zeros((32, 64), dtype=np.float64)
+            for h2 in range(2):
+                m[:, 32 * h2:32 * h2 + 32] = tab[by[:, 32 * h2:32 * h2 + 32]].T
+            return m
+        A, Bt = frag(args[1]), frag(args[2])
+        cregs, c0, cn = self.tuple_regs(w, args[3])
+        D = A @ Bt.T
+        for e in range(16):
+            for h2 in range(2):
+                rows = (e & 3) + 8 * (e >> 2) + 4 * h2
+                cur = cregs[c0 + e][32 * h2:32 * h2 + 32].view(np.float32).astype(np.float64)
+                out = (cur + D[rows, :]).astype(np.float32)
+                dregs[d0 + e][32 * h2:32 * h2 + 32] = out.view(np.uint32)
 
     def mfma(self, w, args):
         """D = A (32 x 16) * B (16 x 32) + C; lane l: A row l % 32, k = 8 (l / 32) + i; B column l % 32, same k; D column l % 32,

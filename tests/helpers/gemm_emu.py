@@ -17,7 +17,39 @@ def bf16_round(x):
     return asm_emu.bf16_to_f32(asm_emu.f32_to_bf16(np.asarray(x, dtype=np.float32)))
 
 
+class ProblemFp8:
+    """the same tile with OCP e4m3 operands: a k-tile is 128 bytes = 128 values per row (K = 128 nk)"""
+
+    def __init__(self, nk, seed=0, rows_a=256, rows_b=256):
+        rng = np.random.default_rng(seed)
+        self.K, self.nk, self.rows_a, self.rows_b = 128 * nk, nk, rows_a, rows_b
+        self.lda, self.ldb, self.ldr = self.K, self.K + 128, 264           # (pitches in ELEMENTS = bytes here)
+        tab = asm_emu.Machine.e4m3_table()
+        codes = lambda n: np.where((c := rng.integers(0, 256, size=(n, self.K), dtype=np.uint8)) & 0x7F == 0x7F, 0x38, c).astype(np.uint8)
+        self.ca, self.cb = codes(rows_a), codes(rows_b)
+        self.a, self.b = tab[self.ca], tab[self.cb]
+        self.r = bf16_round(rng.standard_normal((rows_a, 256)))
+        self.AOFF = 4096
+        self.BOFF = self.AOFF + rows_a * self.lda + 640
+        self.ROFF = self.BOFF + rows_b * self.ldb + 384
+        g = np.full(self.ROFF + 2 * rows_a * self.ldr + 256, 0x7F, dtype=np.uint8)                # e4m3 NaN everywhere else
+        for r in range(rows_a):
+            g[self.AOFF + r * self.lda: self.AOFF + r * self.lda + self.K] = self.ca[r]
+            g[self.ROFF + 2 * r * self.ldr: self.ROFF + 2 * r * self.ldr + 512] = asm_emu.f32_to_bf16(self.r[r]).view(np.uint8)
+        for r in range(rows_b):
+            g[self.BOFF + r * self.ldb: self.BOFF + r * self.ldb + self.K] = self.cb[r]
+        self.gmem = g
+        self.esz = 1
+
+    def reference(self):
+        a = np.zeros((256, self.K)); a[:self.rows_a] = self.a; a[self.rows_a:] = self.a[-1]
+        b = np.zeros((256, self.K)); b[:self.rows_b] = self.b; b[self.rows_b:] = self.b[-1]
+        return a @ b.T
+
+
 class Problem:
+    esz = 2
+
     def __init__(self, nk, seed=0, rows_a=256, rows_b=256, lda=None, ldb=None):
         """one tile: C[256, 256] = A[rows_a, K] B[rows_b, K]^T, K = 64 nk; rows past rows_a / rows_b do not exist (the frame clamps
         the DMA's row index to the last valid one: rmaxa / rmaxb)"""
@@ -51,7 +83,11 @@ class Problem:
 def run_plain(pb, lazy_reads, lazy_dma, mutate=None, va=(1 << 32) - 70000, res=False):
     """-> C [256, 256] float64 as the statement leaves it in the accumulators, instruction count (res: the residual form -- also
     returns the residual tile as the statement hands it to the epilogue, [256, 256] float64)"""
-    lines = GP.emit(res=res)
+    if pb.esz == 1:
+        import gen_gemm_p9_fp8 as GF
+        lines = GF.emit(res)
+    else:
+        lines = GP.emit(res=res)
     if mutate is not None:
         lines = mutate(lines)
     tab = {}
@@ -83,7 +119,7 @@ def run_plain(pb, lazy_reads, lazy_dma, mutate=None, va=(1 << 32) - 70000, res=F
         w.v[5] = (((ln & 7) ^ ((w.id * 4 + (ln >> 4)) & 7)) * 16).astype(np.uint32)           # vslot
         for ks in range(4):
             w.v[ks] = (l31 * 128 + (((2 * ks + h2) ^ sw) * 16)).astype(np.uint32)             # vl0..3
-        sset(w, "lda2", pb.lda * 2), sset(w, "ldb2", pb.ldb * 2)
+        sset(w, "lda2", pb.lda * pb.esz), sset(w, "ldb2", pb.ldb * pb.esz)
         sset(w, "rmaxa", pb.rows_a - 1), sset(w, "rmaxb", pb.rows_b - 1)
         sset(w, "nloop", pb.nk - 2), sset(w, "wm", wm), sset(w, "wn2", 2 + wn), sset(w, "wave1k", SMEM + w.id * 1024)
         sset(w, "pa", va + pb.AOFF), sset(w, "pb", va + pb.BOFF)

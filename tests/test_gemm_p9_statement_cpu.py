@@ -4,7 +4,8 @@ emulator runs the asm text for the four waves of one 256 x 256 tile the way gemm
 LDS-DMA two k-tiles ahead, fragment reads one k-step ahead, one counted wait and one barrier per k-tile, the residual tile fetched
 inside the loop with its catch-up chain for short K -- under the weakest memory ordering the ISA allows (fragment reads and DMA /
 buffer loads land only at the counted wait that covers them), and the accumulators are compared with a float64 A B^T; the harness is
-shown to catch seeded defects.  No GPU."""
+shown to catch seeded defects.  The e4m3 loop (gen_gemm_p9_fp8.py, its block-scaled MFMA emulated with all scales 2^0) runs in the same
+harness.  No GPU."""
 import os
 import sys
 
@@ -98,3 +99,60 @@ def test_residual_wait_is_load_bearing():
         e = relerr(c, ref)
         worst = max(worst, e if np.isfinite(e) else 1.0)
     assert worst > 1e3 * TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the e4m3 loop (scripts/gen_gemm_p9_fp8.py -> gemm_p9_fp8_loop.inc): same ring and DMA protocol, ONE set of 8-register operands that
+# is re-read for the next k-pair right behind its last MFMA, v_mfma_scale_f32_32x32x64_f8f6f4 with all block scales 2^0
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nk,res", [(2, False), (3, False), (7, False), (12, False), (2, True), (6, True), (13, True)])
+def test_fp8_statements_compute_the_tile_under_the_weakest_memory_ordering(nk, res):
+    rows = 256 if nk % 2 == 0 else 200
+    pb = H.ProblemFp8(nk, seed=50 + nk, rows_a=rows)
+    ref = pb.reference()
+    for lazy_reads, lazy_dma in (MODES if nk in (2, 7) else MODES[2:]):
+        out = H.run_plain(pb, lazy_reads, lazy_dma, res=res)
+        assert relerr(out[0], ref) < TOL, (nk, res, lazy_reads, lazy_dma, relerr(out[0], ref))
+        if res:
+            rref = np.zeros((256, 256))
+            rref[:rows] = pb.r
+            assert np.array_equal(out[1], rref)
+
+
+def _reread_one_mfma_early(lines):
+    """the first operand re-read that sits right behind an MFMA moves in front of it: the MFMA then multiplies the NEXT k-pair's bytes"""
+    out = list(lines)
+    start = out.index("1:")                                   # inside the steady-state loop
+    for i in range(start, len(out) - 1):
+        if out[i].startswith("v_mfma") and out[i + 1].startswith("ds_read_b128"):
+            dst = out[i + 1].split()[1].rstrip(",")           # v[a:b]
+            lo = int(dst[2:].split(":")[0])
+            ops = [t.strip() for t in out[i].split(None, 1)[1].split(",")]
+            for src in ops[1:3]:
+                a, b = (int(x) for x in src[2:-1].split(":"))
+                if a <= lo <= b:
+                    out[i], out[i + 1] = out[i + 1], out[i]
+                    return out
+    raise AssertionError("no re-read found behind the MFMA that reads its operand")
+
+
+FP8_MUTATIONS = {
+    "operand re-read one MFMA early": _reread_one_mfma_early,
+    "no barrier": lambda L: [ln for ln in L if ln != "s_barrier"],
+    "DMA wait four too loose": lambda L: [ln.replace("s_waitcnt vmcnt(8)", "s_waitcnt vmcnt(12)") for ln in L],
+}
+
+
+@pytest.mark.parametrize("name", sorted(FP8_MUTATIONS))
+def test_the_harness_sees_seeded_defects_in_the_fp8_loop(name):
+    pb = H.ProblemFp8(7, seed=8)
+    ref = pb.reference()
+    worst = 0.0
+    for lazy_reads, lazy_dma in MODES + [(False, False)]:
+        try:
+            c = H.run_plain(pb, lazy_reads, lazy_dma, mutate=FP8_MUTATIONS[name])[0]
+            e = relerr(c, ref)
+            worst = max(worst, e if np.isfinite(e) else 1.0)
+        except RuntimeError:
+            worst = 1.0
+    assert worst > 1e3 * TOL, (name, worst)
