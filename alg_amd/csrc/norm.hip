@@ -224,6 +224,65 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
   if (live) *(uint4*)ptr = pack8(o);
 }
 
+// The same arithmetic, one wave per TOKEN (round 5): the 2 * heads head vectors of a token share their rotary row, so the 64 cos + 64
+// sin floats a lane group needs (16 per lane) are loaded ONCE per token instead of once per head vector -- in the per-vector kernel above
+// every 16 bytes of qk came with 64 bytes of table through the vector L1.  Four head-vector loads in flight per lane.  Needs
+// 2 * heads % 32 == 0 (CogVideoX: 96); bit-identical to qk_norm_rope_kernel (same helpers, same order per element).
+__global__ __launch_bounds__(256) void qk_norm_rope_token_kernel(bf16_t* __restrict__ qk, const bf16_t* __restrict__ wq,
+                                                                 const bf16_t* __restrict__ bq, const bf16_t* __restrict__ wk,
+                                                                 const bf16_t* __restrict__ bk, const float* __restrict__ cos_tab,
+                                                                 const float* __restrict__ sin_tab, int64_t tokens, int S, int heads,
+                                                                 int text_len, float eps, float q_scale) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7, slot = lane >> 3;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= tokens) return;
+  const int s = (int)(tok % S);
+  const bool roped = s >= text_len && cos_tab;
+  float cs[8], sn[8];
+  if (roped) {
+    const int64_t pos = (int64_t)(s - text_len) * 64 + sub * 8;
+    const float4 c0 = *(const float4*)(cos_tab + pos), c1 = *(const float4*)(cos_tab + pos + 4);
+    const float4 s0 = *(const float4*)(sin_tab + pos), s1 = *(const float4*)(sin_tab + pos + 4);
+    cs[0] = c0.x, cs[1] = c0.y, cs[2] = c0.z, cs[3] = c0.w, cs[4] = c1.x, cs[5] = c1.y, cs[6] = c1.z, cs[7] = c1.w;
+    sn[0] = s0.x, sn[1] = s0.y, sn[2] = s0.z, sn[3] = s0.w, sn[4] = s1.x, sn[5] = s1.y, sn[6] = s1.z, sn[7] = s1.w;
+  }
+  float wqv[8], bqv[8], wkv[8], bkv[8];
+  unpack8(*(const uint4*)(wq + sub * 8), wqv);
+  unpack8(*(const uint4*)(bq + sub * 8), bqv);
+  unpack8(*(const uint4*)(wk + sub * 8), wkv);
+  unpack8(*(const uint4*)(bk + sub * 8), bkv);
+  bf16_t* const base = qk + tok * (int64_t)(2 * heads) * 64 + sub * 8;
+  const int passes = 2 * heads / 8;
+  for (int p0 = 0; p0 < passes; p0 += 4) {
+    uint4 raw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw[u] = *(const uint4*)(base + (int64_t)((p0 + u) * 8 + slot) * 64);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int hv = (p0 + u) * 8 + slot;
+      const bool is_k = hv >= heads;
+      float v[8];
+      unpack8(raw[u], v);
+      float sum = qk_chunk_sum(v);
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      sum += __shfl_xor(sum, 4, 64);
+      const float mean = qk_mean(sum);
+      float q = qk_chunk_sqdev(v, mean);
+      q += __shfl_xor(q, 1, 64);
+      q += __shfl_xor(q, 2, 64);
+      q += __shfl_xor(q, 4, 64);
+      const float rstd = qk_rstd(q, eps);
+      const float qs = is_k ? 1.0f : q_scale;
+      float o[8];
+      qk_ln_chunk(v, mean, rstd, is_k ? wkv : wqv, is_k ? bkv : bqv, roped, qs, o);
+      if (roped) qk_rope_chunk(o, cs, sn, qs);
+      *(uint4*)(base + (int64_t)hv * 64) = pack8(o);
+    }
+  }
+}
+
 }  // namespace alg
 
 using namespace alg;
@@ -307,6 +366,13 @@ extern "C" int alg_qk_norm_rope_scaled(void* qk, const void* wq, const void* bq,
     return ALG_EINVAL;
   }
   const int64_t total_vec = (int64_t)batch * S * 2 * heads;
+  if ((2 * heads) % 32 == 0 && ((int64_t)batch * S + 3) / 4 <= 0x7fffffff) {   // one wave per token: the rotary row is loaded once
+    const int64_t tokens = (int64_t)batch * S;
+    hipLaunchKernelGGL(qk_norm_rope_token_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qk,
+                       (const bf16_t*)wq, (const bf16_t*)bq, (const bf16_t*)wk, (const bf16_t*)bk, cos_tab, sin_tab, tokens, S, heads,
+                       text_len, eps, q_scale);
+    return check_launch("alg_qk_norm_rope");
+  }
   const unsigned grid = (unsigned)((total_vec + 31) / 32);
   hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qk,
                      (const bf16_t*)wq, (const bf16_t*)bq, (const bf16_t*)wk, (const bf16_t*)bk, cos_tab, sin_tab,

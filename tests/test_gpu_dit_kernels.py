@@ -432,7 +432,8 @@ def test_gemm_pair_is_bit_identical_to_the_two_launches(monkeypatch, S, D, N):
 
 @pytest.mark.parametrize("S,heads,N,T,rope,qs", [(17776, 48, 2, 226, True, 0.18033688), (300, 8, 3, 17, True, 1.0),
                                                   (1000, 4, 1, 0, True, 0.18033688), (257, 12, 2, 257, True, 1.0),
-                                                  (530, 4, 2, 100, False, 0.18033688), (300, 6, 1, 17, True, 0.18033688)])
+                                                  (530, 4, 2, 100, False, 0.18033688), (300, 6, 1, 17, True, 0.18033688),
+                                                  (300, 16, 2, 17, True, 0.18033688), (130, 32, 1, 0, False, 1.0)])   # (2 * heads % 32 == 0: one wave per token)
 def test_gemm_pair_qk_is_bit_identical_to_the_pair_launch_plus_qk_norm_rope(monkeypatch, S, heads, N, T, rope, qs):
     """alg_gemm_bf16_pair_qk: the per-head QK LayerNorm + rotary embedding (+ softmax scale on Q) inside the Q|K projection's
     store loop.  Same arithmetic, same reduction tree, same rounding points as qk_norm_rope_kernel (csrc/qk_norm_rope.h), so
