@@ -205,48 +205,48 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_d128_kernel(const P p) 
       }
   };
   for (int set = 0; set < (DUAL ? 2 : 1); ++set) {
-  if (DUAL && set == 1) {
-    // the second key / value set: fresh softmax state, the ring is free once every wave has left the first set's last tile
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
+    if (DUAL && set == 1) {
+      // the second key / value set: fresh softmax state, the ring is free once every wave has left the first set's last tile
+      const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+      const float inv = 1.0f / l_tot;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+      for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        o1[dt * 4 + g].x = pack_bf2(o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv);
-        o1[dt * 4 + g].y = pack_bf2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
-      }
+        for (int g = 0; g < 4; ++g) {
+          o1[dt * 4 + g].x = pack_bf2(o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv);
+          o1[dt * 4 + g].y = pack_bf2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
+        }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) o_acc[i][e] = 0.0f;
-    m_run = -INFINITY;
-    l_run = 0.0f;
-    Skv = p.Skv2;
-    k_rs = p.k2_rs;
-    vt_rs = p.vt2_rs;
-    K = p.k2 + (int64_t)b * p.k2_bs + hk * 128;
-    VT = p.vt2 + (int64_t)b * p.vt2_bs + (int64_t)hk * 128 * vt_rs;
-    v_src0 = VT + (int64_t)v_row * vt_rs + v_slot * 8;
-    v_src1 = v_src0 + (int64_t)64 * vt_rs;
-    n_tiles = (Skv + KVB - 1) / KVB;
-    ragged = (Skv & (KVB - 1)) != 0;
-    __syncthreads();
-  }
-  stage(0, 0);
-  if (CAUSAL) {
-    const int first_masked = (qb * (NW * 32) + wave * 32) / KVB;     // first tile that reaches past this wave's first query
-    for (int t = 0; t < n_tiles; ++t) {                               // (wave-uniform; the barrier inside is hit by all)
-      if (t < first_masked && !(ragged && t == (Skv + KVB - 1) / KVB - 1))
-        tile(t, BoolC<false>{});
-      else
-        tile(t, BoolC<true>{});
+        for (int e = 0; e < 16; ++e) o_acc[i][e] = 0.0f;
+      m_run = -INFINITY;
+      l_run = 0.0f;
+      Skv = p.Skv2;
+      k_rs = p.k2_rs;
+      vt_rs = p.vt2_rs;
+      K = p.k2 + (int64_t)b * p.k2_bs + hk * 128;
+      VT = p.vt2 + (int64_t)b * p.vt2_bs + (int64_t)hk * 128 * vt_rs;
+      v_src0 = VT + (int64_t)v_row * vt_rs + v_slot * 8;
+      v_src1 = v_src0 + (int64_t)64 * vt_rs;
+      n_tiles = (Skv + KVB - 1) / KVB;
+      ragged = (Skv & (KVB - 1)) != 0;
+      __syncthreads();
     }
-  } else {
-    const int n_loop = ragged ? n_tiles - 1 : n_tiles;
-    for (int t = 0; t < n_loop; ++t) tile(t, BoolC<false>{});
-    if (ragged) tile(n_tiles - 1, BoolC<true>{});
-  }
+    stage(0, 0);
+    if (CAUSAL) {
+      const int first_masked = (qb * (NW * 32) + wave * 32) / KVB;     // first tile that reaches past this wave's first query
+      for (int t = 0; t < n_tiles; ++t) {                               // (wave-uniform; the barrier inside is hit by all)
+        if (t < first_masked && !(ragged && t == (Skv + KVB - 1) / KVB - 1))
+          tile(t, BoolC<false>{});
+        else
+          tile(t, BoolC<true>{});
+      }
+    } else {
+      const int n_loop = ragged ? n_tiles - 1 : n_tiles;
+      for (int t = 0; t < n_loop; ++t) tile(t, BoolC<false>{});
+      if (ragged) tile(n_tiles - 1, BoolC<true>{});
+    }
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
