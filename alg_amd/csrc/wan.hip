@@ -125,6 +125,112 @@ __global__ __launch_bounds__(256) void ln_mod_f32_kernel(const bf16_t* __restric
   }
 }
 
+// The modulated, non-affine form (norm1 / norm3 of every Wan block: y = LN(x) * (1 + scale[b]) + shift[b], fp32 parameters), many rows
+// (round 5).  ln_mod_f32_kernel fetches the two fp32 parameter rows for EVERY token row -- 8 D bytes through the vector L1 for 4 D
+// bytes of HBM traffic.  Here a workgroup belongs to one batch item and keeps (1 + scale) | shift in the LDS (8 D bytes, loaded once),
+// a wave runs rpw consecutive rows with the next row's 16-byte loads in flight, and the launcher sizes rpw so that the call is about one
+// resident round of workgroups.  Same operations in the same order per element: bit-identical to ln_mod_f32_kernel (bf16 and e4m3
+// outputs).
+template <int ITERS>
+__global__ __launch_bounds__(256) void ln_mod_f32_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              int64_t mod_bs, int rows, float eps, uint8_t* __restrict__ q8,
+                                                              float* __restrict__ q8_scale, int rpw, int blocks_per_item) {
+  constexpr int D = ITERS * 512;
+  __shared__ __attribute__((aligned(16))) float prm[2 * D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bidx = blockIdx.x / blocks_per_item, blk = blockIdx.x - bidx * blocks_per_item;
+  for (int i = threadIdx.x * 4; i < D; i += 1024) {
+    const float4 a = *(const float4*)(scale + (int64_t)bidx * mod_bs + i);
+    *(float4*)(prm + i) = make_float4(1.0f + a.x, 1.0f + a.y, 1.0f + a.z, 1.0f + a.w);
+    *(float4*)(prm + D + i) = *(const float4*)(shift + (int64_t)bidx * mod_bs + i);
+  }
+  __syncthreads();
+  const int r0 = (blk * 4 + wave) * rpw;
+  if (r0 >= rows) return;
+  const int r1 = r0 + rpw < rows ? r0 + rpw : rows;
+  const int64_t row_base = (int64_t)bidx * rows;
+  uint4 nxt[ITERS];
+  {
+    const bf16_t* xr = x + (row_base + r0) * D + lane * 8;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) nxt[i] = *(const uint4*)(xr + i * 512);
+  }
+  for (int r = r0; r < r1; ++r) {
+    const int64_t row = row_base + r;
+    float v[ITERS][8];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      unpack8(nxt[i], v[i]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[i][k];
+    }
+    if (r + 1 < r1) {
+      const bf16_t* xr = x + (row + 1) * D + lane * 8;
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) nxt[i] = *(const uint4*)(xr + i * 512);
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float d = v[i][k] - mean;
+        q = fmaf(d, d, q);
+      }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+    bf16_t* yr = y ? y + row * D : nullptr;
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int c0 = i * 512 + lane * 8;
+      const float4 s0 = *(const float4*)(prm + c0), s1 = *(const float4*)(prm + c0 + 4);
+      const float4 h0 = *(const float4*)(prm + D + c0), h1 = *(const float4*)(prm + D + c0 + 4);
+      const float s1v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float n = (v[i][k] - mean) * rstd;
+        n = n * s1v[k];
+        n = n + shv[k];
+        o[k] = n;
+      }
+      if (q8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          v[i][k] = rbf(o[k]);
+          amax = fmaxf(amax, fabsf(v[i][k]));
+        }
+      } else {
+        *(uint4*)(yr + c0) = pack8(o);
+      }
+    }
+    if (q8) {
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
+      const float qs = amax > 0.0f ? amax * (1.0f / 448.0f) : 1.0f;
+      const float inv = 1.0f / qs;
+      if (lane == 0) q8_scale[row] = qs;
+      uint8_t* qr = q8 + row * D;
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) {
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = fminf(fmaxf(v[i][k] * inv, -448.0f), 448.0f);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        *(uint2*)(qr + i * 512 + lane * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+      }
+    }
+  }
+}
+
 // any D (the 1280-wide CLIP tokens of WanImageEmbedding): one wave per row, three strided passes over the row
 __global__ __launch_bounds__(256) void ln_mod_f32_generic_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                                  const float* __restrict__ w, const float* __restrict__ bs,
@@ -335,6 +441,22 @@ static int layernorm_mod_entry(const char* who, const void* x, void* y, void* q8
   const dim3 grid((unsigned)((total + 3) / 4)), blk(256);
   hipStream_t s = (hipStream_t)stream;
   bool ok = D % 512 == 0;
+  if (ok && !weight && !bias && scale && shift && total >= 4096 && D <= 6144 && (mod_bstride & 3) == 0 &&
+      !(((uintptr_t)scale | (uintptr_t)shift) & 15)) {
+    // the modulated non-affine form over many rows: parameters in the LDS, rpw rows per wave, about one resident round of workgroups
+    // (three of these 256-thread workgroups fit a CU: 768 on the chip)
+    const int64_t want = (total + 4 * 768 - 1) / (4 * 768);
+    const int rpw = (int)(want < 8 ? 8 : want);
+    const int bpi = (rows + 4 * rpw - 1) / (4 * rpw);
+    bool ok2 = true;
+    {
+      bool& ok = ok2;
+      DISPATCH_ITERS(D / 512, hipLaunchKernelGGL(wan::ln_mod_f32_rows_kernel<IT>, dim3((unsigned)(bpi * batch)), blk, 0, s,
+                                                 (const bf16_t*)x, (bf16_t*)y, scale, shift, mod_bstride, rows, eps, (uint8_t*)q8,
+                                                 q8_scale, rpw, bpi));
+    }
+    if (ok2) return check_launch(who);
+  }
   if (ok) {
     DISPATCH_ITERS(D / 512, hipLaunchKernelGGL(wan::ln_mod_f32_kernel<IT>, grid, blk, 0, s, (const bf16_t*)x, (bf16_t*)y,
                                                weight, bias, scale, shift, mod_bstride, total, rows, eps, (uint8_t*)q8,

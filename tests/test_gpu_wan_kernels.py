@@ -226,6 +226,33 @@ def test_layernorm_mod_f32_fp8_is_norm_then_quantiser(D, affine, mod):
     assert torch.equal(q_got, q_want)
 
 
+@pytest.mark.parametrize("D,rows,batch", [(5120, 5003, 2), (1536, 4100, 1), (3072, 2100, 3)])
+def test_layernorm_mod_f32_many_rows_form_is_bit_identical(D, rows, batch):
+    """From 4,096 rows on the modulated non-affine LayerNorm (norm1 / norm3 of the Wan blocks) runs with its fp32 parameters in the LDS
+    and several rows per wave (ln_mod_f32_rows_kernel); the same rows through calls of fewer than 4,096 rows take the one-row-per-wave
+    kernel: the bf16 output and the e4m3 bytes + row scales must be the same bits."""
+    x = _rand((batch, rows, D), 31, 2.0)
+    g = torch.Generator().manual_seed(32)
+    mod = (torch.randn(batch, 2, D, generator=g) * 0.3).float().to(DEV)        # [b][scale | shift][D], fp32
+    y = torch.full((batch, rows, D), 5.0, dtype=BF, device=DEV)
+    _lib.layernorm_mod_f32(x, y, None, None, mod, mod, 2 * D, batch, rows, D, 1e-6, scale_off=0, shift_off=D)
+    q8 = torch.zeros(batch, rows, D, dtype=torch.uint8, device=DEV)
+    qs = torch.zeros(batch, rows, dtype=torch.float32, device=DEV)
+    _lib.layernorm_mod_f32_fp8(x, q8, qs, None, None, mod, mod, 2 * D, batch, rows, D, 1e-6, scale_off=0, shift_off=D)
+    y_ref, q8_ref, qs_ref = torch.zeros_like(y), torch.zeros_like(q8), torch.zeros_like(qs)
+    for b in range(batch):
+        for a in range(0, rows, 1900):
+            n = min(1900, rows - a)
+            _lib.layernorm_mod_f32(x[b, a:a + n], y_ref[b, a:a + n], None, None, mod[b, 0], mod[b, 1], 0, 1, n, D, 1e-6)
+            _lib.layernorm_mod_f32_fp8(x[b, a:a + n], q8_ref[b, a:a + n], qs_ref[b, a:a + n], None, None, mod[b, 0], mod[b, 1], 0, 1,
+                                       n, D, 1e-6)
+    assert torch.equal(y, y_ref)
+    assert torch.equal(q8, q8_ref) and torch.equal(qs, qs_ref)
+    xf = x.float()
+    ref = torch.nn.functional.layer_norm(xf, (D,), eps=1e-6) * (1 + mod[:, :1]) + mod[:, 1:]
+    assert (y.float() - ref).abs().max().item() < 0.06
+
+
 def test_layernorm_mod_f32_fp8_rejects_unsupported_width():
     x = _rand((1, 4, 1280), 17)
     q = torch.empty(4, 1280, dtype=torch.uint8, device=DEV)
