@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void ln_mod_f32_kernel(const bf16_t* __restric
   }
 }
 
-// The modulated, non-affine form (norm1 / norm3 of every Wan block: y = LN(x) * (1 + scale[b]) + shift[b], fp32 parameters), many rows
-// (round 5).  ln_mod_f32_kernel fetches the two fp32 parameter rows for EVERY token row -- 8 D bytes through the vector L1 for 4 D
+// The modulated, non-affine form (norm1 / norm3 of every Wan block: y = LN(x) * (1 + scale[b]) + shift[b], fp32 parameters) and the
+// affine, unmodulated form (norm2: y = LN(x) * w + b) over many rows (round 5).  ln_mod_f32_kernel fetches the two fp32 parameter rows for EVERY token row -- 8 D bytes through the vector L1 for 4 D
 // bytes of HBM traffic.  Here a workgroup belongs to one batch item and keeps (1 + scale) | shift in the LDS (8 D bytes, loaded once),
 // a wave runs rpw consecutive rows with the next row's 16-byte loads in flight, and the launcher sizes rpw so that the call is about one
 // resident round of workgroups.  Same operations in the same order per element: bit-identical to ln_mod_f32_kernel (bf16 and e4m3
@@ -135,14 +135,16 @@ template <int ITERS>
 __global__ __launch_bounds__(256) void ln_mod_f32_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               int64_t mod_bs, int rows, float eps, uint8_t* __restrict__ q8,
-                                                              float* __restrict__ q8_scale, int rpw, int blocks_per_item) {
+                                                              float* __restrict__ q8_scale, int rpw, int blocks_per_item,
+                                                              int plus_one) {
   constexpr int D = ITERS * 512;
   __shared__ __attribute__((aligned(16))) float prm[2 * D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bidx = blockIdx.x / blocks_per_item, blk = blockIdx.x - bidx * blocks_per_item;
   for (int i = threadIdx.x * 4; i < D; i += 1024) {
     const float4 a = *(const float4*)(scale + (int64_t)bidx * mod_bs + i);
-    *(float4*)(prm + i) = make_float4(1.0f + a.x, 1.0f + a.y, 1.0f + a.z, 1.0f + a.w);
+    // plus_one: the modulation form (n * (1 + scale) + shift); otherwise `scale` / `shift` are the affine weight / bias (n * w + b)
+    *(float4*)(prm + i) = plus_one ? make_float4(1.0f + a.x, 1.0f + a.y, 1.0f + a.z, 1.0f + a.w) : a;
     *(float4*)(prm + D + i) = *(const float4*)(shift + (int64_t)bidx * mod_bs + i);
   }
   __syncthreads();
@@ -441,8 +443,11 @@ static int layernorm_mod_entry(const char* who, const void* x, void* y, void* q8
   const dim3 grid((unsigned)((total + 3) / 4)), blk(256);
   hipStream_t s = (hipStream_t)stream;
   bool ok = D % 512 == 0;
-  if (ok && !weight && !bias && scale && shift && total >= 4096 && D <= 6144 && (mod_bstride & 3) == 0 &&
-      !(((uintptr_t)scale | (uintptr_t)shift) & 15)) {
+  const bool mod_only = !weight && !bias && scale && shift, affine_only = weight && bias && !scale && !shift;
+  const float* p0 = mod_only ? scale : weight;
+  const float* p1 = mod_only ? shift : bias;
+  if (ok && (mod_only || affine_only) && total >= 4096 && D <= 6144 && (!mod_only || (mod_bstride & 3) == 0) &&
+      !(((uintptr_t)p0 | (uintptr_t)p1) & 15)) {
     // the modulated non-affine form over many rows: parameters in the LDS, rpw rows per wave, about one resident round of workgroups
     // (three of these 256-thread workgroups fit a CU: 768 on the chip)
     const int64_t want = (total + 4 * 768 - 1) / (4 * 768);
@@ -452,8 +457,8 @@ static int layernorm_mod_entry(const char* who, const void* x, void* y, void* q8
     {
       bool& ok = ok2;
       DISPATCH_ITERS(D / 512, hipLaunchKernelGGL(wan::ln_mod_f32_rows_kernel<IT>, dim3((unsigned)(bpi * batch)), blk, 0, s,
-                                                 (const bf16_t*)x, (bf16_t*)y, scale, shift, mod_bstride, rows, eps, (uint8_t*)q8,
-                                                 q8_scale, rpw, bpi));
+                                                 (const bf16_t*)x, (bf16_t*)y, p0, p1, mod_only ? mod_bstride : 0, rows, eps,
+                                                 (uint8_t*)q8, q8_scale, rpw, bpi, mod_only ? 1 : 0));
     }
     if (ok2) return check_launch(who);
   }

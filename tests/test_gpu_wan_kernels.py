@@ -251,6 +251,14 @@ def test_layernorm_mod_f32_many_rows_form_is_bit_identical(D, rows, batch):
     xf = x.float()
     ref = torch.nn.functional.layer_norm(xf, (D,), eps=1e-6) * (1 + mod[:, :1]) + mod[:, 1:]
     assert (y.float() - ref).abs().max().item() < 0.06
+    # the affine, unmodulated form (norm2 of a Wan block: fp32 weight and bias shared by the batch) takes the same kernel
+    w, b = (1.0 + mod[0, 0]).contiguous(), mod[0, 1].contiguous()
+    _lib.layernorm_mod_f32(x, y, w, b, None, None, 0, batch, rows, D, 1e-6)
+    for bi in range(batch):
+        for a in range(0, rows, 1900):
+            n = min(1900, rows - a)
+            _lib.layernorm_mod_f32(x[bi, a:a + n], y_ref[bi, a:a + n], w, b, None, None, 0, 1, n, D, 1e-6)
+    assert torch.equal(y, y_ref)
 
 
 def test_layernorm_mod_f32_fp8_rejects_unsupported_width():
