@@ -24,7 +24,7 @@ def quant(x):
     return q, s
 
 
-@pytest.mark.parametrize("rows,K", [(5, 512), (300, 5120), (7, 1152)])
+@pytest.mark.parametrize("rows,K", [(5, 512), (300, 5120), (7, 1152), (41, 13824), (9, 3072)])   # (5120, 13824, 3072: the row-in-registers form)
 def test_quantize_fp8_rows_matches_torch(rows, K):
     x = _rand((rows, K), 1, 3.0)
     x[0] = 0                                           # an all-zero row keeps scale 1
@@ -34,6 +34,16 @@ def test_quantize_fp8_rows_matches_torch(rows, K):
     assert torch.allclose(s, want_s, rtol=1e-6)
     want_q = (x.float() * (1.0 / want_s)[:, None]).clamp(-448, 448).to(F8)
     assert torch.equal(q.view(F8).float(), want_q.float())
+
+
+def test_quantize_fp8_rows_strided_input_is_the_contiguous_result():
+    rows, K, pitch = 37, 5120, 5120 + 13824
+    big = _rand((rows, pitch), 6, 2.0)
+    q0, s0 = quant(big[:, 13824:].contiguous())
+    q1 = torch.empty(rows, K, dtype=torch.uint8, device=DEV)
+    s1 = torch.empty(rows, dtype=torch.float32, device=DEV)
+    _lib.quantize_fp8_rows(big, q1, s1, rows, K, x_rstride=pitch, x_off=13824)
+    assert torch.equal(q0, q1) and torch.equal(s0, s1)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 512, 256), (1000, 640, 1152), (33, 64, 128)])
