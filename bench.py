@@ -916,6 +916,26 @@ def ab_arms(wl, arms, steps=5, warmup=3):
     return res
 
 
+def whole_video_projection(wl, elapsed, forwards):
+    """The C3 - C5 legs time loop iterations 0-1, the 3-pass end of the Wan schedules; a whole video also has 2-pass steps.  PROJECTED
+    whole-video rate: the DiT sample-forwards of every step of the schedule (3 while the reference's lp strength is non-zero, else 2;
+    the HunyuanVideo configuration runs its single-pass branch throughout) times the measured seconds per sample-forward of this leg
+    (taken from N = 3 batches: a 2-sample batch is assumed to cost 2 / 3 of it)."""
+    from alg_amd import lp_utils
+    steps = wl.steps_per_video
+    alg = getattr(wl, "alg", None)
+    if alg is None:                      # c4: one pass per step
+        total = steps
+    else:
+        sig = dict(lp_strength_schedule_type="none", schedule_interval_start_time=0.0, schedule_interval_end_time=0.05,
+                   schedule_linear_start_weight=1.0, schedule_linear_end_weight=0.0, schedule_linear_end_time=0.5,
+                   schedule_exp_decay_rate=10.0)
+        sig.update({k: v for k, v in alg.items() if k in sig})
+        total = sum(3 if lp_utils.get_lp_strength(step_index=i, total_steps=steps, **sig) != 0.0 else 2 for i in range(steps))
+    return {"sample_forwards_per_video": total, "frames_per_s": wl.frames / (total * elapsed / forwards),
+            "what": "projected: schedule's passes per step x this leg's measured seconds per sample-forward"}
+
+
 def other_workloads(args, dev, parallel):
     """BASELINE configs 3 / 4 / 5 on the driver's clock.  After the C2 region (its weights freed), each of
     the other workloads is built at FULL depth and timed for 2 steps after 1 warm-up step through its pipeline's __call__ --
@@ -960,6 +980,7 @@ def other_workloads(args, dev, parallel):
                 "finite": bool(torch.isfinite(wl.last_out.float()).all().item()), "build_seconds": round(t_build, 1),
                 "peak_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                 "ab_attn128_q64_statement": ab,
+                "whole_video_projected": whole_video_projection(wl, elapsed, forwards),
             }
         except Exception as e:   # an auxiliary workload must never take the headline line down
             res[name] = {"error": repr(e)}

@@ -48,3 +48,20 @@ def test_workload_table_matches_baseline_json():
     c2 = bench.WORKLOADS["c2"]
     assert c2.frames == 49 and c2.steps_per_video == 50 and "CogVideoX-5B-I2V" in c2.metric and "CogVideoX-5B-I2V" in base["metric"]
     assert (bench.WORKLOADS["c3"].steps_per_video, bench.WORKLOADS["c4"].frames, bench.WORKLOADS["c5"].fp8) == (40, 129, True)
+
+
+def test_whole_video_projection_counts_the_schedules_passes():
+    """C3: linear decay to 0 at half of 40 steps = 20 three-pass + 20 two-pass steps; C5: interval [0, 0.2] of 50 steps = 10 + 40; C4 runs
+    its single-pass branch throughout"""
+    class W:
+        pass
+    want = {"c3": 100, "c5": 110, "c4": 50}
+    for name, total in want.items():
+        cls = bench.WORKLOADS[name]
+        w = W()
+        w.steps_per_video, w.frames = cls.steps_per_video, cls.frames
+        if hasattr(cls, "alg"):
+            w.alg = cls.alg
+        out = bench.whole_video_projection(w, elapsed=6.0, forwards=6)
+        assert out["sample_forwards_per_video"] == total
+        assert abs(out["frames_per_s"] - cls.frames / total) < 1e-12        # one second per sample-forward
