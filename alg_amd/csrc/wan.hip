@@ -453,14 +453,15 @@ static int layernorm_mod_entry(const char* who, const void* x, void* y, void* q8
     const int64_t want = (total + 4 * 768 - 1) / (4 * 768);
     const int rpw = (int)(want < 8 ? 8 : want);
     const int bpi = (rows + 4 * rpw - 1) / (4 * rpw);
-    bool ok2 = true;
+    bool built = true;   // (DISPATCH_ITERS clears `ok` for a width that is not instantiated: then the one-row kernel below takes the call)
     {
-      bool& ok = ok2;
+      bool ok = true;
       DISPATCH_ITERS(D / 512, hipLaunchKernelGGL(wan::ln_mod_f32_rows_kernel<IT>, dim3((unsigned)(bpi * batch)), blk, 0, s,
                                                  (const bf16_t*)x, (bf16_t*)y, p0, p1, mod_only ? mod_bstride : 0, rows, eps,
                                                  (uint8_t*)q8, q8_scale, rpw, bpi, mod_only ? 1 : 0));
+      built = ok;
     }
-    if (ok2) return check_launch(who);
+    if (built) return check_launch(who);
   }
   if (ok) {
     DISPATCH_ITERS(D / 512, hipLaunchKernelGGL(wan::ln_mod_f32_kernel<IT>, grid, blk, 0, s, (const bf16_t*)x, (bf16_t*)y,
