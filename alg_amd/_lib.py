@@ -305,6 +305,14 @@ def calib_mfma_bf16(sink, iters, seed=1, blocks=0, clocks=None):
     """One launch of the register-only random-operand MFMA loop (csrc/calibrate.hip) on the current stream; returns the number
     of workgroups launched (each 4 waves x 32 * iters MFMAs of 32,768 FLOP)."""
     lib = load_library()
+    if clocks is not None:
+        # the kernel writes 4 uint64 per workgroup: resolve "two per CU" here so the buffer can be checked against it (ADVICE r5)
+        if int(blocks) <= 0:
+            blocks = 2 * torch.cuda.get_device_properties(sink.device).multi_processor_count
+        if not (clocks.is_cuda and clocks.device == sink.device and clocks.dtype == torch.int64 and clocks.is_contiguous()
+                and clocks.numel() >= 4 * int(blocks)):
+            raise AlgHipError("calib_mfma_bf16: clocks must be a contiguous int64 tensor on the sink's device with >= 4 * %d "
+                              "elements" % int(blocks))
     rc = lib.alg_calib_mfma_bf16(_ptr(_dev(sink, "sink")), int(iters), int(seed), int(blocks), _ptr(clocks), _stream())
     if rc <= 0:
         _check(rc if rc < 0 else -1, "alg_calib_mfma_bf16")

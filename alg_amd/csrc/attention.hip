@@ -81,8 +81,6 @@ struct AttnP {
   uint64_t* clk;   // clock tap (calibrate.hip: alg_attn_clock_tap) or NULL: {cycles, wall} at start / end of every 64th workgroup
   int clk_slots;
 };
-extern std::atomic<uint64_t*> g_clock_tap;
-extern std::atomic<int> g_clock_tap_slots;
 
 struct Frag {
   int row_off;  // l31 * 128
@@ -767,7 +765,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_pipe_kernel(const Attn
   const int T = (S + KVB - 1) / KVB;
   const bool ragged = (S & (KVB - 1)) != 0;
   // clock tap (bench.py: the shader clock THIS kernel ran at): scalar reads of two counters, wave 0 of every 64th workgroup
-  const bool tap = p.clk != nullptr && (blockIdx.x & 63) == 0 && wave == 0;
+  const bool tap = p.clk != nullptr && (blockIdx.x & 63) == 0 && (int)(blockIdx.x >> 6) < p.clk_slots && wave == 0;
   uint64_t tap_c0 = 0, tap_r0 = 0;
   if (tap) {
     tap_c0 = __builtin_readcyclecounter();
@@ -918,7 +916,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_pipe_kernel(const Attn
       }
   }
   if (tap && c.lane == 0) {
-    uint64_t* cp = p.clk + (size_t)((blockIdx.x >> 6) % p.clk_slots) * 4;
+    uint64_t* cp = p.clk + (size_t)(blockIdx.x >> 6) * 4;   // one workgroup owns a slot (block / 64 < slots)
     cp[0] = tap_c0, cp[1] = tap_r0, cp[2] = __builtin_readcyclecounter(), cp[3] = wall_clock64();
   }
 }
@@ -971,7 +969,10 @@ static void launch_main41(dim3 g, dim3 blk, hipStream_t s, const alg::AttnP& p) 
   // the pipelined statements address K / V^T / Q with 31-bit byte offsets from the (batch, head) panel bases
   if (pp >= 3 && ((int64_t)(p.S + 4 * alg::KVB) * p.q_rs * 2 >= (1ll << 31) || (int64_t)65 * p.vt_rs * 2 >= (1ll << 31))) pp = 0;
   switch (pp) {
-    case 4: hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel<8>, g, dim3(512), 0, s, p); break;             // the default: one 8-wave workgroup per unit
+    case 4:   // the default: one 8-wave workgroup per unit
+    case 6:   // a call flash_attn_d64_q64() declined (fewer than 12 KV tiles, 31-bit offsets, V^T pitch): the default kernel
+      hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel<8>, g, dim3(512), 0, s, p);
+      break;
     default: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<41, 8>), g, blk, 0, s, p); break;
   }
 }
@@ -1027,9 +1028,7 @@ extern "C" int alg_flash_attn_d64_ex(const void* q, const void* k, const void* v
   p.o_bs = o_bstride; p.o_rs = o_rstride;
   p.scale_log2 = (flags & ALG_ATTN_Q_PRESCALED) ? 1.0f : scale * 1.4426950408889634f;  // m is in log2 units already
   p.prio = 0;
-  p.clk = g_clock_tap.load(std::memory_order_acquire);
-  p.clk_slots = p.clk ? g_clock_tap_slots.load(std::memory_order_relaxed) : 0;
-  if (p.clk_slots <= 0) p.clk = nullptr;
+  p.clk = clock_tap_for((hipStream_t)stream, &p.clk_slots);
   const int nbh = batch * heads;
   const int64_t grid = (int64_t)((nbh + 7) / 8) * 8 * p.q_blocks;
   const dim3 blk(nw * 64);

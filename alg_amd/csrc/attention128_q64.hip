@@ -29,8 +29,6 @@
 #include "attn128_q64_loop.inc"
 
 namespace alg {
-extern std::atomic<uint64_t*> g_clock_tap;
-extern std::atomic<int> g_clock_tap_slots;
 namespace a128q {
 
 constexpr int NW = 4;
@@ -74,7 +72,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
   }
   const int b = bh / p.heads, h = bh - b * p.heads;
   const int Sq = p.Sq, Skv = p.Skv;
-  const bool tap = p.clk != nullptr && (blockIdx.x & 63) == 0 && wave == 0;   // clock tap: see attention.hip
+  const bool tap = p.clk != nullptr && (blockIdx.x & 63) == 0 && (int)(blockIdx.x >> 6) < p.clk_slots && wave == 0;   // clock tap: see attention.hip
   uint64_t tap_c0 = 0, tap_r0 = 0;
   if (tap) {
     tap_c0 = __builtin_readcyclecounter();
@@ -308,7 +306,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d128_q64_kernel(const P p)
     }
   }
   if (tap && x.l31 == 0 && x.h2 == 0) {
-    uint64_t* cp = p.clk + (size_t)((blockIdx.x >> 6) % p.clk_slots) * 4;
+    uint64_t* cp = p.clk + (size_t)(blockIdx.x >> 6) * 4;   // one workgroup owns a slot (block / 64 < slots)
     cp[0] = tap_c0, cp[1] = tap_r0, cp[2] = __builtin_readcyclecounter(), cp[3] = wall_clock64();
   }
 }
@@ -344,9 +342,7 @@ int flash_attn_d128_q64(const void* q, const void* k, const void* vt, void* o, i
   p.q_blocks = (Sq + NW * QW - 1) / (NW * QW);
   p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.vt_bs = vt_bs; p.vt_rs = vt_rs; p.o_bs = o_bs; p.o_rs = o_rs;
   p.scale_log2 = scale * 1.4426950408889634f;
-  p.clk = g_clock_tap.load(std::memory_order_acquire);
-  p.clk_slots = p.clk ? g_clock_tap_slots.load(std::memory_order_relaxed) : 0;
-  if (p.clk_slots <= 0) p.clk = nullptr;
+  p.clk = clock_tap_for((hipStream_t)stream, &p.clk_slots);
   p.use_statement = enabled != 3;
   const int64_t grid = (int64_t)((batch * heads + 7) / 8) * 8 * p.q_blocks;
   if (grid > 0x7fffffff) return 1;

@@ -20,8 +20,6 @@
 #include "attn64_q64_loop.inc"
 
 namespace alg {
-extern std::atomic<uint64_t*> g_clock_tap;
-extern std::atomic<int> g_clock_tap_slots;
 namespace a64q {
 
 constexpr int NW = 4;
@@ -62,7 +60,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const P p) 
   }
   const int b = bh / p.heads, h = bh - b * p.heads;
   const int S = p.S;
-  const bool tap = p.clk != nullptr && (blockIdx.x & 63) == 0 && wave == 0;   // clock tap: see attention.hip
+  const bool tap = p.clk != nullptr && (blockIdx.x & 63) == 0 && (int)(blockIdx.x >> 6) < p.clk_slots && wave == 0;   // clock tap: see attention.hip
   uint64_t tap_c0 = 0, tap_r0 = 0;
   if (tap) {
     tap_c0 = __builtin_readcyclecounter();
@@ -284,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_d64_q64_kernel(const P p) 
     }
   }
   if (tap && x.l31 == 0 && x.h2 == 0) {
-    uint64_t* cp = p.clk + (size_t)((blockIdx.x >> 6) % p.clk_slots) * 4;
+    uint64_t* cp = p.clk + (size_t)(blockIdx.x >> 6) * 4;   // one workgroup owns a slot (block / 64 < slots)
     cp[0] = tap_c0, cp[1] = tap_r0, cp[2] = __builtin_readcyclecounter(), cp[3] = wall_clock64();
   }
 }
@@ -305,9 +303,7 @@ int flash_attn_d64_q64(const void* q, const void* k, const void* vt, void* o, in
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;
   p.batch = batch; p.heads = heads; p.S = S; p.q_blocks = q_blocks;
   p.q_bs = q_bs; p.q_rs = q_rs; p.vt_bs = vt_bs; p.vt_rs = vt_rs; p.o_bs = o_bs; p.o_rs = o_rs;
-  p.clk = g_clock_tap.load(std::memory_order_acquire);
-  p.clk_slots = p.clk ? g_clock_tap_slots.load(std::memory_order_relaxed) : 0;
-  if (p.clk_slots <= 0) p.clk = nullptr;
+  p.clk = clock_tap_for((hipStream_t)stream, &p.clk_slots);
   hipLaunchKernelGGL(flash_attn_d64_q64_kernel, dim3(blocks), dim3(NW * 64), 0, stream, p);
   return check_launch("alg_flash_attn_d64");
 }

@@ -20,7 +20,7 @@ int check_launch(const char* what);
 enum Opt {
   OPT_ATTN_SPLIT_TAIL,  // ALG_ATTN_SPLIT_TAIL   1 (default) | 0: the d = 64 attention as a single launch (no split-KV tail)
   OPT_ATTN_PP,          // ALG_ATTN_PP           4 (8-wave pipelined main launch) | 6: the 64-queries-per-wave statement kernel
-                        //                       (attention64_q64.hip) | 0: the straight loop
+                        //                       (attention64_q64.hip; a call it declines runs the default, 4) | 0: the straight loop
   OPT_ATTN_VARIANT,     // ALG_ATTN_VARIANT      33 (default: lazy running max) | 1: exact running max, fp32 row sums
   OPT_ATTN128_PIPE,     // ALG_ATTN128_PIPE      1 (default: pipelined d = 128 kernel) | 0: the straight loop
   OPT_ATTN128_Q64,      // ALG_ATTN128_Q64       1 (default: 64-queries-per-wave kernel for >= 4,096 keys) | 2: for every call it can
@@ -47,6 +47,38 @@ inline bool device_done(const PerDeviceOnce& o, int slot) {
 }
 inline void device_mark(PerDeviceOnce& o, int slot) {
   if (slot >= 0) o.mask.fetch_or(1ull << slot, std::memory_order_release);
+}
+
+// Compute units of the current device (256 on an MI355X; fewer in a partitioned mode or on another SKU), cached per device: the
+// launchers that size a grid to ONE resident round of waves derive it from this, never from a constant.
+inline int device_cus() {
+  static std::atomic<int> cache[64];
+  const int slot = current_device_slot();
+  if (slot >= 0) {
+    const int c = cache[slot].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+  }
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return 256;   // unknown: the MI355X figure (sizing only -- never correctness)
+  if (slot >= 0) cache[slot].store(cus, std::memory_order_relaxed);
+  return cus;
+}
+
+// Clock tap of the attention kernels (calibrate.hip: alg_attn_clock_tap).  A launch takes the tap only while one is installed AND
+// its stream is not capturing: a device pointer baked into a hipGraph would outlive the buffer it points to.
+extern std::atomic<uint64_t*> g_clock_tap;
+extern std::atomic<int> g_clock_tap_slots;
+inline uint64_t* clock_tap_for(hipStream_t s, int* slots) {
+  *slots = 0;
+  uint64_t* c = g_clock_tap.load(std::memory_order_acquire);
+  const int n = c ? g_clock_tap_slots.load(std::memory_order_relaxed) : 0;
+  if (!c || n <= 0) return nullptr;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+  *slots = n;
+  return c;
 }
 
 typedef unsigned short bf16_t;  // raw bf16 bits

@@ -12,13 +12,21 @@ int launch_gemm_p9_pair(const alg_gemm_args* a, int m_tiles_a, int n_tiles_a, co
                         hipStream_t s);
 int launch_gemm_p9_pair_qk(const alg_gemm_args* a, int m_tiles_a, int n_tiles_a, const alg_gemm_args* b, int m_tiles_b, int n_tiles_b,
                            const alg_qk_norm_rope_args* e, hipStream_t s);
+int launch_gemm_p10(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
+int launch_gemm_p10_pair(const alg_gemm_args* a, int m_tiles_a, int n_tiles_a, const alg_gemm_args* b, int m_tiles_b, int n_tiles_b,
+                         hipStream_t s);
+int launch_gemm_p10_pair_qk(const alg_gemm_args* a, int m_tiles_a, int n_tiles_a, const alg_gemm_args* b, int m_tiles_b, int n_tiles_b,
+                            const alg_qk_norm_rope_args* e, hipStream_t s);
 int launch_gemm_p6_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p9_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
-// ALG_GEMM_PIPE: 9 (default: 4 waves, asm main loop; round 3: faster than the 8-wave ping-pong on all five C2 shapes) | 6 (the
-// 8-wave ping-pong; bit-identical results).  Calls schedule 9 cannot take (K < 128, byte offsets past 32 bits) and the fp8 /
-// convolution operands run schedule 6.
+// ALG_GEMM_PIPE: 10 (default since round 6: schedule 9's 4-wave asm main loop on v_mfma_f32_16x16x32_bf16, the shape that
+// sustains ~10 % more under the package power cap; fp32 rounding points differ from 9 / 6: 32 products per instruction) | 9 (the
+// asm main loop on 32x32x16; round 3: faster than the 8-wave ping-pong on all five C2 shapes) | 6 (the 8-wave ping-pong;
+// bit-identical to 9).  Calls the asm loops cannot take (K < 128, byte offsets past 32 bits) and the convolution operands run
+// schedule 6; e4m3 operands run schedule 9's e4m3 loop under 9 and 10.
 static int gemm_pipe() { return opt(OPT_GEMM_PIPE); }
+static bool asm_pipe() { return gemm_pipe() == 9 || gemm_pipe() == 10; }
 }  // namespace alg
 
 using namespace alg;
@@ -125,15 +133,16 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8, bool valid
   }
   hipStream_t s = (hipStream_t)stream;
   if (fp8) {   // schedule 9 (round 4: the asm loop on the block-scaled MFMA) needs two k-tiles of 128 and 32-bit byte offsets
-    if (gemm_pipe() == 9 && a->K >= 256 && 256 * a->lda + (int64_t)a->K < (1ll << 32) && 256 * a->ldb + (int64_t)a->K < (1ll << 32))
+    if (asm_pipe() && a->K >= 256 && 256 * a->lda + (int64_t)a->K < (1ll << 32) && 256 * a->ldb + (int64_t)a->K < (1ll << 32))
       return launch_gemm_p9_fp8(a, m_tiles, n_tiles, nwg, s);
     return launch_gemm_p6_fp8(a, m_tiles, n_tiles, nwg, s);
   }
   if (a->conv_wp) return launch_gemm_p6_conv(a, m_tiles, n_tiles, nwg, s);
   switch (gemm_pipe()) {
     case 9:   // 4 waves, hand-written asm main loop; needs two k-tiles and 32-bit byte offsets inside a 256-row panel
+    case 10:
       if (a->K >= 128 && 256 * a->lda * 2 + (int64_t)a->K * 2 < (1ll << 32) && 256 * a->ldb * 2 + (int64_t)a->K * 2 < (1ll << 32))
-        return launch_gemm_p9(a, m_tiles, n_tiles, nwg, s);
+        return gemm_pipe() == 10 ? launch_gemm_p10(a, m_tiles, n_tiles, nwg, s) : launch_gemm_p9(a, m_tiles, n_tiles, nwg, s);
       return launch_gemm_p6(a, m_tiles, n_tiles, nwg, s);
     default: return launch_gemm_p6(a, m_tiles, n_tiles, nwg, s);  // 8-wave ping-pong over half-tiles
   }
@@ -158,11 +167,11 @@ extern "C" int alg_gemm_bf16_pair(const alg_gemm_args* a, const alg_gemm_args* b
   int rc = gemm_entry(a, stream, false, true);
   if (rc == ALG_OK) rc = gemm_entry(b, stream, false, true);
   if (rc != ALG_OK) return rc;
-  if (gemm_pipe() == 9 && pair_eligible(a) && pair_eligible(b)) {
+  if (asm_pipe() && pair_eligible(a) && pair_eligible(b)) {
     const int64_t ta = (int64_t)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN) * a->batch;
     const int64_t tb = (int64_t)((b->M + BM - 1) / BM) * ((b->N + BN - 1) / BN) * b->batch;
     if (ta + tb <= 0x7fffffff)
-      return launch_gemm_p9_pair(a, (a->M + BM - 1) / BM, (a->N + BN - 1) / BN, b, (b->M + BM - 1) / BM, (b->N + BN - 1) / BN,
+      return (gemm_pipe() == 10 ? launch_gemm_p10_pair : launch_gemm_p9_pair)(a, (a->M + BM - 1) / BM, (a->N + BN - 1) / BN, b, (b->M + BM - 1) / BM, (b->N + BN - 1) / BN,
                                  (hipStream_t)stream);
   }
   rc = gemm_entry(a, stream, false);
@@ -191,13 +200,13 @@ extern "C" int alg_gemm_bf16_pair_qk(const alg_gemm_args* a, const alg_gemm_args
   }
   // the store loop owns whole head vectors and whole Q / K tiles: heads * 64 a multiple of the 256-column tile, staged epilogue
   // (N % 8 == 0 and 16-byte rows hold by the layout; a per-row bias would take the element-exact path)
-  const bool fused = gemm_pipe() == 9 && pair_eligible(a) && pair_eligible(b) && e->heads % 4 == 0 &&
+  const bool fused = asm_pipe() && pair_eligible(a) && pair_eligible(b) && e->heads % 4 == 0 &&
                      !(a->bias && (a->flags & ALG_GEMM_BIAS_PER_ROW));
   if (fused) {
     const int64_t ta = (int64_t)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN) * a->batch;
     const int64_t tb = (int64_t)((b->M + BM - 1) / BM) * ((b->N + BN - 1) / BN) * b->batch;
     if (ta + tb <= 0x7fffffff)
-      return launch_gemm_p9_pair_qk(a, (a->M + BM - 1) / BM, (a->N + BN - 1) / BN, b, (b->M + BM - 1) / BM, (b->N + BN - 1) / BN, e,
+      return (gemm_pipe() == 10 ? launch_gemm_p10_pair_qk : launch_gemm_p9_pair_qk)(a, (a->M + BM - 1) / BM, (a->N + BN - 1) / BN, b, (b->M + BM - 1) / BM, (b->N + BN - 1) / BN, e,
                                     (hipStream_t)stream);
   }
   rc = alg_gemm_bf16_pair(a, b, stream);

@@ -322,7 +322,7 @@ extern "C" int alg_layernorm_modulate_seg(const void* x, void* y, const void* we
   hipStream_t s = (hipStream_t)stream;
   // many rows with all four parameter rows present (every AdaLN of the CogVideoX / HunyuanVideo blocks): the multi-row form
   if (weight && bias && scale && D <= 3072 && total >= 4096) {
-    const int64_t resident_waves = 2048;                       // 256 CUs x 4 SIMDs x 2 waves of this kernel
+    const int64_t resident_waves = (int64_t)device_cus() * 8;   // CUs x 4 SIMDs x 2 waves of this kernel (2048 on an MI355X)
     const int rpw = (int)std::max<int64_t>(8, (total + resident_waves - 1) / resident_waves);
     const unsigned g2 = (unsigned)((total + 4 * (int64_t)rpw - 1) / (4 * (int64_t)rpw));
 #define LN_ROWS(I)                                                                                                      \

@@ -449,8 +449,9 @@ static int layernorm_mod_entry(const char* who, const void* x, void* y, void* q8
   if (ok && (mod_only || affine_only) && total >= 4096 && D <= 6144 && (!mod_only || (mod_bstride & 3) == 0) &&
       !(((uintptr_t)p0 | (uintptr_t)p1) & 15)) {
     // the modulated non-affine form over many rows: parameters in the LDS, rpw rows per wave, about one resident round of workgroups
-    // (three of these 256-thread workgroups fit a CU: 768 on the chip)
-    const int64_t want = (total + 4 * 768 - 1) / (4 * 768);
+    // (three of these 256-thread workgroups fit a CU: 768 on an MI355X)
+    const int64_t resident_wgs = (int64_t)device_cus() * 3;
+    const int64_t want = (total + 4 * resident_wgs - 1) / (4 * resident_wgs);
     const int rpw = (int)(want < 8 ? 8 : want);
     const int bpi = (rows + 4 * rpw - 1) / (4 * rpw);
     bool built = true;   // (DISPATCH_ITERS clears `ok` for a width that is not instantiated: then the one-row kernel below takes the call)

@@ -24,6 +24,25 @@ SMALL_TENSOR_BYTES = 1 << 20
 # bucket's collective with the device drained on both sides -- start-up only, never on the data path
 BCAST_STATS = {"seconds": 0.0, "bytes": 0, "collectives": 0}
 
+# Every helper below short-circuits at world size 1 (a single-GPU run must not touch a process group).  FORCE_COLLECTIVES (or
+# ALG_DIST_FORCE=1, or force=True on a call) takes the short-circuits away: the collectives then run on a ONE-rank group --
+# how a one-GPU box executes the RCCL code path an 8-GPU node will run (tests/test_gpu_rccl_world1.py).
+FORCE_COLLECTIVES = os.environ.get("ALG_DIST_FORCE") == "1"
+
+
+def _collective(force=False):
+    """True when the helpers must really call torch.distributed: a group exists and has peers, or the caller forces it"""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or force or FORCE_COLLECTIVES)
+
+
+def rccl_version():
+    """Version of the RCCL the "nccl" backend binds ("2.26.6"), or None on a build without it (CPU-only torch)."""
+    try:
+        v = torch.cuda.nccl.version()
+    except Exception:   # noqa: BLE001 -- no RCCL in this torch build
+        return None
+    return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+
 
 def _timed_broadcast(flat, src):
     import time
@@ -39,7 +58,7 @@ def _timed_broadcast(flat, src):
     BCAST_STATS["collectives"] += 1
 
 
-def ranks_seen(device=None):
+def ranks_seen(device=None, force=False):
     """One record per rank -- host, device index, name and the GPU's identity (UUID / PCI bus id as the runtime reports them)
     -- all-gathered, so a multi-GPU bench line can PROVE that N ranks sat on N distinct GPUs (`distinct_gpus`)."""
     import socket
@@ -53,7 +72,7 @@ def ranks_seen(device=None):
                                       getattr(prop, "pci_device_id", "?")))
     else:
         rec.update(device=None, name="cpu", uuid="", pci="")
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _collective(force):
         recs = [None] * dist.get_world_size()
         dist.all_gather_object(recs, rec)
     else:
@@ -69,10 +88,11 @@ def env_world():
     return int(os.environ.get("RANK", "0")), local, int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init_distributed(backend=None):
-    """Initialise the default process group from the torchrun environment; no-op for world_size 1."""
+def init_distributed(backend=None, force=False):
+    """Initialise the default process group from the torchrun environment; no-op for world_size 1 (unless forced: a one-rank
+    group on the chosen backend -- see FORCE_COLLECTIVES)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force or FORCE_COLLECTIVES) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -89,11 +109,11 @@ def shard_videos(num_videos, rank, world):
     return [v for v in range(num_videos) if v % world == rank]
 
 
-def broadcast_state_dict(make_state_dict, shapes, device, src=0, dtype=torch.bfloat16, bucket_bytes=1 << 30):
+def broadcast_state_dict(make_state_dict, shapes, device, src=0, dtype=torch.bfloat16, bucket_bytes=1 << 30, force=False):
     """Rank ``src`` materialises the weights (``make_state_dict()``), every other rank allocates empty tensors of
     ``shapes`` and receives them.  Tensors are coalesced into ~1 GiB flat buckets so the broadcast is a handful of
     large collectives (xGMI is point-to-point: few, large transfers) rather than ~700 small ones."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collective(force):
         return make_state_dict()
     rank = dist.get_rank()
     sd = make_state_dict() if rank == src else None
@@ -123,12 +143,12 @@ def broadcast_state_dict(make_state_dict, shapes, device, src=0, dtype=torch.bfl
     return out
 
 
-def broadcast_loaded_state_dict(sd, device, src=0, bucket_bytes=1 << 30):
+def broadcast_loaded_state_dict(sd, device, src=0, bucket_bytes=1 << 30, force=False):
     """``sd`` is the state dict on rank ``src`` and None elsewhere (only rank ``src`` read the checkpoint from disk):
     names / shapes / dtypes travel as one small object broadcast, the tensors in ~1 GiB flat buckets per dtype (xGMI is
     point-to-point: few, large transfers).  Returns the same dict -- same names, dtypes, bits -- on every rank, tensors on
     ``device``."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collective(force):
         return sd
     rank = dist.get_rank()
     # ``sd`` may be an exception on rank ``src`` (the caller caught a failed read): the status travels first, so every rank
@@ -184,17 +204,17 @@ def _numel(shape):
     return n
 
 
-def max_over_ranks(value, device):
+def max_over_ranks(value, device, force=False):
     """MAX all-reduce of a python float (the bench's timing rule)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collective(force):
         return float(value)
     t = torch.tensor([float(value)], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+def barrier(force=False):
+    if _collective(force):
         dist.barrier()
 
 

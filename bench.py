@@ -818,25 +818,31 @@ def timed_region(wl, warmup, steps, parallel, measure_box=False):
     kinds = {}  # kernel family -> list of event pairs
     wl.step_passes = []
     wl.instrument(kinds)
-    taps = None
+    taps = smi = None
+    try:
+        # the tap is a raw device pointer inside the library: whatever happens in the region, it is taken out again before
+        # `taps` can be freed; the library itself refuses the tap on a capturing stream
+        if measure_box:
+            taps = torch.zeros(512, 4, dtype=torch.int64, device=wl.dev)
+            _lib.attn_clock_tap(taps)
+        parallel.barrier()
+        torch.cuda.synchronize()
+        if measure_box:
+            smi = SmiSampler(wl.dev.index or 0)
+            smi.__enter__()
+        t0 = time.perf_counter()
+        forwards = run_steps(wl, steps)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        if smi is not None:
+            smi.__exit__(None, None, None)
+        wl.instrument(None)
+        if measure_box:
+            _lib.attn_clock_tap(None)
+            torch.cuda.synchronize()
     if measure_box:
-        taps = torch.zeros(512, 4, dtype=torch.int64, device=wl.dev)
-        _lib.attn_clock_tap(taps)
-    parallel.barrier()
-    torch.cuda.synchronize()
-    smi = SmiSampler(wl.dev.index or 0) if measure_box else None
-    if smi is not None:
-        smi.__enter__()
-    t0 = time.perf_counter()
-    forwards = run_steps(wl, steps)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    elapsed = time.perf_counter() - t0
-    if smi is not None:
-        smi.__exit__(None, None, None)
-    wl.instrument(None)
-    if measure_box:
-        _lib.attn_clock_tap(None)
         wl.box = {"attn_kernel_shader_clock_mhz": _lib.clock_mhz_from_taps(taps, _lib.wall_clock_khz()),
                   "attn_kernel_clock_note": "cycle counter / constant-rate counter over the life of every 64th workgroup of the "
                                             "LAST attention launch of the timed region (%s)" % wl.attn_kernel,
@@ -1114,8 +1120,11 @@ def main():
         "dtype": wl.dtype, "data": wl.data, "config": cfgd, "seconds": elapsed,
         "finite": bool(torch.isfinite(wl.last_out.float()).all().item()), "roofline": roofline,
     }
-    if world > 1:
-        # proof that N ranks sat on N distinct GPUs, and what the ONE collective of the data-parallel path cost (start-up only)
+    if world > 1 or parallel.FORCE_COLLECTIVES:
+        # proof that N ranks sat on N distinct GPUs, and what the ONE collective of the data-parallel path cost (start-up only);
+        # ALG_DIST_FORCE=1 runs the same collectives on a one-rank group (the one-GPU rehearsal of the RCCL path)
+        out["dist_backend"] = torch.distributed.get_backend()
+        out["rccl_version"] = parallel.rccl_version() if out["dist_backend"] == "nccl" else None
         seen = parallel.ranks_seen(dev)
         out["ranks_seen"] = seen["ranks"]
         out["distinct_gpus"] = seen["distinct_gpus"]
@@ -1159,7 +1168,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(with_c1=not args.no_c1, c1_budget=args.c1_budget)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -41,8 +41,8 @@ const char* alg_last_error(void);
 /* Run-time options.  The library reads its ALG_* environment variables ONCE, when it is loaded; no launch path calls getenv.
  * A host that changes one of them afterwards calls alg_reload_env() (host-only, no GPU work; not to be called while another
  * thread is inside the library).  The default build knows seven, each selecting between bit-identical or documented-equivalent
- * schedules (README.md "Run-time options"): ALG_ATTN_SPLIT_TAIL, ALG_ATTN_PP (4 = the 8-wave pipelined statement, 6 = the 64-queries-per-wave statement, 0 = the straight
- * loop), ALG_ATTN_VARIANT, ALG_ATTN128_PIPE,
+ * schedules (README.md "Run-time options"): ALG_ATTN_SPLIT_TAIL, ALG_ATTN_PP (4 = the 8-wave pipelined statement, 6 = the 64-queries-per-wave statement -- a call it
+ * declines (fewer than 12 KV tiles, 31-bit offsets, V^T pitch) runs the default, 4 --, 0 = the straight loop), ALG_ATTN_VARIANT, ALG_ATTN128_PIPE,
  * ALG_ATTN128_Q64 (1 = the 64-queries-per-wave d = 128 kernel from 4,096 keys on, the default; 2 = for every call it can
  * take; 0 = off: the escape hatch back to the 32-query pipelined kernel), ALG_GEMM_PIPE, ALG_LOWPASS_PATH.  A value must be
  * a whole decimal integer the build knows; anything else (including "off", "1x", an empty string) leaves the default in
@@ -497,9 +497,11 @@ int alg_calib_mfma_bf16(float* sink, int iters, unsigned seed, int blocks, uint6
 int alg_wall_clock_khz(void);
 
 /* While `buffer` is non-NULL, every launch of the pipelined d = 64 attention and of the 64-query d = 128 attention has one lane
- * of each workgroup whose index is a multiple of 64 store {shader cycles, constant-rate ticks} at its start and end into
- * buffer[(block / 64) % slots][4] (uint64): d cycles / d ticks = the shader clock that kernel ran at.  Results are
- * unaffected.  Host-only call; NULL (the default) switches the taps off. */
+ * of each workgroup whose index is a multiple of 64 -- the first `slots` of them: one workgroup owns a slot -- store {shader
+ * cycles, constant-rate ticks} at its start and end into buffer[block / 64][4] (uint64): d cycles / d ticks = the shader clock
+ * that kernel ran at.  Results are unaffected.  A launch on a CAPTURING stream never takes the tap (the pointer would be baked
+ * into the graph and outlive the buffer).  Host-only call; NULL (the default) switches the taps off; the caller keeps the
+ * buffer alive until it has done so. */
 void alg_attn_clock_tap(uint64_t* buffer, int slots);
 
 #ifdef __cplusplus

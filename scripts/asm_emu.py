@@ -15,7 +15,7 @@ weakest timing the ISA allows:
 A schedule is accepted when it computes the right answer under lazy reads + eager DMA, eager reads + lazy DMA and lazy + lazy.
 MFMA result latency (XDL write -> VALU read wait states) is NOT modelled here: tests check it statically on the listing.
 
-Instruction subset: v_mfma_f32_32x32x16_bf16, v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3, scales 2^0), ds_read_b128, global_load_dwordx4, global_load_lds_dwordx4, buffer_load_dwordx4 .. offen lds, v_exp_f32, v_fma_f32,
+Instruction subset: v_mfma_f32_32x32x16_bf16, v_mfma_f32_16x16x32_bf16, v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3, scales 2^0), ds_read_b128, global_load_dwordx4, global_load_lds_dwordx4, buffer_load_dwordx4 .. offen lds, v_exp_f32, v_fma_f32,
 v_add_f32, v_mul_f32, v_mov_b32, v_add_u32, v_min_u32, v_cvt_pk_bf16_f32, v_cmp_ngt_f32, v_accvgpr_{read,write,mov}_b32, s_add_u32, s_sub_u32,
 s_mov_b32, s_addc_u32, s_cselect_b32, s_lshl_b32 / lshr / and, v_mul_lo_u32, s_cmp_le_u32 / lt / ge / eq / lg, s_branch, s_cbranch_scc1 / scc0 / vccnz / vccz, s_waitcnt, s_barrier, s_nop.
 """
@@ -254,6 +254,9 @@ class Machine:
         if op == "v_mfma_f32_32x32x16_bf16":
             self.mfma(w, args)
             return
+        if op == "v_mfma_f32_16x16x32_bf16":
+            self.mfma16(w, args)
+            return
         if op == "ds_read_b128":
             regs, first, n = self.tuple_regs(w, args[0])
             assert n == 4
@@ -430,6 +433,39 @@ class Machine:
                 with np.errstate(all="ignore"):
                     out[e, 32 * h2:32 * h2 + 32] = (D[row, :] + C[e, 32 * h2:32 * h2 + 32].astype(np.float64)).astype(np.float32)
         dregs[d0:d0 + 16] = out.view(np.uint32)
+
+    def mfma16(self, w, args):
+        """v_mfma_f32_16x16x32_bf16: D = A (16 x 32) * B (32 x 16) + C; lane l: A row l % 16, k = 8 (l / 16) + i; B column l % 16,
+        same k; D column l % 16, register e <-> row 4 (l / 16) + e."""
+        dregs, d0, dn = self.tuple_regs(w, args[0])
+        assert dn == 4
+
+        def frag(tok):
+            regs, f0, n = self.tuple_regs(w, tok)
+            assert n == 4
+            words = regs[f0:f0 + 4]                                   # [4, 64]
+            lo, hi = bf16_to_f32((words & 0xFFFF).astype(np.uint16)), bf16_to_f32((words >> 16).astype(np.uint16))
+            m = np.zeros((16, 32), dtype=np.float64)
+            for g in range(4):
+                for r in range(4):
+                    m[:, 8 * g + 2 * r] = lo[r, 16 * g:16 * g + 16]
+                    m[:, 8 * g + 2 * r + 1] = hi[r, 16 * g:16 * g + 16]
+            return m
+        A, Bt = frag(args[1]), frag(args[2])                           # A[m][k], Bt[n][k]
+        with np.errstate(all="ignore"):
+            D = A @ Bt.T                                                 # [m][n]
+        if args[3] != "0":
+            cregs, c0, cn = self.tuple_regs(w, args[3])
+            assert cn == 4
+            C = cregs[c0:c0 + 4].view(np.float32)
+        else:
+            C = np.zeros((4, 64), dtype=np.float32)
+        out = np.empty((4, 64), dtype=np.float32)
+        for e in range(4):
+            for g in range(4):
+                with np.errstate(all="ignore"):
+                    out[e, 16 * g:16 * g + 16] = (D[4 * g + e, :] + C[e, 16 * g:16 * g + 16].astype(np.float64)).astype(np.float32)
+        dregs[d0:d0 + 4] = out.view(np.uint32)
 
     # ---- run ---------------------------------------------------------------------------------------------------------
     def run(self, max_inst=10_000_000):

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import asm_emu  # noqa: E402
 import gen_gemm_p9 as GP  # noqa: E402
+import gen_gemm_p10 as GP10  # noqa: E402
 
 
 def bf16_round(x):
@@ -80,12 +81,15 @@ class Problem:
         return a.astype(np.float64) @ b.astype(np.float64).T
 
 
-def run_plain(pb, lazy_reads, lazy_dma, mutate=None, va=(1 << 32) - 70000, res=False):
+def run_plain(pb, lazy_reads, lazy_dma, mutate=None, va=(1 << 32) - 70000, res=False, sched=9):
     """-> C [256, 256] float64 as the statement leaves it in the accumulators, instruction count (res: the residual form -- also
-    returns the residual tile as the statement hands it to the epilogue, [256, 256] float64)"""
+    returns the residual tile as the statement hands it to the epilogue, [256, 256] float64).  sched = 10: the 16x16x32 statement
+    (scripts/gen_gemm_p10.py): other fragment addresses, other (register, lane) -> (row, column) map, same frame otherwise."""
     if pb.esz == 1:
         import gen_gemm_p9_fp8 as GF
         lines = GF.emit(res)
+    elif sched == 10:
+        lines = GP10.emit(res=res)
     else:
         lines = GP.emit(res=res)
     if mutate is not None:
@@ -119,6 +123,11 @@ def run_plain(pb, lazy_reads, lazy_dma, mutate=None, va=(1 << 32) - 70000, res=F
         w.v[5] = (((ln & 7) ^ ((w.id * 4 + (ln >> 4)) & 7)) * 16).astype(np.uint32)           # vslot
         for ks in range(4):
             w.v[ks] = (l31 * 128 + (((2 * ks + h2) ^ sw) * 16)).astype(np.uint32)             # vl0..3
+        if sched == 10:
+            l15, g4 = ln & 15, ln >> 4
+            for ks in range(2):
+                w.v[ks] = (l15 * 128 + (((4 * ks + g4) ^ ((l15 >> 1) & 7)) * 16)).astype(np.uint32)
+            w.v[2] = w.v[3] = np.full(64, 0xDEAD0000, dtype=np.uint32)                        # unused by schedule 10
         sset(w, "lda2", pb.lda * pb.esz), sset(w, "ldb2", pb.ldb * pb.esz)
         sset(w, "rmaxa", pb.rows_a - 1), sset(w, "rmaxb", pb.rows_b - 1)
         sset(w, "nloop", pb.nk - 2), sset(w, "wm", wm), sset(w, "wn2", 2 + wn), sset(w, "wave1k", SMEM + w.id * 1024)
@@ -141,8 +150,13 @@ def run_plain(pb, lazy_reads, lazy_dma, mutate=None, va=(1 << 32) - 70000, res=F
             for nt in range(4):
                 for e in range(16):
                     # C^T layout: D = MFMA(B fragment, A fragment): lane column = the A row (m), register row = the B row (n)
-                    mrow = wm * 128 + mt * 32 + l31
-                    ncol = wn * 128 + nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2
+                    if sched == 10:   # 16 x 16 blocks: quad q = 2 bm + bn of the 32 x 32 region, lane = (m & 15, n quad)
+                        q, i = e >> 2, e & 3
+                        mrow = wm * 128 + mt * 32 + 16 * (q >> 1) + (ln & 15)
+                        ncol = wn * 128 + nt * 32 + 16 * (q & 1) + 4 * (ln >> 4) + i
+                    else:
+                        mrow = wm * 128 + mt * 32 + l31
+                        ncol = wn * 128 + nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2
                     C[mrow, ncol] = w.a[16 * (4 * mt + nt) + e].view(np.float32)
     if not res:
         return C, n, lines

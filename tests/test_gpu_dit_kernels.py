@@ -26,10 +26,10 @@ def rel_err(got, ref):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.fixture(params=["9", "6"], ids=["4waves-asm-loop", "pingpong-halftiles"])
+@pytest.fixture(params=["10", "9", "6"], ids=["4waves-asm-loop-16x16x32", "4waves-asm-loop", "pingpong-halftiles"])
 def gemm_pipe(request, monkeypatch):
-    """Every GEMM test runs on both built schedules (9 = the default since round 3; 6 = the fp8-small-K / convolution schedule and
-    the bit-identity reference)."""
+    """Every GEMM test runs on the three built schedules (10 = schedule 9's loop on v_mfma_f32_16x16x32_bf16, round 6; 9 = the
+    asm loop on 32x32x16, round 3; 6 = the fp8-small-K / convolution schedule and 9's bit-identity reference)."""
     monkeypatch.setenv("ALG_GEMM_PIPE", request.param)
     return request.param
 

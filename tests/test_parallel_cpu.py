@@ -342,3 +342,33 @@ def test_world_size_8_pairs_ragged_jobs_and_load_failure():
 
 def test_process_group_timeout_outlasts_a_video():
     assert parallel.DIST_TIMEOUT_S >= 3600      # C4 / C5: 9-13 minutes per video; ranks with fewer jobs wait in the barrier
+
+
+def _forced_world1_worker(port, out):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    assert parallel.init_distributed(backend="gloo") == (0, 0, 1) and not dist.is_initialized()   # unforced: still a no-op
+    parallel.init_distributed(backend="gloo", force=True)
+    g = torch.Generator().manual_seed(5)
+    sd = {"a": torch.randn(40, 9, generator=g).to(torch.bfloat16), "b": torch.randint(0, 9, (5,), generator=g),
+          "c": torch.randn(300, generator=g).to(torch.float8_e4m3fn)}
+    n0 = parallel.BCAST_STATS["collectives"]
+    same = parallel.broadcast_loaded_state_dict(sd, "cpu") is sd and parallel.BCAST_STATS["collectives"] == n0
+    got = parallel.broadcast_loaded_state_dict(sd, "cpu", bucket_bytes=256, force=True)
+    bits = all(torch.equal(got[k].view(torch.uint8), sd[k].view(torch.uint8)) and got[k] is not sd[k] for k in sd)
+    seen = parallel.ranks_seen(None, force=True)
+    parallel.barrier(force=True)
+    out.put((same, bits, parallel.BCAST_STATS["collectives"] - n0, parallel.max_over_ranks(2.5, "cpu", force=True), len(seen["ranks"])))
+    dist.destroy_process_group()
+
+
+def test_forced_one_rank_group_runs_the_collectives():
+    """the one-GPU rehearsal of the RCCL path (tests/test_gpu_rccl_world1.py) rests on this switch: force=True takes the
+    world-size-1 short-circuits away, the default keeps them"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_world1_worker, args=(_free_port(), q))
+    p.start()
+    same, bits, n_coll, mx, n_ranks = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert same and bits and n_coll >= 3 and mx == 2.5 and n_ranks == 1
