@@ -38,7 +38,7 @@ static const OptDef g_defs[OPT_COUNT] = {
     {"ALG_ATTN_VARIANT", 33, 2, {1, 33}},
     {"ALG_ATTN128_PIPE", 1, 2, {0, 1}},
     {"ALG_ATTN128_Q64", 1, 4, {0, 1, 2, 3}},
-    {"ALG_GEMM_PIPE", 9, 3, {6, 9, 10}},
+    {"ALG_GEMM_PIPE", 10, 3, {6, 9, 10}},
     {"ALG_LOWPASS_PATH", 0, 0, {}},
 };
 static std::atomic<int> g_opt[OPT_COUNT];

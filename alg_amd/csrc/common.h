@@ -25,7 +25,9 @@ enum Opt {
   OPT_ATTN128_PIPE,     // ALG_ATTN128_PIPE      1 (default: pipelined d = 128 kernel) | 0: the straight loop
   OPT_ATTN128_Q64,      // ALG_ATTN128_Q64       1 (default: 64-queries-per-wave kernel for >= 4,096 keys) | 2: for every call it can
                         //                       take (>= 512 keys) | 3: as 2, statement off (the frame's C++ tile body only: tests) | 0: off
-  OPT_GEMM_PIPE,        // ALG_GEMM_PIPE         9 (default) | 6: the 8-wave ping-pong schedule (bit-identical results)
+  OPT_GEMM_PIPE,        // ALG_GEMM_PIPE         10 (default since round 6: the asm main loop on v_mfma_f32_16x16x32_bf16) | 9: the asm main
+                        //                       loop on 32x32x16 | 6: the 8-wave ping-pong schedule (9 and 6 are bit-identical; 10 sums 32
+                        //                       products per instruction: other fp32 rounding points, same error bound)
   OPT_LOWPASS_PATH,     // ALG_LOWPASS_PATH      0 auto | 1 plane-per-workgroup | 2 lowpass_v2 | 3 lowpass_v3 at any plane
                         //                       count | 4 global-memory passes (all bit-identical)
   OPT_COUNT

@@ -859,7 +859,8 @@ AB_ARMS = [
     ("attn_8wave_statement_vs_q64", "env", "ALG_ATTN_PP", "6", "round 5: the default 8-wave 32-query d = 64 statement vs the 64-queries-per-wave statement (attention64_q64.hip, ALG_ATTN_PP=6); > 0: the default is faster"),
     ("attn_pipelined", "env", "ALG_ATTN_PP", "0", "round 3: pipelined d = 64 attention vs the straight loop"),
     ("attn_split_tail", "env", "ALG_ATTN_SPLIT_TAIL", "0", "round 2: split-KV tail of the attention launch vs a single launch"),
-    ("gemm_schedule9", "env", "ALG_GEMM_PIPE", "6", "round 3: GEMM schedule 9 (asm K loop) vs the 8-wave ping-pong"),
+    ("gemm_schedule10", "env", "ALG_GEMM_PIPE", "9", "round 6: GEMM schedule 10 (the asm K loop on v_mfma_f32_16x16x32_bf16) vs schedule 9 (the same loop on 32x32x16)"),
+    ("gemm_schedule9", "env", "ALG_GEMM_PIPE", "6", "round 3: the asm K loop (here: schedule 10) vs the 8-wave ping-pong"),
     ("pair_qkv", "attr", "pair_qkv", 0, "round 4: Q|K and V^T projections as one persistent launch vs two launches"),
     ("events", "events", None, None, "the bench's own HIP-event brackets around every kernel family, switched ON (headline region has them)"),
 ]

@@ -380,6 +380,15 @@ def test_pingpong_gemm_race_screen(monkeypatch):
                 assert torch.equal(c, outs[base]), (M, N, K)
             outs.setdefault(pipe, c)
         assert torch.equal(outs["6"], outs[base]) and torch.equal(outs["9"], outs[base]), (M, N, K)
+        # schedule 10 (the default since round 6) sums 32 products per MFMA: other rounding points, so its screen is run-to-run
+        # equality plus one bf16 step from the reference
+        monkeypatch.setenv("ALG_GEMM_PIPE", "10")
+        c10 = [torch.empty(M, N, dtype=BF, device="cuda") for _ in range(3)]
+        for c in c10:
+            _lib.gemm(a, w, c, M, N, K, K, K, N)
+        assert torch.equal(c10[0], c10[1]) and torch.equal(c10[0], c10[2]), (M, N, K)
+        d = (c10[0].float() - outs[base].float()).abs()
+        assert bool((d <= 2.0 ** -7 * outs[base].float().abs() + 1e-3 * outs[base].float().abs().max()).all()), (M, N, K)
 
 
 @pytest.mark.parametrize("S,D,N", [(17776, 3072, 2), (300, 512, 3), (1000, 256, 1), (257, 128, 2)])
@@ -389,6 +398,7 @@ def test_gemm_pair_is_bit_identical_to_the_two_launches(monkeypatch, S, D, N):
     separate calls, at the C2 shape and at shapes with edge tiles in both problems; under ALG_GEMM_PIPE=6 and for calls the pair
     form cannot take (K = 64; a residual) it is the two launches one after the other; bad arguments are rejected before any
     launch."""
+    monkeypatch.setenv("ALG_GEMM_PIPE", "9")   # (schedule 10's pair tests: test_gpu_gemm_p10.py; 9 and 6 share their bits)
     g = torch.Generator(device="cuda").manual_seed(S + D)
     rn = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g, device="cuda") * sc).to(BF)
     S_pad = (S + 63) // 64 * 64
@@ -421,7 +431,7 @@ def test_gemm_pair_is_bit_identical_to_the_two_launches(monkeypatch, S, D, N):
     monkeypatch.setenv("ALG_GEMM_PIPE", "6")
     got = paired()
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
-    monkeypatch.delenv("ALG_GEMM_PIPE")
+    monkeypatch.setenv("ALG_GEMM_PIPE", "9")
     qk = torch.zeros(N, S, 2 * D, dtype=BF, device="cuda")
     bad = (((y, wqk, qk, S, 2 * D, D - 8, D, D, 2 * D), dict(batch=N, strideA=S * D, strideC=S * 2 * D)), calls(qk, qk)[0])
     with pytest.raises(_lib.AlgHipError):                                   # K % 64 != 0 in the FIRST problem: nothing launched
@@ -440,6 +450,7 @@ def test_gemm_pair_qk_is_bit_identical_to_the_pair_launch_plus_qk_norm_rope(monk
     the bits are those of alg_gemm_bf16_pair followed by alg_qk_norm_rope_scaled: at the C2 shape, with edge tiles in M, text /
     video boundaries inside a 16-row group, no text tokens, only text tokens, no rotary tables, and (heads = 6: a tile would
     straddle Q | K) through the documented fallback; V^T is untouched by the fusion; ALG_GEMM_PIPE=6 takes the fallback too."""
+    monkeypatch.setenv("ALG_GEMM_PIPE", "9")   # (schedule 10: test_gpu_gemm_p10.py)
     D = heads * 64
     g = torch.Generator(device="cuda").manual_seed(S + heads)
     rn = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g, device="cuda") * sc).to(BF)
@@ -475,7 +486,7 @@ def test_gemm_pair_qk_is_bit_identical_to_the_pair_launch_plus_qk_norm_rope(monk
     qk1, vt1 = fresh()
     _lib.gemm_pair_qk(*calls(qk1, vt1), wq, bq, wk, bk, cos, sin, heads, T, 1e-6, q_scale=qs)
     assert torch.equal(qk1, qk0) and torch.equal(vt1, vt0)
-    monkeypatch.delenv("ALG_GEMM_PIPE")
+    monkeypatch.setenv("ALG_GEMM_PIPE", "9")
     with pytest.raises(_lib.AlgHipError):                                   # not the [S][2][heads][64] layout: rejected, nothing launched
         _lib.gemm_pair_qk(*calls(qk1, vt1), wq, bq, wk, bk, cos, sin, heads + 1, T, 1e-6)
     with pytest.raises(_lib.AlgHipError):                                   # cos without sin
