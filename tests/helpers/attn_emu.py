@@ -420,3 +420,110 @@ def run_pipe128_statement(pb, lazy_reads, lazy_dma, t0=1, mutate=None):
         O2 += probs(t) @ vf[t * KVB:(t + 1) * KVB]
         l2 += fsum(t)
     return O2 / l2[:, None], t_exit, codes, n, lines
+
+
+def swk(row):
+    """the m16 kernel's K-tile chunk XOR: depends on the row PART of a fragment only (bits 0-2 and 4), not on its block (j, u)"""
+    return ((row & 7) >> 1) | (((row >> 4) & 1) << 2)
+
+
+def run_m16_statement(pb, lazy_reads, lazy_dma, t0=1, mutate=None):
+    """flash_attn_d64_m16_kernel's statement (scripts/gen_attn_m16.py: the d = 64 attention on v_mfma_f32_16x16x32_bf16) for one
+    256-query unit: eight waves x 32 queries = two 16-query blocks per wave, K / V^T tiles of 8 KiB through four-slot rings (one
+    1 KiB piece of each per wave and tile; the K tile under the kernel's own chunk XOR swk), O in 32 "+a" operands (block (db, qb) at
+    4 (2 db + qb)), two running row sums per lane, pre-scaled scores with a zero offset, whole groups of four iterations while
+    t + 4 <= tend = T - 3."""
+    import gen_attn_m16 as GM
+    assert pb.d == 64 and pb.prescaled and not pb.ragged
+    lines = GM.emit()
+    if mutate is not None:
+        lines = mutate(lines)
+    T, TILE, NW = pb.T, 8192, 8
+    tend = T - 3
+    KL, VL = 0, 4 * TILE
+    tab = {"o%d" % i: "a%d" % (80 + i) for i in range(32)}
+    names_v = ["l0", "l1", "kvo0", "vvo0", "qvo0", "qvo1", "lk0", "lk1", "lv0", "lv1"]
+    for i, n in enumerate(names_v):
+        tab[n] = "v%d" % i
+    for i, n in enumerate(("t", "code", "kstep", "tend", "wk", "wv")):
+        tab[n] = "s%d" % i
+    for i, n in enumerate(("kb", "vb", "qb")):
+        tab[n] = "s[%d:%d]" % (8 + 2 * i, 9 + 2 * i)
+    m = asm_emu.Machine(asm_emu.bind(lines, tab), n_waves=NW, gmem=pb.gmem, lazy_reads=lazy_reads, lazy_dma=lazy_dma)
+    qf, kf, vf = pb.q.astype(np.float64), pb.k.astype(np.float64), pb.v.astype(np.float64)
+    s_all = qf @ kf.T                                      # log2 units already
+    probs = lambda t: bf16_round(np.exp2(s_all[:, t * KVB:(t + 1) * KVB])).astype(np.float64)
+    fsum = lambda t: np.exp2(s_all[:, t * KVB:(t + 1) * KVB]).astype(np.float32).astype(np.float64).sum(axis=1)
+    O, l = np.zeros((pb.Sq, 64)), np.zeros(pb.Sq)
+    for t in range(t0):
+        O += probs(t) @ vf[t * KVB:(t + 1) * KVB]
+        l += fsum(t)
+
+    def stage8(which, tile):
+        for wave in range(NW):
+            lane = np.arange(64)
+            tid = wave * 64 + lane
+            row = tid >> 3
+            for ln in range(64):
+                if which == "k":
+                    slot = (tid[ln] & 7) ^ swk(int(row[ln]))
+                    src = pb.KOFF + ((tile * KVB + row[ln]) * pb.k_rs + slot * 8) * 2
+                    dst = KL + (tile & 3) * TILE + wave * 1024 + ln * 16
+                else:
+                    slot = (tid[ln] & 7) ^ ((tid[ln] >> 4) & 7)
+                    src = pb.VOFF + (row[ln] * pb.vt_rs + slot * 8 + tile * KVB) * 2
+                    dst = VL + (tile & 3) * TILE + wave * 1024 + ln * 16
+                m.lds[dst:dst + 16] = pb.gmem[src:src + 16]
+    for t in range(t0 - 1, t0 + 3):
+        stage8("k", t)
+    for t in range(t0 - 1, t0 + 2):
+        stage8("v", t)
+
+    def sset(w, name, val):
+        r = asm_emu.parse_reg(tab[name])
+        w.s[r[1]] = np.uint32(int(val) & 0xFFFFFFFF)
+        if r[2] == 2:
+            w.s[r[1] + 1] = np.uint32(int(val) >> 32)
+
+    def vset(w, name, arr):
+        a = np.asarray(arr)
+        w.v[asm_emu.parse_reg(tab[name])[1]] = a.view(np.uint32) if a.dtype == np.float32 else a.astype(np.int64).astype(np.uint32)
+    for w in m.waves:
+        lane = np.arange(64)
+        r15, g4, tid = lane & 15, lane >> 4, w.id * 64 + lane
+        srow = tid >> 3
+        sset(w, "t", t0), sset(w, "tend", tend), sset(w, "kstep", KVB * pb.k_rs * 2)
+        sset(w, "wk", KL + w.id * 1024), sset(w, "wv", VL + w.id * 1024)
+        sset(w, "kb", pb.KOFF), sset(w, "vb", pb.VOFF), sset(w, "qb", pb.QOFF)
+        for qb in range(2):
+            q_row = w.id * 32 + 16 * qb + r15
+            vset(w, "qvo%d" % qb, (q_row * pb.q_rs + g4 * 8) * 2)
+            vset(w, "l%d" % qb, np.where(g4 == 0, l[q_row], 0.0).astype(np.float32))
+        rowpart = r15 + 8 * (r15 >> 3)
+        for ks in range(2):
+            vset(w, "lk%d" % ks, KL + rowpart * 128 + (((4 * ks + g4) ^ swk(rowpart)) * 16))
+            vset(w, "lv%d" % ks, VL + r15 * 128 + (((4 * ks + g4) ^ ((r15 >> 1) & 7)) * 16))
+        vset(w, "kvo0", (((t0 + 3) * KVB + srow) * pb.k_rs + ((tid & 7) ^ swk(srow)) * 8) * 2)
+        vset(w, "vvo0", (srow * pb.vt_rs + ((tid & 7) ^ ((tid >> 4) & 7)) * 8 + (t0 + 2) * KVB) * 2)
+        for i in range(32):
+            blk, e = i >> 2, i & 3
+            db, qb = blk >> 1, blk & 1
+            w.a[80 + i] = O[w.id * 32 + 16 * qb + r15, 16 * db + 4 * g4 + e].astype(np.float32).view(np.uint32)
+    n = m.run()
+    t_exit = int(m.waves[0].s[asm_emu.parse_reg(tab["t"])[1]])
+    codes = [int(w.s[asm_emu.parse_reg(tab["code"])[1]]) for w in m.waves]
+    O2, l2 = np.zeros((pb.Sq, 64)), np.zeros(pb.Sq)
+    for w in m.waves:
+        lane = np.arange(64)
+        r15, g4 = lane & 15, lane >> 4
+        for qb in range(2):
+            q_row = w.id * 32 + 16 * qb + r15
+            np.add.at(l2, q_row, w.v[asm_emu.parse_reg(tab["l%d" % qb])[1]].view(np.float32).astype(np.float64))
+        for i in range(32):
+            blk, e = i >> 2, i & 3
+            db, qb = blk >> 1, blk & 1
+            O2[w.id * 32 + 16 * qb + r15, 16 * db + 4 * g4 + e] = w.a[80 + i].view(np.float32)
+    for t in range(t_exit, T):
+        O2 += probs(t) @ vf[t * KVB:(t + 1) * KVB]
+        l2 += fsum(t)
+    return O2 / l2[:, None], t_exit, codes, n, lines
