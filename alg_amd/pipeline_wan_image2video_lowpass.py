@@ -96,6 +96,9 @@ class WanImageToVideoPipeline:
         self._current_timestep = None
         self._attention_kwargs = None
         self._interrupt = False
+        # measurement hook (bench.py: a 2-pass step of the schedule timed without the 3-pass steps in front of it): loop iterations
+        # below this index are skipped exactly as interrupted ones are (wan:845-846: `continue`).  0 = the reference's loop.
+        self._first_step = 0
         self._lp_cache = {}
 
     @classmethod
@@ -457,7 +460,7 @@ class WanImageToVideoPipeline:
                                                   width, num_frames, torch.float32, device, generator, latents)
 
         for i, t in enumerate(timesteps):
-            if self._interrupt:
+            if self._interrupt or i < self._first_step:
                 continue
             self._current_timestep = t
             strength = None

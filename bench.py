@@ -923,24 +923,78 @@ def ab_arms(wl, arms, steps=5, warmup=3):
     return res
 
 
-def whole_video_projection(wl, elapsed, forwards):
-    """The C3 - C5 legs time loop iterations 0-1, the 3-pass end of the Wan schedules; a whole video also has 2-pass steps.  PROJECTED
-    whole-video rate: the DiT sample-forwards of every step of the schedule (3 while the reference's lp strength is non-zero, else 2;
-    the HunyuanVideo configuration runs its single-pass branch throughout) times the measured seconds per sample-forward of this leg
-    (taken from N = 3 batches: a 2-sample batch is assumed to cost 2 / 3 of it)."""
+def schedule_passes(wl):
+    """passes per loop iteration of the workload's schedule: 3 while the reference's lp strength is non-zero, else 2 (wan:882-894);
+    the HunyuanVideo configuration runs its single-pass branch throughout (hy:1196-1235)"""
     from alg_amd import lp_utils
     steps = wl.steps_per_video
     alg = getattr(wl, "alg", None)
-    if alg is None:                      # c4: one pass per step
-        total = steps
+    if alg is None:
+        return [1] * steps
+    sig = dict(lp_strength_schedule_type="none", schedule_interval_start_time=0.0, schedule_interval_end_time=0.05,
+               schedule_linear_start_weight=1.0, schedule_linear_end_weight=0.0, schedule_linear_end_time=0.5,
+               schedule_exp_decay_rate=10.0)
+    sig.update({k: v for k, v in alg.items() if k in sig})
+    return [3 if lp_utils.get_lp_strength(step_index=i, total_steps=steps, **sig) != 0.0 else 2 for i in range(steps)]
+
+
+def time_two_pass_step(wl, parallel):
+    """the C3 / C5 legs time loop iterations 0-1 (3-pass); a whole video also has 2-pass steps, whose launches
+    quantise differently on 256 CUs.  One 2-pass step, MEASURED: the pipeline's loop entered at the schedule's first 2-pass
+    iteration (`_first_step`: earlier iterations are skipped the way interrupted ones are), one warm-up step, one timed step.
+    Returns seconds per 2-pass step, or None when the schedule has no 2-pass step (or the pipeline no such hook)."""
+    passes = schedule_passes(wl)
+    if 2 not in passes or not hasattr(wl.pipe, "_first_step"):
+        return None
+    first = passes.index(2)
+    if first + 2 > len(passes) or passes[first + 1] != 2:
+        return None
+    wl.pipe._first_step = first
+    last = {}
+
+    def run(n_exec):
+        trace = []
+
+        def cb(pipe, i, t, kw):
+            if i + 1 >= first + n_exec:
+                pipe._interrupt = True            # (iterations are counted from 0: this one was number first + n_exec - 1)
+            return {}
+        wl.last_out = wl.pipe(callback_on_step_end=cb, step_trace=trace, **wl.kwargs).frames
+        last["passes"] = [r[2] for r in trace]
+    try:
+        run(1)                                    # warm-up: the 2-sample launch shapes, the filter at this strength
+        torch.cuda.synchronize()
+        parallel.barrier()
+        t0 = time.perf_counter()
+        run(2)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    finally:
+        wl.pipe._first_step = 0
+    if last["passes"] != [2, 2]:
+        raise RuntimeError("expected two 2-pass steps from iteration %d on, the pipeline ran %r" % (first, last["passes"]))
+    return elapsed / 2.0
+
+
+def whole_video_projection(wl, elapsed, forwards, two_pass_seconds=None):
+    """PROJECTED whole-video rate of a C3 - C5 leg from MEASURED per-step times: the leg's timed steps are loop iterations 0-1
+    (3-pass for Wan, the single pass of the HunyuanVideo branch), `two_pass_seconds` one measured 2-pass step (time_two_pass_step);
+    a video = n3 x t3 + n2 x t2.  Without a measured 2-pass step the old assumption stands in (a 2-sample forward costs 2 / 3 of
+    a 3-sample one) and the record says so."""
+    passes = schedule_passes(wl)
+    total = sum(passes)
+    n3, n2, n1 = passes.count(3), passes.count(2), passes.count(1)
+    t_leg_step = elapsed / 2.0                                     # the leg times 2 steps
+    if n2 and two_pass_seconds is not None:
+        seconds = (n3 + n1) * t_leg_step + n2 * two_pass_seconds
+        what = "projected from two MEASURED step times: %d x %.3f s (loop iterations 0-1) + %d x %.3f s (one 2-pass step, iteration %d)" % (
+            n3 + n1, t_leg_step, n2, two_pass_seconds, passes.index(2) + 1)
     else:
-        sig = dict(lp_strength_schedule_type="none", schedule_interval_start_time=0.0, schedule_interval_end_time=0.05,
-                   schedule_linear_start_weight=1.0, schedule_linear_end_weight=0.0, schedule_linear_end_time=0.5,
-                   schedule_exp_decay_rate=10.0)
-        sig.update({k: v for k, v in alg.items() if k in sig})
-        total = sum(3 if lp_utils.get_lp_strength(step_index=i, total_steps=steps, **sig) != 0.0 else 2 for i in range(steps))
-    return {"sample_forwards_per_video": total, "frames_per_s": wl.frames / (total * elapsed / forwards),
-            "what": "projected: schedule's passes per step x this leg's measured seconds per sample-forward"}
+        seconds = total * elapsed / forwards
+        what = "projected: schedule's passes per step x this leg's measured seconds per sample-forward"
+    return {"sample_forwards_per_video": total, "frames_per_s": wl.frames / seconds, "seconds_per_video": seconds,
+            "three_pass_steps": n3, "two_pass_steps": n2, "one_pass_steps": n1,
+            "seconds_per_three_pass_step": t_leg_step if n3 else None, "seconds_per_two_pass_step": two_pass_seconds, "what": what}
 
 
 def other_workloads(args, dev, parallel):
@@ -959,6 +1013,7 @@ def other_workloads(args, dev, parallel):
             t_build = time.perf_counter() - t_build
             elapsed, forwards, ms = timed_region(wl, 1, 2, parallel)
             rl = wl.roofline(ms, forwards, elapsed)
+            two_pass = time_two_pass_step(wl, parallel)      # one measured 2-pass step of the schedule (None for c4)
             # same process, same box, same steps: the 64-query statement kernel (default) against the 32-query pipelined kernel
             # (ALG_ATTN128_Q64=0; round 4's compiler-scheduled 64-query kernel measured +2.6 ... 3.2 % over it at C4)
             ab = None
@@ -987,7 +1042,7 @@ def other_workloads(args, dev, parallel):
                 "finite": bool(torch.isfinite(wl.last_out.float()).all().item()), "build_seconds": round(t_build, 1),
                 "peak_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                 "ab_attn128_q64_statement": ab,
-                "whole_video_projected": whole_video_projection(wl, elapsed, forwards),
+                "whole_video_projected": whole_video_projection(wl, elapsed, forwards, two_pass),
             }
         except Exception as e:   # an auxiliary workload must never take the headline line down
             res[name] = {"error": repr(e)}

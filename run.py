@@ -182,12 +182,22 @@ def run_job(pipe, config, args, job):
     logger.info("Starting video generation...")
     log_subset = {k: v for k, v in pipe_kwargs.items() if not torch.is_tensor(v) and k not in ("image", "generator")}
     logger.info(f"Pipeline arguments: {log_subset}")
+    import time
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    t_call = time.perf_counter()
     video_output = pipe(**pipe_kwargs)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    t_call = time.perf_counter() - t_call
     frames = video_output.frames
     out_path = job["output_path"]
+    timing = {"config": args.config, "call_seconds": t_call, "num_inference_steps": pipe_kwargs.get("num_inference_steps"),
+              "output_type": pipe_kwargs.get("output_type")}
     if pipe_kwargs.get("output_type") == "latent":
         torch.save(frames.cpu(), out_path)
         logger.info(f"Saved final latents {tuple(frames.shape)} to: {out_path}")
+        _write_timing(args, timing)
         return out_path
     video_frames = frames[0]
     logger.info(f"Video generation complete. Received {len(video_frames)} frames.")
@@ -196,9 +206,24 @@ def run_job(pipe, config, args, job):
     arr = np.stack([np.asarray(f) for f in video_frames])  # [T, H, W, C] (run.py:121-125)
     if arr.dtype != np.uint8:   # output_type "np" (the Wan / HunyuanVideo default): floats in [0, 1] -> (x * 255).clamp.to(uint8)
         arr = np.clip(arr.astype(np.float32) * 255.0, 0, 255).astype(np.uint8)
+    t_write = time.perf_counter()
     video_io.write_video(out_path, arr, fps=config["video"]["fps"])   # .mp4 -> ISO-BMFF container (run.py:127-133)
+    t_write = time.perf_counter() - t_write
     logger.info(f"Saved {arr.shape} frames (fps {config['video']['fps']}) to: {out_path}")
+    timing.update(frames=int(arr.shape[0]), height=int(arr.shape[1]), width=int(arr.shape[2]), write_seconds=t_write,
+                  frames_per_s_call=arr.shape[0] / t_call, frames_per_s_call_plus_write=arr.shape[0] / (t_call + t_write))
+    logger.info("Timing: __call__ (loop + VAE decode) %.2f s, writer %.2f s -> %.3f frames/s" % (
+        t_call, t_write, timing["frames_per_s_call_plus_write"]))
+    _write_timing(args, timing)
     return out_path
+
+
+def _write_timing(args, timing):
+    """extension (--timing_json): what one job took -- the figure a user of the reference would read off run.py:116-133"""
+    if getattr(args, "timing_json", None):
+        import json
+        with open(args.timing_json, "a") as f:
+            f.write(json.dumps(timing) + "\n")
 
 
 def load_jobs(args):
@@ -271,6 +296,8 @@ def make_parser():
                         help="extension: YAML/JSON list of {image_path, prompt, output_path[, seed]}, sharded over the GPUs")
     parser.add_argument("--gpus", type=int, default=1,
                         help="extension: data-parallel over this many GPUs of the node (one process each, weights broadcast once)")
+    parser.add_argument("--timing_json", type=str, default=None,
+                        help="extension: append one JSON line per job with the seconds of pipe.__call__ (loop + VAE decode) and of the writer")
     parser.add_argument("--generator_device", type=str, default=None, choices=["cpu", "cuda"],
                         help="extension: where the seed-42 generator lives (default: the run's device, as run.py:94)")
     return parser

@@ -65,3 +65,9 @@ def test_whole_video_projection_counts_the_schedules_passes():
         out = bench.whole_video_projection(w, elapsed=6.0, forwards=6)
         assert out["sample_forwards_per_video"] == total
         assert abs(out["frames_per_s"] - cls.frames / total) < 1e-12        # one second per sample-forward
+        # with a MEASURED 2-pass step (round 6): n3 steps at the leg's step time (elapsed / 2) + n2 steps at the measured time
+        out = bench.whole_video_projection(w, elapsed=6.0, forwards=6, two_pass_seconds=2.5)
+        n3, n2, n1 = out["three_pass_steps"], out["two_pass_steps"], out["one_pass_steps"]
+        assert (n3, n2, n1) == {"c3": (20, 20, 0), "c5": (10, 40, 0), "c4": (0, 0, 50)}[name]
+        if n2:                                                               # (c4 has no 2-pass step: the per-forward formula stands)
+            assert abs(out["seconds_per_video"] - (n3 * 3.0 + n2 * 2.5)) < 1e-9 and "MEASURED" in out["what"]
