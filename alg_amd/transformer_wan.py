@@ -84,6 +84,8 @@ def parameter_shapes(cfg):
         for n, d in (("image_embedder.norm1", I), ("image_embedder.norm2", D)):
             s[ce + n + ".weight"] = ((d,), BF)
             s[ce + n + ".bias"] = ((d,), BF)
+        if cfg.pos_embed_seq_len is not None:   # first-last-frame checkpoints (FLF2V): learned position embedding of the 2 x 257 image tokens
+            s[ce + "image_embedder.pos_embed"] = ((1, cfg.pos_embed_seq_len, I), BF)
     for l in range(cfg.num_layers):
         b = f"blocks.{l}."
         s[b + "scale_shift_table"] = ((1, 6, D), f32)
@@ -126,6 +128,8 @@ def synthetic_state_dict(cfg, seed=1234, device="cuda"):
             t = 1.0 + 0.1 * r()
         elif name.endswith("bias"):
             t = 0.02 * r()
+        elif name.endswith("pos_embed"):
+            t = 0.5 * r()
         else:
             t = r() / math.prod(shape[1:]) ** 0.5
         sd[name] = t.to(dt)
@@ -147,8 +151,8 @@ class WanTransformer3DModel:
             raise NotImplementedError("the Wan DiT path is built for rms_norm_across_heads and head_dim 128")
         if tuple(config.patch_size)[0] != 1:
             raise NotImplementedError("temporal patch size 1 only (every Wan 2.1 checkpoint)")
-        if config.pos_embed_seq_len is not None:
-            raise NotImplementedError("first-last-frame (FLF2V) image position embedding is not built")
+        if config.pos_embed_seq_len is not None and config.image_dim is None:
+            raise ValueError("pos_embed_seq_len (FLF2V) needs an image embedder (image_dim)")
         self.config = config
         self.device = torch.device(device)
         dev = self.device
@@ -181,6 +185,8 @@ class WanTransformer3DModel:
             w.in2_w, w.in2_b = f32(ie + "norm2.weight"), f32(ie + "norm2.bias")
             w.if1_w, w.if1_b = bf(ie + "ff.net.0.proj.weight"), bf(ie + "ff.net.0.proj.bias")
             w.if2_w, w.if2_b = bf(ie + "ff.net.2.weight"), bf(ie + "ff.net.2.bias")
+            # FLF2V (wan:805-812 hands [first, last] CLIP embeddings as 2 x 257 tokens): WanImageEmbedding.pos_embed [1, 514, I]
+            w.img_pos = bf(ie + "pos_embed").reshape(-1, config.image_dim) if config.pos_embed_seq_len is not None else None
         w.tables = torch.stack([f32(f"blocks.{l}.scale_shift_table").reshape(6, D)
                                 for l in range(config.num_layers)]).contiguous()      # [L, 6, D]
         w.table_out = f32("scale_shift_table").reshape(1, 2, D).contiguous()
@@ -335,6 +341,14 @@ class WanTransformer3DModel:
         D, Ff, heads = cfg.dim, cfg.ffn_dim, cfg.num_attention_heads
         S = F_ * (H // ph) * (W // pw)
         n_txt = encoder_hidden_states.shape[1]
+        if encoder_hidden_states_image is not None and cfg.pos_embed_seq_len is not None:
+            # FLF2V: the [first, last] image embeddings arrive as separate batch rows ([2 N, 257, I], wan:805-812 + wan:904-908) and
+            # are one sample's 2 x 257 tokens: WanImageEmbedding views them as [N, 514, I] before anything else
+            b2, s2, i2 = encoder_hidden_states_image.shape
+            if (b2 * s2) % cfg.pos_embed_seq_len or b2 * s2 // cfg.pos_embed_seq_len != N:
+                raise ValueError("FLF2V: encoder_hidden_states_image %s does not view as [%d, %d, %d]" % (
+                    tuple(encoder_hidden_states_image.shape), N, cfg.pos_embed_seq_len, i2))
+            encoder_hidden_states_image = encoder_hidden_states_image.reshape(N, cfg.pos_embed_seq_len, i2)
         n_img = encoder_hidden_states_image.shape[1] if encoder_hidden_states_image is not None else 0
         ws = self._workspace(N, S, n_txt, n_img)
         S_pad, scale = ws.S_pad, 1.0 / math.sqrt(cfg.attention_head_dim)
@@ -361,6 +375,8 @@ class WanTransformer3DModel:
         if n_img:
             I = cfg.image_dim
             im = encoder_hidden_states_image.to(BF).contiguous()
+            if w.img_pos is not None:   # x + pos_embed in the embedder's dtype (one bf16 rounding), per sample (the table has no batch)
+                im = torch.stack([_lib.lincomb([(1.0, im[n]), (1.0, w.img_pos)], BF) for n in range(N)])
             _lib.layernorm_mod_f32(im, ws.img_n, w.in1_w, w.in1_b, None, None, 0, N, n_img, I, 1e-5)
             G(ws.img_n, w.if1_w, ws.img_h, N * n_img, I, I, I, I, I, bias=w.if1_b)
             _lib.gelu_erf_(ws.img_h)

@@ -179,6 +179,16 @@ def _sdpa(q, k, v, kv_len, max_scores=1 << 28):
     return out
 
 
+def patch_embed(x, weight, bias, patch):
+    """Conv3d(kernel = stride = patch)(x).flatten(2).transpose(1, 2) written as a linear layer over the unfolded patches (rows
+    (c, dt, dy, dx): the Conv3d weight's own memory order) -- the formulation the product's patchify + GEMM uses.  Pinned against
+    F.conv3d itself in tests/test_oracle_patch_embed_cpu.py."""
+    B, C, F_, H, Wd = x.shape
+    pt, ph, pw = patch
+    hp = x.reshape(B, C, F_ // pt, pt, H // ph, ph, Wd // pw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
+    return F.linear(hp.reshape(B, -1, C * pt * ph * pw), weight.reshape(weight.shape[0], -1), bias)
+
+
 def hy_forward(cfg: HyConfig, sd, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask,
                pooled_projections, guidance=None, dtype=torch.float32):
     """hidden_states [B, C, F, H, W]; timestep [B]; text [B, L, text_dim]; mask [B, L] (prefix of ones);
@@ -207,8 +217,7 @@ def hy_forward(cfg: HyConfig, sd, hidden_states, timestep, encoder_hidden_states
     # ---- patch embed ----
     # x_embedder = Conv3d(kernel = stride = patch): one dot product per output voxel over its own patch, i.e. a linear layer over
     # the unfolded patches (rows (c, dt, dy, dx): the weight's own memory order)
-    hp = hidden_states.to(dtype).reshape(B, C, F_ // pt, pt, H // p, p, Wd // p, p).permute(0, 2, 4, 6, 1, 3, 5, 7)
-    x = F.linear(hp.reshape(B, -1, C * pt * p * p), W_("x_embedder.proj.weight").reshape(D, -1), W_("x_embedder.proj.bias"))
+    x = patch_embed(hidden_states.to(dtype), W_("x_embedder.proj.weight"), W_("x_embedder.proj.bias"), (pt, p, p))
 
     # ---- token refiner ----
     ce = "context_embedder."

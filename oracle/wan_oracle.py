@@ -33,6 +33,7 @@ class WanConfig:
     image_dim: int = 1280
     added_kv_proj_dim: int = 5120
     rope_max_seq_len: int = 1024
+    pos_embed_seq_len: int = None      # FLF2V checkpoints: 2 x 257 (WanImageEmbedding.pos_embed)
 
     @property
     def dim(self):
@@ -67,6 +68,8 @@ def param_shapes(cfg: WanConfig):
         s[ce + "image_embedder.ff.net.2.bias"] = ((D,), bf)
         s[ce + "image_embedder.norm2.weight"] = ((D,), bf)
         s[ce + "image_embedder.norm2.bias"] = ((D,), bf)
+        if cfg.pos_embed_seq_len is not None:
+            s[ce + "image_embedder.pos_embed"] = ((1, cfg.pos_embed_seq_len, I), bf)
     for l in range(cfg.num_layers):
         b = f"blocks.{l}."
         s[b + "scale_shift_table"] = ((1, 6, D), f32)
@@ -106,6 +109,8 @@ def init_weights(cfg: WanConfig, seed=0):
             t = torch.randn(shape, generator=g) / shape[-1] ** 0.5
         elif name.endswith("bias"):
             t = 0.02 * torch.randn(shape, generator=g)
+        elif name.endswith("pos_embed"):
+            t = 0.5 * torch.randn(shape, generator=g)        # comparable with the CLIP tokens it is added to
         else:
             fan_in = math.prod(shape[1:])
             t = torch.randn(shape, generator=g) / fan_in ** 0.5
@@ -175,6 +180,16 @@ FP8_LINEARS = ("attn1.to_q", "attn1.to_k", "attn1.to_v", "attn1.to_out.0", "attn
                "ffn.net.2")   # the seven large linears of a block (to_q | to_k are one GEMM in the product) -- BASELINE config 5
 
 
+def patch_embed(x, weight, bias, patch):
+    """Conv3d(kernel = stride = patch)(x).flatten(2).transpose(1, 2) written as a linear layer over the unfolded patches (rows
+    (c, dt, dy, dx): the Conv3d weight's own memory order) -- the formulation the product's patchify + GEMM uses.  Pinned against
+    F.conv3d itself in tests/test_oracle_patch_embed_cpu.py."""
+    B, C, F_, H, Wd = x.shape
+    pt, ph, pw = patch
+    hp = x.reshape(B, C, F_ // pt, pt, H // ph, ph, Wd // pw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
+    return F.linear(hp.reshape(B, -1, C * pt * ph * pw), weight.reshape(weight.shape[0], -1), bias)
+
+
 def wan_forward(cfg: WanConfig, sd, hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image,
                 dtype=torch.float32, collect=None, fp8=False):
     """hidden_states [B, 36, F, H, W]; timestep [B]; text [B, 512, 4096]; image [B, 257, 1280] or None.
@@ -195,8 +210,7 @@ def wan_forward(cfg: WanConfig, sd, hidden_states, timestep, encoder_hidden_stat
     cos, sin = rope_tables(cfg, F_, H, Wd)
     # patch_embedding = Conv3d(kernel = stride = patch_size): every output voxel is one dot product over its own patch, i.e.
     # a linear layer over the unfolded patches (rows (c, dt, dy, dx), the weight's own memory order)
-    hp = hidden_states.to(dtype).reshape(B, C, F_ // pt, pt, H // ph, ph, Wd // pw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
-    x = F.linear(hp.reshape(B, -1, C * pt * ph * pw), W_("patch_embedding.weight").reshape(D, -1), W_("patch_embedding.bias"))
+    x = patch_embed(hidden_states.to(dtype), W_("patch_embedding.weight"), W_("patch_embedding.bias"), (pt, ph, pw))
     ce = "condition_embedder."
     half = cfg.freq_dim // 2
     exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=hidden_states.device) / half
@@ -211,6 +225,11 @@ def wan_forward(cfg: WanConfig, sd, hidden_states, timestep, encoder_hidden_stat
     n_img = 0
     if encoder_hidden_states_image is not None:
         im = encoder_hidden_states_image.to(dtype)
+        if cfg.pos_embed_seq_len is not None:
+            # diffusers WanImageEmbedding.forward: view(-1, 2 * seq_len, embed_dim) + pos_embed -- the pipeline hands the first and the
+            # last frame's CLIP tokens as two batch rows per sample (/root/reference/pipeline_wan_image2video_lowpass.py:805-812)
+            im = im.reshape(-1, 2 * im.shape[1], im.shape[2])
+            im = (im + sd[ce + "image_embedder.pos_embed"].to(dtype)).to(dtype)
         im = _ln(im, sd[ce + "image_embedder.norm1.weight"], sd[ce + "image_embedder.norm1.bias"], 1e-5).to(dtype)
         im = lin(F.gelu(lin(im, ce + "image_embedder.ff.net.0.proj")), ce + "image_embedder.ff.net.2")
         im = _ln(im, sd[ce + "image_embedder.norm2.weight"], sd[ce + "image_embedder.norm2.bias"], 1e-5).to(dtype)

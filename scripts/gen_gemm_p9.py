@@ -22,7 +22,7 @@ trips (K / 64 - 2); wm, wn wave coordinates; wave1k = lds base + wave * 1024; t0
 """
 import os
 
-# experiment knobs (scripts/experiments/p9_build_variant.sh): timing ablations produce garbage results
+# experiment knobs (round 3-5 timing ablations, docs/lab_notebook_r5.md item 20): they produce garbage results
 NO_DMA = os.environ.get("P9_NO_DMA") == "1"          # no LDS-DMA inside the loop (the prologue's two k-tiles are re-read)
 NO_READS = os.environ.get("P9_NO_READS") == "1"      # no fragment reads inside the loop
 NO_BARRIER = os.environ.get("P9_NO_BARRIER") == "1"  # no s_barrier inside the loop

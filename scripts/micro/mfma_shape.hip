@@ -69,6 +69,32 @@ KERNEL(k1, K1_ASM, CLOB64)
 KERNEL(k2, K2_ASM, CLOB256)
 KERNEL(k3, K3_ASM, CLOB256)
 
+// e4m3 operands (8 registers = 32 bytes per lane) on v_mfma_scale_f32_{32x32x64,16x16x128}_f8f6f4, block scales 2^0: 4 x the FLOP of
+// the bf16 loops per trip.  Random bytes with the NaN codes (0x7f / 0xff) replaced.
+typedef int i8v __attribute__((ext_vector_type(8)));
+#define KERNEL8(NAME, ASM)                                                                             \
+  __global__ __launch_bounds__(256) void NAME(float* sink, int iters, unsigned seed, uint64_t* clocks) { \
+    Tap t;                                                                                             \
+    t.start();                                                                                         \
+    i8v w[4], x[4];                                                                                    \
+    for (int j = 0; j < 4; ++j)                                                                        \
+      for (int i = 0; i < 8; ++i) {                                                                    \
+        unsigned a = hashu(seed + (blockIdx.x * 256u + threadIdx.x) * 131u + j * 17u + i), b = hashu(a + 77u); \
+        a &= 0x7e7e7e7eu | 0x80808080u, b &= 0x7e7e7e7eu | 0x80808080u;   /* never exponent + mantissa all ones */ \
+        w[j][i] = (int)a, x[j][i] = (int)b;                                                            \
+      }                                                                                                \
+    int n = __builtin_amdgcn_readfirstlane(iters);                                                     \
+    const int sc = 0x7f7f7f7f;                                                                         \
+    asm volatile(ASM : [n] "+s"(n)                                                                     \
+                 : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), \
+                   [x3] "v"(x[3]), [sc] "v"(sc)                                                        \
+                 : "scc", CLOB256);                                                                    \
+    if (n == 12345) sink[0] = 1.0f;                                                                    \
+    t.stop(clocks);                                                                                    \
+  }
+KERNEL8(k4, K4_ASM)
+KERNEL8(k5, K5_ASM)
+
 int main(int argc, char** argv) {
   const double secs = argc > 1 ? atof(argv[1]) : 3.0;
   const int rounds = argc > 2 ? atoi(argv[2]) : 2;
@@ -79,20 +105,23 @@ int main(int argc, char** argv) {
   int khz = 0;
   hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
   const int iters = 20000;
-  const char* names[4] = {"32x32x16, 4 chains", "16x16x32, 16 chains", "32x32x16, 4x4 blocks (256 acc)", "16x16x32, 8x8 blocks (256 acc)"};
+  const char* names[6] = {"32x32x16, 4 chains", "16x16x32, 16 chains", "32x32x16, 4x4 blocks (256 acc)", "16x16x32, 8x8 blocks (256 acc)",
+                          "e4m3 32x32x64 scaled, 256 acc", "e4m3 16x16x128 scaled, 256 acc"};
   for (int wps = 2; wps >= 1; --wps) {
     dim3 grid(pr.multiProcessorCount * wps), blk(256);
     hipMalloc(&d, 4);
     hipMalloc(&clk, grid.x * 16);
     for (int r = 0; r < rounds; ++r)
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < 6; ++s) {
         if (wps == 2 && s >= 2) continue;   // 256 accumulators: one wave per SIMD only
         auto launch = [&]() {
           switch (s) {
             case 0: hipLaunchKernelGGL(k0, grid, blk, 0, 0, d, iters, 1u + r, clk); break;
             case 1: hipLaunchKernelGGL(k1, grid, blk, 0, 0, d, iters, 1u + r, clk); break;
             case 2: hipLaunchKernelGGL(k2, grid, blk, 0, 0, d, iters, 1u + r, clk); break;
-            default: hipLaunchKernelGGL(k3, grid, blk, 0, 0, d, iters, 1u + r, clk); break;
+            case 3: hipLaunchKernelGGL(k3, grid, blk, 0, 0, d, iters, 1u + r, clk); break;
+            case 4: hipLaunchKernelGGL(k4, grid, blk, 0, 0, d, iters, 1u + r, clk); break;
+            default: hipLaunchKernelGGL(k5, grid, blk, 0, 0, d, iters, 1u + r, clk); break;
           }
         };
         launch();
@@ -106,7 +135,7 @@ int main(int argc, char** argv) {
           hipEventRecord(a), launch(), hipEventRecord(b), hipEventSynchronize(b);
           float ms;
           hipEventElapsedTime(&ms, a, b);
-          const double tf = 32.0 * 32768.0 * iters * grid.x * 4 / (ms * 1e-3) / 1e12;
+          const double tf = (s >= 4 ? 4.0 : 1.0) * 32.0 * 32768.0 * iters * grid.x * 4 / (ms * 1e-3) / 1e12;
           if (n == 0) first = tf;
           last = tf, ++n;
           hipEventDestroy(a), hipEventDestroy(b);
@@ -115,7 +144,7 @@ int main(int argc, char** argv) {
         hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
         const double mhz = khz > 0 && h[1] ? (double)h[0] / ((double)h[1] / khz) / 1e3 : 0.0;
         printf("%d waves/SIMD  %-34s first %6.0f sustained %6.0f TFLOP/s  clock %5.0f MHz  pipe-busy %.3f\n", wps, names[s], first,
-               last, mhz, mhz > 0 ? last * 1e12 / (pr.multiProcessorCount * 4 * 1024.0 * mhz * 1e6) : 0.0);
+               last, mhz, mhz > 0 ? last * 1e12 / (pr.multiProcessorCount * 4 * (s >= 4 ? 2048.0 : 1024.0) * mhz * 1e6) : 0.0);
         fflush(stdout);
       }
     hipFree(d), hipFree(clk);

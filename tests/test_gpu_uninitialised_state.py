@@ -5,7 +5,7 @@ scalar registers -- inside a forward every launch follows a DIFFERENT kernel.  t
 vector registers of every SIMD, the 160 KiB of LDS of every CU and s[16:99] + vcc with one bit pattern (NaN, huge, negative,
 all-ones, zero) right in front of each launch; the result must equal the unpoisoned launch bit for bit.  (Round 4: built to test
 the "uninitialised register" explanation of the shelved 64-queries-per-wave attention's first-round mismatches; that kernel passes
-too -- scripts/experiments/q64_poison_probe.py, profiles/r4_poison_probe.jsonl -- so the explanation is excluded.)"""
+too -- round 4's poison probe, profiles/r4_poison_probe.jsonl -- so the explanation is excluded.)"""
 import pytest
 import torch
 

@@ -54,6 +54,34 @@ def test_wan_forward_small(N, image):
     assert torch.equal(out1[0], out[0])
 
 
+@pytest.mark.parametrize("N", [2, 3])
+def test_wan_forward_first_last_frame_image_position_embedding(N):
+    """FLF2V checkpoints (`last_image=`, /root/reference/pipeline_wan_image2video_lowpass.py:603,805-812): the first and the last
+    frame's CLIP tokens arrive as TWO batch rows per sample ([2 N, 257, I]); WanImageEmbedding views them as [N, 514, I], adds its
+    learned position embedding, and the blocks attend 514 image tokens.  Against the fp32 oracle on the bf16-eager floor; the
+    position embedding must matter (the same inputs without it give another result)."""
+    kw = dict(num_attention_heads=4, ffn_dim=1024, num_layers=2, text_dim=64, image_dim=64, added_kv_proj_dim=512, pos_embed_seq_len=514)
+    cfg, ocfg = WanTransformerConfig(**kw), wan_oracle.WanConfig(**kw)
+    sd = wan_oracle.init_weights(ocfg, seed=7)
+    assert set(sd) == set(parameter_shapes(cfg)) and sd["condition_embedder.image_embedder.pos_embed"].shape == (1, 514, 64)
+    model = WanTransformer3DModel(cfg, sd, device=DEV)
+    x, txt, _ = inputs(N, 3, 16, 24, 8)
+    g = torch.Generator().manual_seed(80)
+    img = torch.randn(2 * N, 257, 64, generator=g).to(BF)            # [first_0, last_0, first_1, last_1, ...]
+    t = torch.tensor([500.0] * N)
+    ref = wan_oracle.wan_forward(ocfg, sd, x.float(), t, txt.float(), img.float())
+    run = lambda m, im: m(hidden_states=x.to(DEV), timestep=t.to(DEV), encoder_hidden_states=txt.to(DEV),
+                          encoder_hidden_states_image=im.to(DEV), return_dict=False)[0]
+    out = run(model, img)
+    assert out.shape == ref.shape
+    check_floor("wan_forward_flf2v_N%d" % N, out, ref, wan_oracle.wan_forward(ocfg, sd, x, t, txt, img, dtype=BF))
+    sd0 = dict(sd)
+    sd0["condition_embedder.image_embedder.pos_embed"] = torch.zeros_like(sd["condition_embedder.image_embedder.pos_embed"])
+    assert rel(run(WanTransformer3DModel(cfg, sd0, device=DEV), img), out) > 1e-3
+    with pytest.raises(ValueError, match="FLF2V"):                     # one batch row per sample: not a first / last pair
+        run(model, img[:N])
+
+
 def test_wan_forward_ragged_tokens_and_scalar_timestep():
     cfg, ocfg = small(layers=1, heads=8)
     sd = wan_oracle.init_weights(ocfg, seed=5)

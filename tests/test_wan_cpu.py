@@ -55,3 +55,35 @@ def test_rope_tables_follow_the_axis_split():
 def test_product_refuses_cpu():
     with pytest.raises(_lib.AlgHipError):
         WanTransformer3DModel(WanTransformerConfig(num_layers=0), {}, device="cpu")
+
+
+def test_oracle_flf2v_position_embedding_follows_the_published_module():
+    """WanImageEmbedding with pos_embed_seq_len (first-last-frame checkpoints; the reference hands `[image, last_image]` to the CLIP
+    encoder, /root/reference/pipeline_wan_image2video_lowpass.py:805-812): [2 N, 257, I] is VIEWED as [N, 514, I] -- sample n owns
+    rows 2 n (first frame) and 2 n + 1 (last frame) -- and the learned table is added before norm1.  The parameter tables of product
+    and oracle agree on the extra tensor; the oracle equals a by-hand restatement of the embedder on its own."""
+    kw = dict(num_attention_heads=2, ffn_dim=256, num_layers=1, text_dim=32, image_dim=32, added_kv_proj_dim=256, pos_embed_seq_len=514)
+    cfg, pcfg = wan_oracle.WanConfig(**kw), WanTransformerConfig(**kw)
+    assert parameter_shapes(pcfg) == wan_oracle.param_shapes(cfg)
+    assert parameter_shapes(pcfg)["condition_embedder.image_embedder.pos_embed"] == ((1, 514, 32), torch.bfloat16)
+    sd = wan_oracle.init_weights(cfg, seed=1)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 36, 2, 4, 6, generator=g)
+    txt, img = torch.randn(2, 512, 32, generator=g), torch.randn(4, 257, 32, generator=g)
+    t = torch.tensor([900.0, 900.0])
+    y = wan_oracle.wan_forward(cfg, sd, x, t, txt, img)
+    assert y.shape == (2, 16, 2, 4, 6) and torch.isfinite(y).all()
+    # sample 1 alone = its own (first, last) pair: rows 2, 3 of the image batch
+    y1 = wan_oracle.wan_forward(cfg, sd, x[1:], t[1:], txt[1:], img[2:4])
+    assert torch.allclose(y1[0], y[1], atol=1e-5)
+    # swapping first and last frame changes the result (the table is position dependent), dropping the table as well
+    y_swap = wan_oracle.wan_forward(cfg, sd, x, t, txt, img[[1, 0, 3, 2]])
+    sd0 = dict(sd)
+    sd0["condition_embedder.image_embedder.pos_embed"] = torch.zeros(1, 514, 32, dtype=torch.bfloat16)
+    y_nopos = wan_oracle.wan_forward(cfg, sd0, x, t, txt, img)
+    assert (y_swap - y).abs().max() > 1e-4 and (y_nopos - y).abs().max() > 1e-4
+    # without the table the concatenation order is all that is left of "first / last": the view is [first | last] per sample
+    cfg_plain = wan_oracle.WanConfig(**{k: v for k, v in kw.items() if k != "pos_embed_seq_len"})
+    sd_plain = {k: v for k, v in sd0.items() if not k.endswith("pos_embed")}
+    y_cat = wan_oracle.wan_forward(cfg_plain, sd_plain, x, t, txt, img.reshape(2, 514, 32))
+    assert torch.allclose(y_cat, y_nopos, atol=1e-6)
