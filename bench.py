@@ -856,6 +856,7 @@ def timed_region(wl, warmup, steps, parallel, measure_box=False):
 # transformer; "env": an ALG_* option of the library (re-read with alg_reload_env); "events": the bench's own HIP-event brackets
 # switched ON (what the instrumented headline region pays for them).
 AB_ARMS = [
+    ("attn_m16_statement", "env", "ALG_ATTN_PP", "7", "round 6: the d = 64 8-wave statement on v_mfma_f32_16x16x32_bf16 (attention64_m16.hip, ALG_ATTN_PP=7) as the OFF arm; > 0: the default (32x32x16 statement) is faster"),
     ("attn_8wave_statement_vs_q64", "env", "ALG_ATTN_PP", "6", "round 5: the default 8-wave 32-query d = 64 statement vs the 64-queries-per-wave statement (attention64_q64.hip, ALG_ATTN_PP=6); > 0: the default is faster"),
     ("attn_pipelined", "env", "ALG_ATTN_PP", "0", "round 3: pipelined d = 64 attention vs the straight loop"),
     ("attn_split_tail", "env", "ALG_ATTN_SPLIT_TAIL", "0", "round 2: split-KV tail of the attention launch vs a single launch"),
@@ -869,21 +870,31 @@ AB_ARMS = [
 def ab_arms(wl, arms, steps=5, warmup=3):
     from alg_amd import _lib
 
-    def timed(with_events=False):
+    box = {}     # arm -> package power / sclk during its timed steps (the arms' clocks say whether a delta is cycles or clock)
+
+    def timed(with_events=False, tag=None):
         run_steps(wl, warmup)
         kinds = {} if with_events else None
         if with_events:
             wl.instrument(kinds)
+        smi = SmiSampler(wl.dev.index or 0)
+        smi.__enter__()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_steps(wl, steps)
-        torch.cuda.synchronize()
+        try:
+            run_steps(wl, steps)
+            torch.cuda.synchronize()
+        finally:
+            smi.__exit__(None, None, None)
+            if with_events:
+                wl.instrument(None)
         dt = (time.perf_counter() - t0) / steps * 1e3
-        if with_events:
-            wl.instrument(None)
+        sm = smi.summary()
+        if tag is not None and sm:
+            box[tag] = {"power_w": round(sm["power_w"]["mean"], 1), "sclk_mhz": round(sm["sclk_mhz"]["mean"], 1)}
         return dt
 
-    res = {"steps": steps, "warmup": warmup, "default_ms_per_step": [timed()], "arms": {}}
+    res = {"steps": steps, "warmup": warmup, "default_ms_per_step": [timed(tag="default_first")], "arms": {}}
     for name, kind, key, off, what in arms:
         rec = {"what": what}
         try:
@@ -893,7 +904,7 @@ def ab_arms(wl, arms, steps=5, warmup=3):
                 old = getattr(wl.model, key)
                 setattr(wl.model, key, type(old)(off))
                 try:
-                    rec["off_ms_per_step"] = timed()
+                    rec["off_ms_per_step"] = timed(tag=name)
                 finally:
                     setattr(wl.model, key, old)
             elif kind == "env":
@@ -901,7 +912,7 @@ def ab_arms(wl, arms, steps=5, warmup=3):
                 os.environ[key] = off
                 _lib.reload_env()
                 try:
-                    rec["off_ms_per_step"] = timed()
+                    rec["off_ms_per_step"] = timed(tag=name)
                 finally:
                     if old is None:
                         os.environ.pop(key, None)
@@ -910,11 +921,12 @@ def ab_arms(wl, arms, steps=5, warmup=3):
                     _lib.reload_env()
                 rec["off"] = "%s=%s" % (key, off)
             else:
-                rec["off_ms_per_step"] = timed(with_events=True)
+                rec["off_ms_per_step"] = timed(with_events=True, tag=name)
         except Exception as e:
             rec["error"] = repr(e)
         res["arms"][name] = rec
-    res["default_ms_per_step"].append(timed())
+    res["default_ms_per_step"].append(timed(tag="default_last"))
+    res["smi_per_arm"] = box
     base = sum(res["default_ms_per_step"]) / 2
     res["default_spread_pct"] = round(abs(res["default_ms_per_step"][0] - res["default_ms_per_step"][1]) / base * 100, 2)
     for rec in res["arms"].values():
