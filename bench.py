@@ -49,16 +49,18 @@ def event_ms(pairs):
     return [a.elapsed_time(b) for a, b in pairs]
 
 
-def pmc_traffic(kernel_substr, profiles=("profiles/r5_pmc_summary.txt", "profiles/r4_pmc_summary.txt", "profiles/r3_pmc_summary.txt", "profiles/r2_pmc_summary.txt", "profiles/r1_pmc_summary.txt")):
+def pmc_traffic(kernel_substr, profiles=("profiles/r6_pmc_bench_run.txt", "profiles/r5_pmc_summary.txt", "profiles/r4_pmc_summary.txt", "profiles/r3_pmc_summary.txt", "profiles/r2_pmc_summary.txt", "profiles/r1_pmc_summary.txt"), samples=2):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
     collected in separate passes and reported in KiB).  gfx950 correction from MI355X_MICROARCH.md section HBM: a wide
     coalesced 16-B/lane stream (our global_load_lds staging) is tallied at half its bytes in FETCH_SIZE -> x2.
-    The PMC passes profile the kernel micro-benchmark (scripts/kbench.py) at the N = 2 C2 shape, i.e. a two-pass step."""
+    Round 6: the first profile is a PMC pass over the BENCH command itself (scripts/gpu_r6_pmc.sh), summarised per (kernel, grid):
+    the `samples`-sample launch of the step is picked by its grid (a 3-sample C2 launch has 1.5 x the workgroups of a 2-sample
+    one); the older profiles are kernel micro-benchmarks (scripts/kbench.py) at the N = 2 shape."""
     for profile in profiles:
         path = os.path.join(ROOT, profile)
         if not os.path.exists(path):
             continue
-        per_kernel = {}   # kernel name as printed -> {counter: mean}; the main launch is the one that fetches most
+        per_kernel = {}   # kernel name as printed (+ grid) -> {counter: mean}
         with open(path) as f:
             for line in f:
                 if kernel_substr in line and "mean=" in line:
@@ -66,12 +68,27 @@ def pmc_traffic(kernel_substr, profiles=("profiles/r5_pmc_summary.txt", "profile
                         if (" " + name + " ") in line:
                             kname = line.split(name)[0].strip()
                             per_kernel.setdefault(kname, {})[name] = float(line.rsplit("mean=", 1)[1])
-        full = [v for v in per_kernel.values() if len(v) == 2]
-        if full:
-            vals = max(full, key=lambda v: v["FETCH_SIZE"])
-            return dict(bytes_per_launch=(2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
-                        fetch_kib_raw=vals["FETCH_SIZE"], write_kib_raw=vals["WRITE_SIZE"], samples_per_launch=2,
-                        source=profile)
+        full = {k: v for k, v in per_kernel.items() if len(v) == 2}
+        if not full:
+            continue
+        by_grid = {}
+        for k, v in full.items():
+            if "[grid=" in k:
+                try:
+                    by_grid[int(k.split("[grid=")[1].rstrip("]"))] = v
+                except ValueError:
+                    pass
+        if by_grid:
+            # the main launches of a bench run: the largest grids; 3-sample = the largest, 2-sample = the next distinct size
+            grids = sorted(by_grid, reverse=True)
+            main = [g for g in grids if g >= 0.5 * grids[0]]
+            pick = main[0] if (samples == 3 or len(main) == 1) else main[1]
+            vals, n_samples = by_grid[pick], (3 if pick == main[0] and len(main) > 1 else samples)
+        else:
+            vals, n_samples = max(full.values(), key=lambda v: v["FETCH_SIZE"]), 2
+        return dict(bytes_per_launch=(2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+                    fetch_kib_raw=vals["FETCH_SIZE"], write_kib_raw=vals["WRITE_SIZE"], samples_per_launch=n_samples,
+                    source=profile)
     return None
 
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc CSV output: per kernel name, mean counter value per dispatch."""
+"""Summarise rocprofv3 --pmc CSV output: per kernel name, mean counter value per dispatch.
+PMC_BY_GRID=1: per (kernel name, grid size) -- a bench run launches the same kernel for 2-sample and 3-sample steps."""
 import csv
 import glob
 import os
@@ -7,6 +8,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+BY_GRID = os.environ.get("PMC_BY_GRID") == "1"
 allc = defaultdict(dict)          # kernel -> counter -> mean, over all passes (for the derived ratios at the end)
 for d in sorted(glob.glob(os.path.join(root, "*_p*"))):
     if not os.path.isdir(d):
@@ -18,11 +20,12 @@ for d in sorted(glob.glob(os.path.join(root, "*_p*"))):
                 k = row.get("Kernel_Name", "?")
                 if "alg" not in k:
                     continue
-                acc[k[:60]][row.get("Counter_Name", "?")].append(float(row.get("Counter_Value", 0)))
+                key = k[:60] + (" [grid=%s]" % row.get("Grid_Size", "?") if BY_GRID else "")
+                acc[key][row.get("Counter_Name", "?")].append(float(row.get("Counter_Value", 0)))
     print("==", os.path.basename(d))
     for k, cs in acc.items():
         for c, v in sorted(cs.items()):
-            print("  %-60s %-28s n=%-4d mean=%.4g" % (k, c, len(v), sum(v) / len(v)))
+            print("  %-*s %-28s n=%-4d mean=%.4g" % (80 if BY_GRID else 60, k, c, len(v), sum(v) / len(v)))
             allc[k][c] = sum(v) / len(v)
 print("== derived (per kernel; SQ_INSTS_VALU counts every VALU instruction once, MFMAs included -- calibrated below; 1024 SIMDs;")
 print("   MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over the launch's shader cycles, taken as GRBM_GUI_ACTIVE / 8 (one instance")
