@@ -956,24 +956,19 @@ using namespace alg;
 
 // Main launch of the pre-scaled form: 4 = the pipelined kernel, one 8-wave workgroup per 256-query unit (default since round 3:
 // asm steady-state loop, every MFMA followed by one score pair of the softmax), 0 = the straight loop (variant 41; same
-// softmax, fp32 summation order differs); 6 = attention64_q64.hip (64 queries per wave), taken by flash_attn_d64_q64() before
-// this function is reached.
+// softmax, fp32 summation order differs); 7 = attention64_m16.hip (the statement on 16x16x32 MFMAs), taken by
+// flash_attn_d64_m16() before this function is reached.
 namespace alg {
-// attention64_q64.hip: the 64-queries-per-wave statement kernel as the main launch (ALG_ATTN_PP=6); 1 = not covered
-int flash_attn_d64_q64(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S, int q_blocks,
-                       int64_t q_bs, int64_t q_rs, int64_t vt_bs, int64_t vt_rs, int64_t o_bs, int64_t o_rs, unsigned blocks,
-                       hipStream_t stream);
 // attention64_m16.hip: the 8-wave statement kernel on v_mfma_f32_16x16x32_bf16 as the main launch (ALG_ATTN_PP=7); 1 = not covered
 int flash_attn_d64_m16(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S, int q_blocks,
                        int64_t q_bs, int64_t q_rs, int64_t vt_bs, int64_t vt_rs, int64_t o_bs, int64_t o_rs, unsigned blocks,
                        hipStream_t stream);
-// the main launch by one of the other files (ALG_ATTN_PP = 6 / 7), or 1: attention.hip's own kernels take the call
+// the main launch by another file (ALG_ATTN_PP = 7), or 1: attention.hip's own kernels take the call
 static int main_launch_elsewhere(const void* q, const void* k, const void* vt, void* o, int batch, int heads, int S, int q_blocks,
                                  int64_t q_bs, int64_t q_rs, int64_t vt_bs, int64_t vt_rs, int64_t o_bs, int64_t o_rs,
                                  unsigned blocks, hipStream_t stream) {
   const int pp = opt(OPT_ATTN_PP);
   if (pp == 7) return flash_attn_d64_m16(q, k, vt, o, batch, heads, S, q_blocks, q_bs, q_rs, vt_bs, vt_rs, o_bs, o_rs, blocks, stream);
-  if (pp == 6) return flash_attn_d64_q64(q, k, vt, o, batch, heads, S, q_blocks, q_bs, q_rs, vt_bs, vt_rs, o_bs, o_rs, blocks, stream);
   return 1;
 }
 }
@@ -983,8 +978,7 @@ static void launch_main41(dim3 g, dim3 blk, hipStream_t s, const alg::AttnP& p) 
   if (pp >= 3 && ((int64_t)(p.S + 4 * alg::KVB) * p.q_rs * 2 >= (1ll << 31) || (int64_t)65 * p.vt_rs * 2 >= (1ll << 31))) pp = 0;
   switch (pp) {
     case 4:   // the default: one 8-wave workgroup per unit
-    case 6:   // a call flash_attn_d64_q64() / flash_attn_d64_m16() declined (fewer than 12 KV tiles, 31-bit offsets, V^T pitch): the
-    case 7:   // 8-wave 32x32x16 statement kernel
+    case 7:   // a call flash_attn_d64_m16() declined (fewer than 12 KV tiles, 31-bit offsets, V^T pitch): the 32x32x16 statement kernel
       hipLaunchKernelGGL(alg::flash_attn_d64_pipe_kernel<8>, g, dim3(512), 0, s, p);
       break;
     default: hipLaunchKernelGGL((alg::flash_attn_d64_kernel<41, 8>), g, blk, 0, s, p); break;

@@ -34,7 +34,7 @@ struct OptDef {
 };
 static const OptDef g_defs[OPT_COUNT] = {
     {"ALG_ATTN_SPLIT_TAIL", 1, 2, {0, 1}},
-    {"ALG_ATTN_PP", 4, 4, {0, 4, 6, 7}},
+    {"ALG_ATTN_PP", 4, 3, {0, 4, 7}},
     {"ALG_ATTN_VARIANT", 33, 2, {1, 33}},
     {"ALG_ATTN128_PIPE", 1, 2, {0, 1}},
     {"ALG_ATTN128_Q64", 1, 4, {0, 1, 2, 3}},

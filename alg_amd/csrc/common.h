@@ -19,8 +19,9 @@ int check_launch(const char* what);
 // capi.hip's table and in README.md).
 enum Opt {
   OPT_ATTN_SPLIT_TAIL,  // ALG_ATTN_SPLIT_TAIL   1 (default) | 0: the d = 64 attention as a single launch (no split-KV tail)
-  OPT_ATTN_PP,          // ALG_ATTN_PP           4 (8-wave pipelined main launch) | 6: the 64-queries-per-wave statement kernel
-                        //                       (attention64_q64.hip; a call it declines runs the default, 4) | 0: the straight loop
+  OPT_ATTN_PP,          // ALG_ATTN_PP           4 (8-wave pipelined main launch, v_mfma_f32_32x32x16_bf16) | 7: the same construction on
+                        //                       v_mfma_f32_16x16x32_bf16 (attention64_m16.hip; a call it declines runs the default, 4) |
+                        //                       0: the straight loop
   OPT_ATTN_VARIANT,     // ALG_ATTN_VARIANT      33 (default: lazy running max) | 1: exact running max, fp32 row sums
   OPT_ATTN128_PIPE,     // ALG_ATTN128_PIPE      1 (default: pipelined d = 128 kernel) | 0: the straight loop
   OPT_ATTN128_Q64,      // ALG_ATTN128_Q64       1 (default: 64-queries-per-wave kernel for >= 4,096 keys) | 2: for every call it can

@@ -265,11 +265,11 @@ def filter_microbench(dev):
         pmc = FILTER_PMC_BYTES.get(name)
         if pmc is not None:   # rocprofv3 FETCH_SIZE (x 2, gfx950) + WRITE_SIZE of the same launch shape, committed under profiles/
             out[name].update(pmc_mbytes=pmc / 1e6, pmc_over_algorithmic=pmc / nbytes, pmc_gbs=pmc / (ms / 1e3) / 1e9,
-                             pmc_source="profiles/r3_pmc_filters_hbm.txt")
+                             pmc_source="profiles/r6_pmc_filters_hbm.txt")
     return out
 
 
-# HBM-side bytes per launch of the three batched filter shapes from the committed --pmc passes (profiles/r3_pmc_filters_hbm.txt:
+# HBM-side bytes per launch of the three batched filter shapes from the committed --pmc passes (profiles/r6_pmc_filters_hbm.txt, re-taken in round 6:
 # 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes): they equal the algorithmic bytes to 0.1-1.1 % -- nothing is re-read.
 FILTER_PMC_BYTES = {
     "down_up_c5_8videos_f32": (2 * 9.462e4 + 1.89e5) * 1024.0,
@@ -874,7 +874,6 @@ def timed_region(wl, warmup, steps, parallel, measure_box=False):
 # switched ON (what the instrumented headline region pays for them).
 AB_ARMS = [
     ("attn_m16_statement", "env", "ALG_ATTN_PP", "7", "round 6: the d = 64 8-wave statement on v_mfma_f32_16x16x32_bf16 (attention64_m16.hip, ALG_ATTN_PP=7) as the OFF arm; > 0: the default (32x32x16 statement) is faster"),
-    ("attn_8wave_statement_vs_q64", "env", "ALG_ATTN_PP", "6", "round 5: the default 8-wave 32-query d = 64 statement vs the 64-queries-per-wave statement (attention64_q64.hip, ALG_ATTN_PP=6); > 0: the default is faster"),
     ("attn_pipelined", "env", "ALG_ATTN_PP", "0", "round 3: pipelined d = 64 attention vs the straight loop"),
     ("attn_split_tail", "env", "ALG_ATTN_SPLIT_TAIL", "0", "round 2: split-KV tail of the attention launch vs a single launch"),
     ("gemm_schedule10", "env", "ALG_GEMM_PIPE", "9", "round 6: GEMM schedule 10 (the asm K loop on v_mfma_f32_16x16x32_bf16) vs schedule 9 (the same loop on 32x32x16)"),

@@ -41,8 +41,9 @@ const char* alg_last_error(void);
 /* Run-time options.  The library reads its ALG_* environment variables ONCE, when it is loaded; no launch path calls getenv.
  * A host that changes one of them afterwards calls alg_reload_env() (host-only, no GPU work; not to be called while another
  * thread is inside the library).  The default build knows seven, each selecting between bit-identical or documented-equivalent
- * schedules (README.md "Run-time options"): ALG_ATTN_SPLIT_TAIL, ALG_ATTN_PP (4 = the 8-wave pipelined statement, 6 = the 64-queries-per-wave statement -- a call it
- * declines (fewer than 12 KV tiles, 31-bit offsets, V^T pitch) runs the default, 4 --, 0 = the straight loop), ALG_ATTN_VARIANT, ALG_ATTN128_PIPE,
+ * schedules (README.md "Run-time options"): ALG_ATTN_SPLIT_TAIL, ALG_ATTN_PP (4 = the 8-wave pipelined statement on v_mfma_f32_32x32x16_bf16, 7 = the same construction on
+ * v_mfma_f32_16x16x32_bf16 -- a call it declines (fewer than 12 KV tiles, 31-bit offsets, V^T pitch) runs the default, 4 --, 0 = the
+ * straight loop), ALG_ATTN_VARIANT, ALG_ATTN128_PIPE,
  * ALG_ATTN128_Q64 (1 = the 64-queries-per-wave d = 128 kernel from 4,096 keys on, the default; 2 = for every call it can
  * take; 0 = off: the escape hatch back to the 32-query pipelined kernel), ALG_GEMM_PIPE, ALG_LOWPASS_PATH.  A value must be
  * a whole decimal integer the build knows; anything else (including "off", "1x", an empty string) leaves the default in

@@ -230,7 +230,7 @@ def test_static_hazard_rules_of_the_statements(width):
 
 def test_committed_incs_are_what_the_generator_emits(tmp_path, cfg128, cfg64):
     assert not G.EXP and G.DMA_STRIDE == 2 and G.DMA_SHIFT == 0        # no timing-experiment knob leaks into the committed text
-    for cfg, name in ((cfg128, "attn128_q64_loop.inc"), (cfg64, "attn64_q64_loop.inc")):
+    for cfg, name in ((cfg128, "attn128_q64_loop.inc"),):      # (the d = 64 mode's kernel left the library in round 6; the mode still runs above)
         out = tmp_path / name
         G.write(cfg, str(out))
         assert out.read_bytes() == open(os.path.join(ROOT, "alg_amd", "csrc", name), "rb").read(), name

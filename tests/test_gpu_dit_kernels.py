@@ -292,13 +292,14 @@ def test_qk_norm_rope_scaled_and_prescaled_attention(device):
 
 @pytest.mark.parametrize("Bn,S2,H2", [(1, 512, 2), (2, 1000, 3), (1, 513, 1), (1, 575, 2), (1, 640, 1), (1, 700, 2), (1, 832, 1),
                                        (1, 2050, 2), (8, 1200, 1)])
-def test_flash_attention_d64_q64_kernel(device, monkeypatch, Bn, S2, H2):
-    """attention64_q64.hip (64 queries per wave, the generated statement attn64_q64_loop.inc behind a C++ frame; ALG_ATTN_PP=6 for
-    pre-scaled calls over >= 12 KV tiles) against fp32 SDPA and against attention.hip's 8-wave 32-query kernel (ALG_ATTN_PP=4)
-    on the same tensors: ragged tails, tile counts that leave 0-3 tiles behind the statement's groups of four, rows whose
-    first-tile max is beyond +-64 (non-zero offset: those waves never enter the statement) next to rows in the zero-offset form,
-    late dominant keys (the statement refuses the tile, the exact path runs, the statement is RE-ENTERED), query blocks ending
-    mid-wave; 8 x 1 heads = enough units for the split-KV tail plan to engage next to the q64 main launch."""
+def test_flash_attention_d64_m16_kernel(device, monkeypatch, Bn, S2, H2):
+    """attention64_m16.hip (round 6: the 8-wave statement kernel on v_mfma_f32_16x16x32_bf16 -- 16 x 16 score blocks, two queries per
+    lane, the K-fragment row map that makes a lane's S blocks the PV operand in V^T's stored order; ALG_ATTN_PP=7 for pre-scaled calls
+    over >= 12 KV tiles) against fp32 SDPA and against attention.hip's 32x32x16 statement kernel (ALG_ATTN_PP=4) on the same
+    tensors: ragged tails (the 16 x 16 layout's own key mask), tile counts that leave 0-3 tiles behind the statement's groups of
+    four, rows whose first-tile max is beyond +-64 (non-zero offset: those waves never enter the statement) next to rows in the
+    zero-offset form, late dominant keys (the statement refuses the tile, the exact path runs), query blocks ending mid-wave; 8 x 1
+    heads = enough units for the split-KV tail plan to engage next to the m16 main launch.  Run-to-run identical."""
     g = torch.Generator().manual_seed(S2 + H2)
     c = 0.125 * 1.4426950408889634
     q, k, v = rnd((Bn, S2, H2, 64), g), rnd((Bn, S2, H2, 64), g), rnd((Bn, S2, H2, 64), g)
@@ -316,7 +317,7 @@ def test_flash_attention_d64_q64_kernel(device, monkeypatch, Bn, S2, H2):
     vt[:, :, torch.tensor([swap23(n) for n in range(S2)])] = v.reshape(Bn, S2, D).transpose(1, 2)
     vt = vt.to(device)
     outs, errs = {}, {}
-    for flag in ("6", "4"):
+    for flag in ("7", "4"):
         monkeypatch.setenv("ALG_ATTN_PP", flag)
         o = torch.full((Bn, S2, D), 3.0, dtype=BF, device=device)
         _lib.flash_attn_d64(qkb, qkb, vt, o, Bn, H2, S2, S2 * 2 * D, 2 * D, D * S_pad, S_pad, S2 * D, D, 0.125, k_off=D,
@@ -326,13 +327,13 @@ def test_flash_attention_d64_q64_kernel(device, monkeypatch, Bn, S2, H2):
         assert torch.isfinite(got).all(), flag
         errs[flag] = ((got - ref).abs().max().item(), (got - ref).abs().mean().item())
     assert errs["4"][0] <= 3e-2 and errs["4"][1] <= 2e-3, errs
-    assert errs["6"][0] <= 3e-2 and errs["6"][1] <= 2e-3, errs
-    assert (outs["6"].float() - outs["4"].float()).abs().max().item() <= 3.2e-2
-    monkeypatch.setenv("ALG_ATTN_PP", "6")
-    o2 = torch.empty_like(outs["6"])
+    assert errs["7"][0] <= 3e-2 and errs["7"][1] <= 2e-3, errs
+    assert (outs["7"].float() - outs["4"].float()).abs().max().item() <= 3.2e-2
+    monkeypatch.setenv("ALG_ATTN_PP", "7")
+    o2 = torch.empty_like(outs["7"])
     _lib.flash_attn_d64(qkb, qkb, vt, o2, Bn, H2, S2, S2 * 2 * D, 2 * D, D * S_pad, S_pad, S2 * D, D, 0.125, k_off=D,
                         q_prescaled=True)
-    assert torch.equal(o2, outs["6"])
+    assert torch.equal(o2, outs["7"])
 
 
 def test_patchify_unpatchify_timestep(device):
@@ -596,8 +597,8 @@ def test_pipelined_attention_kernel(device, monkeypatch, Bn, S2, H2):
     vt = vt.to(device)
     outs, errs = {}, {}
     # 7 = the 8-wave statement on v_mfma_f32_16x16x32_bf16 (attention64_m16.hip, round 6), 4 = the 8-wave statement on 32x32x16,
-    # 6 = the 64-queries-per-wave statement, 0 = the straight loop
-    forms = ("7", "4", "6", "0")
+    # 0 = the straight loop
+    forms = ("7", "4", "0")
     for pp in forms:
         monkeypatch.setenv("ALG_ATTN_PP", pp)
         o = torch.full((Bn, S2, D), 3.0, dtype=BF, device=device)
