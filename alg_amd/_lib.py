@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("ALG_HIP_LIB") or os.path.join(_HERE, "libalg_hip.so")
 ALG_F32, ALG_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
 GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS, GEMM_GATE_F32, GEMM_GATE_SEG_STRIDE = 1, 4, 8, 16
+GEMM_B_PACKED11 = 32     # B is the panel pack_b_p11 wrote (GEMM schedule 11: the weight straight into registers in fragment order)
 
 EXPORTS = (
     "alg_version", "alg_last_error", "alg_reload_env", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16", "alg_gemm_bf16_pair", "alg_gemm_bf16_pair_qk",
@@ -105,6 +106,9 @@ def load_library():
     lib.alg_down_up_workspace_bytes.argtypes = [c_int64] + [c_int] * 4
     lib.alg_gaussian_blur_workspace_bytes.argtypes = [c_int64] + [c_int] * 3
     lib.alg_flash_attn_d64_workspace_bytes.argtypes = [c_int] * 4
+    lib.alg_pack_b_p11_bytes.argtypes = [c_int, c_int]
+    lib.alg_pack_b_p11_bytes.restype = c_int64
+    lib.alg_pack_b_p11.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]
     lib.alg_cfg_ddim_step.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_float, c_float, c_float,
                                       c_float, c_float, c_void_p]
     lib.alg_cfg_combine.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_void_p]
@@ -726,6 +730,10 @@ def gemm_args(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=No
     """The alg_gemm_args struct of one call (offsets in elements)."""
     args = GemmArgs()
     fp8 = a_scale is not None
+    if isinstance(B, PackedB):
+        if (B.N, B.K) != (N, K) or b_off or strideB:
+            raise AlgHipError("packed B was built for N = %d, K = %d (shared by the batch, no offset)" % (B.N, B.K))
+        flags |= GEMM_B_PACKED11
     args.A = A.data_ptr() + A.element_size() * a_off
     args.B = B.data_ptr() + B.element_size() * b_off
     if fp8:
@@ -745,6 +753,29 @@ def gemm_args(A, B, C, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, gate=No
     args.seg_split, args.act, args.flags = seg_split, act, flags
     args.perm_col0 = perm_col0
     return args, fp8
+
+
+class PackedB:
+    """An nn.Linear weight [N, K] (bf16) re-ordered for GEMM schedule 11 (alg_pack_b_p11): pass it as `B` of `gemm` and the call
+    sets ALG_GEMM_B_PACKED11 itself.  Packed once when a model is loaded; the values are the weight's, only their order differs."""
+
+    def __init__(self, w):
+        lib = load_library()
+        _dev(w, "weight")
+        if w.dtype != torch.bfloat16 or w.dim() != 2 or w.stride(1) != 1:
+            raise AlgHipError("PackedB takes a 2-D bf16 weight with unit column stride")
+        self.N, self.K = int(w.shape[0]), int(w.shape[1])
+        nbytes = int(lib.alg_pack_b_p11_bytes(self.N, self.K))
+        if nbytes <= 0:
+            raise AlgHipError("PackedB: K = %d must be a positive multiple of 64" % self.K)
+        self.data = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        _check(lib.alg_pack_b_p11(_ptr(w), _ptr(self.data), self.N, self.K, int(w.stride(0)), _stream()), "alg_pack_b_p11")
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    def element_size(self):
+        return 2
 
 
 def gemm(*a, **kw):

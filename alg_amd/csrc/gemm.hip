@@ -17,6 +17,7 @@ int launch_gemm_p10_pair(const alg_gemm_args* a, int m_tiles_a, int n_tiles_a, c
                          hipStream_t s);
 int launch_gemm_p10_pair_qk(const alg_gemm_args* a, int m_tiles_a, int n_tiles_a, const alg_gemm_args* b, int m_tiles_b, int n_tiles_b,
                             const alg_qk_norm_rope_args* e, hipStream_t s);
+int launch_gemm_p11(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p9_fp8(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
 int launch_gemm_p6_conv(const alg_gemm_args* a, int m_tiles, int n_tiles, int64_t nwg, hipStream_t s);
@@ -138,6 +139,16 @@ static int gemm_entry(const alg_gemm_args* a, void* stream, bool fp8, bool valid
     return launch_gemm_p6_fp8(a, m_tiles, n_tiles, nwg, s);
   }
   if (a->conv_wp) return launch_gemm_p6_conv(a, m_tiles, n_tiles, nwg, s);
+  if (a->flags & ALG_GEMM_B_PACKED11) {
+    // the caller packed B for schedule 11 (alg_pack_b_p11): that schedule or nothing (B cannot be read any other way)
+    if (a->K < 128 || 256 * a->lda * 2 + (int64_t)a->K * 2 >= (1ll << 32) || a->strideB != 0 ||
+        (a->flags & (ALG_GEMM_BIAS_PER_ROW | ALG_GEMM_PERMUTE_COLS)) || ((uintptr_t)a->B & 15)) {
+      set_error("alg_gemm_bf16: a packed B (ALG_GEMM_B_PACKED11) needs K >= 128, 32-bit byte offsets inside a 256-row A panel, a B shared by "
+                "the batch (strideB = 0) and a plain column layout (no per-row bias / column permutation)");
+      return ALG_EINVAL;
+    }
+    return launch_gemm_p11(a, m_tiles, n_tiles, nwg, s);
+  }
   switch (gemm_pipe()) {
     case 9:   // 4 waves, hand-written asm main loop; needs two k-tiles and 32-bit byte offsets inside a 256-row panel
     case 10:

@@ -138,6 +138,8 @@ int alg_unipc_update(const float* x, const float* m0, const float* m1, const flo
 #define ALG_GEMM_BIAS_PER_ROW 1   /* bias indexed by output row (used for the transposed V projection) */
 #define ALG_GEMM_PERMUTE_COLS 4   /* store column n at n with bits 2 and 3 swapped (MFMA k-order for V^T) */
 #define ALG_GEMM_GATE_SEG_STRIDE 16 /* gate[1] sits gate_seg_stride elements after gate[0] instead of N */
+#define ALG_GEMM_B_PACKED11 32     /* B is NOT [N][K] but the panel alg_pack_b_p11 wrote from it (ldb ignored, strideB must be 0): the call runs
+                                     GEMM schedule 11 -- 1 x 4 waves, the weight fetched straight into registers in MFMA-fragment order */
 #define ALG_GEMM_GATE_F32 8       /* gate is float32 and C = bf16(R + gate * bf16(acc + bias)) with ONE final rounding
                                      (WanTransformerBlock: (x.float() + out * gate_msa).type_as(x)) */
 
@@ -170,6 +172,14 @@ typedef struct alg_gemm_args {
 /* C = R + gate * act(A @ B^T + bias)   (bias optional; either act or the residual(+gate) form).  K % 64 == 0, lda/ldb % 8 == 0,
  * A and B 16-byte aligned.  M and N are arbitrary (edge tiles clamp loads and guard stores). */
 int alg_gemm_bf16(const alg_gemm_args* args, void* stream);
+
+/* Packs an nn.Linear weight W [N][K] (bf16, row pitch ldb elements) for GEMM schedule 11 (ALG_GEMM_B_PACKED11): per (256-row tile of W,
+ * 64-deep k-tile) 32 KiB in MFMA-fragment order, rows past N zero.  alg_pack_b_p11_bytes(N, K) = ceil(N / 256) * (K / 64) * 32768 is the
+ * size of `packed` (caller-owned, 16-byte aligned).  K % 64 == 0, K >= 128.  Done once when a model is loaded; the reference's
+ * nn.Linear weights (e.g. the attn1.to_q / ff.net.* tensors behind /root/reference/pipeline_cogvideox_image2video_lowpass.py:1082) keep
+ * their values -- only the order in memory changes. */
+int64_t alg_pack_b_p11_bytes(int N, int K);
+int alg_pack_b_p11(const void* w, void* packed, int N, int K, int64_t ldb, void* stream);
 
 /* Two independent alg_gemm_bf16 calls as ONE persistent launch when both are plain (no residual, gate, activation or
  * convolution addressing; the Q|K and V^T projections of a DiT block, cog:1082-1090, read the same activations): the tiles of

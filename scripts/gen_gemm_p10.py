@@ -57,9 +57,17 @@ FIRST_CLOBBERED_VGPR = 155
 # scratch SGPR roles (as schedule 9)
 P, SA, SB, DA, T, T2, MA, MB, DB, CNT = ("%%[t%d]" % i for i in range(10))
 
-# experiment knobs (timing only: results are garbage)
+# experiment knobs.  NO_DMA / NO_READS are timing-only ablations (garbage results); the others are placement variants that stay
+# correct (the emulator suite runs them: tests/test_gemm_p10_statement_cpu.py::test_placement_variants_stay_correct)
 NO_DMA = os.environ.get("P10_NO_DMA") == "1"
 NO_READS = os.environ.get("P10_NO_READS") == "1"
+B1_ROWS = [int(x) for x in os.environ.get("P10_B1_ROWS", "2,3,4,5").split(",")]   # rows that read B set 1 (eight reads over these rows)
+DMA_GAP = int(os.environ.get("P10_DMA_GAP", "3"))                    # gap of a row (0..7) that carries its LDS-DMA piece
+B_EARLY_GAP = int(os.environ.get("P10_B_EARLY_GAP", "6"))
+# TIMING ONLY (garbage results): B's eight LDS-DMA pieces per k-tile become eight plain global_load_dwordx4 into registers (the B
+# fragment reads stay and stand in for the doubled A reads of a 1 x 4 wave layout): what a weight operand fetched straight into
+# registers would cost in issue slots, against the LDS-DMA pieces it replaces
+B_DIRECT = os.environ.get("P10_B_DIRECT") == "1"
 
 
 def read_a(ks, bi, slot):
@@ -76,6 +84,8 @@ def dma(panel, i):
     off = OFFA(i) if panel == "a" else OFFB(i)
     base = "%[pa]" if panel == "a" else "%[pb]"
     dst = DA if panel == "a" else DB
+    if B_DIRECT and panel == "b":
+        return ("s_nop 0", ["global_load_dwordx4 %s, %s, %s" % (FB(i >> 2, i & 3), off, base), "v_add_u32 %s, 0x80, %s" % (off, off)])
     return ("s_add_u32 m0, %s, %d" % (dst, (i >> 2) * SLOT + (i & 3) * 4096),
             ["global_load_lds_dwordx4 %s, %s" % (off, base), "v_add_u32 %s, 0x80, %s" % (off, off)])
 
@@ -138,15 +148,19 @@ def ktile(b_early, a_dma, barrier, b_late, res_copy=None):
             put_read(8 * r, read_a((r + 2) >> 3, (r + 2) & 7, (r + 2) & 3))
         elif barrier:
             put_read(8 * r, read_a(0, r - 14, (r + 2) & 3))
-    for r in (2, 3, 4, 5):           # B set 1 = k-step 1 of this k-tile
-        put_read(8 * r + 2, read_b(1, 2 * (r - 2), 1))
-        put_read(8 * r + 5, read_b(1, 2 * (r - 2) + 1, 1))
+    nb1 = len(B1_ROWS)
+    assert 8 % nb1 == 0 and max(B1_ROWS) < 8      # (set 1 is consumed from row 8 on)
+    per = 8 // nb1
+    b1_gaps = {1: (2,), 2: (2, 5), 4: (1, 2, 5, 6), 8: (0, 1, 2, 3, 4, 5, 6, 7)}[per]
+    for k, r in enumerate(B1_ROWS):           # B set 1 = k-step 1 of this k-tile
+        for q in range(per):
+            put_read(8 * r + b1_gaps[q], read_b(1, per * k + q, 1))
     if b_early:
         for i in range(4):
-            put_dma(8 * i + 6, "b", 4 + i)
+            put_dma(8 * i + B_EARLY_GAP, "b", 4 + i)
     if a_dma:
         for i in range(8):
-            put_dma(8 * (4 + i) + 3, "a", i)
+            put_dma(8 * (4 + i) + DMA_GAP, "a", i)
     if res_copy is not None:
         lds = res_loads(res_copy)
         for k, ins in enumerate(lds):

@@ -135,6 +135,19 @@ def main():
         cases["attn128"] = (lambda: _lib.flash_attn_d128(qw, kw, vtw, ow, N, Hw, Sw, Sw, Sw * Dw, Dw, Sw * Dw, Dw,
                                                          Dw * Sw_pad, Sw_pad, Sw * Dw, Dw, 128 ** -0.5),
                             4.0 * N * Hw * Sw * Sw * 128, "flop")
+    if only & {"gemm_qk_p11", "gemm_out_p11", "gemm_ff1_p11", "gemm_ff2_p11"}:
+        # GEMM schedule 11: the weight packed in fragment order and loaded straight into registers (1 x 4 wave layout)
+        pqk, pwo, pf1, pf2 = (_lib.PackedB(t) for t in (wqk, wo, wf1, wf2))
+        cases["gemm_qk_p11"] = (lambda: G(y, pqk, qk, S, 2 * D, D, D, D, 2 * D, bias=bqk, batch=N, strideA=S * D, strideC=S * 2 * D),
+                                2.0 * N * S * D * 2 * D, "flop")
+        cases["gemm_out_p11"] = (lambda: G(att, pwo, x, S, D, D, D, D, D, bias=bo, R=x, ldr=D, gate=mod, gate_off=4 * D,
+                                           strideGate=12 * D, seg_split=T, batch=N, strideA=S * D, strideC=S * D, strideR=S * D),
+                                 2.0 * N * S * D * D, "flop")
+        cases["gemm_ff1_p11"] = (lambda: G(y, pf1, h, S, F4, D, D, D, F4, bias=bf1, act=_lib.ACT_GELU_TANH, batch=N, strideA=S * D,
+                                           strideC=S * F4), 2.0 * N * S * D * F4, "flop")
+        cases["gemm_ff2_p11"] = (lambda: G(h, pf2, x, S, D, F4, F4, F4, D, bias=bf2, R=x, ldr=D, gate=mod, gate_off=10 * D,
+                                           strideGate=12 * D, seg_split=T, batch=N, strideA=S * F4, strideC=S * D, strideR=S * D),
+                                 2.0 * N * S * D * F4, "flop")
     res = {}
     for name, (fn, work, kind) in cases.items():
         if only and name not in only:

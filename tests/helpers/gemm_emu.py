@@ -173,3 +173,108 @@ def run_plain(pb, lazy_reads, lazy_dma, mutate=None, va=(1 << 32) - 70000, res=F
                     R[row, col] = asm_emu.bf16_to_f32((word & 0xFFFF).astype(np.uint16))
                     R[row, col + 1] = asm_emu.bf16_to_f32((word >> 16).astype(np.uint16))
     return C, R, n, lines
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# schedule 11 (scripts/gen_gemm_p11.py): 1 x 4 wave layout, A through the LDS ring, B pre-packed in fragment order and loaded
+# straight into registers
+# ---------------------------------------------------------------------------------------------------------------------
+def pack_b_p11(b, nk):
+    """what alg_pack_b_p11 writes for ONE 256-column tile: [k-tile][wave 4][k-step 2][n-block 4][lane 64][8 bf16]; rows past the
+    operand's last row are zeros"""
+    rows = b.shape[0]
+    out = np.zeros((nk, 4, 2, 4, 64, 8), dtype=np.uint16)
+    bb = asm_emu.f32_to_bf16(b)
+    for w in range(4):
+        for bj in range(4):
+            for lane in range(64):
+                n = 64 * w + 16 * bj + (lane & 15)
+                if n >= rows:
+                    continue
+                g = lane >> 4
+                for kt in range(nk):
+                    for ks in range(2):
+                        k0 = 64 * kt + 32 * ks + 8 * g
+                        out[kt, w, ks, bj, lane] = bb[n, k0:k0 + 8]
+    return out
+
+
+def run_p11(pb, lazy_reads, lazy_dma, mutate=None, va=(1 << 32) - 70000, res=False):
+    """-> C [256, 256] float64 as schedule 11's statement leaves it in the accumulators (+ the residual tile in the residual form)"""
+    import gen_gemm_p11 as GP11
+    lines = GP11.emit(res=res)
+    if mutate is not None:
+        lines = mutate(lines)
+    # the packed B panel lives behind the problem's own image (A, row-major B -- unused here --, R)
+    packed = pack_b_p11(pb.b, pb.nk).reshape(-1).view(np.uint8)
+    POFF = (pb.gmem.size + 255) // 256 * 256 + 128
+    gmem = np.full(POFF + packed.size + 512, 0xC0, dtype=np.uint8)
+    gmem[:pb.gmem.size] = pb.gmem
+    gmem[1:POFF:2] = np.where(np.arange(1, POFF, 2) >= pb.gmem.size, 0x7F, gmem[1:POFF:2])      # (bf16 NaN in the gap)
+    gmem[POFF:POFF + packed.size] = packed
+    gmem[POFF + packed.size:] = 0xFF                                                              # NaN behind the panel
+    tab = {}
+    if res:
+        for i in range(32):
+            tab["r%d" % i] = "v[%d:%d]" % (16 + 4 * i, 19 + 4 * i)
+        tab["rvoff"], tab["ldr16"], tab["rs"] = "v6", "s18", "s[24:27]"
+    for i, n in enumerate(("vl0", "vl1", "vrow", "vslot", "vb0", "vb1")):
+        tab[n] = "v%d" % i
+    for i in range(10):
+        tab["t%d" % i] = "s%d" % i
+    for i, n in enumerate(("lda2", "rmaxa", "nloop", "wave1k")):
+        tab[n] = "s%d" % (10 + i)
+    tab["pa"], tab["db"] = "s[20:21]", "s[28:31]"
+    m = asm_emu.Machine(asm_emu.bind(lines, tab), n_waves=4, gmem=gmem, lazy_reads=lazy_reads, lazy_dma=lazy_dma, gmem_va=va)
+
+    def sset(w, name, val):
+        r = asm_emu.parse_reg(tab[name])
+        w.s[r[1]] = np.uint32(int(val) & 0xFFFFFFFF)
+        if r[2] == 2:
+            w.s[r[1] + 1] = np.uint32(int(val) >> 32)
+    for w in m.waves:
+        ln = np.arange(64)
+        l15, g4 = ln & 15, ln >> 4
+        w.v[2] = (w.id * 8 + (ln >> 3)).astype(np.uint32)                                     # vrow
+        w.v[3] = (((ln & 7) ^ ((w.id * 4 + (ln >> 4)) & 7)) * 16).astype(np.uint32)           # vslot
+        for ks in range(2):
+            w.v[ks] = (l15 * 128 + (((4 * ks + g4) ^ ((l15 >> 1) & 7)) * 16)).astype(np.uint32)
+        w.v[4] = (ln * 16).astype(np.uint32)
+        w.v[5] = (ln * 16 + 4096).astype(np.uint32)
+        sset(w, "lda2", pb.lda * 2), sset(w, "rmaxa", pb.rows_a - 1), sset(w, "nloop", pb.nk - 2), sset(w, "wave1k", w.id * 1024)
+        sset(w, "pa", va + pb.AOFF)
+        base = va + POFF + w.id * 8192
+        for i, val in enumerate((base & 0xFFFFFFFF, (base >> 32) & 0xFFFF, pb.nk * 32768 - w.id * 8192 - 24576 + 8192, 0x00020000)):
+            w.s[28 + i] = np.uint32(val)
+        if res:
+            w.v[6] = (((ln >> 2) * pb.ldr + w.id * 64 + (ln & 3) * 8) * 2).astype(np.uint32)
+            sset(w, "ldr16", pb.ldr * 32)
+            rb = va + pb.ROFF
+            for i, val in enumerate((rb & 0xFFFFFFFF, (rb >> 32) & 0xFFFF, ((pb.rows_a - 1) * pb.ldr + 256) * 2, 0x00020000)):
+                w.s[24 + i] = np.uint32(val)
+    n = m.run()
+    C = np.zeros((256, 256))
+    for w in m.waves:
+        ln = np.arange(64)
+        for mt in range(8):
+            for nt in range(2):
+                for e in range(16):
+                    q, i = e >> 2, e & 3
+                    mrow = mt * 32 + 16 * (q >> 1) + (ln & 15)
+                    ncol = w.id * 64 + nt * 32 + 16 * (q & 1) + 4 * (ln >> 4) + i
+                    C[mrow, ncol] = w.a[16 * (2 * mt + nt) + e].view(np.float32)
+    if not res:
+        return C, n, lines
+    R = np.zeros((256, 256))
+    for w in m.waves:
+        ln = np.arange(64)
+        for mt in range(8):
+            for nt in range(2):
+                for half in range(2):
+                    it = ((mt * 2 + nt) << 1) | half
+                    for k in range(4):
+                        word = w.v[16 + 4 * it + k]
+                        row, col = mt * 32 + 16 * half + (ln >> 2), w.id * 64 + nt * 32 + (ln & 3) * 8 + 2 * k
+                        R[row, col] = asm_emu.bf16_to_f32((word & 0xFFFF).astype(np.uint16))
+                        R[row, col + 1] = asm_emu.bf16_to_f32((word >> 16).astype(np.uint16))
+    return C, R, n, lines

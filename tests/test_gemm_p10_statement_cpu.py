@@ -152,3 +152,25 @@ def test_residual_wait_is_load_bearing():
         e = relerr(c, ref)
         worst = max(worst, e if np.isfinite(e) else 1.0)
     assert worst > 1e3 * TOL
+
+
+@pytest.mark.parametrize("env", [{"P10_B1_ROWS": "0,1,2,3"}, {"P10_B1_ROWS": "0,1,2,3,4,5,6,7"}, {"P10_DMA_GAP": "6"},
+                                 {"P10_B1_ROWS": "1,3,5,7", "P10_DMA_GAP": "7", "P10_B_EARLY_GAP": "4"}])
+def test_placement_variants_stay_correct(env, monkeypatch):
+    """the generator's placement knobs (which rows read B set 1, which gap of a row carries its LDS-DMA piece) move instructions, never
+    the protocol: the computed waits follow, and every variant still computes the tile under lazy reads + lazy DMA"""
+    import importlib
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    importlib.reload(G10)
+    try:
+        H.GP10 = G10
+        for nk, res in ((5, False), (9, True)):
+            pb = H.Problem(nk, seed=40 + nk)
+            out = H.run_plain(pb, True, True, res=res, sched=10)
+            assert relerr(out[0], pb.reference()) < TOL, (env, nk, res)
+    finally:
+        for k in env:
+            monkeypatch.delenv(k)
+        importlib.reload(G10)
+        H.GP10 = G10
