@@ -25,6 +25,7 @@ HBM layout (all bf16, allocated once per batch size N and reused every step):
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, asdict
 from typing import Optional
 
@@ -101,6 +102,11 @@ class CogVideoXTransformer3DModel:
         # measured on the same box (profiles/r4_fuse_qk_norm_ab.txt) the ~20 VALU operations per element cost more in a
         # one-wave-per-SIMD store loop (+9.5 ms per step) than the stand-alone kernel at full occupancy (8.4 ms per step)
         self.fuse_qk_norm = False
+        # True (default): the attention-output and feed-forward weights are also kept packed in MFMA-fragment order
+        # (alg_pack_b_p11, once, here) and those three GEMMs run schedule 11 (1 x 4 waves, the weight straight from L2 into registers;
+        # bit-identical to schedule 10).  False, or ALG_GEMM_PIPE set to another schedule than 10: the row-major weights (A/B runs).
+        # The Q|K projection stays on the pair launch with V^T (whose B operand is the activation).
+        self.packed_weights = True
         self._sincos = {}
         dev = self.device
         w = weights
@@ -153,6 +159,8 @@ class CogVideoXTransformer3DModel:
             L["bf1"] = _bf(w[b + "ff.net.0.proj.bias"], dev)
             L["wf2"] = _bf(w[b + "ff.net.2.weight"], dev)
             L["bf2"] = _bf(w[b + "ff.net.2.bias"], dev)
+            for nm in ("wo", "wf1", "wf2"):
+                L["p" + nm] = _lib.PackedB(L[nm])
             self.layers.append(L)
         # norm_out: chunk order (shift, scale) -> (shift, shift, scale, scale) so both segments are valid
         ow, ob = w["norm_out.linear.weight"], w["norm_out.linear.bias"]
@@ -369,6 +377,8 @@ class CogVideoXTransformer3DModel:
         prescale = self.attn_prescale
         q_scale = scale * 1.4426950408889634 if prescale else 1.0
         F4 = cfg.ff_inner_mult * D
+        packed = self.packed_weights and os.environ.get("ALG_GEMM_PIPE", "10") == "10"
+        wo_k, wf1_k, wf2_k = ("pwo", "pwf1", "pwf2") if packed else ("wo", "wf1", "wf2")
         for li, L in enumerate(self.layers):
             m1 = li * 12 * D          # norm1: shift @+0, scale @+2D, gate @+4D (each [2][D])
             m2 = m1 + 6 * D           # norm2
@@ -391,13 +401,13 @@ class CogVideoXTransformer3DModel:
                                    cfg.qk_norm_eps, q_scale=q_scale)
             TM("attn", _lib.flash_attn_d64, qk, qk, vt, att, N, Hn, S, S * 2 * D, 2 * D, D * S_pad, S_pad, S * D, D, scale,
                                 k_off=D, q_prescaled=prescale)
-            TM("gemm_out", G, att, L["wo"], x, S, D, D, D, D, D, bias=L["bo"], R=x, ldr=D, gate=mod, gate_off=m1 + 4 * D,
+            TM("gemm_out", G, att, L[wo_k], x, S, D, D, D, D, D, bias=L["bo"], R=x, ldr=D, gate=mod, gate_off=m1 + 4 * D,
               strideGate=self.mod_cols, seg_split=T, batch=N, strideA=S * D, strideC=S * D, strideR=S * D)
             TM("ln_mod", _lib.layernorm_modulate, x, y, L["norm2_w"], L["norm2_b"], mod, mod, self.mod_cols, N, S, D,
                T, cfg.norm_eps, scale_off=m2 + 2 * D, shift_off=m2)
-            TM("gemm_ff1", G, y, L["wf1"], h, S, F4, D, D, D, F4, bias=L["bf1"], act=_lib.ACT_GELU_TANH, batch=N, strideA=S * D,
+            TM("gemm_ff1", G, y, L[wf1_k], h, S, F4, D, D, D, F4, bias=L["bf1"], act=_lib.ACT_GELU_TANH, batch=N, strideA=S * D,
               strideC=S * F4)
-            TM("gemm_ff2", G, h, L["wf2"], x, S, D, F4, F4, F4, D, bias=L["bf2"], R=x, ldr=D, gate=mod, gate_off=m2 + 4 * D,
+            TM("gemm_ff2", G, h, L[wf2_k], x, S, D, F4, F4, F4, D, bias=L["bf2"], R=x, ldr=D, gate=mod, gate_off=m2 + 4 * D,
               strideGate=self.mod_cols, seg_split=T, batch=N, strideA=S * F4, strideC=S * D, strideR=S * D)
 
         # 4. norm_final over the joint sequence, AdaLayerNorm on the video tokens, proj_out, unpatchify

@@ -147,6 +147,10 @@ class WanTransformer3DModel:
         self.pair_qkv = True     # bf16: Q|K and V^T projections of a block as one alg_gemm_bf16_pair launch (bit-identical)
         self.dual_cross = True   # I2V: text + image cross-attention of a block as one alg_flash_attn_d128_dual launch (bit-identical to two launches + add)
         self.fuse_quant = True   # fp8: the modulated LayerNorm writes the e4m3 tokens + row scales itself (bit-identical to the quantiser pass)
+        # bf16: the five weight-times-token linears of a block outside the Q|K / V^T pair (out, cross q, cross out, ff1, ff2) keep a copy
+        # packed in MFMA-fragment order (alg_pack_b_p11) and run GEMM schedule 11 (bit-identical to schedule 10); False, or
+        # ALG_GEMM_PIPE set to another schedule than 10: the row-major weights
+        self.packed_weights = True
         if config.qk_norm != "rms_norm_across_heads" or config.attention_head_dim != 128:
             raise NotImplementedError("the Wan DiT path is built for rms_norm_across_heads and head_dim 128")
         if tuple(config.patch_size)[0] != 1:
@@ -220,6 +224,8 @@ class WanTransformer3DModel:
                     sc = torch.empty(wt.shape[0], dtype=torch.float32, device=dev)
                     _lib.quantize_fp8_rows(wt, q, sc, wt.shape[0], wt.shape[1])
                     setattr(L, name, (q, sc))          # the bf16 copy is dropped: half the weight memory
+            else:
+                L.packed = {name: _lib.PackedB(getattr(L, name)) for name in ("wo", "cq_w", "co_w", "f1_w", "f2_w")}
             self.blocks.append(L)
         self.w = w
         self._ws = {}
@@ -389,7 +395,7 @@ class WanTransformer3DModel:
             """C = epilogue(A @ W^T): bf16, or e4m3 operands when the block weights are quantised (A is re-quantised per
             token unless the previous call already left its e4m3 copy in the workspace)."""
             if not self.fp8:
-                return T(name, G, A, Wt, C, M_, N_, K_, lda, K_, ldc, **kw)
+                return T(name, G, A, (packed.get(id(Wt)) or Wt) if packed else Wt, C, M_, N_, K_, lda, K_, ldc, **kw)
             if requant:
                 T("quant", _lib.quantize_fp8_rows, A, ws.q8, ws.q8s, N * S, K_, x_rstride=lda)
             sa = kw.pop("strideA", 0)
@@ -405,7 +411,11 @@ class WanTransformer3DModel:
                 return T("ln_mod", _lib.layernorm_mod_f32_fp8, ws.x, ws.q8, ws.q8s, wgt, bia, sc, sh, bs, N, S, D, cfg.eps, **kw)
             return T("ln_mod", _lib.layernorm_mod_f32, ws.x, ws.y, wgt, bia, sc, sh, bs, N, S, D, cfg.eps, **kw)
 
+        use_packed = not self.fp8 and self.packed_weights and os.environ.get("ALG_GEMM_PIPE", "10") == "10"
+        packed = None
         for li, L in enumerate(self.blocks):
+            if use_packed:   # lin() looks the row-major weight up by identity
+                packed = {id(getattr(L, name)): pw for name, pw in L.packed.items()}
             m0 = li * N * 6 * D  # element offset of this block's [N, 6, D] modulation: shift, scale, gate, c_shift, c_scale, c_gate
             # ---- self-attention ----
             ln_mod(None, None, ws.mod, ws.mod, mod_bs, scale_off=m0 + D, shift_off=m0)

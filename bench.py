@@ -876,7 +876,8 @@ AB_ARMS = [
     ("attn_m16_statement", "env", "ALG_ATTN_PP", "7", "round 6: the d = 64 8-wave statement on v_mfma_f32_16x16x32_bf16 (attention64_m16.hip, ALG_ATTN_PP=7) as the OFF arm; > 0: the default (32x32x16 statement) is faster"),
     ("attn_pipelined", "env", "ALG_ATTN_PP", "0", "round 3: pipelined d = 64 attention vs the straight loop"),
     ("attn_split_tail", "env", "ALG_ATTN_SPLIT_TAIL", "0", "round 2: split-KV tail of the attention launch vs a single launch"),
-    ("gemm_schedule10", "env", "ALG_GEMM_PIPE", "9", "round 6: GEMM schedule 10 (the asm K loop on v_mfma_f32_16x16x32_bf16) vs schedule 9 (the same loop on 32x32x16)"),
+    ("gemm_schedule11", "attr", "packed_weights", 0, "round 6: out / ff1 / ff2 on GEMM schedule 11 (1 x 4 waves, the weight pre-packed and loaded straight into registers) vs schedule 10 for all"),
+    ("gemm_schedule10", "env", "ALG_GEMM_PIPE", "9", "round 6: GEMM schedules 10 / 11 (the asm K loop on v_mfma_f32_16x16x32_bf16) vs schedule 9 (the same loop on 32x32x16) for all"),
     ("gemm_schedule9", "env", "ALG_GEMM_PIPE", "6", "round 3: the asm K loop (here: schedule 10) vs the 8-wave ping-pong"),
     ("pair_qkv", "attr", "pair_qkv", 0, "round 4: Q|K and V^T projections as one persistent launch vs two launches"),
     ("events", "events", None, None, "the bench's own HIP-event brackets around every kernel family, switched ON (headline region has them)"),

@@ -59,6 +59,13 @@ ACC = lambda bi, bj: "a[%d:%d]" % (acc_index(bi, bj), acc_index(bi, bj) + 3)
 P, SA, KB, DA, T, T2, PAR, X7, X8, CNT = ("%%[t%d]" % i for i in range(10))
 
 NO_B_WAIT = os.environ.get("P11_NO_B_WAIT") == "1"      # TIMING ONLY: nothing waits for the B loads
+NO_DMA = os.environ.get("P11_NO_DMA") == "1"            # TIMING ONLY: no LDS-DMA piece of A is issued in the loop
+NO_READS = os.environ.get("P11_NO_READS") == "1"        # TIMING ONLY: no A fragment is read in the loop
+NO_B = os.environ.get("P11_NO_B") == "1"                # TIMING ONLY: no B fragment is loaded in the loop
+# rows (0-27) whose second gap issues one LDS-DMA piece of A(kt + 2) / one B fragment load of k-tile kt + 1
+DMA_ROWS = [int(x) for x in os.environ.get("P11_DMA_ROWS", "8,10,12,14,16,18,20,22").split(",")]
+B_ROWS = [int(x) for x in os.environ.get("P11_B_ROWS", "0,1,2,3,4,5,6,7").split(",")]
+assert len(DMA_ROWS) == 8 and len(B_ROWS) == 8 and max(DMA_ROWS + B_ROWS) < BAR and sorted(DMA_ROWS) == DMA_ROWS and sorted(B_ROWS) == B_ROWS
 
 
 def read_a(ks, bi, slot):
@@ -114,19 +121,20 @@ def ktile(par, b_next, a_dma, barrier, res_copy=None):
     # last read of this k-tile, row 31's, was issued in row 28: two rows earlier), behind it rows 30 / 31 read rows 0, 1 / 2 of the next
     for r in range(32 - AHEAD):
         tgt = r + AHEAD
-        gaps[4 * r].append(read_a(tgt >> 4, tgt & 15, tgt & 3))
-    if barrier:
+        if not NO_READS:
+            gaps[4 * r].append(read_a(tgt >> 4, tgt & 15, tgt & 3))
+    if barrier and not NO_READS:
         gaps[4 * 30].append(read_a(0, 0, 0))
         gaps[4 * 30 + 2].append(read_a(0, 1, 1))
         gaps[4 * 31].append(read_a(0, 2, 2))
-    if b_next:
+    if b_next and not NO_B:
         for f in range(8):
-            gaps[4 * f + 1].append(load_b(par ^ 1, f))
-        gaps[4 * 7 + 2].append("s_add_u32 %s, %s, 0x8000" % (KB, KB))
-    if a_dma:
+            gaps[4 * B_ROWS[f] + (1 if B_ROWS[f] not in DMA_ROWS else 3)].append(load_b(par ^ 1, f))
+        gaps[4 * B_ROWS[7] + 2].append("s_add_u32 %s, %s, 0x8000" % (KB, KB))
+    if a_dma and not NO_DMA:
         for i in range(8):
             m0, rest = dma_a(i)
-            gaps[4 * (8 + 2 * i) + 1] += [m0, "s_nop 0"] + rest
+            gaps[4 * DMA_ROWS[i] + 1] += [m0, "s_nop 0"] + rest
     if res_copy is not None:
         lds = res_loads(res_copy)     # (load, load, add, load, load, add)
         gaps[4 * 24 + 1] += lds[0:1]
@@ -140,8 +148,11 @@ def ktile(par, b_next, a_dma, barrier, res_copy=None):
         r, bj = j >> 2, j & 3
         ks, bi = r >> 4, r & 15
         if j == 4 * BAR and barrier:
-            allowed = (8 if a_dma else 0) + (4 if res_copy is not None else 0)
-            if NO_B_WAIT:
+            # in-order counter: everything issued BEFORE the first piece of A(kt + 2) must have landed
+            late_b = sum(1 for f in range(8) if B_ROWS[f] > DMA_ROWS[0]) if (b_next and a_dma) else 0
+            assert late_b == 0 or NO_B_WAIT, "a B load behind the first A piece would need the A pieces waited for as well"
+            allowed = (8 if a_dma and not NO_DMA else 0) + (4 if res_copy is not None else 0)
+            if NO_B_WAIT and b_next and not NO_B:
                 allowed += 8
             body += ["s_waitcnt vmcnt(%d) lgkmcnt(0)" % allowed, "s_barrier"] + advance()
         body.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (ACC(bi, bj), FB(par, 4 * ks + bj), FA(r & 3), ACC(bi, bj)))
@@ -168,7 +179,7 @@ def prologue():
     out += ["v_accvgpr_write_b32 a%d, 0" % i for i in range(256)]
     out += ["s_mov_b32 %s, 0" % P] + addr_math()
     out += ["s_waitcnt vmcnt(8)", "s_barrier"]        # B(0) and A(0) have landed (A(1) may be in flight)
-    out += [read_a(0, r, r & 3) for r in range(AHEAD)]
+    out += [read_a(0, r, r & 3) for r in range(AHEAD) if not NO_READS]
     # the last AHEAD rows of a k-tile read the next k-tile's rows 0 .. AHEAD - 1 in this order: row 28 reads rows (28 + AHEAD - 32 ...)
     return out
 

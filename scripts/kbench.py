@@ -159,6 +159,20 @@ def main():
         res[name] = dict(ms=round(med, 4), best_ms=round(best, 4), rate=round(rate, 1),
                          unit="TFLOP/s" if kind == "flop" else "GB/s")
         print("%-14s %9.3f ms (best %9.3f)  %8.1f %s" % (name, med, best, rate, res[name]["unit"]), flush=True)
+        if name.startswith("gemm_") and hasattr(_lib.load_library(), "alg_dbg_gemm_tap"):
+            # experiment builds with the per-workgroup clock tap (scripts/build_p1x_variant.sh ... TAP=1): the shader clock the launch
+            # ran at, the share of the K-loop statements in the workgroup's cycles, and MFMA-issue cycles / loop cycles
+            import ctypes
+            fn(); torch.cuda.synchronize()
+            buf = (ctypes.c_uint64 * 4096)()
+            if _lib.load_library().alg_dbg_gemm_tap(buf) == 0:
+                t = torch.tensor(list(buf), dtype=torch.float64).view(1024, 4)
+                t = t[t[:, 3] > 0]
+                K = F4 if "ff2" in name else D
+                mhz = (t[:, 0] / t[:, 1]).mean().item() * _lib.wall_clock_khz() / 1e3
+                busy = (t[:, 3] * (K // 64) * 128 * 16 / t[:, 2]).mean().item()
+                print("    tap: %d workgroups, clock %.0f MHz, K loops %.1f %% of the cycles, MFMA issue / loop cycles %.3f, tiles/wg %.2f"
+                      % (t.shape[0], mhz, 100 * (t[:, 2] / t[:, 0]).mean().item(), busy, t[:, 3].mean().item()), flush=True)
     if args.check and (not only or "attn" in only):
         # spot-check attention rows of one head against fp32 SDPA on the GPU (torch as checker)
         b, hh = N - 1, 5

@@ -61,6 +61,14 @@ def test_dit_forward_small(device):
     # determinism
     out3 = model(hs.to(device), ehs.to(device), ts, image_rotary_emb=rope, return_dict=False)[0]
     assert torch.equal(out, out3)
+    # the packed weights of GEMM schedule 11 (default) and the row-major ones on schedule 10 give the same bits
+    assert model.packed_weights
+    model.packed_weights = False
+    try:
+        out4 = model(hs.to(device), ehs.to(device), ts, image_rotary_emb=rope, return_dict=False)[0]
+    finally:
+        model.packed_weights = True
+    assert torch.equal(out, out4)
 
 
 def test_dit_forward_wider_and_ragged_tokens(device):

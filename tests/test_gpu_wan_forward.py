@@ -111,6 +111,22 @@ def test_wan_forward_dual_cross_attention_is_bit_identical_to_two_launches_and_t
     assert torch.equal(one, two) and bool(torch.isfinite(one.float()).all())
 
 
+def test_wan_forward_packed_weights_are_bit_identical_to_the_row_major_ones():
+    """`packed_weights` (default, bf16): out / cross-q / cross-out / ff1 / ff2 on GEMM schedule 11 with the weight packed in fragment
+    order -- the same bits as the row-major weights on schedule 10, through the whole forward (ragged token count)."""
+    cfg, ocfg = small(layers=2, heads=8)
+    sd = wan_oracle.init_weights(ocfg, seed=6)
+    model = WanTransformer3DModel(cfg, sd, device=DEV)
+    x, txt, img = inputs(2, 5, 14, 18, 6)
+    t = torch.tensor(501.0)
+    assert model.packed_weights and all(len(L.packed) == 5 for L in model.blocks)
+    run = lambda: model(x.to(DEV), t, txt.to(DEV), img.to(DEV), return_dict=False)[0].clone()
+    one = run()
+    model.packed_weights = False
+    two = run()
+    assert torch.equal(one, two) and bool(torch.isfinite(one.float()).all())
+
+
 def test_wan_alg_sampler_with_hip_dit():
     """wan:843-927 end to end: HIP filters + batch assembly + HIP DiT + CFG combine + UniPC, vs the loop oracle driving
     the fp32 oracle DiT on the CPU."""
