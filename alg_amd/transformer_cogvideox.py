@@ -105,7 +105,8 @@ class CogVideoXTransformer3DModel:
         # True (default): the attention-output and feed-forward weights are also kept packed in MFMA-fragment order
         # (alg_pack_b_p11, once, here) and those three GEMMs run schedule 11 (1 x 4 waves, the weight straight from L2 into registers;
         # bit-identical to schedule 10).  False, or ALG_GEMM_PIPE set to another schedule than 10: the row-major weights (A/B runs).
-        # The Q|K projection stays on the pair launch with V^T (whose B operand is the activation).
+        # The Q|K projection stays on the pair launch with V^T (whose B operand is the activation): on schedule 11 with V^T as its own
+        # launch the step was 0.4 % slower (profiles/r6_bench_steps10_ab_packed_qk.json).
         self.packed_weights = True
         self._sincos = {}
         dev = self.device
