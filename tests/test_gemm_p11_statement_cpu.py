@@ -84,9 +84,18 @@ def test_statement_shape_per_k_tile():
     assert sorted(acc) == sorted(4 * list(range(0, 256, 4)))          # two k-tiles x two k-steps per accumulator block
     for a, b in zip(body, body[1:]):
         assert not (a.startswith("s_add_u32 m0") and b.startswith("global_load_lds"))
-    # a k-tile's MFMAs read ONE B set, its B loads write the other
-    for half, (rd, wr) in enumerate((("v[19", "v[2"), ("v[2", "v[19"))):
-        pass
+    # a k-tile's MFMAs read ONE B set (v[192:223] / v[224:255]), its B loads write the other
+    n_mfma, halves = 0, [[], []]
+    for ln in body:
+        if ln.startswith("v_mfma"):
+            halves[n_mfma // 128].append(("rd", int(re.search(r", v\[(\d+):\d+\], v\[", ln).group(1))))
+            n_mfma += 1
+        elif ln.startswith("buffer_load_dwordx4"):
+            halves[min(n_mfma, 255) // 128].append(("wr", int(re.match(r"buffer_load_dwordx4 v\[(\d+):", ln).group(1))))
+    for kt, ops in enumerate(halves):
+        rd = {(r - 192) // 32 for kind, r in ops if kind == "rd"}
+        wr = {(r - 192) // 32 for kind, r in ops if kind == "wr"}
+        assert rd == {kt} and wr == {kt ^ 1}, (kt, rd, wr)
 
 
 def _replace_all(lines, old, new):
