@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 evidence run.  usage: bash scripts/gpu_r5_profile.sh [tests] [bench] [prof] [profwl] [pmc]
+# Evidence run (rounds 5 and 6: TAG=r6).  usage: [TAG=r6] bash scripts/gpu_r5_profile.sh [tests] [bench] [prof] [profwl] [pmc]
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 TAG=${TAG:-r5}
@@ -17,6 +17,8 @@ for w in ${@:-bench prof}; do
       cd /tmp
       timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profd5 -o $TAG -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-other-workloads --no-ab --no-calibration > $O/${TAG}_bench_default_under_rocprof.json 2> $O/profd5.err
       echo "prof exit $?"
+      python $R/scripts/rocprof_timed_region.py $(find $O/profd5 -name "*kernel_trace*" | head -1) $O/${TAG}_bench_default_under_rocprof.json > $O/${TAG}_bench_default_rocprof_vs_events.json 2>&1
+      cat $O/${TAG}_bench_default_rocprof_vs_events.json
       find $O/profd5 -name "*kernel_trace*" -delete
       cp $(find $O/profd5 -name "*kernel_stats*" | head -1) $O/${TAG}_bench_default_kernel_stats.csv
       rm -rf $O/profd5
