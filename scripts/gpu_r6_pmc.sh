@@ -3,7 +3,7 @@
 #   1. over the BENCH command itself (short form of the driver's line: 1 warm-up + 4 timed steps = two 3-sample and two 2-sample
 #      steps), summarised per (kernel, grid): roofline.traffic of the bench line is then from the run it annotates
 #   2. the filter kernels' HBM-side bytes again (r3_pmc_filters_hbm.txt was two rounds old)
-#   3. GEMM schedule 10 next to schedule 9, and the two d = 64 attention statements, in the kernel micro-benchmark
+#   3. GEMM schedules 10 / 11 next to schedule 9, and the two d = 64 attention statements, in the kernel micro-benchmark
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r6pmc; mkdir -p $O; export TMPDIR=/tmp
 cd /tmp
@@ -32,7 +32,7 @@ for ctrs in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VME
   i=$((i+1))
   for arm in "p10 ALG_GEMM_PIPE=10 ALG_ATTN_PP=4" "p9m16 ALG_GEMM_PIPE=9 ALG_ATTN_PP=7"; do
     set -- $arm; tag=$1; shift
-    env "$@" timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $K/${tag}_p$i -o p -- python $R/scripts/kbench.py --only gemm_qkv,gemm_out,gemm_ff1,gemm_ff2,attn_model_scores --iters 2 > /dev/null 2> $K/${tag}_p$i.err
+    env "$@" timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $K/${tag}_p$i -o p -- python $R/scripts/kbench.py --only gemm_qkv,gemm_out,gemm_ff1,gemm_ff2,gemm_out_p11,gemm_ff1_p11,gemm_ff2_p11,attn_model_scores --iters 2 > /dev/null 2> $K/${tag}_p$i.err
   done
 done
 python $R/scripts/pmc_summary.py $K > $O/r6_pmc_summary.txt 2>&1
