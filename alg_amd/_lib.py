@@ -22,7 +22,7 @@ GEMM_BIAS_PER_ROW, GEMM_PERMUTE_COLS, GEMM_GATE_F32, GEMM_GATE_SEG_STRIDE = 1, 4
 GEMM_B_PACKED11 = 32     # B is the panel pack_b_p11 wrote (GEMM schedule 11: the weight straight into registers in fragment order)
 
 EXPORTS = (
-    "alg_version", "alg_last_error", "alg_reload_env", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16", "alg_gemm_bf16_pair", "alg_gemm_bf16_pair_qk",
+    "alg_version", "alg_last_error", "alg_reload_env", "alg_down_up", "alg_gaussian_blur", "alg_cfg_ddim_step", "alg_gemm_bf16", "alg_gemm_bf16_pair", "alg_gemm_bf16_pair_qk", "alg_pack_b_p11", "alg_pack_b_p11_bytes",
     "alg_flash_attn_d64", "alg_layernorm_modulate", "alg_qk_norm_rope", "alg_patchify", "alg_unpatchify",
     "alg_timestep_embedding", "alg_cfg_combine", "alg_lincomb", "alg_unipc_update", "alg_concat_cast", "alg_flash_attn_d128", "alg_layernorm_mod_f32", "alg_layernorm_mod_f32_fp8", "alg_rmsnorm_rope",
     "alg_wan_modulation", "alg_patchify3d", "alg_unpatchify3d", "alg_timestep_embedding_f32", "alg_linear_f32",
@@ -34,7 +34,7 @@ EXPORTS = (
     "alg_flash_attn_d64_workspace_bytes", "alg_calib_mfma_bf16", "alg_wall_clock_khz", "alg_attn_clock_tap",
 )
 _RET_I64 = ("alg_vae_groupnorm_workspace", "alg_lowpass_tables_bytes", "alg_down_up_workspace_bytes",
-            "alg_gaussian_blur_workspace_bytes", "alg_flash_attn_d64_workspace_bytes")
+            "alg_gaussian_blur_workspace_bytes", "alg_flash_attn_d64_workspace_bytes", "alg_pack_b_p11_bytes")
 
 
 class AlgHipError(RuntimeError):
