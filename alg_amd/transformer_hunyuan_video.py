@@ -199,6 +199,7 @@ class HunyuanVideoTransformer3DModel:
             L.nq_c, L.nk_c = bf(b + "attn.norm_added_q.weight"), bf(b + "attn.norm_added_k.weight")
             L.f1, L.f2 = lin(b + "ff.net.0.proj"), lin(b + "ff.net.2")
             L.f1_c, L.f2_c = lin(b + "ff_context.net.0.proj"), lin(b + "ff_context.net.2")
+            L.packed = {id(t): _lib.PackedB(t) for t in (L.wqk, L.o[0], L.f1[0], L.f2[0])}     # the latent stream's linears (see packed_weights)
             self.dual.append(L)
         self.single = []
         for l in range(config.num_single_layers):
@@ -210,12 +211,17 @@ class HunyuanVideoTransformer3DModel:
             L.v = lin(b + "attn.to_v")
             L.nq, L.nk = bf(b + "attn.norm_q.weight"), bf(b + "attn.norm_k.weight")
             L.mlp, L.out = lin(b + "proj_mlp"), lin(b + "proj_out")
+            L.packed = {id(t): _lib.PackedB(t) for t in (L.wqk, L.mlp[0], L.out[0])}
             self.single.append(L)
         w.ada_out, w.out = lin("norm_out.linear"), lin("proj_out")
         self.w = w
         self._ws = {}
         self._rope_cache = {}
         self.profile = None  # set to a dict to collect (start, stop) HIP event pairs per kernel family of the large launches
+        # True (default): the weight-times-token linears of the latent / joint stream (Q|K, out, ff1, ff2; single blocks: Q|K, proj_mlp,
+        # proj_out) keep a copy packed in MFMA-fragment order (alg_pack_b_p11) and run GEMM schedule 11 (bit-identical to schedule 10);
+        # False, or ALG_GEMM_PIPE set to another schedule than 10: the row-major weights.  The prompt stream's few rows stay as they are.
+        self.packed_weights = True
 
     @classmethod
     def from_synthetic(cls, config=None, seed=1234, device="cuda"):
@@ -419,6 +425,8 @@ class HunyuanVideoTransformer3DModel:
 
         # ---- dual-stream blocks: latent rows [0, S) and text rows [S, J) of the joint buffer ----
         AM = D + M
+        use_packed = self.packed_weights and os.environ.get("ALG_GEMM_PIPE", "10") == "10"
+        PK = lambda Lw_, t: (Lw_.packed.get(id(t)) or t) if use_packed else t     # the packed copy of a block's weight, if it has one
         for Lw in self.dual:
             ada(Lw.ada, ws.semb2 if tr else ws.semb1, ws.mod, 6 * D, tr)     # [N][2][6D] (token replace) or [N][6D]
             mv = ws.mod
@@ -428,7 +436,7 @@ class HunyuanVideoTransformer3DModel:
               x_bstride=J * D, y_bstride=J * D, scale_off=D, shift_off=0)
             _lib.layernorm_modulate_seg(ws.x, ws.y, None, None, ws.modc, ws.modc, 6 * D, 0, N, L, D, 0, 1e-6,
                                         x_bstride=J * D, y_bstride=J * D, x_off=S * D, y_off=S * D, scale_off=D, shift_off=0)
-            T("gemm_qk", G, ws.y, Lw.wqk, ws.qk, S, 2 * D, D, D, D, 2 * D, bias=Lw.bqk, batch=N, strideA=J * D, strideC=J * 2 * D)
+            T("gemm_qk", G, ws.y, PK(Lw, Lw.wqk), ws.qk, S, 2 * D, D, D, D, 2 * D, bias=Lw.bqk, batch=N, strideA=J * D, strideC=J * 2 * D)
             G(ws.y, Lw.wqk_c, ws.qk, L, 2 * D, D, D, D, 2 * D, bias=Lw.bqk_c, batch=N, strideA=J * D, strideC=J * 2 * D,
               a_off=S * D, c_off=S * 2 * D)
             T("gemm_vt", G, Lw.v[0], ws.y, ws.vt, D, S, D, D, D, ws.J_pad, bias=Lw.v[1], batch=N, strideB=J * D,
@@ -441,7 +449,7 @@ class HunyuanVideoTransformer3DModel:
             _lib.headnorm_rope_(ws.qk, Lw.nq_c, None, None, 2 * D, J * 2 * D, N, L, heads, 0, 1e-6, x_off=S * 2 * D)
             _lib.headnorm_rope_(ws.qk, Lw.nk_c, None, None, 2 * D, J * 2 * D, N, L, heads, 0, 1e-6, x_off=S * 2 * D + D)
             attention()
-            T("gemm_out", G, ws.am, Lw.o[0], ws.x, S, D, D, AM, D, D, bias=Lw.o[1], R=ws.x, ldr=D, gate=mv, gate_off=2 * D,
+            T("gemm_out", G, ws.am, PK(Lw, Lw.o[0]), ws.x, S, D, D, AM, D, D, bias=Lw.o[1], R=ws.x, ldr=D, gate=mv, gate_off=2 * D,
               strideGate=mod_bs, gate_seg_stride=seg, seg_split=split, batch=N, strideA=J * AM, strideC=J * D, strideR=J * D)
             G(ws.am, Lw.o_c[0], ws.x, L, D, D, AM, D, D, bias=Lw.o_c[1], R=ws.x, ldr=D, gate=ws.modc, gate_off=2 * D,
               strideGate=6 * D, gate_seg_stride=0, batch=N, strideA=J * AM, strideC=J * D, strideR=J * D, a_off=S * AM,
@@ -451,11 +459,11 @@ class HunyuanVideoTransformer3DModel:
             _lib.layernorm_modulate_seg(ws.x, ws.y, None, None, ws.modc, ws.modc, 6 * D, 0, N, L, D, 0, 1e-6,
                                         x_bstride=J * D, y_bstride=J * D, x_off=S * D, y_off=S * D, scale_off=4 * D,
                                         shift_off=3 * D)
-            T("gemm_ff1", G, ws.y, Lw.f1[0], ws.am, S, M, D, D, D, AM, bias=Lw.f1[1], act=_lib.ACT_GELU_TANH, batch=N,
+            T("gemm_ff1", G, ws.y, PK(Lw, Lw.f1[0]), ws.am, S, M, D, D, D, AM, bias=Lw.f1[1], act=_lib.ACT_GELU_TANH, batch=N,
               strideA=J * D, strideC=J * AM, c_off=D)
             G(ws.y, Lw.f1_c[0], ws.am, L, M, D, D, D, AM, bias=Lw.f1_c[1], act=_lib.ACT_GELU_TANH, batch=N, strideA=J * D,
               strideC=J * AM, a_off=S * D, c_off=S * AM + D)
-            T("gemm_ff2", G, ws.am, Lw.f2[0], ws.x, S, D, M, AM, M, D, bias=Lw.f2[1], R=ws.x, ldr=D, gate=mv, gate_off=5 * D,
+            T("gemm_ff2", G, ws.am, PK(Lw, Lw.f2[0]), ws.x, S, D, M, AM, M, D, bias=Lw.f2[1], R=ws.x, ldr=D, gate=mv, gate_off=5 * D,
               strideGate=mod_bs, gate_seg_stride=seg, seg_split=split, batch=N, strideA=J * AM, strideC=J * D, strideR=J * D,
               a_off=D)
             G(ws.am, Lw.f2_c[0], ws.x, L, D, M, AM, M, D, bias=Lw.f2_c[1], R=ws.x, ldr=D, gate=ws.modc, gate_off=5 * D,
@@ -471,14 +479,14 @@ class HunyuanVideoTransformer3DModel:
                 G(ws.semb1, Lw.ada[0], ws.mod, N, 3 * D, D, D, D, 3 * D, bias=Lw.ada[1])
             T("ln_mod", _lib.layernorm_modulate_seg, ws.x, ws.y, None, None, ws.mod, ws.mod, smod_bs, sseg, N, J, D, split, 1e-6,
               scale_off=D, shift_off=0)
-            T("gemm_ff1", G, ws.y, Lw.mlp[0], ws.am, N * J, M, D, D, D, AM, bias=Lw.mlp[1], act=_lib.ACT_GELU_TANH, c_off=D)
-            T("gemm_qk", G, ws.y, Lw.wqk, ws.qk, N * J, 2 * D, D, D, D, 2 * D, bias=Lw.bqk)
+            T("gemm_ff1", G, ws.y, PK(Lw, Lw.mlp[0]), ws.am, N * J, M, D, D, D, AM, bias=Lw.mlp[1], act=_lib.ACT_GELU_TANH, c_off=D)
+            T("gemm_qk", G, ws.y, PK(Lw, Lw.wqk), ws.qk, N * J, 2 * D, D, D, D, 2 * D, bias=Lw.bqk)
             T("gemm_vt", G, Lw.v[0], ws.y, ws.vt, D, J, D, D, D, ws.J_pad, bias=Lw.v[1], batch=N, strideB=J * D,
               strideC=D * ws.J_pad, flags=_lib.GEMM_BIAS_PER_ROW | _lib.GEMM_PERMUTE_COLS)
             T("headnorm_rope", _lib.headnorm_rope_, ws.qk, Lw.nq, cos, sin, 2 * D, J * 2 * D, N, J, heads, S, 1e-6)
             T("headnorm_rope", _lib.headnorm_rope_, ws.qk, Lw.nk, cos, sin, 2 * D, J * 2 * D, N, J, heads, S, 1e-6, x_off=D)
             attention()
-            T("gemm_out_mlp", G, ws.am, Lw.out[0], ws.x, J, D, AM, AM, AM, D, bias=Lw.out[1], R=ws.x, ldr=D, gate=ws.mod, gate_off=2 * D,
+            T("gemm_out_mlp", G, ws.am, PK(Lw, Lw.out[0]), ws.x, J, D, AM, AM, AM, D, bias=Lw.out[1], R=ws.x, ldr=D, gate=ws.mod, gate_off=2 * D,
               strideGate=smod_bs, gate_seg_stride=sseg, seg_split=split, batch=N, strideA=J * AM, strideC=J * D,
               strideR=J * D)
 

@@ -68,6 +68,38 @@ def test_schedule11_batched_activations_shared_weight(monkeypatch, form):
     assert torch.equal(got, want)
 
 
+def test_schedule11_strided_operands_and_offsets(monkeypatch):
+    """the addressing forms the HunyuanVideo blocks use (not on schedule 11 in the product, but a PackedB must be safe wherever a weight is):
+    A as a column window of a wider buffer (lda > K, a_off), C into a column window (ldc > N, c_off), the residual at a row offset, the
+    per-segment gate of token replacement (gate_seg_stride), batch strides that are not M * ld"""
+    monkeypatch.setenv("ALG_GEMM_PIPE", "10")
+    g = torch.Generator(device="cuda").manual_seed(14)
+    rn = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g, device="cuda") * sc).to(BF)
+    nb, J, S, D, Mff = 2, 333, 300, 256, 512
+    AM = D + Mff
+    am, y = rn(nb, J, AM), rn(nb, J, D)
+    w_o, b_o, w_f1, b_f1 = rn(D, D, sc=0.05), rn(D), rn(Mff, D, sc=0.05), rn(Mff)
+    mod = rn(nb, 2, 6 * D, sc=0.5)
+    x0 = rn(nb, J, D)
+
+    def run(wo, wf1):
+        x, h = x0.clone(), am.clone()
+        # out-projection of the latent rows: A = the first D columns of the [J][D + Mff] buffer, gate per segment at a stride
+        _lib.gemm(h, wo, x, S, D, D, AM, D, D, bias=b_o, R=x, ldr=D, gate=mod, gate_off=2 * D, strideGate=12 * D, gate_seg_stride=6 * D,
+                  seg_split=100, batch=nb, strideA=J * AM, strideC=J * D, strideR=J * D)
+        # ... of the prompt rows: row offsets on A, C and R
+        _lib.gemm(h, wo, x, J - S, D, D, AM, D, D, bias=b_o, R=x, ldr=D, gate=mod, gate_off=2 * D, strideGate=12 * D, gate_seg_stride=0,
+                  batch=nb, strideA=J * AM, strideC=J * D, strideR=J * D, a_off=S * AM, c_off=S * D, r_off=S * D)
+        # ff1 with GELU into the column window [D, D + Mff) of the wide buffer
+        _lib.gemm(y, wf1, h, S, Mff, D, D, D, AM, bias=b_f1, act=_lib.ACT_GELU_TANH, batch=nb, strideA=J * D, strideC=J * AM, c_off=D)
+        return x, h
+
+    want = run(w_o, w_f1)
+    got = run(_lib.PackedB(w_o), _lib.PackedB(w_f1))
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert torch.equal(got[1][:, :, :D], am[:, :, :D]) and torch.equal(got[1][:, S:], am[:, S:])    # nothing outside the windows is written
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 250, 192), (33, 6, 128), (513, 1001, 256)])
 def test_schedule11_element_exact_epilogue(monkeypatch, M, N, K):
     monkeypatch.setenv("ALG_GEMM_PIPE", "10")

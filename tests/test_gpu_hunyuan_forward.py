@@ -96,6 +96,13 @@ def test_hunyuan_forward_small(mode):
                  None if guid is None else guid.to(DEV), return_dict=False)[0]
     assert torch.equal(out2[1], out[1])
     check_floor("hunyuan_forward_padded_garbage_" + mode, out2[0], ref[0], eager[0])
+    # the packed weights of GEMM schedule 11 (default) and the row-major ones on schedule 10 give the same bits
+    assert model.packed_weights
+    model.packed_weights = False
+    out3 = model(x.to(DEV), t.to(DEV), txt.to(DEV), mask.to(DEV).to(BF), pooled.to(DEV), None if guid is None else guid.to(DEV),
+                 return_dict=False)[0]
+    model.packed_weights = True
+    assert torch.equal(out3, out)
 
 
 def test_hunyuan_forward_latent_tokens_not_a_multiple_of_16():
