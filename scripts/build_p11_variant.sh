@@ -5,7 +5,7 @@
 set -eu
 R=$(cd "$(dirname "$0")/.." && pwd); tag=$1; shift
 D=$R/alg_amd/csrc/build_$tag; mkdir -p $D
-TAPFLAG=""; for kv in "$@"; do [ "$kv" = "TAP=1" ] && TAPFLAG="$TAPFLAG -DALG_GEMM_TAP"; [ "$kv" = "NOSTORE=1" ] && TAPFLAG="$TAPFLAG -DALG_ABL_NOSTORE"; done   # TAP=1: the per-workgroup clock tap (scripts/probes/gemm_tap.py)
+TAPFLAG=""; for kv in "$@"; do [ "$kv" = "TAP=1" ] && TAPFLAG="$TAPFLAG -DALG_GEMM_TAP"; [ "$kv" = "NOSTORE=1" ] && TAPFLAG="$TAPFLAG -DALG_ABL_NOSTORE"; case "$kv" in GROUP_M=*) TAPFLAG="$TAPFLAG -DALG_GROUP_M_OVERRIDE=${kv#GROUP_M=}";; esac; done   # TAP=1: the per-workgroup clock tap (scripts/probes/gemm_tap.py)
 env "$@" P11_OUT=$D/gemm_p11_loop.inc python $R/scripts/gen_gemm_p11.py > /dev/null
 cd $R/alg_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops \
