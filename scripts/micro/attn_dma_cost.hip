@@ -55,6 +55,8 @@ __device__ __forceinline__ unsigned hashu(unsigned x) {
 KERNEL(mix_none, MIX_NONE_ASM)
 KERNEL(mix_dma, MIX_DMA_ASM)
 KERNEL(mix_reg, MIX_REG_ASM)
+KERNEL(mix_bar1, MIX_BAR1_ASM)
+KERNEL(mix_bar2, MIX_BAR2_ASM)
 
 int main(int argc, char** argv) {
   const double secs = argc > 1 ? atof(argv[1]) : 3.0;
@@ -80,16 +82,19 @@ int main(int argc, char** argv) {
     hipMemcpy(src, h, nsrc, hipMemcpyHostToDevice);
     free(h);
   }
-  const char* names[3] = {"d64 mix alone", "d64 mix + 2 LDS-DMA pieces per tile", "d64 mix + 2 plain loads + 2 ds_write_b128 per tile"};
+  const char* names[5] = {"d64 mix alone", "d64 mix + 2 LDS-DMA pieces per tile", "d64 mix + 2 plain loads + 2 ds_write_b128 per tile",
+                          "... LDS-DMA + wait and barrier per tile", "... LDS-DMA + wait and barrier per TWO tiles"};
   for (int r = 0; r < rounds; ++r)
-    for (int s = 0; s < 3; ++s) {
-      const int iters = 40000;
+    for (int s = 0; s < 5; ++s) {
+      const int iters = s >= 3 ? 20000 : 40000;   // the barrier arms run two tiles per trip
       dim3 grid(pr.multiProcessorCount);
       auto launch = [&]() {
         switch (s) {
           case 0: hipLaunchKernelGGL(mix_none, grid, dim3(512), 0, 0, d, iters, 1u + r, clk, src); break;
           case 1: hipLaunchKernelGGL(mix_dma, grid, dim3(512), 0, 0, d, iters, 1u + r, clk, src); break;
-          default: hipLaunchKernelGGL(mix_reg, grid, dim3(512), 0, 0, d, iters, 1u + r, clk, src); break;
+          case 2: hipLaunchKernelGGL(mix_reg, grid, dim3(512), 0, 0, d, iters, 1u + r, clk, src); break;
+          case 3: hipLaunchKernelGGL(mix_bar1, grid, dim3(512), 0, 0, d, iters, 1u + r, clk, src); break;
+          default: hipLaunchKernelGGL(mix_bar2, grid, dim3(512), 0, 0, d, iters, 1u + r, clk, src); break;
         }
       };
       launch();
@@ -102,7 +107,7 @@ int main(int argc, char** argv) {
         hipEventRecord(a), launch(), hipEventRecord(b), hipEventSynchronize(b);
         float ms;
         hipEventElapsedTime(&ms, a, b);
-        last = 16 * 32768.0 * iters * grid.x * 8 / (ms * 1e-3) / 1e12;
+        last = (s >= 3 ? 32 : 16) * 32768.0 * iters * grid.x * 8 / (ms * 1e-3) / 1e12;
         hipEventDestroy(a), hipEventDestroy(b);
       }
       uint64_t h[2];
