@@ -62,6 +62,7 @@ NO_B_WAIT = os.environ.get("P11_NO_B_WAIT") == "1"      # TIMING ONLY: nothing w
 NO_DMA = os.environ.get("P11_NO_DMA") == "1"            # TIMING ONLY: no LDS-DMA piece of A is issued in the loop
 NO_READS = os.environ.get("P11_NO_READS") == "1"        # TIMING ONLY: no A fragment is read in the loop
 NO_B = os.environ.get("P11_NO_B") == "1"                # TIMING ONLY: no B fragment is loaded in the loop
+NO_BARRIER = os.environ.get("P11_NO_BARRIER") == "1"    # TIMING ONLY: the per-k-tile workgroup barrier is dropped (the counted wait stays)
 # rows (0-27) whose second gap issues one LDS-DMA piece of A(kt + 2) / one B fragment load of k-tile kt + 1
 DMA_ROWS = [int(x) for x in os.environ.get("P11_DMA_ROWS", "8,10,12,14,16,18,20,22").split(",")]
 B_ROWS = [int(x) for x in os.environ.get("P11_B_ROWS", "0,1,2,3,4,5,6,7").split(",")]
@@ -154,7 +155,7 @@ def ktile(par, b_next, a_dma, barrier, res_copy=None):
             allowed = (8 if a_dma and not NO_DMA else 0) + (4 if res_copy is not None else 0)
             if NO_B_WAIT and b_next and not NO_B:
                 allowed += 8
-            body += ["s_waitcnt vmcnt(%d) lgkmcnt(0)" % allowed, "s_barrier"] + advance()
+            body += ["s_waitcnt vmcnt(%d) lgkmcnt(0)" % allowed] + ([] if NO_BARRIER else ["s_barrier"]) + advance()
         body.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (ACC(bi, bj), FB(par, 4 * ks + bj), FA(r & 3), ACC(bi, bj)))
         body += gaps[j]
     return body
